@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE ITSELF (build container only).
+
+Run from the repo root:   python tests/golden/make_golden.py [group ...]
+
+* integer / index work (G1 subsampling, G2 radius neighbours, G3 pyramid) comes
+  from oracle/_ref/libref.so = the reference C++ core compiled unmodified
+  (oracle/Makefile, oracle/ref_shim.cpp);
+* floating-point work (G4 KPConv fwd/bwd, G5 blocks, G6 fusion) comes from
+  importing the reference's Python modules (models.blocks, kernels.kernel_points,
+  mvpnet/FeatureAggregation_dummy_test.py) with cwd=/root/reference/KPConv-PyTorch
+  and running them on torch-CPU;
+* k-NN comes from scikit-learn's NearestNeighbors(algorithm='ball_tree'), the
+  reference's call (ScanNet_sphere_color.py:448-449).
+
+Only DATA (inputs + expected outputs) is written; no reference source text.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+OUT = os.path.join(ROOT, "tests", "golden")
+REFROOT = "/root/reference"
+sys.path.insert(0, ROOT)
+sys.dont_write_bytecode = True
+
+from oracle import cport  # noqa: E402
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("wrote", path, {k: getattr(v, "shape", None) for k, v in arrs.items()})
+
+
+def room_cloud(rng, n, radius=1.2):
+    """Small synthetic 'room' (floor, two walls, table slab) cropped to a ball."""
+    parts = []
+    m = n // 4
+    parts.append(np.stack([rng.uniform(-2, 2, m), rng.uniform(-2, 2, m), np.zeros(m)], 1))
+    parts.append(np.stack([np.full(m, -0.8), rng.uniform(-2, 2, m), rng.uniform(0, 2, m)], 1))
+    parts.append(np.stack([rng.uniform(-2, 2, m), np.full(m, 0.9), rng.uniform(0, 2, m)], 1))
+    parts.append(np.stack([rng.uniform(-0.5, 0.6, m), rng.uniform(-0.6, 0.3, m), np.full(m, 0.75)], 1))
+    p = np.concatenate(parts, 0) + rng.normal(0, 0.005, (4 * m, 3))
+    c = np.array([0, 0, 0.8])
+    p = p[np.sum((p - c) ** 2, 1) < radius ** 2] - c
+    return p.astype(np.float32)
+
+
+# ---------------------------------------------------------------------------
+
+def g1_subsample():
+    assert cport.ref() is not None, "build oracle/_ref first (make -C oracle ref)"
+    rng = np.random.default_rng(101)
+    # (a) points only, one cloud, 4096 uniform points
+    p = (rng.random((4096, 3)) * [2.0, 2.0, 0.5]).astype(np.float32)
+    sp, sl = cport.subsample_batch(p, [4096], dl=0.08, impl="ref")
+    save("g1_sub_4096", points=p, lens=np.array([4096], np.int32), dl=np.float32(0.08), out_points=sp, out_lens=sl)
+    # (b) ragged batch of room clouds incl. a tiny cloud, network-path call (points only)
+    clouds = [room_cloud(rng, 24000), room_cloud(rng, 9000, 0.9), (rng.random((5, 3)) * 0.01).astype(np.float32)]
+    p = np.concatenate(clouds, 0)
+    lens = np.array([c.shape[0] for c in clouds], np.int32)
+    sp, sl = cport.subsample_batch(p, lens, dl=0.04, impl="ref")
+    save("g1_sub_batch", points=p, lens=lens, dl=np.float32(0.04), out_points=sp, out_lens=sl)
+    # (c) scene-load call: features (colours) + labels, single cloud (wrapper.cpp:338 'subsample')
+    p = room_cloud(rng, 40000)
+    f = rng.random((p.shape[0], 3)).astype(np.float32)
+    l = rng.integers(0, 20, (p.shape[0], 1)).astype(np.int32)
+    o = cport.subsample(p, f, l, dl=0.06, impl="ref")
+    save("g1_sub_feat_lab", points=p, features=f, labels=l, dl=np.float32(0.06),
+         out_points=o[0], out_features=o[1], out_labels=o[2])
+    # (d) max_p truncation
+    p = (rng.random((3000, 3))).astype(np.float32)
+    lens = np.array([1000, 2000], np.int32)
+    sp, sl = cport.subsample_batch(p, lens, dl=0.1, max_p=150, impl="ref")
+    save("g1_sub_maxp", points=p, lens=lens, dl=np.float32(0.1), max_p=np.int32(150), out_points=sp, out_lens=sl)
+
+
+def assert_tie_free(q, s, ql, sl, r, allow=False):
+    """Count rows holding equal-d2 pairs (the reference order inside such a tie group is
+    std::sort-over-KD-tree-traversal defined, i.e. unspecified). Conv fixtures (q == s) must be
+    tie-free; pool/upsample fixtures legitimately contain ties (a 2-point voxel's barycentre is
+    equidistant from both points) and are compared with tie groups as sets."""
+    ties = 0
+    q0 = s0 = 0
+    r2 = np.float32(r) * np.float32(r)
+    for nq, ns in zip(ql, sl):
+        qq, ss = q[q0:q0 + nq], s[s0:s0 + ns]
+        for i in range(0, nq, 512):
+            d = qq[i:i + 512, None, :] - ss[None]
+            d2 = (d[..., 0] * d[..., 0] + d[..., 1] * d[..., 1]) + d[..., 2] * d[..., 2]
+            d2 = np.where(d2 < r2, d2, np.inf)
+            srt = np.sort(d2, axis=1)
+            eq = (srt[:, 1:] == srt[:, :-1]) & np.isfinite(srt[:, 1:])
+            ties += int(eq.any(axis=1).sum())
+        q0 += nq
+        s0 += ns
+    assert allow or ties == 0, "tie in golden neighbour fixture"
+    return ties
+
+
+def g2_neighbors():
+    assert cport.ref() is not None
+    rng = np.random.default_rng(202)
+    # conv neighbours, B=1
+    raw = room_cloud(rng, 16000)
+    p, lens = cport.subsample_batch(raw, [raw.shape[0]], dl=0.04, impl="ref")
+    assert_tie_free(p, p, lens, lens, 0.1)
+    nb = cport.radius_neighbors_batch(p, p, lens, lens, 0.1, impl="ref")
+    save("g2_nb_conv_b1", queries=p, supports=p, q_lens=lens, s_lens=lens, radius=np.float32(0.1), out=nb)
+    # ragged B=3 pool + upsample, with an isolated query (empty neighbourhood) in cloud 1
+    raws = [room_cloud(rng, 9000), room_cloud(rng, 5000, 0.8), room_cloud(rng, 2500, 0.6)]
+    raw = np.concatenate(raws, 0)
+    rl = np.array([c.shape[0] for c in raws], np.int32)
+    s, sl = cport.subsample_batch(raw, rl, dl=0.04, impl="ref")
+    q, qlens = cport.subsample_batch(s, sl, dl=0.08, impl="ref")
+    q = q.copy()
+    q[qlens[0] + 3] = [5.0, 5.0, 5.0]   # far from everything in its own cloud
+    t_pool = assert_tie_free(q, s, qlens, sl, 0.1, allow=True)
+    pool = cport.radius_neighbors_batch(q, s, qlens, sl, 0.1, impl="ref")
+    t_up = assert_tie_free(s, q, sl, qlens, 0.2, allow=True)
+    up = cport.radius_neighbors_batch(s, q, sl, qlens, 0.2, impl="ref")
+    save("g2_nb_pool_up_b3", fine=s, fine_lens=sl, coarse=q, coarse_lens=qlens,
+         r_pool=np.float32(0.1), r_up=np.float32(0.2), out_pool=pool, out_up=up,
+         tied_rows_pool=np.int32(t_pool), tied_rows_up=np.int32(t_up))
+    # volumetric cloud with 200 coincident query/support points (d2 == 0)
+    v = (rng.random((3000, 3)) * 0.6).astype(np.float32)
+    lens = np.array([3000], np.int32)
+    qv = np.concatenate([v[:200], (rng.random((300, 3)) * 0.6).astype(np.float32)], 0)
+    assert_tie_free(qv, v, [500], [3000], 0.07)
+    nb = cport.radius_neighbors_batch(qv, v, [500], [3000], 0.07, impl="ref")
+    save("g2_nb_volumetric", queries=qv, supports=v, q_lens=np.array([500], np.int32), s_lens=lens,
+         radius=np.float32(0.07), out=nb)
+
+
+def _ref_blocks():
+    os.chdir(os.path.join(REFROOT, "KPConv-PyTorch"))
+    if os.getcwd() not in sys.path:
+        sys.path.insert(0, os.getcwd())
+    import models.blocks as rb
+    return rb
+
+
+def g4_kpconv():
+    import torch
+    rb = _ref_blocks()
+    rng = np.random.default_rng(404)
+
+    def lattice(n_side, pitch=0.04):
+        gx, gy = np.meshgrid(np.arange(n_side), np.arange(n_side), indexing="ij")
+        p = np.stack([gx.ravel() * pitch, gy.ravel() * pitch, np.zeros(n_side * n_side)], 1)
+        p[:, :2] += rng.uniform(-0.015, 0.015, (p.shape[0], 2))
+        p[:, 2] = 0.02 * np.sin(p[:, 0] * 7.0) + rng.uniform(-0.004, 0.004, p.shape[0])
+        return p.astype(np.float32)
+
+    def run(name, q, s, idx, cin, cout, extent, radius, influence="linear", aggregation="sum",
+            deformable=False, modulated=False, seed=0):
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        m = rb.KPConv(15, 3, cin, cout, extent, radius, KP_influence=influence,
+                      aggregation_mode=aggregation, deformable=deformable, modulated=modulated)
+        if deformable:
+            # non-trivial offsets: the reference initialises offset weights like any KPConv
+            with torch.no_grad():
+                m.offset_bias.normal_(0, 0.05)
+        x = torch.randn(s.shape[0], cin, requires_grad=True)
+        tq, ts, ti = torch.from_numpy(q), torch.from_numpy(s), torch.from_numpy(idx.astype(np.int64))
+        y = m(tq, ts, ti, x)
+        g = torch.randn_like(y)
+        loss = (y * g).sum()
+        extra = {}
+        if deformable:
+            # add the regulariser's two inputs so their gradients are pinned too
+            loss = loss + (m.min_d2.sum() + (m.deformed_KP ** 2).sum()) * 0.5
+            extra.update(min_d2=m.min_d2.detach().numpy(), deformed_KP=m.deformed_KP.detach().numpy(),
+                         offset_weights=m.offset_conv.weights.detach().numpy(),
+                         offset_kernel_points=m.offset_conv.kernel_points.detach().numpy(),
+                         offset_bias=m.offset_bias.detach().numpy())
+        loss.backward()
+        if deformable:
+            extra.update(offset_weights_grad=m.offset_conv.weights.grad.numpy(),
+                         offset_bias_grad=m.offset_bias.grad.numpy())
+        save(name, q=q, s=s, idx=idx.astype(np.int32), x=x.detach().numpy(),
+             kernel_points=m.kernel_points.detach().numpy(), weights=m.weights.detach().numpy(),
+             extent=np.float32(extent), radius=np.float32(radius), y=y.detach().numpy(), g=g.numpy(),
+             x_grad=x.grad.numpy(), weights_grad=m.weights.grad.numpy(), **extra)
+
+    # config 1: 64x64 lattice, conv radius 0.1, extent 0.048, Cin=Cout=64
+    p = lattice(64)
+    lens = np.array([p.shape[0]], np.int32)
+    nb = cport.radius_neighbors_batch(p, p, lens, lens, 0.1, impl="ref")
+    run("g4_kpconv_config1", p, p, nb, 64, 64, 0.048, 0.1)
+    # smaller clouds for the variants
+    p = lattice(24)
+    lens = np.array([p.shape[0]], np.int32)
+    nb = cport.radius_neighbors_batch(p, p, lens, lens, 0.1, impl="ref")
+    run("g4_kpconv_gaussian", p, p, nb, 16, 24, 0.048, 0.1, influence="gaussian")
+    run("g4_kpconv_constant", p, p, nb, 7, 9, 0.048, 0.1, influence="constant")
+    run("g4_kpconv_closest", p, p, nb, 12, 8, 0.048, 0.1, aggregation="closest")
+    run("g4_kpconv_cin66", p, p, nb, 66, 64, 0.048, 0.1)
+    run("g4_kpconv_cin2", p, p, nb, 2, 64, 0.048, 0.1)
+    # strided: queries = subsampled cloud, idx = pools (cropped to 20 columns like neighborhood_limits)
+    q, ql = cport.subsample_batch(p, lens, dl=0.08, impl="ref")
+    pool = cport.radius_neighbors_batch(q, p, ql, lens, 0.1, impl="ref")[:, :20]
+    run("g4_kpconv_strided", q, p, pool, 32, 32, 0.048, 0.1)
+    # deformable (+ modulated): neighbourhoods at the deform radius 6.0/2.5*0.1
+    nbd = cport.radius_neighbors_batch(p, p, lens, lens, 0.24, impl="ref")
+    run("g4_kpconv_deform", p, p, nbd, 16, 16, 0.048, 0.1, deformable=True)
+    run("g4_kpconv_deform_mod", p, p, nbd, 16, 16, 0.048, 0.1, deformable=True, modulated=True)
+    # pooling helpers
+    x = torch.randn(p.shape[0], 10)
+    save("g4_pools", x=x.numpy(), pool_idx=pool.astype(np.int32),
+         max_pool=rb.max_pool(x, torch.from_numpy(pool.astype(np.int64))).numpy(),
+         closest_pool=rb.closest_pool(x, torch.from_numpy(pool.astype(np.int64))).numpy())
+
+
+GROUPS = {"g1": g1_subsample, "g2": g2_neighbors, "g4": g4_kpconv}
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or list(GROUPS)
+    for g in todo:
+        cwd = os.getcwd()
+        GROUPS[g]()
+        os.chdir(cwd)

@@ -1,0 +1,64 @@
+"""ctypes binding of libmvkpconv.so (C ABI: include/mvkpconv.h).
+
+There is NO fallback: if the HIP library is missing or stale this module raises. PyTorch is used
+only as the owner of device memory and streams -- every signature is plain pointers and sizes.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmvkpconv.so")
+ABI_VERSION = 1
+
+_vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+_SIGNATURES = {
+    "mvk_abi_version": (C.c_int, []),
+    "mvk_last_error": (C.c_char_p, []),
+    "mvk_kpconv_gather_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
+                                        _vp, _vp, _vp, _vp]),
+    "mvk_kpconv_scatter_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i, _f, _i, _i,
+                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvk_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
+    "mvk_max_pool_fwd": (C.c_int, [_vp, _i64, _i, _vp, _i, _i64, _i, _vp, _vp, _vp]),
+    "mvk_max_pool_bwd": (C.c_int, [_vp, _vp, _vp, _i, _i64, _i, _i64, _i, _vp, _vp]),
+    "mvk_gather_rows_fwd": (C.c_int, [_vp, _i64, _i, _vp, _i, _i64, _i64, _vp, _vp]),
+    "mvk_gather_rows_bwd": (C.c_int, [_vp, _vp, _i, _i64, _i64, _i64, _i, _vp, _vp]),
+    "mvk_grid_subsample_workspace": (C.c_int64, [_i64, _i]),
+    "mvk_grid_subsample_batch": (C.c_int, [_vp, _i64, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp,
+                                           _vp, _i64, _vp]),
+    "mvk_radius_neighbors_workspace": (C.c_int64, [_i64, _i64, _i]),
+    "mvk_radius_neighbors_batch": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _vp,
+                                             _vp, _i64, _vp]),
+    "mvk_unproject_depth": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mvk_knn_f64": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i, _vp, _vp]),
+    "mvk_group_points_fwd": (C.c_int, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
+    "mvk_group_points_bwd": (C.c_int, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+_lib = None
+
+
+def lib():
+    """The loaded library. Raises (never falls back) when it is absent or has the wrong ABI."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libmvkpconv.so is not built (%s). Run `python __graft_entry__.py build` -- there is "
+                "no CPU fallback for the MV-KPConv hot path." % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError = missing export = stale build: loud
+            fn.restype = res
+            fn.argtypes = args
+        if l.mvk_abi_version() != ABI_VERSION:
+            raise RuntimeError("libmvkpconv.so ABI %d != expected %d; rebuild" % (l.mvk_abi_version(), ABI_VERSION))
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError(lib().mvk_last_error().decode("utf-8", "replace"))

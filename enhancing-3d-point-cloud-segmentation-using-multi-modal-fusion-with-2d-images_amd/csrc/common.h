@@ -1,0 +1,36 @@
+// Shared host-side helpers of libmvkpconv.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mvkpconv.h"
+
+extern "C" void mvk_set_error(const char* fmt, ...);
+
+#define MVK_CHECK_HIP(expr)                                                           \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      mvk_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,  \
+                    __LINE__);                                                        \
+      return -2;                                                                      \
+    }                                                                                 \
+  } while (0)
+
+#define MVK_REQUIRE(cond, ...)   \
+  do {                           \
+    if (!(cond)) {               \
+      mvk_set_error(__VA_ARGS__); \
+      return -1;                 \
+    }                            \
+  } while (0)
+
+static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// neighbour index load: int32 or int64 storage, -1 for shadow / out of range
+template <bool IDX64>
+__device__ __forceinline__ int load_idx(const void* idx, int64_t pos, int64_t Ns) {
+  int64_t j = IDX64 ? ((const int64_t*)idx)[pos] : (int64_t)((const int32_t*)idx)[pos];
+  return (j >= 0 && j < Ns) ? (int)j : -1;
+}

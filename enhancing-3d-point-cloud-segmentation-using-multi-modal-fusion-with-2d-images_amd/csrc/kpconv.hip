@@ -1,0 +1,519 @@
+// KPConv gather / correlate / aggregate kernels for gfx950 (CDNA4, wave64).
+//
+// Replaces the ~15 ATen ops of KPConv.forward (reference
+// KPConv-PyTorch/models/blocks.py:277-367) and their autograd backward by two
+// fused kernels that never materialise [N,H,3], [N,H,K,3], [N,H,K] or [N,H,Cin]:
+//
+//   gather  (forward)  A[n,k,c]  = sum_h w[n,h,k] * x+[idx[n,h], c]
+//   scatter (backward) dx[idx[n,h],c] += sum_k w[n,h,k] * dA[n,k,c]
+//
+// w[n,h,k] is a pure function of geometry (q, s, kernel points, extent), so the
+// backward recomputes it instead of storing [N,H,K].
+//
+// Work decomposition (one 64-lane wavefront per workgroup):
+//   * a wave owns PPW = 64/LPP query points; LPP lanes ("a point group") own one
+//     point, each lane 4 consecutive channels (16-byte loads of the feature rows:
+//     a group reads one 4*LPP*4-byte row per instruction, the wave PPW rows);
+//   * neighbours are processed in chunks of HC = LPP per point (PPW*HC = 64):
+//       A1  lane (p,h): index load, support xyz gather, centring   -> LDS rel[64]
+//       A2  16 rounds: lane = (p,h,k) item, kernel-point correlation -> LDS w[p][h][16]
+//       B   per neighbour: 16-byte row load, 4 ds_read_b128 of w (broadcast inside
+//           the group), 15 x 4 FMAs into register accumulators A[k][c..c+3]
+//   * epilogue: 15 coalesced 16-byte-per-lane stores of A[n,k,:].
+// The generic kernel (any Cin, deformable, backward) maps lane = channel and one
+// point per wave (PPW = 1, HC = 64); its neighbour loop is wave-uniform.
+#include "common.h"
+
+#define KMAX 16
+
+namespace {
+
+struct KPParams {
+  const float* q;
+  const float* s;
+  const void* idx;
+  const float* x;
+  const float* kp;
+  const float* offsets;  // [Nq,K,3] or null
+  float* min_d2;         // [Nq,K] or null
+  float* A;              // fwd: out [Nq,K,Cin]; bwd: in dA
+  float* dx;             // bwd out [Ns,Cin]
+  const float* g_min_d2; // bwd deformable
+  float* d_offsets;      // bwd deformable out [Nq,K,3]
+  int64_t Nq, Ns;
+  int H, Cin, K;
+  float extent;
+  int influence, aggregation;
+};
+
+__device__ __forceinline__ float influence_w(float d2, float extent, int influence) {
+  // blocks.py:329-344
+  if (influence == MVK_INFL_LINEAR) return fmaxf(1.0f - sqrtf(d2) / extent, 0.0f);
+  if (influence == MVK_INFL_GAUSSIAN) {
+    float sig = extent * 0.3f;
+    return expf(-d2 / (2.0f * sig * sig + 1e-9f));
+  }
+  return 1.0f;
+}
+
+// ---------------------------------------------------------------------------
+// Phase A (shared): fills rel[64] (xyz + neighbour row or -1) and w[64][16].
+// Lane mapping: A1 lane = ph = p*HC + h ; A2 item = t*64 + lane, k = lane & 15, ph = item >> 4.
+// WPAD = extra floats between consecutive points' weight blocks (bank spreading).
+// Returns the lane's neighbour row j (A1 mapping) so callers can shuffle it.
+// ---------------------------------------------------------------------------
+template <int PPW, int HC, int WPAD, bool IDX64, bool DEFORM>
+__device__ __forceinline__ int phase_a(const KPParams& P, int64_t n0, int h0, int lane,
+                                       float4* rel, float* wl, float qx, float qy, float qz,
+                                       bool nvalid, float kx, float ky, float kz,
+                                       float* run_min /* DEFORM only, PPW==1 */) {
+  const int p = lane / HC, h = lane % HC;
+  const int64_t n = n0 + p;
+  int j = -2;  // -2: no entry, -1: shadow entry
+  float rx = 0.f, ry = 0.f, rz = 0.f;
+  if (nvalid && h0 + h < P.H) {
+    j = load_idx<IDX64>(P.idx, n * P.H + h0 + h, P.Ns);
+    if (j >= 0) {
+      const float* sp = P.s + (int64_t)j * 3;
+      rx = sp[0] - qx;
+      ry = sp[1] - qy;
+      rz = sp[2] - qz;
+    } else {  // shadow support point (1e6,1e6,1e6), blocks.py:277
+      rx = 1e6f - qx;
+      ry = 1e6f - qy;
+      rz = 1e6f - qz;
+    }
+  }
+  rel[lane] = make_float4(rx, ry, rz, __int_as_float(j));
+  __syncthreads();
+
+  const int k = lane & 15;
+  const float ext2 = P.extent * P.extent;
+#pragma unroll
+  for (int t = 0; t < 16; ++t) {
+    const int ph = t * 4 + (lane >> 4);
+    const float4 r = rel[ph];
+    const int jj = __float_as_int(r.w);
+    float dx = r.x - kx, dy = r.y - ky, dz = r.z - kz;
+    float d2 = dx * dx + dy * dy + dz * dz;  // blocks.py:294-297
+    float w = 0.f;
+    if (jj >= 0 && k < P.K) w = influence_w(d2, P.extent, P.influence);
+    if (P.aggregation == MVK_AGG_CLOSEST) {
+      // one-hot of argmin_k d2 (first minimum), blocks.py:349-351
+      float bd = (k < P.K) ? d2 : INFINITY;
+      int bk = k;
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        float od = __shfl_xor(bd, m, 16);
+        int ok = __shfl_xor(bk, m, 16);
+        if (od < bd || (od == bd && ok < bk)) {
+          bd = od;
+          bk = ok;
+        }
+      }
+      if (bk != k) w = 0.f;
+    }
+    if (DEFORM) {
+      // neighbours out of range of every deformed kernel point are dropped (blocks.py:306-325)
+      unsigned long long m = __ballot(jj >= 0 && k < P.K && d2 < ext2);
+      bool inrange = ((m >> (lane & 48)) & 0xFFFFull) != 0ull;
+      if (!inrange) {
+        w = 0.f;
+        if (k == 0 && jj >= 0) rel[ph].w = __int_as_float(-1);
+      }
+      // running min_h d2 over real + shadow entries (blocks.py:303)
+      if (jj >= -1 && k < P.K) *run_min = fminf(*run_min, d2);
+    }
+    wl[(ph / HC) * (HC * 16 + WPAD) + (ph % HC) * 16 + k] = w;
+  }
+  __syncthreads();
+  return j;
+}
+
+// ---------------------------------------------------------------------------
+// Vector gather kernel: Cin % 4 == 0, Cin <= 4*LPP*NCH.
+// ---------------------------------------------------------------------------
+template <int LPP, int NCH, bool IDX64>
+__global__ __launch_bounds__(64) void kpconv_gather_vec(KPParams P) {
+  constexpr int PPW = 64 / LPP, HC = LPP, WPAD = 4;
+  __shared__ float4 rel[64];
+  __shared__ float wl[PPW * (HC * 16 + WPAD)];
+  const int lane = threadIdx.x;
+  const int64_t n0 = (int64_t)blockIdx.x * PPW;
+  // A-phase identity of this lane
+  const int pa = lane / HC;
+  const bool nvalid_a = n0 + pa < P.Nq;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (nvalid_a) {
+    const float* qp = P.q + (n0 + pa) * 3;
+    qx = qp[0];
+    qy = qp[1];
+    qz = qp[2];
+  }
+  const int k = lane & 15;
+  float kx = 0.f, ky = 0.f, kz = 0.f;
+  if (k < P.K) {
+    kx = P.kp[k * 3];
+    ky = P.kp[k * 3 + 1];
+    kz = P.kp[k * 3 + 2];
+  }
+  // B-phase identity
+  const int p = lane / LPP, cl = lane % LPP;
+  const int64_t n = n0 + p;
+  const bool nvalid = n < P.Nq;
+
+  float4 acc[NCH][KMAX - 1];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int kk = 0; kk < KMAX - 1; ++kk) acc[c][kk] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int h0 = 0; h0 < P.H; h0 += HC) {
+    int j = phase_a<PPW, HC, WPAD, IDX64, false>(P, n0, h0, lane, rel, wl, qx, qy, qz, nvalid_a,
+                                                  kx, ky, kz, nullptr);
+    if (__ballot(j >= 0) == 0ull) continue;  // whole chunk is padding for every point of the wave
+    const float* wrow = wl + p * (HC * 16 + WPAD);
+#pragma unroll 4
+    for (int hh = 0; hh < HC; ++hh) {
+      const int jj = __shfl(j, p * HC + hh);
+      if (jj >= 0 && nvalid) {
+        const float4* w4 = reinterpret_cast<const float4*>(wrow + hh * 16);
+        const float4 wa = w4[0], wb = w4[1], wc = w4[2], wd = w4[3];
+        const float wv[16] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w,
+                              wc.x, wc.y, wc.z, wc.w, wd.x, wd.y, wd.z, wd.w};
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+          const int c4 = (cl + c * LPP) * 4;
+          if (c4 < P.Cin) {
+            const float4 xv = *reinterpret_cast<const float4*>(P.x + (int64_t)jj * P.Cin + c4);
+#pragma unroll
+            for (int kk = 0; kk < KMAX - 1; ++kk) {
+              acc[c][kk].x += wv[kk] * xv.x;
+              acc[c][kk].y += wv[kk] * xv.y;
+              acc[c][kk].z += wv[kk] * xv.z;
+              acc[c][kk].w += wv[kk] * xv.w;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (nvalid) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const int c4 = (cl + c * LPP) * 4;
+      if (c4 < P.Cin) {
+#pragma unroll
+        for (int kk = 0; kk < KMAX - 1; ++kk)
+          if (kk < P.K)
+            *reinterpret_cast<float4*>(P.A + (n * P.K + kk) * P.Cin + c4) = acc[c][kk];
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Generic lane = channel kernel (one point per wave). MODE 0: forward gather
+// (any Cin, rigid or deformable). MODE 1: backward scatter (+ deformable grads).
+// Channels handled: c = c0 + lane + 64*slot, slot < NSLOT.
+// ---------------------------------------------------------------------------
+template <int NSLOT, bool IDX64, int MODE, bool DEFORM>
+__global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
+  constexpr int HC = 64, WPAD = 0;
+  __shared__ float4 rel[64];
+  __shared__ float wl[64 * 16];
+  __shared__ float cf[DEFORM && MODE == 1 ? 64 * 16 * 3 : 1];  // dw/d(offset) per (h,k,dim)
+  const int lane = threadIdx.x;
+  const int64_t n = blockIdx.x;
+  const float* qp = P.q + n * 3;
+  const float qx = qp[0], qy = qp[1], qz = qp[2];
+  const int k = lane & 15;
+  float kx = 0.f, ky = 0.f, kz = 0.f;
+  if (k < P.K) {
+    kx = P.kp[k * 3];
+    ky = P.kp[k * 3 + 1];
+    kz = P.kp[k * 3 + 2];
+    if (DEFORM) {  // deformed kernel point (blocks.py:287)
+      const float* o = P.offsets + (n * P.K + k) * 3;
+      kx += o[0];
+      ky += o[1];
+      kz += o[2];
+    }
+  }
+  float run_min = INFINITY;
+
+  float acc[NSLOT][KMAX - 1];  // MODE 0: A accumulators; MODE 1: dA values
+  float S[(DEFORM && MODE == 1) ? NSLOT : 1][(DEFORM && MODE == 1) ? (KMAX - 1) * 3 : 1];
+#pragma unroll
+  for (int sidx = 0; sidx < NSLOT; ++sidx) {
+    const int c = c0 + lane + 64 * sidx;
+#pragma unroll
+    for (int kk = 0; kk < KMAX - 1; ++kk) {
+      if (MODE == 0)
+        acc[sidx][kk] = 0.f;
+      else
+        acc[sidx][kk] = (c < P.Cin && kk < P.K) ? P.A[(n * P.K + kk) * P.Cin + c] : 0.f;
+    }
+    if (DEFORM && MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < (KMAX - 1) * 3; ++e) S[sidx][e] = 0.f;
+    }
+  }
+
+  for (int h0 = 0; h0 < P.H; h0 += HC) {
+    int j = phase_a<1, HC, WPAD, IDX64, DEFORM>(P, n, h0, lane, rel, wl, qx, qy, qz, true, kx, ky,
+                                                 kz, &run_min);
+    if (DEFORM && MODE == 1) {
+      // d w[h,k] / d offset[k,:] for the linear influence:  w = 1 - sqrt(d2)/ext  (w > 0)
+      //   dw/dd2 = -1/(2 ext sqrt(d2));  dd2/doff = -2 (rel - kpdef)   =>  (rel - kpdef) / (ext sqrt(d2))
+      // gaussian: w = exp(-d2/den): dw/doff = w * 2 (rel - kpdef) / den.  constant: 0.
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int ph = t * 4 + (lane >> 4);
+        const float4 r = rel[ph];
+        const float w = wl[ph * 16 + k];
+        float ddx = r.x - kx, ddy = r.y - ky, ddz = r.z - kz;
+        float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+        float sc = 0.f;
+        if (w > 0.f && k < P.K) {
+          if (P.influence == MVK_INFL_LINEAR)
+            sc = d2 > 0.f ? 1.0f / (P.extent * sqrtf(d2)) : 0.f;
+          else if (P.influence == MVK_INFL_GAUSSIAN) {
+            float sig = P.extent * 0.3f;
+            sc = 2.0f * w / (2.0f * sig * sig + 1e-9f);
+          }
+        }
+        cf[(ph * 16 + k) * 3 + 0] = sc * ddx;
+        cf[(ph * 16 + k) * 3 + 1] = sc * ddy;
+        cf[(ph * 16 + k) * 3 + 2] = sc * ddz;
+      }
+      __syncthreads();
+    }
+    if (__ballot(j >= 0) != 0ull) {
+      const int hend = min(HC, P.H - h0);
+      for (int hh = 0; hh < hend; ++hh) {
+        const int jj = __builtin_amdgcn_readfirstlane(__float_as_int(rel[hh].w));
+        if (jj < 0) continue;  // wave-uniform
+        const float4* w4 = reinterpret_cast<const float4*>(wl + hh * 16);
+        const float4 wa = w4[0], wb = w4[1], wc = w4[2], wd = w4[3];
+        const float wv[16] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w,
+                              wc.x, wc.y, wc.z, wc.w, wd.x, wd.y, wd.z, wd.w};
+#pragma unroll
+        for (int sidx = 0; sidx < NSLOT; ++sidx) {
+          const int c = c0 + lane + 64 * sidx;
+          if (c < P.Cin) {
+            if (MODE == 0) {
+              const float xv = P.x[(int64_t)jj * P.Cin + c];
+#pragma unroll
+              for (int kk = 0; kk < KMAX - 1; ++kk) acc[sidx][kk] += wv[kk] * xv;
+            } else {
+              float contrib = 0.f;
+#pragma unroll
+              for (int kk = 0; kk < KMAX - 1; ++kk) contrib += wv[kk] * acc[sidx][kk];
+              atomicAdd(P.dx + (int64_t)jj * P.Cin + c, contrib);
+              if (DEFORM) {
+                const float xv = P.x[(int64_t)jj * P.Cin + c];
+                const float* cfr = cf + hh * 16 * 3;
+#pragma unroll
+                for (int e = 0; e < (KMAX - 1) * 3; ++e) S[sidx][e] += xv * cfr[e];
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  if (MODE == 0) {
+#pragma unroll
+    for (int sidx = 0; sidx < NSLOT; ++sidx) {
+      const int c = c0 + lane + 64 * sidx;
+      if (c < P.Cin) {
+#pragma unroll
+        for (int kk = 0; kk < KMAX - 1; ++kk)
+          if (kk < P.K) P.A[(n * P.K + kk) * P.Cin + c] = acc[sidx][kk];
+      }
+    }
+    if (DEFORM && P.min_d2 != nullptr && c0 == 0) {
+      float m = run_min;
+      m = fminf(m, __shfl_xor(m, 16));
+      m = fminf(m, __shfl_xor(m, 32));
+      if (lane < 16 && lane < P.K) P.min_d2[n * P.K + lane] = m;
+    }
+  } else if (DEFORM) {
+    // d_offsets[n,k,d] (+)= sum_c S_c[k][d] * dA[n,k,c]   (see header comment / DESIGN.md)
+#pragma unroll
+    for (int kk = 0; kk < KMAX - 1; ++kk) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        float v = 0.f;
+#pragma unroll
+        for (int sidx = 0; sidx < NSLOT; ++sidx) v += S[sidx][kk * 3 + d] * acc[sidx][kk];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+        if (lane == 0 && kk < P.K) atomicAdd(P.d_offsets + (n * P.K + kk) * 3 + d, v);
+      }
+    }
+  }
+}
+
+// min_d2 backward for the deformable path: d min_d2[n,k] / d offset[n,k,:] = -2 (rel[h*] - kpdef)
+// with h* = argmin_h d2 (first minimum). One lane per (n,k).
+template <bool IDX64>
+__global__ void kpconv_min_d2_bwd(KPParams P) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= P.Nq * P.K) return;
+  const int64_t n = t / P.K;
+  const int k = (int)(t % P.K);
+  const float g = P.g_min_d2[t];
+  const float* o = P.offsets + t * 3;
+  const float kx = P.kp[k * 3] + o[0], ky = P.kp[k * 3 + 1] + o[1], kz = P.kp[k * 3 + 2] + o[2];
+  const float qx = P.q[n * 3], qy = P.q[n * 3 + 1], qz = P.q[n * 3 + 2];
+  float best = INFINITY, bx = 0.f, by = 0.f, bz = 0.f;
+  for (int h = 0; h < P.H; ++h) {
+    int j = load_idx<IDX64>(P.idx, n * P.H + h, P.Ns);
+    float sx = 1e6f, sy = 1e6f, sz = 1e6f;
+    if (j >= 0) {
+      sx = P.s[(int64_t)j * 3];
+      sy = P.s[(int64_t)j * 3 + 1];
+      sz = P.s[(int64_t)j * 3 + 2];
+    }
+    float dx = (sx - qx) - kx, dy = (sy - qy) - ky, dz = (sz - qz) - kz;
+    float d2 = dx * dx + dy * dy + dz * dz;
+    if (d2 < best) {
+      best = d2;
+      bx = dx;
+      by = dy;
+      bz = dz;
+    }
+  }
+  atomicAdd(P.d_offsets + t * 3 + 0, -2.f * bx * g);
+  atomicAdd(P.d_offsets + t * 3 + 1, -2.f * by * g);
+  atomicAdd(P.d_offsets + t * 3 + 2, -2.f * bz * g);
+}
+
+template <int LPP, int NCH>
+int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
+  constexpr int PPW = 64 / LPP;
+  dim3 grid((unsigned)cdiv64(P.Nq, PPW)), block(64);
+  if (idx64)
+    hipLaunchKernelGGL((kpconv_gather_vec<LPP, NCH, true>), grid, block, 0, st, P);
+  else
+    hipLaunchKernelGGL((kpconv_gather_vec<LPP, NCH, false>), grid, block, 0, st, P);
+  return 0;
+}
+
+template <int MODE, bool DEFORM>
+int launch_lane_channel(const KPParams& P, int idx64, hipStream_t st) {
+  dim3 grid((unsigned)P.Nq), block(64);
+  for (int c0 = 0; c0 < P.Cin; c0 += 512) {
+    int cw = P.Cin - c0 < 512 ? P.Cin - c0 : 512;
+    int ns = (cw + 63) / 64;
+#define LC(NS)                                                                                       \
+  if (idx64)                                                                                         \
+    hipLaunchKernelGGL((kpconv_lane_channel<NS, true, MODE, DEFORM>), grid, block, 0, st, P, c0);    \
+  else                                                                                               \
+    hipLaunchKernelGGL((kpconv_lane_channel<NS, false, MODE, DEFORM>), grid, block, 0, st, P, c0);
+    if (DEFORM && MODE == 1) {
+      // register budget: S[NSLOT][45] -> keep slots small, more launches
+      for (int cc = c0; cc < c0 + cw; cc += 64) {
+        KPParams Q = P;
+        if (idx64)
+          hipLaunchKernelGGL((kpconv_lane_channel<1, true, MODE, DEFORM>), grid, block, 0, st, Q, cc);
+        else
+          hipLaunchKernelGGL((kpconv_lane_channel<1, false, MODE, DEFORM>), grid, block, 0, st, Q, cc);
+      }
+    } else if (ns <= 1) {
+      LC(1)
+    } else if (ns <= 2) {
+      LC(2)
+    } else if (ns <= 4) {
+      LC(4)
+    } else {
+      LC(8)
+    }
+#undef LC
+  }
+  return 0;
+}
+
+int check_common(int64_t Nq, int64_t Ns, int H, int Cin, int K, int influence, int aggregation) {
+  MVK_REQUIRE(Nq >= 0 && Ns >= 0 && H >= 0 && Cin > 0, "kpconv: bad sizes Nq=%lld Ns=%lld H=%d Cin=%d",
+              (long long)Nq, (long long)Ns, H, Cin);
+  MVK_REQUIRE(K >= 1 && K < KMAX, "kpconv: kernel size K=%d unsupported (1..%d)", K, KMAX - 1);
+  MVK_REQUIRE(influence >= 0 && influence <= 2, "Unknown influence function type (config.KP_influence)");
+  MVK_REQUIRE(aggregation == 0 || aggregation == 1, "Unknown convolution mode. Should be 'closest' or 'sum'");
+  MVK_REQUIRE(Nq < (1ll << 31), "kpconv: Nq too large for one launch");
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                                     const void* idx, int idx64, int H, const float* x, int Cin,
+                                     const float* kp, int K, float extent, int influence,
+                                     int aggregation, const float* offsets, float* min_d2,
+                                     float* A_out, void* stream) {
+  if (int e = check_common(Nq, Ns, H, Cin, K, influence, aggregation)) return e;
+  if (Nq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  KPParams P{};
+  P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets; P.min_d2 = min_d2;
+  P.A = A_out; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
+  P.influence = influence; P.aggregation = aggregation;
+  if (H == 0) {
+    MVK_CHECK_HIP(hipMemsetAsync(A_out, 0, sizeof(float) * Nq * K * Cin, st));
+    if (offsets == nullptr) return 0;
+  }
+  if (offsets != nullptr) {
+    launch_lane_channel<0, true>(P, idx64, st);
+  } else if (Cin % 4 == 0 && Cin <= 512 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)A_out % 16 == 0)) {
+    int c4 = Cin / 4;
+    if (c4 <= 1) launch_vec<1, 1>(P, idx64, st);
+    else if (c4 <= 2) launch_vec<2, 1>(P, idx64, st);
+    else if (c4 <= 4) launch_vec<4, 1>(P, idx64, st);
+    else if (c4 <= 8) launch_vec<8, 1>(P, idx64, st);
+    else if (c4 <= 16) launch_vec<16, 1>(P, idx64, st);
+    else if (c4 <= 32) launch_vec<32, 1>(P, idx64, st);
+    else if (c4 <= 64) launch_vec<64, 1>(P, idx64, st);
+    else launch_vec<64, 2>(P, idx64, st);
+  } else {
+    launch_lane_channel<0, false>(P, idx64, st);
+  }
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                                      const void* idx, int idx64, int H, int Cin, const float* kp,
+                                      int K, float extent, int influence, int aggregation,
+                                      const float* dA, float* dx, const float* x,
+                                      const float* offsets, const float* g_min_d2,
+                                      float* d_offsets, void* stream) {
+  if (int e = check_common(Nq, Ns, H, Cin, K, influence, aggregation)) return e;
+  if (Nq == 0 || H == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  KPParams P{};
+  P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets;
+  P.A = const_cast<float*>(dA); P.dx = dx; P.g_min_d2 = g_min_d2; P.d_offsets = d_offsets;
+  P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
+  P.influence = influence; P.aggregation = aggregation;
+  if (offsets != nullptr) {
+    MVK_REQUIRE(x != nullptr && d_offsets != nullptr, "kpconv bwd: deformable needs x and d_offsets");
+    MVK_REQUIRE(aggregation == MVK_AGG_SUM, "kpconv bwd: deformable + 'closest' aggregation has no offset gradient path");
+    launch_lane_channel<1, true>(P, idx64, st);
+    if (g_min_d2 != nullptr) {
+      int64_t tot = Nq * K;
+      if (idx64)
+        hipLaunchKernelGGL((kpconv_min_d2_bwd<true>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, P);
+      else
+        hipLaunchKernelGGL((kpconv_min_d2_bwd<false>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, P);
+    }
+  } else {
+    launch_lane_channel<1, false>(P, idx64, st);
+  }
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,113 @@
+// Row gathers of the KPConv blocks: max_pool / closest_pool (reference
+// KPConv-PyTorch/models/blocks.py:35-66 gather, :79-91 closest_pool, :94-110 max_pool)
+// fused so that the [N2,H,D] gathered tensor is never materialised.
+// One lane per (row n, channel c), c fastest => coalesced row reads and writes.
+#include "common.h"
+
+namespace {
+
+template <bool IDX64>
+__global__ void max_pool_fwd_k(const float* __restrict__ x, int64_t Ns, int C, const void* idx,
+                               int64_t Nq, int H, float* __restrict__ out, int32_t* __restrict__ arg) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Nq * C) return;
+  const int64_t n = t / C;
+  const int c = (int)(t % C);
+  float best = -INFINITY;
+  int bh = 0;
+  for (int h = 0; h < H; ++h) {
+    const int j = load_idx<IDX64>(idx, n * H + h, Ns);
+    const float v = j >= 0 ? x[(int64_t)j * C + c] : 0.f;  // zero shadow row takes part (blocks.py:103)
+    if (v > best) {
+      best = v;
+      bh = h;
+    }
+  }
+  out[t] = H > 0 ? best : 0.f;
+  if (arg) arg[t] = bh;
+}
+
+template <bool IDX64>
+__global__ void max_pool_bwd_k(const float* __restrict__ g, const int32_t* __restrict__ arg,
+                               const void* idx, int64_t Nq, int H, int64_t Ns, int C,
+                               float* __restrict__ dx) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Nq * C) return;
+  const int64_t n = t / C;
+  const int c = (int)(t % C);
+  const int j = load_idx<IDX64>(idx, n * H + arg[t], Ns);
+  if (j >= 0) atomicAdd(dx + (int64_t)j * C + c, g[t]);
+}
+
+template <bool IDX64>
+__global__ void gather_rows_fwd_k(const float* __restrict__ x, int64_t Ns, int C, const void* idx,
+                                  int64_t Nq, int64_t stride, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Nq * C) return;
+  const int64_t n = t / C;
+  const int c = (int)(t % C);
+  const int j = load_idx<IDX64>(idx, n * stride, Ns);
+  out[t] = j >= 0 ? x[(int64_t)j * C + c] : 0.f;
+}
+
+template <bool IDX64>
+__global__ void gather_rows_bwd_k(const float* __restrict__ g, const void* idx, int64_t Nq,
+                                  int64_t stride, int64_t Ns, int C, float* __restrict__ dx) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Nq * C) return;
+  const int64_t n = t / C;
+  const int c = (int)(t % C);
+  const int j = load_idx<IDX64>(idx, n * stride, Ns);
+  if (j >= 0) atomicAdd(dx + (int64_t)j * C + c, g[t]);
+}
+
+inline dim3 grid1d(int64_t total) { return dim3((unsigned)cdiv64(total, 256)); }
+
+}  // namespace
+
+#define DISPATCH_IDX(kern, ...)                                                   \
+  if (idx64)                                                                      \
+    hipLaunchKernelGGL((kern<true>), grid1d(total), dim3(256), 0, st, __VA_ARGS__); \
+  else                                                                            \
+    hipLaunchKernelGGL((kern<false>), grid1d(total), dim3(256), 0, st, __VA_ARGS__)
+
+extern "C" int mvk_max_pool_fwd(const float* x, int64_t Ns, int C, const void* idx, int idx64,
+                                int64_t Nq, int H, float* out, int32_t* arg, void* stream) {
+  MVK_REQUIRE(C > 0 && Nq >= 0 && H >= 0, "max_pool: bad sizes");
+  const int64_t total = Nq * C;
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_IDX(max_pool_fwd_k, x, Ns, C, idx, Nq, H, out, arg);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_max_pool_bwd(const float* g, const int32_t* arg, const void* idx, int idx64,
+                                int64_t Nq, int H, int64_t Ns, int C, float* dx, void* stream) {
+  const int64_t total = Nq * C;
+  if (total == 0 || H == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_IDX(max_pool_bwd_k, g, arg, idx, Nq, H, Ns, C, dx);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_gather_rows_fwd(const float* x, int64_t Ns, int C, const void* idx, int idx64,
+                                   int64_t Nq, int64_t idx_stride, float* out, void* stream) {
+  const int64_t total = Nq * C;
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_IDX(gather_rows_fwd_k, x, Ns, C, idx, Nq, idx_stride, out);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_gather_rows_bwd(const float* g, const void* idx, int idx64, int64_t Nq,
+                                   int64_t idx_stride, int64_t Ns, int C, float* dx, void* stream) {
+  const int64_t total = Nq * C;
+  if (total == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_IDX(gather_rows_bwd_k, g, idx, Nq, idx_stride, Ns, C, dx);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,152 @@
+/* mvkpconv.h -- C ABI of the MI355X-native MV-KPConv hot path (libmvkpconv.so).
+ *
+ * Drop-in boundary. Every entry point takes plain
+ * pointers and sizes; all data pointers are DEVICE pointers (HBM) unless the
+ * parameter name ends in _host. `stream` is a hipStream_t passed as void*
+ * (NULL = the default stream). Functions only enqueue work unless documented
+ * as synchronising. Return value: 0 on success, negative on error
+ * (mvk_last_error() holds the message; Python maps it to RuntimeError with the
+ * reference's message strings where the reference defines one).
+ *
+ * Reference interfaces replaced (paths relative to /root/reference/):
+ *   mvk_grid_subsample_*      KPConv-PyTorch/cpp_wrappers/cpp_subsampling/wrapper.cpp:62-333 (subsample_batch),
+ *                             :338-566 (subsample) -> grid_subsampling/grid_subsampling.cpp:5-211
+ *   mvk_radius_neighbors_*    KPConv-PyTorch/cpp_wrappers/cpp_neighbors/wrapper.cpp:58-238 (batch_query)
+ *                             -> neighbors/neighbors.cpp:211-332
+ *   mvk_kpconv_*              KPConv-PyTorch/models/blocks.py:237-374 (KPConv.forward) and its autograd backward
+ *   mvk_max_pool_*, mvk_gather_rows_*  KPConv-PyTorch/models/blocks.py:35-66,79-110
+ *   mvk_group_points_*        mvpnet/ops/cuda/group_points.cpp:16-19 (group_points_forward/backward),
+ *                             mvpnet/ops/cuda/group_points_kernel.cu:25-145
+ *   mvk_knn_f64               KPConv-PyTorch/datasets/ScanNet_sphere_color.py:448-451 (sklearn ball_tree k-NN)
+ *   mvk_unproject_depth       KPConv-PyTorch/datasets/ScanNet_sphere_color.py:66-72,409-417
+ */
+#ifndef MVKPCONV_H
+#define MVKPCONV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MVK_ABI_VERSION 1
+
+/* influence / aggregation codes (blocks.py:329-354) */
+#define MVK_INFL_CONSTANT 0
+#define MVK_INFL_LINEAR 1
+#define MVK_INFL_GAUSSIAN 2
+#define MVK_AGG_SUM 0
+#define MVK_AGG_CLOSEST 1
+
+int mvk_abi_version(void);
+const char* mvk_last_error(void);
+
+/* ---------------- KPConv: gather + correlation + aggregation ------------- */
+
+/* A[n,k,c] = sum_h w[n,h,k] * x+[idx[n,h], c]        
+ *   q [Nq,3] f32, s [Ns,3] f32, idx [Nq,H] int32 or int64 (idx64 != 0), values in [0,Ns]
+ *   (Ns = shadow neighbour), x [Ns,Cin] f32, kp [K,3] f32 (K <= 16).
+ *   offsets: NULL (rigid) or [Nq,K,3] f32 = deformed kernel point displacements already scaled
+ *   by KP_extent (blocks.py:266,287); when non-NULL neighbours out of range of every deformed
+ *   kernel point are dropped (blocks.py:300-325) and min_d2 [Nq,K] (may be NULL) receives
+ *   min_h d2 (blocks.py:303).
+ *   A_out [Nq,K,Cin] f32. */
+int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                          const void* idx, int idx64, int H, const float* x, int Cin,
+                          const float* kp, int K, float extent, int influence, int aggregation,
+                          const float* offsets, float* min_d2, float* A_out, void* stream);
+
+/* dx[idx[n,h], c] += sum_k w[n,h,k] * dA[n,k,c]   (shadow rows discarded).
+ * dx [Ns,Cin] must be zero-initialised by the caller (accumulated with f32 atomics).
+ * Deformable extras (all NULL for rigid):
+ *   x, offsets as in the forward; d_offsets [Nq,K,3] receives
+ *   sum_h <x+[idx[n,h]], dA[n,k,:]> * dw/d(offset)  plus the min_d2 path g_min_d2 [Nq,K] (may be NULL). */
+int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                           const void* idx, int idx64, int H, int Cin,
+                           const float* kp, int K, float extent, int influence, int aggregation,
+                           const float* dA, float* dx,
+                           const float* x, const float* offsets, const float* g_min_d2,
+                           float* d_offsets, void* stream);
+
+/* ---------------- fp32 MFMA GEMM (the K x Cin x Cout contraction) -------- */
+
+/* C[M,N] (+)= op(A)[M,Kd] @ op(B)[Kd,N], fp32 in / fp32 accumulate on v_mfma_f32_32x32x2_f32.
+ *   transA == 0: A is [M,Kd] row-major (lda = Kd);  transA != 0: A is stored [Kd,M] (lda = M).
+ *   transB == 0: B is [Kd,N] row-major (ldb = N);   transB != 0: B is stored [N,Kd] (ldb = Kd).
+ *   accumulate != 0: C += (C must be initialised); split_k > 1 partitions Kd over workgroups and
+ *   accumulates with f32 atomics (C must then be zero- or value-initialised by the caller and
+ *   accumulate is implied).
+ *   KPConv uses: y = A @ W (NN), dA = g @ W^T (NT), dW = A^T @ g (TN, split over points). */
+int mvk_gemm_f32(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd,
+                 int transA, int transB, int accumulate, int split_k, void* stream);
+
+/* ---------------- row gathers of blocks.py ------------------------------- */
+
+/* out[n,:] = max_h x+[idx[n,h],:]  (zero shadow row participates, blocks.py:94-110);
+ * arg [Nq,C] int32 (may be NULL) receives the winning h for the backward. */
+int mvk_max_pool_fwd(const float* x, int64_t Ns, int C, const void* idx, int idx64, int64_t Nq,
+                     int H, float* out, int32_t* arg, void* stream);
+/* dx[idx[n,arg[n,c]], c] += g[n,c] (dx zero-initialised by the caller). */
+int mvk_max_pool_bwd(const float* g, const int32_t* arg, const void* idx, int idx64, int64_t Nq,
+                     int H, int64_t Ns, int C, float* dx, void* stream);
+/* out[n,:] = x+[idx[n*stride],:]  (closest_pool = first column, blocks.py:79-91). */
+int mvk_gather_rows_fwd(const float* x, int64_t Ns, int C, const void* idx, int idx64, int64_t Nq,
+                        int64_t idx_stride, float* out, void* stream);
+int mvk_gather_rows_bwd(const float* g, const void* idx, int idx64, int64_t Nq, int64_t idx_stride,
+                        int64_t Ns, int C, float* dx, void* stream);
+
+/* ---------------- input pyramid ------------------------------------------ */
+
+/* Scratch size in bytes needed by mvk_grid_subsample_batch for N points in B clouds. */
+int64_t mvk_grid_subsample_workspace(int64_t N, int B);
+
+/* Voxel-grid barycentre subsampling of a stacked batch, bit-identical (values and ORDER) to the
+ * reference. pts [N,3] f32, lens_host [B] int32 (HOST), optional feats [N,fdim]
+ * f32. Outputs (device): out_pts [N,3] (capacity N rows), out_feats [N,fdim] or NULL,
+ * out_lens [B] int32. The per-cloud counts are also copied to out_lens_host [B] (HOST) --
+ * this call SYNCHRONISES the stream once to return them. max_p as in the reference (0 = no cap).
+ * Integer labels (majority vote) are only on the scene-loading path and stay on the CPU. */
+int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32_t* lens_host, int B,
+                             const float* feats, int fdim, float dl, int max_p,
+                             float* out_pts, float* out_feats, int32_t* out_lens,
+                             int32_t* out_lens_host, void* workspace, int64_t workspace_bytes,
+                             void* stream);
+
+int64_t mvk_radius_neighbors_workspace(int64_t Nq, int64_t Ns, int B);
+
+/* Fixed-radius neighbours of a stacked batch: out [Nq,width] int32, row = indices (into the stacked
+ * support array) of all supports of the same cloud with float32 d2 < r*r, ascending d2 (ties:
+ * ascending index), padded with Ns.
+ *   Phase 1 (out == NULL): counts every row, returns max count in *width_host (SYNCHRONISES).
+ *   Phase 2 (out != NULL): fills out [Nq,width] keeping the `width` nearest of every row
+ *   (width may be smaller than the max count = the reference's neighborhood_limits crop,
+ *   datasets/common.py:411-421). q_lens_host / s_lens_host are HOST arrays. */
+int mvk_radius_neighbors_batch(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                               const int32_t* q_lens_host, const int32_t* s_lens_host, int B,
+                               float radius, int32_t* out, int width, int* width_host,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------- 2D -> 3D fusion ----------------------------------------- */
+
+/* depth (nv,h,w) uint16 millimetres, cam_inv [3,3] f64 (inverse intrinsics), poses [nv,4,4] f32
+ * -> xyz (nv,h,w,3) f64 world coordinates, valid (nv,h,w) uint8 (camera-frame z > 0). */
+int mvk_unproject_depth(const uint16_t* depth, int nv, int h, int w, const double* cam_inv,
+                        const float* poses, double* xyz, uint8_t* valid, void* stream);
+
+/* Exact brute-force k-NN in float64 (LDS-tiled): queries [nq,3] f32 (promoted to f64 like
+ * sklearn does), keys [nk,3] f64 with key_valid [nk] uint8 (NULL = all valid);
+ * out_idx [nq,k] int64 = key indices ascending by distance (ties: ascending index), k <= 8. */
+int mvk_knn_f64(const float* queries, int64_t nq, const double* keys, const uint8_t* key_valid,
+                int64_t nk, int k, int64_t* out_idx, void* stream);
+
+/* group_points forward: points [B,C,N1] f32, index [B,N2,K] int64 -> out [B,C,N2,K]. */
+int mvk_group_points_fwd(const float* points, const int64_t* index, int B, int C, int64_t N1,
+                         int64_t N2, int K, float* out, void* stream);
+/* backward: grad_in [B,C,N1] (zero-initialised by the caller) += scatter of grad_out. */
+int mvk_group_points_bwd(const float* grad_out, const int64_t* index, int B, int C, int64_t N1,
+                         int64_t N2, int K, float* grad_in, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MVKPCONV_H */

@@ -31,7 +31,8 @@ _SIGNATURES = {
     "mvk_radius_neighbors_batch": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _vp,
                                              _vp, _i64, _vp]),
     "mvk_unproject_depth": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
-    "mvk_knn_f64": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i, _vp, _vp]),
+    "mvk_knn_workspace": (C.c_int64, [_i64, _i64, _i]),
+    "mvk_knn_f64": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),
     "mvk_group_points_fwd": (C.c_int, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
     "mvk_group_points_bwd": (C.c_int, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
 }

@@ -19,9 +19,9 @@ SOURCES = [
     ("kpconv.hip", []),
     ("gemm.hip", []),
     ("pool.hip", []),
-    # ("subsample.hip", ["-ffp-contract=off"]),
-    # ("neighbors.hip", ["-ffp-contract=off"]),
-    # ("fusion.hip", ["-ffp-contract=off"]),
+    ("subsample.hip", ["-ffp-contract=off"]),
+    ("neighbors.hip", ["-ffp-contract=off"]),
+    ("fusion.hip", ["-ffp-contract=off"]),
 ]
 
 
@@ -41,7 +41,7 @@ def _stale(target, deps):
 
 def build_library(force=False, verbose=False):
     hipcc = _hipcc()
-    common = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "mvkpconv.h"),
+    common = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "blockscan.h"), os.path.join(HERE, "..", "include", "mvkpconv.h"),
               os.path.join(HERE, "..", "include", "mvk_prime_list.h"), os.path.abspath(__file__)]
     objs = []
     for src, extra in SOURCES:

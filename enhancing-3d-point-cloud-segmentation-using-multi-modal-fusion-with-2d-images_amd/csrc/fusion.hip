@@ -1,0 +1,259 @@
+// Multi-view 2D -> 3D fusion inputs on gfx950:
+//   * depth back-projection   (reference KPConv-PyTorch/datasets/ScanNet_sphere_color.py:66-72, :409-417)
+//   * exact k-NN of sphere points among the unprojected pixels, float64, brute force with the keys
+//     tiled through LDS (reference: scikit-learn NearestNeighbors(ball_tree), :448-451)
+//   * group_points gather / scatter-add (reference mvpnet/ops/cuda/group_points_kernel.cu:25-145)
+// Compiled with -ffp-contract=off: the float64 products and sums are evaluated exactly in the
+// written order, like the NumPy / scikit-learn code they replace.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// xyz_cam = (Kinv . [u, v, 1]) * depth ;  valid = z_cam > 0 ;  xyz_world = xyz_cam . R^T + t
+// ---------------------------------------------------------------------------------------------
+struct Cam {
+  double kinv[9];
+};
+
+__global__ void unproject_kernel(const uint16_t* __restrict__ depth, int nv, int h, int w, Cam cam,
+                                 const float* __restrict__ poses, double* __restrict__ xyz,
+                                 uint8_t* __restrict__ valid) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t hw = (int64_t)h * w;
+  if (t >= nv * hw) return;
+  const int view = (int)(t / hw);
+  const int pix = (int)(t % hw);
+  const double u = (double)(pix % w), v = (double)(pix / w);
+  // depth: uint16 mm -> float32 / 1000.f (ScanNet_sphere_color.py:410), then promoted to float64
+  const double d = (double)((float)depth[t] / 1000.f);
+  double c[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) c[r] = ((cam.kinv[r * 3] * u + cam.kinv[r * 3 + 1] * v) + cam.kinv[r * 3 + 2]) * d;
+  valid[t] = c[2] > 0.0;
+  const float* P = poses + view * 16;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+    xyz[t * 3 + r] = ((c[0] * (double)P[r * 4] + c[1] * (double)P[r * 4 + 1]) + c[2] * (double)P[r * 4 + 2]) +
+                     (double)P[r * 4 + 3];
+}
+
+// ---------------------------------------------------------------------------------------------
+// brute-force k-NN, float64. One lane = one query; a 256-lane workgroup stages 256 keys at a time
+// in LDS (coalesced loads, broadcast reads); top-k kept sorted in registers (k <= 8).
+// Keys are split into `nsplit` contiguous ranges (grid.y) so that small query sets still fill the
+// chip; a merge kernel combines the per-split candidates.
+// ---------------------------------------------------------------------------------------------
+constexpr int KNN_T = 256;
+constexpr int KMAXNN = 8;
+
+template <int K>
+__device__ __forceinline__ void topk_insert(double (&bd)[K], int64_t (&bi)[K], double d2, int64_t j) {
+  if (d2 < bd[K - 1] || (d2 == bd[K - 1] && j < bi[K - 1])) {
+    bd[K - 1] = d2;
+    bi[K - 1] = j;
+#pragma unroll
+    for (int p = K - 1; p > 0; --p) {
+      if (bd[p] < bd[p - 1] || (bd[p] == bd[p - 1] && bi[p] < bi[p - 1])) {
+        double td = bd[p]; bd[p] = bd[p - 1]; bd[p - 1] = td;
+        int64_t ti = bi[p]; bi[p] = bi[p - 1]; bi[p - 1] = ti;
+      }
+    }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(KNN_T) void knn_partial_kernel(const float* __restrict__ q, int64_t nq,
+                                                            const double* __restrict__ keys,
+                                                            const uint8_t* __restrict__ kvalid,
+                                                            int64_t nk, int64_t per_split,
+                                                            double* __restrict__ pd,
+                                                            int64_t* __restrict__ pi) {
+  __shared__ double kx[KNN_T], ky[KNN_T], kz[KNN_T];
+  __shared__ int kok[KNN_T];
+  const int64_t i = (int64_t)blockIdx.x * KNN_T + threadIdx.x;
+  const int64_t kbeg = (int64_t)blockIdx.y * per_split, kend = min(nk, kbeg + per_split);
+  double qx = 0, qy = 0, qz = 0;
+  if (i < nq) {
+    qx = (double)q[i * 3];
+    qy = (double)q[i * 3 + 1];
+    qz = (double)q[i * 3 + 2];
+  }
+  double bd[K];
+  int64_t bi[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    bd[c] = INFINITY;
+    bi[c] = INT64_MAX;
+  }
+  for (int64_t k0 = kbeg; k0 < kend; k0 += KNN_T) {
+    const int64_t j = k0 + threadIdx.x;
+    if (j < kend) {
+      kx[threadIdx.x] = keys[j * 3];
+      ky[threadIdx.x] = keys[j * 3 + 1];
+      kz[threadIdx.x] = keys[j * 3 + 2];
+      kok[threadIdx.x] = kvalid ? (int)kvalid[j] : 1;
+    } else {
+      kok[threadIdx.x] = 0;
+    }
+    __syncthreads();
+    const int cnt = (int)min((int64_t)KNN_T, kend - k0);
+    for (int t = 0; t < cnt; ++t) {
+      if (!kok[t]) continue;  // uniform across the workgroup
+      const double dx = qx - kx[t], dy = qy - ky[t], dz = qz - kz[t];
+      double d2 = 0.0;
+      d2 += dx * dx;
+      d2 += dy * dy;
+      d2 += dz * dz;
+      topk_insert<K>(bd, bi, d2, k0 + t);
+    }
+    __syncthreads();
+  }
+  if (i < nq) {
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      pd[((int64_t)blockIdx.y * nq + i) * K + c] = bd[c];
+      pi[((int64_t)blockIdx.y * nq + i) * K + c] = bi[c];
+    }
+  }
+}
+
+template <int K>
+__global__ void knn_merge_kernel(const double* __restrict__ pd, const int64_t* __restrict__ pi, int nsplit,
+                                 int64_t nq, int kout, int64_t* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nq) return;
+  double bd[K];
+  int64_t bi[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    bd[c] = INFINITY;
+    bi[c] = INT64_MAX;
+  }
+  for (int s = 0; s < nsplit; ++s)
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      const double d = pd[((int64_t)s * nq + i) * K + c];
+      const int64_t j = pi[((int64_t)s * nq + i) * K + c];
+      if (j != INT64_MAX) topk_insert<K>(bd, bi, d, j);
+    }
+#pragma unroll
+  for (int c = 0; c < K; ++c)
+    if (c < kout) out[i * kout + c] = bi[c] == INT64_MAX ? -1 : bi[c];
+}
+
+// ---------------------------------------------------------------------------------------------
+// group_points: out[b,c,n,k] = in[b,c,idx[b,n,k]]; one lane per output element, (n,k) fastest so
+// index reads and output writes are coalesced; the gather itself is element granular by nature
+// (channel-major feature maps), served by L2 / Infinity Cache.
+// ---------------------------------------------------------------------------------------------
+__global__ void group_points_fwd_kernel(const float* __restrict__ in, const int64_t* __restrict__ idx, int B,
+                                        int C, int64_t N1, int64_t NK, float* __restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)B * C * NK) return;
+  const int64_t e = t % NK;
+  const int64_t bc = t / NK;
+  const int64_t b = bc / C;
+  const int64_t j = idx[b * NK + e];
+  out[t] = (j >= 0 && j < N1) ? in[bc * N1 + j] : 0.f;
+}
+
+__global__ void group_points_bwd_kernel(const float* __restrict__ go, const int64_t* __restrict__ idx, int B,
+                                        int C, int64_t N1, int64_t NK, float* __restrict__ gi) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)B * C * NK) return;
+  const int64_t e = t % NK;
+  const int64_t bc = t / NK;
+  const int64_t b = bc / C;
+  const int64_t j = idx[b * NK + e];
+  if (j >= 0 && j < N1) atomicAdd(gi + bc * N1 + j, go[t]);  // group_points_kernel.cu:85-87
+}
+
+}  // namespace
+
+extern "C" int mvk_unproject_depth(const uint16_t* depth, int nv, int h, int w, const double* cam_inv,
+                                   const float* poses, double* xyz, uint8_t* valid, void* stream) {
+  MVK_REQUIRE(nv >= 0 && h > 0 && w > 0, "unproject: bad sizes");
+  if (nv == 0) return 0;
+  Cam cam;
+  for (int i = 0; i < 9; ++i) cam.kinv[i] = cam_inv[i];  // HOST pointer: 9 doubles
+  const int64_t tot = (int64_t)nv * h * w;
+  hipLaunchKernelGGL(unproject_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream, depth,
+                     nv, h, w, cam, poses, xyz, valid);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+namespace {
+// key splits: enough (query block x key range) workgroups to give every CU ~4 of them
+void knn_plan(int64_t nq, int64_t nk, int* nsplit_out, int64_t* per_split_out) {
+  const int64_t qblocks = cdiv64(nq > 0 ? nq : 1, KNN_T);
+  const int64_t keys = nk > 0 ? nk : 1;
+  int64_t nsplit = cdiv64(1024, qblocks);
+  const int64_t max_split = cdiv64(keys, 4 * KNN_T);
+  if (nsplit > max_split) nsplit = max_split;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > 64) nsplit = 64;
+  const int64_t per_split = cdiv64(cdiv64(keys, nsplit), KNN_T) * KNN_T;
+  *nsplit_out = (int)cdiv64(keys, per_split);
+  *per_split_out = per_split;
+}
+}  // namespace
+
+extern "C" int64_t mvk_knn_workspace(int64_t nq, int64_t nk, int k) {
+  int nsplit;
+  int64_t per;
+  knn_plan(nq, nk, &nsplit, &per);
+  return (int64_t)nsplit * (nq > 0 ? nq : 1) * (k <= 3 ? 3 : 8) * 16 + 64;
+}
+
+extern "C" int mvk_knn_f64(const float* queries, int64_t nq, const double* keys, const uint8_t* key_valid,
+                           int64_t nk, int k, int64_t* out_idx, void* workspace, int64_t workspace_bytes,
+                           void* stream) {
+  MVK_REQUIRE(k >= 1 && k <= KMAXNN, "knn: k=%d unsupported (1..%d)", k, KMAXNN);
+  MVK_REQUIRE(nq >= 0 && nk >= 0, "knn: bad sizes");
+  if (nq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  int nsplit;
+  int64_t per_split;
+  knn_plan(nq, nk, &nsplit, &per_split);
+  const int KK = k <= 3 ? 3 : 8;
+  MVK_REQUIRE(workspace && workspace_bytes >= mvk_knn_workspace(nq, nk, k), "knn: workspace too small");
+  double* pd = (double*)workspace;
+  int64_t* pi = (int64_t*)((char*)workspace + (int64_t)nsplit * nq * KK * 8);
+  dim3 grid((unsigned)cdiv64(nq, KNN_T), (unsigned)nsplit);
+  if (KK == 3) {
+    hipLaunchKernelGGL((knn_partial_kernel<3>), grid, dim3(KNN_T), 0, st, queries, nq, keys, key_valid, nk,
+                       per_split, pd, pi);
+    hipLaunchKernelGGL((knn_merge_kernel<3>), dim3((unsigned)cdiv64(nq, 256)), dim3(256), 0, st, pd, pi, nsplit,
+                       nq, k, out_idx);
+  } else {
+    hipLaunchKernelGGL((knn_partial_kernel<8>), grid, dim3(KNN_T), 0, st, queries, nq, keys, key_valid, nk,
+                       per_split, pd, pi);
+    hipLaunchKernelGGL((knn_merge_kernel<8>), dim3((unsigned)cdiv64(nq, 256)), dim3(256), 0, st, pd, pi, nsplit,
+                       nq, k, out_idx);
+  }
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_group_points_fwd(const float* points, const int64_t* index, int B, int C, int64_t N1,
+                                    int64_t N2, int K, float* out, void* stream) {
+  MVK_REQUIRE(B >= 0 && C >= 0 && N1 >= 0 && N2 >= 0 && K >= 0, "group_points: bad sizes");
+  const int64_t tot = (int64_t)B * C * N2 * K;
+  if (tot == 0) return 0;
+  hipLaunchKernelGGL(group_points_fwd_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
+                     points, index, B, C, N1, N2 * K, out);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_group_points_bwd(const float* grad_out, const int64_t* index, int B, int C, int64_t N1,
+                                    int64_t N2, int K, float* grad_in, void* stream) {
+  const int64_t tot = (int64_t)B * C * N2 * K;
+  if (tot == 0) return 0;
+  hipLaunchKernelGGL(group_points_bwd_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
+                     grad_out, index, B, C, N1, N2 * K, grad_in);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}

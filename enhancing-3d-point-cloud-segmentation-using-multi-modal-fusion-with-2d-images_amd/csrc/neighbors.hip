@@ -1,0 +1,316 @@
+// Fixed-radius neighbour search on gfx950 with the reference's result contract
+// (KPConv-PyTorch/cpp_wrappers/cpp_neighbors/neighbors/neighbors.cpp:211-332 + nanoflann
+// radiusSearch): for every query, all supports OF THE SAME CLOUD with float32
+//   d2 = ((dx*dx) + dy*dy) + dz*dz < radius*radius          (nanoflann.hpp:433-441, :249-251)
+// sorted by ascending d2 (ties: ascending index), indices into the stacked support array,
+// rows padded with Ns. Compiled with -ffp-contract=off so d2 is bit-identical to x86-64.
+//
+// The KD-tree is an implementation detail of the reference; here:
+//   build  (one 1024-thread workgroup per cloud): support bounding box -> uniform grid with
+//          cell >= 1.001 r (cells grow if the box would need too many) -> counting sort of the
+//          supports by x-fastest linear cell id (histogram atomics, block scan, scatter of
+//          {x,y,z,index} records). Rows of 3 x-adjacent cells are contiguous in that order.
+//   query  (one wavefront per query): the 27-cell neighbourhood = 9 contiguous record ranges;
+//          lanes stride over the flattened candidates (16-byte coalesced record loads), test
+//          d2 < r2, wave-ballot compaction into an LDS list, rank-by-counting sort in LDS,
+//          coalesced row write + padding.
+// Phase 1 (count) and phase 2 (fill) of the C ABI run the same candidate scan.
+#include "common.h"
+#include "blockscan.h"
+
+namespace {
+
+constexpr int LIST_CAP = 1024;  // in-range neighbours per query held in LDS (8 KB / wave)
+
+struct CloudGrid {
+  float gmin[3];
+  float cell;
+  int dims[3];
+  int cell_base;  // offset of this cloud's cell_start array
+};
+
+struct NbWs {
+  CloudGrid* grids;   // B
+  int* cell_start;    // sum_b (cap_b + 1)
+  int* cell_fill;     // same size
+  float4* recs;       // Ns records sorted by cell
+  int* qoffs;         // B + 1
+  int* soffs;         // B + 1
+  int* counts;        // Nq
+  int* maxcount;      // 1
+  int* overflow;      // 1
+};
+
+__host__ __device__ inline int64_t cell_cap(int64_t ns) { return 4 * ns + 4096; }
+
+__global__ __launch_bounds__(TPB) void nb_build_kernel(const float* __restrict__ s, NbWs W, float radius) {
+  __shared__ float red[6][TPB / 64];
+  __shared__ CloudGrid G;
+  __shared__ int sh[TPB / 64 + 2];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int off = W.soffs[b], n = W.soffs[b + 1] - off;
+  int64_t base = 0;
+  for (int i = 0; i < b; ++i) base += cell_cap(W.soffs[i + 1] - W.soffs[i]) + 1;
+  const float* P = s + (int64_t)off * 3;
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = tid; i < n; i += TPB)
+    for (int c = 0; c < 3; ++c) {
+      float v = P[i * 3 + c];
+      mn[c] = fminf(mn[c], v);
+      mx[c] = fmaxf(mx[c], v);
+    }
+  for (int c = 0; c < 3; ++c) {
+    float a = mn[c], z = mx[c];
+    for (int o = 32; o >= 1; o >>= 1) {
+      a = fminf(a, __shfl_xor(a, o));
+      z = fmaxf(z, __shfl_xor(z, o));
+    }
+    if (lane == 0) {
+      red[c][wv] = a;
+      red[3 + c][wv] = z;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float lo[3], hi[3];
+    for (int c = 0; c < 3; ++c) {
+      lo[c] = red[c][0];
+      hi[c] = red[3 + c][0];
+      for (int i = 1; i < TPB / 64; ++i) {
+        lo[c] = fminf(lo[c], red[c][i]);
+        hi[c] = fmaxf(hi[c], red[3 + c][i]);
+      }
+      if (n == 0) lo[c] = hi[c] = 0.f;
+    }
+    // cell slightly larger than r: a pair closer than r can then never be two cells apart,
+    // whatever the rounding of (p - gmin) / cell (candidate filter only; the test is exact)
+    float cell = radius * 1.001f;
+    if (!(cell > 0.f)) cell = 1e-6f;
+    const int64_t cap = cell_cap(n);
+    int d[3];
+    while (true) {
+      int64_t prod = 1;
+      bool ok = true;
+      for (int c = 0; c < 3; ++c) {
+        float e = floorf((hi[c] - lo[c]) / cell);
+        if (!(e < 2.0e6f)) ok = false;
+        d[c] = ok ? (int)e + 1 : 1;
+        prod *= d[c];
+        if (prod > cap) ok = false;
+      }
+      if (ok) break;
+      cell *= 1.3f;
+    }
+    for (int c = 0; c < 3; ++c) {
+      G.gmin[c] = lo[c];
+      G.dims[c] = d[c];
+    }
+    G.cell = cell;
+    G.cell_base = (int)base;
+    W.grids[b] = G;
+  }
+  __syncthreads();
+  const int ncell = G.dims[0] * G.dims[1] * G.dims[2];
+  int* cstart = W.cell_start + base;
+  int* cfill = W.cell_fill + base;
+  for (int i = tid; i <= ncell; i += TPB) {
+    cstart[i] = 0;
+    cfill[i] = 0;
+  }
+  __syncthreads();
+  const float gx = G.gmin[0], gy = G.gmin[1], gz = G.gmin[2], cell = G.cell;
+  const int dx = G.dims[0], dy = G.dims[1];
+  for (int i = tid; i < n; i += TPB) {
+    int cx = (int)floorf((P[i * 3] - gx) / cell), cy = (int)floorf((P[i * 3 + 1] - gy) / cell),
+        cz = (int)floorf((P[i * 3 + 2] - gz) / cell);
+    atomicAdd(&cstart[(cz * dy + cy) * dx + cx], 1);
+  }
+  __syncthreads();
+  block_scan_array(cstart, ncell + 1, sh, false);  // cstart[c] = first record of cell c; [ncell] = n
+  for (int i = tid; i < n; i += TPB) {
+    const float x = P[i * 3], y = P[i * 3 + 1], z = P[i * 3 + 2];
+    int cx = (int)floorf((x - gx) / cell), cy = (int)floorf((y - gy) / cell), cz = (int)floorf((z - gz) / cell);
+    const int c = (cz * dy + cy) * dx + cx;
+    const int pos = cstart[c] + atomicAdd(&cfill[c], 1);
+    W.recs[off + pos] = make_float4(x, y, z, __int_as_float(off + i));  // stacked support index
+  }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(64) void nb_query_kernel(const float* __restrict__ q, NbWs W, int B,
+                                                      float radius, int64_t Ns, int* __restrict__ out,
+                                                      int width) {
+  __shared__ float ld2[FILL ? LIST_CAP : 1];
+  __shared__ int lidx[FILL ? LIST_CAP : 1];
+  const int64_t i = blockIdx.x;
+  const int lane = threadIdx.x;
+  int b = 0;
+  while (b + 1 < B && i >= W.qoffs[b + 1]) ++b;
+  const CloudGrid G = W.grids[b];
+  const int soff = W.soffs[b];
+  const int* cstart = W.cell_start + G.cell_base;
+  const float qx = q[i * 3], qy = q[i * 3 + 1], qz = q[i * 3 + 2];
+  const float r2 = radius * radius;  // neighbors.cpp:226
+  // query cell (may lie outside the support grid)
+  const float fx = floorf((qx - G.gmin[0]) / G.cell), fy = floorf((qy - G.gmin[1]) / G.cell),
+              fz = floorf((qz - G.gmin[2]) / G.cell);
+  int rs = 0, re = 0;  // record range of row `lane` (9 rows: dy,dz in -1..1)
+  if (lane < 9 && fabsf(fx) < 4.0e6f && fabsf(fy) < 4.0e6f && fabsf(fz) < 4.0e6f) {
+    const int cx = (int)fx, cy = (int)fy + (lane % 3) - 1, cz = (int)fz + (lane / 3) - 1;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.dims[0] - 1);
+    if (cy >= 0 && cy < G.dims[1] && cz >= 0 && cz < G.dims[2] && x0 <= x1) {
+      const int row = (cz * G.dims[1] + cy) * G.dims[0];
+      rs = cstart[row + x0];
+      re = cstart[row + x1 + 1];
+    }
+  }
+  // inclusive scan of row lengths over lanes 0..8
+  int len = re - rs, pre = len;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    int y = __shfl_up(pre, o);
+    if (lane >= o) pre += y;
+  }
+  const int total = __shfl(pre, 8);
+  int n = 0;  // in-range count (wave-uniform)
+  for (int c0 = 0; c0 < total; c0 += 64) {
+    const int c = c0 + lane;
+    bool hit = false;
+    float d2 = 0.f;
+    int idx = 0;
+    // locate the row of candidate c (shuffles stay outside divergent control flow)
+    int rec = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int pend = __shfl(pre, r), plen = __shfl(len, r), pstart = __shfl(rs, r);
+      if (c < pend && c >= pend - plen) rec = pstart + (c - (pend - plen));
+    }
+    if (c < total) {
+      const float4 p = W.recs[soff + rec];
+      const float ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
+      d2 = 0.0f;
+      d2 += ddx * ddx;
+      d2 += ddy * ddy;
+      d2 += ddz * ddz;
+      hit = d2 < r2;  // nanoflann.hpp:249-251
+      idx = __float_as_int(p.w);
+    }
+    const unsigned long long m = __ballot(hit);
+    if (FILL && hit) {
+      const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
+      if (pos < LIST_CAP) {
+        ld2[pos] = d2;
+        lidx[pos] = idx;
+      }
+    }
+    n += __popcll(m);
+  }
+  if (!FILL) {
+    if (lane == 0) {
+      W.counts[i] = n;
+      atomicMax(W.maxcount, n);
+    }
+    return;
+  }
+  if (n > LIST_CAP) {
+    if (lane == 0) atomicExch(W.overflow, 1);
+    n = LIST_CAP;
+  }
+  __syncthreads();
+  // rank-by-counting sort on (d2, idx)
+  for (int e = lane; e < n; e += 64) {
+    const float d = ld2[e];
+    const int id = lidx[e];
+    int rank = 0;
+    for (int u = 0; u < n; ++u) {
+      const float du = ld2[u];
+      const int iu = lidx[u];
+      rank += (du < d) || (du == d && iu < id);
+    }
+    if (rank < width) out[i * width + rank] = id;
+  }
+  for (int c = n + lane; c < width; c += 64) out[i * width + c] = (int)Ns;  // neighbors.cpp:324
+}
+
+struct Carver {
+  char* p;
+  template <typename T>
+  T* take(int64_t count) {
+    uintptr_t a = ((uintptr_t)p + 15) & ~(uintptr_t)15;
+    p = (char*)a + sizeof(T) * count;
+    return (T*)a;
+  }
+};
+
+int64_t ws_bytes(int64_t Nq, int64_t Ns, int B) {
+  int64_t cells = cell_cap(Ns) + (int64_t)B * (4096 + 1 + 4);
+  return (int64_t)B * sizeof(CloudGrid) + 2 * cells * 4 + (Ns + 1) * 16 + 2 * (int64_t)(B + 1) * 4 +
+         (Nq + 1) * 4 + 64 + 16 * 12;
+}
+
+}  // namespace
+
+extern "C" int64_t mvk_radius_neighbors_workspace(int64_t Nq, int64_t Ns, int B) { return ws_bytes(Nq, Ns, B); }
+
+extern "C" int mvk_radius_neighbors_batch(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                                          const int32_t* q_lens_host, const int32_t* s_lens_host,
+                                          int B, float radius, int32_t* out, int width,
+                                          int* width_host, void* workspace, int64_t workspace_bytes,
+                                          void* stream) {
+  MVK_REQUIRE(B >= 1 && Nq >= 0 && Ns >= 0 && Nq < (1ll << 31) && Ns < (1ll << 29), "neighbors: bad sizes");
+  MVK_REQUIRE(radius > 0.f, "neighbors: radius must be positive");
+  MVK_REQUIRE(workspace && workspace_bytes >= ws_bytes(Nq, Ns, B), "neighbors: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  static thread_local int offs_h[2 * 4097];
+  MVK_REQUIRE(B <= 4096, "neighbors: more than 4096 clouds in a batch");
+  int64_t tq = 0, ts = 0;
+  for (int b = 0; b < B; ++b) {
+    MVK_REQUIRE(q_lens_host[b] >= 0 && s_lens_host[b] >= 0, "neighbors: negative batch length");
+    offs_h[b] = (int)tq;
+    offs_h[B + 1 + b] = (int)ts;
+    tq += q_lens_host[b];
+    ts += s_lens_host[b];
+  }
+  offs_h[B] = (int)tq;
+  offs_h[2 * B + 1] = (int)ts;
+  MVK_REQUIRE(tq == Nq && ts == Ns, "neighbors: batch lengths do not sum to the point counts");
+
+  Carver cv{(char*)workspace};
+  NbWs W;
+  int64_t cells = cell_cap(Ns) + (int64_t)B * (4096 + 1 + 4);
+  W.grids = cv.take<CloudGrid>(B);
+  W.cell_start = cv.take<int>(cells);
+  W.cell_fill = cv.take<int>(cells);
+  W.recs = cv.take<float4>(Ns + 1);
+  W.qoffs = cv.take<int>(B + 1);
+  W.soffs = cv.take<int>(B + 1);
+  W.counts = cv.take<int>(Nq + 1);
+  W.maxcount = cv.take<int>(1);
+  W.overflow = cv.take<int>(1);
+  MVK_REQUIRE(cv.p <= (char*)workspace + workspace_bytes, "neighbors: workspace carve overflow");
+
+  MVK_CHECK_HIP(hipMemcpyAsync(W.qoffs, offs_h, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
+  MVK_CHECK_HIP(hipMemcpyAsync(W.soffs, offs_h + B + 1, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
+  MVK_CHECK_HIP(hipMemsetAsync(W.maxcount, 0, sizeof(int), st));
+  MVK_CHECK_HIP(hipMemsetAsync(W.overflow, 0, sizeof(int), st));
+  hipLaunchKernelGGL(nb_build_kernel, dim3(B), dim3(TPB), 0, st, s, W, radius);
+  if (out == nullptr) {
+    MVK_REQUIRE(width_host != nullptr, "neighbors: phase 1 needs width_host");
+    if (Nq > 0)
+      hipLaunchKernelGGL((nb_query_kernel<false>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns,
+                         (int*)nullptr, 0);
+    MVK_CHECK_HIP(hipGetLastError());
+    MVK_CHECK_HIP(hipMemcpyAsync(width_host, W.maxcount, sizeof(int), hipMemcpyDeviceToHost, st));
+    MVK_CHECK_HIP(hipStreamSynchronize(st));
+    return 0;
+  }
+  MVK_REQUIRE(width >= 0, "neighbors: negative width");
+  if (Nq > 0 && width > 0)
+    hipLaunchKernelGGL((nb_query_kernel<true>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width);
+  MVK_CHECK_HIP(hipGetLastError());
+  int ovf = 0;
+  MVK_CHECK_HIP(hipMemcpyAsync(&ovf, W.overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+  MVK_CHECK_HIP(hipStreamSynchronize(st));
+  MVK_REQUIRE(ovf == 0, "neighbors: a query has more than %d in-range supports (LDS list capacity)", LIST_CAP);
+  return 0;
+}

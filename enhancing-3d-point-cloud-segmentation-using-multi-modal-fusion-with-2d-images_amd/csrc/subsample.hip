@@ -1,0 +1,399 @@
+// Voxel-grid barycentre subsampling on gfx950, bit-identical (values AND output order) to the
+// reference CPU extension (KPConv-PyTorch/cpp_wrappers/cpp_subsampling/grid_subsampling/
+// grid_subsampling.cpp:5-211, grid_subsampling.h:10-80, cpp_utils/cloud/cloud.cpp:27-67).
+//
+// Compiled with -ffp-contract=off: the reference is x86-64 without FMA, and its float32
+// arithmetic (true division, floor, sequential in-order sums) is reproduced exactly.
+//
+// One 1024-thread workgroup per cloud runs every phase of that cloud back to back (phases are
+// separated by __syncthreads(); all scratch lives in an HBM workspace that stays L2 resident):
+//   P1  min / max corner, origin, grid dims                         (cloud.cpp:27-67, :25-31)
+//   P2  voxel key per point (:53-56) -> open-addressing hash table insert (64-bit CAS);
+//       first[slot] = min point index (= first occurrence of the voxel)
+//   P3  flag first occurrences, block scan -> voxel id in FIRST-OCCURRENCE order, which is the
+//       insertion order of the reference's unordered_map (:59-60)
+//   P4-6 member counts, segment offsets (scan), scatter of point indices into segments
+//   P7  one lane per voxel: sort its members by point index (segments are tiny) and accumulate
+//       the float32 sums sequentially in input order (grid_subsampling.h:74-79); barycentre =
+//       sum * (float)(1.0/count) (:87), feature mean = fsum / (float)count (:90-94)
+//   P8  emulate libstdc++'s unordered_map<size_t,...> iteration order: one
+//       "epoch" per bucket-count of the growth schedule 13, 29, 59, 127, ... ; in each epoch the
+//       new list position of every element is
+//           #elements in buckets first touched later  +  #same-bucket elements processed later
+//       computed with atomics + a block scan, no sequential list walk
+//   P9  write barycentres in that order to the cloud's staging rows
+// A second tiny kernel compacts the clouds (prefix over B) and applies max_p.
+#include "common.h"
+#include "blockscan.h"
+#include "../../include/mvk_prime_list.h"
+
+namespace {
+
+constexpr unsigned long long EMPTY_KEY = ~0ull;
+
+struct SubWs {
+  // per point (N)
+  int* slot;      // hash slot of the point's voxel
+  int* member;    // point indices grouped by voxel
+  int* scan;      // scratch for scans / flags
+  // hash table (4N)
+  unsigned long long* hkey;
+  int* hfirst;
+  int* hvox;
+  // per voxel (N)
+  unsigned long long* vkey;
+  int* vcount;
+  int* vseg;
+  int* vcursor;
+  float* vbary;   // 3N
+  float* vfeat;   // N*fdim
+  int* tau;
+  int* posnew;
+  int* nextb;
+  int* tarr;
+  // per bucket (3N + 32B)
+  int* ft;
+  int* bcnt;
+  int* bhead;
+  // per cloud
+  int* out_count;  // B
+  // staging (N rows)
+  float* stage_pts;
+  float* stage_feat;
+};
+
+// Bucket-count schedule of libstdc++'s unordered_map (13, 29, 59, 127, ...): nb[e+1] =
+// next_bkt(2 * nb[e]); identical for every cloud, computed once on the host.
+struct Schedule {
+  unsigned long long nb[48];
+};
+
+__device__ __forceinline__ unsigned int hash64(unsigned long long k) {
+  k ^= k >> 33;
+  k *= 0xff51afd7ed558ccdull;
+  k ^= k >> 33;
+  return (unsigned int)k;
+}
+
+__global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __restrict__ pts,
+                                                               const float* __restrict__ feats,
+                                                               int fdim, const int* __restrict__ offs,
+                                                               float dl, SubWs W, int B,
+                                                               Schedule sched) {
+  __shared__ float red[6][TPB / 64];
+  __shared__ float corner[8];  // org xyz, NX, NY as bits
+  __shared__ unsigned long long dims[2];
+  __shared__ int sh[TPB / 64 + 2];
+  const int b = blockIdx.x;
+  const int off = offs[b], n = offs[b + 1] - off;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (n == 0) {
+    if (tid == 0) W.out_count[b] = 0;
+    return;
+  }
+  const float* P = pts + (int64_t)off * 3;
+
+  // ---- P1: min / max
+  float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+  for (int i = tid; i < n; i += TPB)
+    for (int c = 0; c < 3; ++c) {
+      float v = P[i * 3 + c];
+      mn[c] = fminf(mn[c], v);
+      mx[c] = fmaxf(mx[c], v);
+    }
+  for (int c = 0; c < 3; ++c) {
+    float a = mn[c], z = mx[c];
+    for (int o = 32; o >= 1; o >>= 1) {
+      a = fminf(a, __shfl_xor(a, o));
+      z = fmaxf(z, __shfl_xor(z, o));
+    }
+    if (lane == 0) {
+      red[c][wv] = a;
+      red[3 + c][wv] = z;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float inv = 1 / dl;  // grid_subsampling.cpp:27
+    float o3[3], m3[3];
+    for (int c = 0; c < 3; ++c) {
+      float a = red[c][0], z = red[3 + c][0];
+      for (int i = 1; i < TPB / 64; ++i) {
+        a = fminf(a, red[c][i]);
+        z = fmaxf(z, red[3 + c][i]);
+      }
+      o3[c] = floorf(a * inv) * dl;
+      m3[c] = z;
+      corner[c] = o3[c];
+    }
+    dims[0] = (unsigned long long)floorf((m3[0] - o3[0]) / dl) + 1;  // :30
+    dims[1] = (unsigned long long)floorf((m3[1] - o3[1]) / dl) + 1;  // :31
+  }
+  __syncthreads();
+  const float ox = corner[0], oy = corner[1], oz = corner[2];
+  const unsigned long long NX = dims[0], NY = dims[1];
+
+  // ---- P2: hash insert
+  unsigned int T = 2;
+  while (T < 2u * (unsigned)n) T <<= 1;
+  unsigned long long* hkey = W.hkey + (int64_t)off * 4;
+  int* hfirst = W.hfirst + (int64_t)off * 4;
+  int* hvox = W.hvox + (int64_t)off * 4;
+  for (unsigned int i = tid; i < T; i += TPB) {
+    hkey[i] = EMPTY_KEY;
+    hfirst[i] = 0x7fffffff;
+  }
+  __syncthreads();
+  int* slot = W.slot + off;
+  for (int i = tid; i < n; i += TPB) {
+    unsigned long long iX = (unsigned long long)floorf((P[i * 3] - ox) / dl);      // :53
+    unsigned long long iY = (unsigned long long)floorf((P[i * 3 + 1] - oy) / dl);  // :54
+    unsigned long long iZ = (unsigned long long)floorf((P[i * 3 + 2] - oz) / dl);  // :55
+    unsigned long long key = iX + NX * iY + NX * NY * iZ;                          // :56
+    unsigned int h = hash64(key) & (T - 1);
+    while (true) {
+      unsigned long long prev = atomicCAS(&hkey[h], EMPTY_KEY, key);
+      if (prev == EMPTY_KEY || prev == key) break;
+      h = (h + 1) & (T - 1);
+    }
+    slot[i] = (int)h;
+    atomicMin(&hfirst[h], i);
+  }
+  __syncthreads();
+
+  // ---- P3: first-occurrence flags -> voxel ids in insertion order
+  int* scan = W.scan + off;
+  for (int i = tid; i < n; i += TPB) scan[i] = (ld_agent(&hfirst[slot[i]]) == i) ? 1 : 0;
+  __syncthreads();
+  const int M = block_scan_array(scan, n, sh, false);
+  unsigned long long* vkey = W.vkey + off;
+  int* vcount = W.vcount + off;
+  int* vseg = W.vseg + off;
+  int* vcursor = W.vcursor + off;
+  for (int i = tid; i < n; i += TPB) {
+    const int s = slot[i];
+    if (ld_agent(&hfirst[s]) == i) {
+      hvox[s] = scan[i];
+      vkey[scan[i]] = ld_agent(&hkey[s]);
+    }
+  }
+  for (int v = tid; v < M; v += TPB) {
+    vcount[v] = 0;
+    vcursor[v] = 0;
+  }
+  __syncthreads();
+  // ---- P4: counts
+  for (int i = tid; i < n; i += TPB) atomicAdd(&vcount[hvox[slot[i]]], 1);
+  __syncthreads();
+  // ---- P5: segment offsets
+  for (int v = tid; v < M; v += TPB) vseg[v] = ld_agent(&vcount[v]);
+  __syncthreads();
+  block_scan_array(vseg, M, sh, false);
+  // ---- P6: scatter members
+  int* member = W.member + off;
+  for (int i = tid; i < n; i += TPB) {
+    const int v = hvox[slot[i]];
+    member[vseg[v] + atomicAdd(&vcursor[v], 1)] = i;
+  }
+  __syncthreads();
+  // ---- P7: ordered sums
+  float* vbary = W.vbary + (int64_t)off * 3;
+  float* vfeat = fdim > 0 ? W.vfeat + (int64_t)off * fdim : nullptr;
+  const float* F = fdim > 0 ? feats + (int64_t)off * fdim : nullptr;
+  for (int v = tid; v < M; v += TPB) {
+    int* m = member + vseg[v];
+    const int c = ld_agent(&vcount[v]);
+    for (int a = 1; a < c; ++a) {  // insertion sort by point index
+      int key = m[a], z = a - 1;
+      while (z >= 0 && m[z] > key) {
+        m[z + 1] = m[z];
+        --z;
+      }
+      m[z + 1] = key;
+    }
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    for (int a = 0; a < c; ++a) {
+      const float* p = P + (int64_t)m[a] * 3;
+      sx += p[0];
+      sy += p[1];
+      sz += p[2];
+    }
+    const float r = (float)(1.0 / (double)c);  // :87, cloud.h:120
+    vbary[v * 3] = sx * r;
+    vbary[v * 3 + 1] = sy * r;
+    vbary[v * 3 + 2] = sz * r;
+    if (fdim > 0) {
+      const float cf = (float)c;
+      for (int d = 0; d < fdim; ++d) {
+        float s = 0.f;
+        for (int a = 0; a < c; ++a) s += F[(int64_t)m[a] * fdim + d];
+        vfeat[(int64_t)v * fdim + d] = s / cf;  // :90-94
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- P8: unordered_map iteration order
+  int* tau = W.tau + off;
+  int* posnew = W.posnew + off;
+  int* nextb = W.nextb + off;
+  int* tarr = W.tarr + off;
+  int* ft = W.ft + (int64_t)off * 3 + 32 * b;
+  int* bcnt = W.bcnt + (int64_t)off * 3 + 32 * b;
+  int* bhead = W.bhead + (int64_t)off * 3 + 32 * b;
+  int epoch = 0;
+  unsigned long long nb = sched.nb[0];
+  int start = 0;
+  while (start < M) {
+    const int end = (unsigned long long)M < nb ? M : (int)nb;  // elements [0,end) live in this epoch
+    for (int v = start + tid; v < end; v += TPB) tau[v] = v;   // new elements: processed in insertion order
+    for (unsigned long long i = tid; i < nb; i += TPB) {
+      ft[i] = 0x7fffffff;
+      bcnt[i] = 0;
+      bhead[i] = -1;
+    }
+    for (int t = tid; t < end; t += TPB) tarr[t] = 0;
+    __syncthreads();
+    for (int v = tid; v < end; v += TPB) {
+      const int bk = (int)(vkey[v] % nb);
+      atomicMin(&ft[bk], tau[v]);
+      atomicAdd(&bcnt[bk], 1);
+      nextb[v] = atomicExch(&bhead[bk], v);
+    }
+    __syncthreads();
+    for (int v = tid; v < end; v += TPB) {
+      const int bk = (int)(vkey[v] % nb);
+      if (ld_agent(&ft[bk]) == tau[v]) tarr[tau[v]] = ld_agent(&bcnt[bk]);
+    }
+    __syncthreads();
+    block_scan_array(tarr, end, sh, true);  // tarr[t] = #elements in buckets first touched after t
+    for (int v = tid; v < end; v += TPB) {
+      const int bk = (int)(vkey[v] % nb);
+      const int tv = tau[v];
+      int later = 0;
+      for (int u = ld_agent(&bhead[bk]); u >= 0; u = nextb[u]) later += (tau[u] > tv);
+      posnew[v] = tarr[ld_agent(&ft[bk])] + later;
+    }
+    __syncthreads();
+    for (int v = tid; v < end; v += TPB) tau[v] = posnew[v];
+    __syncthreads();
+    start = end;
+    nb = sched.nb[++epoch];
+  }
+  // ---- P9: staging rows in iteration order
+  float* sp = W.stage_pts + (int64_t)off * 3;
+  float* sf = fdim > 0 ? W.stage_feat + (int64_t)off * fdim : nullptr;
+  for (int v = tid; v < M; v += TPB) {
+    const int o = tau[v];
+    sp[o * 3] = vbary[v * 3];
+    sp[o * 3 + 1] = vbary[v * 3 + 1];
+    sp[o * 3 + 2] = vbary[v * 3 + 2];
+    for (int d = 0; d < fdim; ++d) sf[(int64_t)o * fdim + d] = vfeat[(int64_t)v * fdim + d];
+  }
+  if (tid == 0) W.out_count[b] = M;
+}
+
+// Compacts the per-cloud staging rows into the stacked output and applies max_p
+// (grid_subsampling.cpp:181-204).
+__global__ void subsample_compact_kernel(const int* __restrict__ offs, SubWs W, int B, int fdim,
+                                         int max_p, float* __restrict__ out_pts,
+                                         float* __restrict__ out_feats, int* __restrict__ out_lens) {
+  const int b = blockIdx.y;
+  int base = 0;
+  for (int i = 0; i < b; ++i) base += min(W.out_count[i], max_p);
+  const int m = min(W.out_count[b], max_p);
+  if (blockIdx.x == 0 && threadIdx.x == 0) out_lens[b] = m;
+  const int off = offs[b];
+  for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < m; o += gridDim.x * blockDim.x) {
+    for (int c = 0; c < 3; ++c) out_pts[(int64_t)(base + o) * 3 + c] = W.stage_pts[(int64_t)(off + o) * 3 + c];
+    for (int d = 0; d < fdim; ++d)
+      out_feats[(int64_t)(base + o) * fdim + d] = W.stage_feat[(int64_t)(off + o) * fdim + d];
+  }
+}
+
+struct Carver {
+  char* p;
+  char* end;
+  template <typename T>
+  T* take(int64_t count) {
+    uintptr_t a = ((uintptr_t)p + 15) & ~(uintptr_t)15;
+    T* r = (T*)a;
+    p = (char*)a + sizeof(T) * count;
+    return r;
+  }
+};
+
+int64_t ws_bytes(int64_t N, int B, int fdim) {
+  int64_t n = N > 0 ? N : 1;
+  int64_t bytes = 0;
+  bytes += 3 * n * 4;                       // slot member scan
+  bytes += 4 * n * (8 + 4 + 4);             // hash
+  bytes += n * (8 + 4 * 3 + 12 + 4 * 4);    // vkey vcount vseg vcursor vbary tau posnew nextb tarr
+  bytes += n * (int64_t)fdim * 4 * 2;       // vfeat + stage_feat
+  bytes += 3 * (3 * n + 32 * (int64_t)B) * 4;  // ft bcnt bhead
+  bytes += (int64_t)(B + 1) * 4 * 2;        // out_count, offs
+  bytes += n * 12;                          // stage_pts
+  return bytes + 64 * 32;
+}
+
+}  // namespace
+
+extern "C" int64_t mvk_grid_subsample_workspace(int64_t N, int B) { return ws_bytes(N, B, 16); }
+
+extern "C" int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32_t* lens_host, int B,
+                                        const float* feats, int fdim, float dl, int max_p,
+                                        float* out_pts, float* out_feats, int32_t* out_lens,
+                                        int32_t* out_lens_host, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+  MVK_REQUIRE(B >= 1 && N >= 0 && N < (1ll << 29), "subsample: bad sizes N=%lld B=%d", (long long)N, B);
+  MVK_REQUIRE(dl > 0.f, "subsample: sampleDl must be positive");
+  MVK_REQUIRE(fdim >= 0 && (fdim == 0 || (feats && out_feats)), "subsample: features pointer missing");
+  MVK_REQUIRE(workspace != nullptr && workspace_bytes >= ws_bytes(N, B, fdim),
+              "subsample: workspace too small (%lld < %lld)", (long long)workspace_bytes,
+              (long long)ws_bytes(N, B, fdim));
+  hipStream_t st = (hipStream_t)stream;
+  int64_t tot = 0;
+  int* offs_h = (int*)alloca(sizeof(int) * (B + 1));
+  for (int b = 0; b < B; ++b) {
+    MVK_REQUIRE(lens_host[b] >= 0, "subsample: negative batch length");
+    offs_h[b] = (int)tot;
+    tot += lens_host[b];
+  }
+  offs_h[B] = (int)tot;
+  MVK_REQUIRE(tot == N, "subsample: batch lengths sum to %lld, not N=%lld", (long long)tot, (long long)N);
+  if (max_p < 1) max_p = (int)(N > 0 ? N : 1);  // grid_subsampling.cpp:134-135
+
+  const int64_t n = N > 0 ? N : 1;
+  Carver cv{(char*)workspace, (char*)workspace + workspace_bytes};
+  SubWs W;
+  W.slot = cv.take<int>(n); W.member = cv.take<int>(n); W.scan = cv.take<int>(n);
+  W.hkey = cv.take<unsigned long long>(4 * n); W.hfirst = cv.take<int>(4 * n); W.hvox = cv.take<int>(4 * n);
+  W.vkey = cv.take<unsigned long long>(n); W.vcount = cv.take<int>(n); W.vseg = cv.take<int>(n);
+  W.vcursor = cv.take<int>(n); W.vbary = cv.take<float>(3 * n);
+  W.vfeat = cv.take<float>(n * (fdim > 0 ? fdim : 0) + 1);
+  W.tau = cv.take<int>(n); W.posnew = cv.take<int>(n); W.nextb = cv.take<int>(n); W.tarr = cv.take<int>(n);
+  W.ft = cv.take<int>(3 * n + 32 * B); W.bcnt = cv.take<int>(3 * n + 32 * B); W.bhead = cv.take<int>(3 * n + 32 * B);
+  W.out_count = cv.take<int>(B + 1);
+  int* offs_d = cv.take<int>(B + 1);
+  W.stage_pts = cv.take<float>(3 * n);
+  W.stage_feat = cv.take<float>(n * (fdim > 0 ? fdim : 0) + 1);
+  MVK_REQUIRE(cv.p <= cv.end, "subsample: workspace carve overflow");
+
+  // _Prime_rehash_policy::_M_need_rehash: first allocation 13 buckets, then
+  // next_bkt(max(count + 2, 2 * nb)) = next_bkt(2 * nb) each time count reaches nb.
+  Schedule sched;
+  sched.nb[0] = 13;
+  for (int e = 1; e < 48; ++e) sched.nb[e] = mvk_next_bkt(2 * sched.nb[e - 1]);
+  MVK_CHECK_HIP(hipMemcpyAsync(offs_d, offs_h, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(subsample_cloud_kernel, dim3(B), dim3(TPB), 0, st, pts, feats, fdim, offs_d, dl, W, B, sched);
+  int gx = (int)cdiv64(n, 256 * (int64_t)B);
+  if (gx < 1) gx = 1;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(subsample_compact_kernel, dim3(gx, B), dim3(256), 0, st, offs_d, W, B, fdim, max_p,
+                     out_pts, out_feats, out_lens);
+  MVK_CHECK_HIP(hipGetLastError());
+  if (out_lens_host)
+    MVK_CHECK_HIP(hipMemcpyAsync(out_lens_host, out_lens, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+  MVK_CHECK_HIP(hipStreamSynchronize(st));  // offs_h (stack) and out_lens_host must be settled on return
+  return 0;
+}

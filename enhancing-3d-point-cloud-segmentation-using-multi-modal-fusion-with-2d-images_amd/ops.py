@@ -221,3 +221,152 @@ def max_pool(x, inds):
 def closest_pool(x, inds):
     """blocks.py:79-91 (first column = closest neighbour because rows are sorted)."""
     return _GatherRowsFn.apply(x, inds)
+
+
+# --------------------------------------------------------------------------------------------
+# input pyramid: grid subsampling + radius neighbours (device resident)
+# --------------------------------------------------------------------------------------------
+
+import numpy as _np
+
+_WS = {}
+
+
+def _workspace(tag, nbytes, device):
+    """Grow-only HBM scratch per (tag, device); owned by the Python host layer, handed to the C ABI."""
+    key = (tag, device.index)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _lens_host(lens):
+    if isinstance(lens, torch.Tensor):
+        lens = lens.detach().cpu().numpy()
+    return _np.ascontiguousarray(lens, dtype=_np.int32)
+
+
+def grid_subsample_batch(points, lens, features=None, dl=0.1, max_p=0):
+    """Device version of cpp_subsampling.subsample_batch (wrapper.cpp:62-333), points / features only.
+
+    points [N,3] f32 (HBM), lens host int32 [B]. Returns (s_points [M,3] HBM, s_lens np.int32 [B][, s_features]).
+    Bit-identical to the reference incl. output order. Synchronises once (the counts come back to the host)."""
+    _dev(points, features)
+    points = _f32c(points)
+    lens_h = _lens_host(lens)
+    N, B = points.shape[0], int(lens_h.shape[0])
+    fdim = 0
+    if features is not None:
+        features = _f32c(features)
+        fdim = features.shape[1]
+    ws_bytes = lib().mvk_grid_subsample_workspace(N, B) + 8 * N * max(fdim - 16, 0)
+    ws = _workspace("sub", ws_bytes, points.device)
+    out_pts = torch.empty((max(N, 1), 3), device=points.device, dtype=torch.float32)
+    out_f = torch.empty((max(N, 1), fdim), device=points.device, dtype=torch.float32) if fdim else None
+    out_lens = torch.empty((B,), device=points.device, dtype=torch.int32)
+    out_lens_h = _np.empty((B,), _np.int32)
+    check(lib().mvk_grid_subsample_batch(_p(points), N, lens_h.ctypes.data_as(C.c_void_p), B, _p(features), fdim,
+                                         float(dl), int(max_p), _p(out_pts), _p(out_f), _p(out_lens),
+                                         out_lens_h.ctypes.data_as(C.c_void_p), _p(ws), ws.numel(), _stream()))
+    M = int(out_lens_h.sum())
+    res = [out_pts[:M], out_lens_h]
+    if fdim:
+        res.append(out_f[:M])
+    return tuple(res)
+
+
+def radius_neighbors_batch(queries, supports, q_lens, s_lens, radius, limit=None):
+    """Device version of cpp_neighbors.batch_query (wrapper.cpp:58-238): int32 [Nq, W] in HBM.
+
+    limit=None: W = the data-dependent max count (one extra counting pass + host sync, like the
+    reference's two-pass fill); limit=k: keep the k nearest per row (= big_neighborhood_filter,
+    datasets/common.py:411-421) without the counting pass."""
+    _dev(queries, supports)
+    q, s = _f32c(queries), _f32c(supports)
+    ql, sl = _lens_host(q_lens), _lens_host(s_lens)
+    if ql.shape[0] != sl.shape[0]:
+        raise RuntimeError("Wrong number of batch elements: different for queries and supports ")
+    Nq, Ns, B = q.shape[0], s.shape[0], int(ql.shape[0])
+    ws = _workspace("nb", lib().mvk_radius_neighbors_workspace(Nq, Ns, B), q.device)
+    args = (_p(q), Nq, _p(s), Ns, ql.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), B, float(radius))
+    if limit is None:
+        w = C.c_int(0)
+        check(lib().mvk_radius_neighbors_batch(*args, None, 0, C.byref(w), _p(ws), ws.numel(), _stream()))
+        width = int(w.value)
+    else:
+        width = int(limit)
+    out = torch.empty((Nq, width), device=q.device, dtype=torch.int32)
+    if width > 0 and Nq > 0:
+        check(lib().mvk_radius_neighbors_batch(*args, _p(out), width, None, _p(ws), ws.numel(), _stream()))
+    return out
+
+
+# --------------------------------------------------------------------------------------------
+# 2D -> 3D fusion
+# --------------------------------------------------------------------------------------------
+
+def unproject_depth(depth_mm, cam_matrix, poses):
+    """depth (nv,h,w) uint16/int16-compatible HBM tensor [mm], cam_matrix (>=3x3) float32 host array
+    (already rescaled to the image size), poses (nv,4,4) f32 HBM -> (xyz (nv,h,w,3) f64, valid (nv,h,w) bool).
+    ScanNet_sphere_color.py:66-72,409-417 (float64 because the pixel grid is int64 there)."""
+    _dev(depth_mm, poses)
+    nv, h, w = depth_mm.shape
+    d16 = depth_mm.to(torch.int16).contiguous() if depth_mm.dtype != torch.int16 else depth_mm.contiguous()
+    kinv = _np.linalg.inv(_np.asarray(cam_matrix, dtype=_np.float32)[:3, :3]).astype(_np.float64)  # :71 (f32 inverse)
+    kinv = _np.ascontiguousarray(kinv)
+    poses = _f32c(poses)
+    xyz = torch.empty((nv, h, w, 3), device=depth_mm.device, dtype=torch.float64)
+    valid = torch.empty((nv, h, w), device=depth_mm.device, dtype=torch.uint8)
+    check(lib().mvk_unproject_depth(_p(d16), nv, h, w, kinv.ctypes.data_as(C.c_void_p), _p(poses), _p(xyz),
+                                    _p(valid), _stream()))
+    return xyz, valid.bool()
+
+
+def knn_pixels(sphere_points, image_xyz, image_mask, k=3):
+    """Exact k-NN (float64) of sphere points among valid unprojected pixels -> flat pixel indices
+    view*h*w + row*w + col, int64 [ns,k] (ScanNet_sphere_color.py:436-451)."""
+    _dev(sphere_points, image_xyz, image_mask)
+    q = _f32c(sphere_points)
+    keys = image_xyz.reshape(-1, 3).to(torch.float64).contiguous()
+    valid = image_mask.reshape(-1).to(torch.uint8).contiguous()
+    nq, nk = q.shape[0], keys.shape[0]
+    ws = _workspace("knn", lib().mvk_knn_workspace(nq, nk, k), q.device)
+    out = torch.empty((nq, k), device=q.device, dtype=torch.int64)
+    check(lib().mvk_knn_f64(_p(q), nq, _p(keys), _p(valid), nk, int(k), _p(out), _p(ws), ws.numel(), _stream()))
+    return out
+
+
+class _GroupPointsFn(torch.autograd.Function):
+    """mvpnet/ops/group_points.py:5-17."""
+
+    @staticmethod
+    def forward(ctx, points, index):
+        _dev(points, index)
+        if index.dtype != torch.int64:
+            raise RuntimeError("group_points: index must be int64")
+        if points.dim() != 3 or index.dim() != 3 or points.shape[0] != index.shape[0]:
+            raise RuntimeError("group_points: expected points (B,C,N1) and index (B,N2,K)")
+        points, index = _f32c(points), index.contiguous()
+        B, Cc, N1 = points.shape
+        _, N2, K = index.shape
+        out = torch.empty((B, Cc, N2, K), device=points.device, dtype=torch.float32)
+        check(lib().mvk_group_points_fwd(_p(points), _p(index), B, Cc, N1, N2, K, _p(out), _stream()))
+        ctx.save_for_backward(index)
+        ctx.n1 = N1
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (index,) = ctx.saved_tensors
+        g = _f32c(grad_out)
+        B, Cc, N2, K = g.shape
+        gi = torch.zeros((B, Cc, ctx.n1), device=g.device, dtype=torch.float32)
+        check(lib().mvk_group_points_bwd(_p(g), _p(index), B, Cc, ctx.n1, N2, K, _p(gi), _stream()))
+        return gi, None
+
+
+def group_points(points, index):
+    """points (B,C,N1), index (B,N2,K) int64 -> (B,C,N2,K) (mvpnet/ops/group_points.py:20-31)."""
+    return _GroupPointsFn.apply(points, index)

@@ -128,16 +128,18 @@ int mvk_radius_neighbors_batch(const float* q, int64_t Nq, const float* s, int64
 
 /* ---------------- 2D -> 3D fusion ----------------------------------------- */
 
-/* depth (nv,h,w) uint16 millimetres, cam_inv [3,3] f64 (inverse intrinsics), poses [nv,4,4] f32
+/* depth (nv,h,w) uint16 millimetres, cam_inv_host [3,3] f64 (HOST; inverse intrinsics), poses [nv,4,4] f32
  * -> xyz (nv,h,w,3) f64 world coordinates, valid (nv,h,w) uint8 (camera-frame z > 0). */
-int mvk_unproject_depth(const uint16_t* depth, int nv, int h, int w, const double* cam_inv,
+int mvk_unproject_depth(const uint16_t* depth, int nv, int h, int w, const double* cam_inv_host,
                         const float* poses, double* xyz, uint8_t* valid, void* stream);
 
 /* Exact brute-force k-NN in float64 (LDS-tiled): queries [nq,3] f32 (promoted to f64 like
  * sklearn does), keys [nk,3] f64 with key_valid [nk] uint8 (NULL = all valid);
  * out_idx [nq,k] int64 = key indices ascending by distance (ties: ascending index), k <= 8. */
+int64_t mvk_knn_workspace(int64_t nq, int64_t nk, int k);
 int mvk_knn_f64(const float* queries, int64_t nq, const double* keys, const uint8_t* key_valid,
-                int64_t nk, int k, int64_t* out_idx, void* stream);
+                int64_t nk, int k, int64_t* out_idx, void* workspace, int64_t workspace_bytes,
+                void* stream);
 
 /* group_points forward: points [B,C,N1] f32, index [B,N2,K] int64 -> out [B,C,N2,K]. */
 int mvk_group_points_fwd(const float* points, const int64_t* index, int B, int C, int64_t N1,

@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Benchmark of the MV-KPConv hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic spheres whose RAW inputs are
+already resident in HBM: first subsampling at dl + 5-level pyramid (HIP), for the fusion variants
+2D encoder (PyTorch-ROCm) + depth unprojection + 3-NN + group_points + FeatureAggregation, KPFCNN
+forward, loss, backward, gradient all-reduce (N > 1), clip, SGD step -- the step sequence of the
+reference's trainer (utils/trainer.py:179-195) plus the input pyramid its DataLoader workers build.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload early|baseline|middle|late]
+                    [--spheres S] [--no-cpu-baseline]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU, RCCL): spheres are sharded data
+parallel (weak scaling: S spheres per GPU), gradients all-reduced in one flat bucket.
+Rank 0 prints ONE JSON line (see DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="early", choices=["early", "baseline", "middle", "late"])
+    ap.add_argument("--spheres", type=int, default=1, help="spheres per GPU per step")
+    ap.add_argument("--views", type=int, default=3)
+    ap.add_argument("--deformable", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-steps", type=int, default=1)
+    return ap.parse_args()
+
+
+class FlatAllReduce:
+    """Data-parallel gradient exchange: one flat fp32 bucket, RCCL all-reduce (sum) / world size.
+    (~97.5 MB for the baseline KPFCNN; xGMI ring time ~1 ms, far below the step.)"""
+
+    def __init__(self, params, world):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = world
+        self.flat = None
+
+    def __call__(self):
+        grads = [p.grad for p in self.params if p.grad is not None]
+        if not grads:
+            return
+        n = sum(g.numel() for g in grads)
+        if self.flat is None or self.flat.numel() != n:
+            self.flat = torch.empty(n, device=grads[0].device, dtype=torch.float32)
+        torch._foreach_copy_(list(self.flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
+        dist.all_reduce(self.flat)
+        self.flat.div_(self.world)
+        torch._foreach_copy_([g.reshape(-1) for g in grads], list(self.flat.split([g.numel() for g in grads])))
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import mvkpconv
+    syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
+    torch.manual_seed(1234)           # same initial weights on every rank
+    np.random.seed(1234)
+    cfg = syn.make_config(args.workload, deformable=args.deformable, modulated=args.deformable and args.workload == "late")
+    net = syn.build_model(cfg, dev)
+    net.train()
+    if hasattr(net, "net_2d"):
+        for m in net.net_2d._modules.values():   # frozen 2D encoder stays in eval mode (architectures_sphere.py:234-237)
+            m.train(False)
+    params = [p for p in net.parameters() if p.requires_grad]
+    deform = [p for n, p in net.named_parameters() if p.requires_grad and "offset" in n]
+    other = [p for n, p in net.named_parameters() if p.requires_grad and "offset" not in n]
+    opt = torch.optim.SGD([{"params": other}, {"params": deform, "lr": cfg.learning_rate * cfg.deform_lr_factor}],
+                          lr=cfg.learning_rate, momentum=cfg.momentum, weight_decay=cfg.weight_decay)  # trainer.py:72-79
+    reducer = FlatAllReduce(params, world) if world > 1 else None
+
+    # ---- synthetic raw inputs, staged in HBM once (data-parallel: different spheres per rank)
+    spheres = [syn.raw_sphere(seed=1000 * rank + i) for i in range(args.spheres)]
+    fusion = args.workload != "baseline"
+    views = [syn.sphere_views(s, nv=args.views) for s in spheres] if fusion else None
+    staged = syn.stage_spheres(spheres, dev, views)
+    limits = syn.calibrate_limits(cfg, staged)
+
+    def step():
+        batch, lens = syn.build_batch(cfg, staged, limits, torch.int32)
+        opt.zero_grad(set_to_none=True)
+        out = net(batch, cfg)
+        loss = net.loss(out, batch.labels)
+        loss.backward()
+        if reducer is not None:
+            reducer()
+        torch.nn.utils.clip_grad_value_(params, cfg.grad_clip_norm)     # trainer.py:193
+        opt.step()
+        return lens, loss
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        lens, loss = step()
+    ops.profile_reset(enabled=True)           # HIP events around every gather launch (current stream)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        lens, loss = step()
+    sync()
+    dt = time.perf_counter() - t0
+    ops.profile_reset_keep = None
+    recs = ops._PROF["rec"]
+    ops._PROF["on"] = False
+    # mean real-neighbour counts of every neighbour matrix of this (fixed) synthetic batch, computed
+    # outside the timed region: (Nq, Ns, H) -> H_eff
+    hb, _ = syn.build_batch(cfg, staged, limits, torch.int32)
+    h_eff = {}
+    for l in range(len(hb.points)):
+        ns = hb.points[l].shape[0]
+        for m in (hb.neighbors[l], hb.pools[l]):
+            if m.shape[0] > 0:
+                h_eff[(m.shape[0], ns, m.shape[1])] = float((m < ns).sum().item()) / m.shape[0]
+    ops._PROF["rec"] = recs
+    prof = ops.profile_collect(h_eff)
+    ops.profile_reset(enabled=False)
+
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    pts = torch.tensor([float(sum(lens))], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(pts, op=dist.ReduceOp.SUM)
+    dt = t.item()
+    total_points = pts.item() * args.steps
+
+    if rank == 0:
+        res = {
+            "metric": "input points/s through MV-KPConv KPFCNN forward+backward (pyramid + fusion + fwd + bwd + SGD)",
+            "value": total_points / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%s_fusion_kpfcnn5_sphere20k_x%d_per_gpu%s" % (
+                args.workload, args.spheres, "_deformable" if args.deformable else ""),
+                "points_per_step_per_gpu": int(sum(lens)), "views": args.views if fusion else 0,
+                "image_hw": [120, 160] if fusion else None, "parallelism": "dp%d" % world,
+                "final_loss": float(loss.item())},
+            "roofline": roofline(prof),
+        }
+        if not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, net, staged, limits, spheres, args)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def roofline(prof):
+    """Dominant KPConv gather launch class: achieved = algorithmic gathered bytes / average launch
+    duration (HIP events), against the HBM peak. Bytes per launch:
+        B_g = Nq*H_eff*(Cin*4 + 12 + 4) + Nq*12 + Nq*K*Cin*4."""
+    if not prof:
+        return None
+    best = max(prof.values(), key=lambda r: r["total_ms"])
+    avg_ms = best["total_ms"] / best["launches"]
+    achieved = best["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": best["kernel"],
+            "launch": best["shape"], "avg_launch_us": avg_ms * 1e3, "launches": best["launches"],
+            "algorithmic_bytes_per_launch": best["bytes_per_launch"]}
+
+
+def cpu_baseline(cfg, net, staged, limits, spheres, args):
+    """The oracle timed on the host cores (rank 0, N = 1 only): C restatement of the pyramid (single
+    thread, like the reference extension) + unfused PyTorch-ops port of the network on all cores.
+    Bounded sample: `cpu_baseline_steps` step(s) over ONE sphere of the same workload."""
+    import mvkpconv
+    from oracle import cport, torch_port
+    syn = mvkpconv.sub("synthetic")
+    cores = min(os.cpu_count() or 1, 16)      # the 1-GPU box's CPU share; more threads only add OpenMP overhead
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    net2d = None
+    if cfg.variant != "baseline":
+        net2d = syn.build_model(cfg, torch.device("cpu")).net_2d
+        net2d.load_state_dict({k[len("net_2d."):]: v for k, v in sd.items() if k.startswith("net_2d.")})
+        for m in net2d._modules.values():
+            m.train(False)
+    # GPU-built batch gives the fusion inputs; the CPU leg rebuilds the pyramid itself
+    one = {k: (v[:1] if isinstance(v, list) else v) for k, v in staged.items()}
+    batch, lens = syn.build_batch(cfg, one, limits, torch.int64)
+    cb = torch_port.batch_to_cpu(batch)
+    raw = spheres[0]["points"]
+    leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and
+            ("weight" in k or "bias" in k) and not k.startswith("net_2d.") and "running" not in k}
+
+    def cpu_step():
+        t0 = time.perf_counter()
+        # pyramid: first subsampling + per level neighbours / subsampling / pool / upsample neighbours
+        p, l = cport.subsample_batch(raw, [raw.shape[0]], dl=cfg.first_subsampling_dl)
+        r = cfg.first_subsampling_dl * cfg.conv_radius
+        for lvl in range(5):
+            cport.radius_neighbors_batch(p, p, l, l, r, impl="ref" if cport.ref() else "oracle")
+            if lvl < 4:
+                q, ql = cport.subsample_batch(p, l, dl=2 * r / cfg.conv_radius, impl="ref" if cport.ref() else "oracle")
+                cport.radius_neighbors_batch(q, p, ql, l, r, impl="ref" if cport.ref() else "oracle")
+                cport.radius_neighbors_batch(p, q, l, ql, 2 * r, impl="ref" if cport.ref() else "oracle")
+                p, l = q, ql
+            r *= 2
+        t1 = time.perf_counter()
+        sdl = dict(sd)
+        sdl.update(leaf)
+        out, reg = torch_port.forward(sdl, cfg, cb, net2d, training=True)
+        loss = torch_port.loss_fn(out, cb["labels"], reg, cfg)
+        loss.backward()
+        for v in leaf.values():
+            v.grad = None
+        return t1 - t0, time.perf_counter() - t1
+
+    a, b = cpu_step()  # warm-up (also the sample itself when one step already exceeds the time bound)
+    tp = tn = 0.0
+    n = 0
+    if a + b < 20.0:
+        for _ in range(args.cpu_baseline_steps):
+            a, b = cpu_step()
+            tp += a
+            tn += b
+            n += 1
+    else:
+        tp, tn, n = a, b, 1
+    return {"value": lens[0] * n / (tp + tn), "unit": "points/s", "cores": cores,
+            "kind": "port",
+            "sample": "%d step(s) of ONE %d-point sphere of the same workload: pyramid by %s (1 thread, %.0f ms/step) "
+                      "+ unfused PyTorch-CPU network fwd+bwd on %d threads (%.0f ms/step); no optimizer step" % (
+                          n, lens[0], "the compiled reference core (oracle/_ref)" if cport.ref() else "the C oracle",
+                          tp / n * 1e3, cores, tn / n * 1e3)}
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,10 @@ struct SubWs {
   int* vcursor;
   float* vbary;   // 3N
   float* vfeat;   // N*fdim
+  int* vlab;      // N*ldim
+  int* lab_key;   // N (first-seen distinct labels of a voxel, at its segment offset)
+  int* lab_cnt;   // N
+  int* errflag;   // 1
   int* tau;
   int* posnew;
   int* nextb;
@@ -60,6 +64,7 @@ struct SubWs {
   // staging (N rows)
   float* stage_pts;
   float* stage_feat;
+  int* stage_lab;
 };
 
 // Bucket-count schedule of libstdc++'s unordered_map (13, 29, 59, 127, ...): nb[e+1] =
@@ -75,9 +80,53 @@ __device__ __forceinline__ unsigned int hash64(unsigned long long k) {
   return (unsigned int)k;
 }
 
+// Majority label of one voxel: first maximum in the iteration order of the reference's
+// unordered_map<int,int> histogram (grid_subsampling.cpp:100-101). Distinct labels arrive in
+// first-seen (= insertion) order; the order emulation is the per-epoch rank rule of P8 evaluated by
+// one lane with O(d^2) loops (d = distinct labels in the voxel, <= MAXLAB).
+constexpr int MAXLAB = 64;
+__device__ int label_vote(const int* L, const int* Cn, int nd, const Schedule& sched) {
+  if (nd == 1) return L[0];
+  int tau[MAXLAB], ftv[MAXLAB], posn[MAXLAB];
+  int start = 0, epoch = 0;
+  unsigned long long nb = sched.nb[0];
+  while (start < nd) {
+    const int end = (unsigned long long)nd < nb ? nd : (int)nb;
+    for (int v = start; v < end; ++v) tau[v] = v;
+    for (int v = 0; v < end; ++v) {
+      const unsigned long long bv = (unsigned long long)(long long)L[v] % nb;   // hash<int> = sign-extending cast
+      int f = tau[v];
+      for (int u = 0; u < end; ++u)
+        if ((unsigned long long)(long long)L[u] % nb == bv && tau[u] < f) f = tau[u];
+      ftv[v] = f;
+    }
+    for (int v = 0; v < end; ++v) {
+      const unsigned long long bv = (unsigned long long)(long long)L[v] % nb;
+      int r = 0;
+      for (int u = 0; u < end; ++u) {
+        const bool same = (unsigned long long)(long long)L[u] % nb == bv;
+        r += same ? (tau[u] > tau[v]) : (ftv[u] > ftv[v]);
+      }
+      posn[v] = r;
+    }
+    for (int v = 0; v < end; ++v) tau[v] = posn[v];
+    start = end;
+    nb = sched.nb[++epoch];
+  }
+  int best = L[0], bestc = -1;
+  for (int r = 0; r < nd; ++r)
+    for (int v = 0; v < nd; ++v)
+      if (tau[v] == r && Cn[v] > bestc) {
+        bestc = Cn[v];
+        best = L[v];
+      }
+  return best;
+}
+
 __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __restrict__ pts,
                                                                const float* __restrict__ feats,
-                                                               int fdim, const int* __restrict__ offs,
+                                                               int fdim, const int* __restrict__ labels,
+                                                               int ldim, const int* __restrict__ offs,
                                                                float dl, SubWs W, int B,
                                                                Schedule sched) {
   __shared__ float red[6][TPB / 64];
@@ -230,6 +279,27 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
         vfeat[(int64_t)v * fdim + d] = s / cf;  // :90-94
       }
     }
+    for (int d = 0; d < ldim; ++d) {  // label histograms in first-seen order (grid_subsampling.h:44-52)
+      int* Lk = W.lab_key + off + vseg[v];
+      int* Lc = W.lab_cnt + off + vseg[v];
+      int nd = 0;
+      for (int a = 0; a < c; ++a) {
+        const int l = labels[((int64_t)off + m[a]) * ldim + d];
+        int z = 0;
+        while (z < nd && Lk[z] != l) ++z;
+        if (z == nd) {
+          Lk[nd] = l;
+          Lc[nd] = 0;
+          ++nd;
+        }
+        Lc[z] += 1;
+      }
+      if (nd > MAXLAB) {
+        atomicExch(W.errflag, 1);
+        nd = MAXLAB;
+      }
+      W.vlab[((int64_t)off + v) * ldim + d] = label_vote(Lk, Lc, nd, sched);
+    }
   }
   __syncthreads();
 
@@ -289,15 +359,17 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
     sp[o * 3 + 1] = vbary[v * 3 + 1];
     sp[o * 3 + 2] = vbary[v * 3 + 2];
     for (int d = 0; d < fdim; ++d) sf[(int64_t)o * fdim + d] = vfeat[(int64_t)v * fdim + d];
+    for (int d = 0; d < ldim; ++d) W.stage_lab[((int64_t)off + o) * ldim + d] = W.vlab[((int64_t)off + v) * ldim + d];
   }
   if (tid == 0) W.out_count[b] = M;
 }
 
 // Compacts the per-cloud staging rows into the stacked output and applies max_p
 // (grid_subsampling.cpp:181-204).
-__global__ void subsample_compact_kernel(const int* __restrict__ offs, SubWs W, int B, int fdim,
+__global__ void subsample_compact_kernel(const int* __restrict__ offs, SubWs W, int B, int fdim, int ldim,
                                          int max_p, float* __restrict__ out_pts,
-                                         float* __restrict__ out_feats, int* __restrict__ out_lens) {
+                                         float* __restrict__ out_feats, int* __restrict__ out_labels,
+                                         int* __restrict__ out_lens) {
   const int b = blockIdx.y;
   int base = 0;
   for (int i = 0; i < b; ++i) base += min(W.out_count[i], max_p);
@@ -308,6 +380,8 @@ __global__ void subsample_compact_kernel(const int* __restrict__ offs, SubWs W, 
     for (int c = 0; c < 3; ++c) out_pts[(int64_t)(base + o) * 3 + c] = W.stage_pts[(int64_t)(off + o) * 3 + c];
     for (int d = 0; d < fdim; ++d)
       out_feats[(int64_t)(base + o) * fdim + d] = W.stage_feat[(int64_t)(off + o) * fdim + d];
+    for (int d = 0; d < ldim; ++d)
+      out_labels[(int64_t)(base + o) * ldim + d] = W.stage_lab[(int64_t)(off + o) * ldim + d];
   }
 }
 
@@ -323,13 +397,14 @@ struct Carver {
   }
 };
 
-int64_t ws_bytes(int64_t N, int B, int fdim) {
+int64_t ws_bytes(int64_t N, int B, int fdim, int ldim) {
   int64_t n = N > 0 ? N : 1;
   int64_t bytes = 0;
   bytes += 3 * n * 4;                       // slot member scan
   bytes += 4 * n * (8 + 4 + 4);             // hash
   bytes += n * (8 + 4 * 3 + 12 + 4 * 4);    // vkey vcount vseg vcursor vbary tau posnew nextb tarr
   bytes += n * (int64_t)fdim * 4 * 2;       // vfeat + stage_feat
+  bytes += n * (int64_t)ldim * 4 * 2 + n * 8 + 64;  // vlab + stage_lab, lab_key, lab_cnt, errflag
   bytes += 3 * (3 * n + 32 * (int64_t)B) * 4;  // ft bcnt bhead
   bytes += (int64_t)(B + 1) * 4 * 2;        // out_count, offs
   bytes += n * 12;                          // stage_pts
@@ -338,19 +413,23 @@ int64_t ws_bytes(int64_t N, int B, int fdim) {
 
 }  // namespace
 
-extern "C" int64_t mvk_grid_subsample_workspace(int64_t N, int B) { return ws_bytes(N, B, 16); }
+extern "C" int64_t mvk_grid_subsample_workspace(int64_t N, int B, int fdim, int ldim) {
+  return ws_bytes(N, B, fdim, ldim);
+}
 
 extern "C" int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32_t* lens_host, int B,
-                                        const float* feats, int fdim, float dl, int max_p,
-                                        float* out_pts, float* out_feats, int32_t* out_lens,
+                                        const float* feats, int fdim, const int32_t* labels, int ldim,
+                                        float dl, int max_p, float* out_pts, float* out_feats,
+                                        int32_t* out_labels, int32_t* out_lens,
                                         int32_t* out_lens_host, void* workspace,
                                         int64_t workspace_bytes, void* stream) {
   MVK_REQUIRE(B >= 1 && N >= 0 && N < (1ll << 29), "subsample: bad sizes N=%lld B=%d", (long long)N, B);
   MVK_REQUIRE(dl > 0.f, "subsample: sampleDl must be positive");
   MVK_REQUIRE(fdim >= 0 && (fdim == 0 || (feats && out_feats)), "subsample: features pointer missing");
-  MVK_REQUIRE(workspace != nullptr && workspace_bytes >= ws_bytes(N, B, fdim),
+  MVK_REQUIRE(ldim >= 0 && (ldim == 0 || (labels && out_labels)), "subsample: labels pointer missing");
+  MVK_REQUIRE(workspace != nullptr && workspace_bytes >= ws_bytes(N, B, fdim, ldim),
               "subsample: workspace too small (%lld < %lld)", (long long)workspace_bytes,
-              (long long)ws_bytes(N, B, fdim));
+              (long long)ws_bytes(N, B, fdim, ldim));
   hipStream_t st = (hipStream_t)stream;
   int64_t tot = 0;
   int* offs_h = (int*)alloca(sizeof(int) * (B + 1));
@@ -371,12 +450,15 @@ extern "C" int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32
   W.vkey = cv.take<unsigned long long>(n); W.vcount = cv.take<int>(n); W.vseg = cv.take<int>(n);
   W.vcursor = cv.take<int>(n); W.vbary = cv.take<float>(3 * n);
   W.vfeat = cv.take<float>(n * (fdim > 0 ? fdim : 0) + 1);
+  W.vlab = cv.take<int>(n * (ldim > 0 ? ldim : 0) + 1);
+  W.lab_key = cv.take<int>(n); W.lab_cnt = cv.take<int>(n); W.errflag = cv.take<int>(1);
   W.tau = cv.take<int>(n); W.posnew = cv.take<int>(n); W.nextb = cv.take<int>(n); W.tarr = cv.take<int>(n);
   W.ft = cv.take<int>(3 * n + 32 * B); W.bcnt = cv.take<int>(3 * n + 32 * B); W.bhead = cv.take<int>(3 * n + 32 * B);
   W.out_count = cv.take<int>(B + 1);
   int* offs_d = cv.take<int>(B + 1);
   W.stage_pts = cv.take<float>(3 * n);
   W.stage_feat = cv.take<float>(n * (fdim > 0 ? fdim : 0) + 1);
+  W.stage_lab = cv.take<int>(n * (ldim > 0 ? ldim : 0) + 1);
   MVK_REQUIRE(cv.p <= cv.end, "subsample: workspace carve overflow");
 
   // _Prime_rehash_policy::_M_need_rehash: first allocation 13 buckets, then
@@ -385,15 +467,20 @@ extern "C" int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32
   sched.nb[0] = 13;
   for (int e = 1; e < 48; ++e) sched.nb[e] = mvk_next_bkt(2 * sched.nb[e - 1]);
   MVK_CHECK_HIP(hipMemcpyAsync(offs_d, offs_h, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(subsample_cloud_kernel, dim3(B), dim3(TPB), 0, st, pts, feats, fdim, offs_d, dl, W, B, sched);
+  MVK_CHECK_HIP(hipMemsetAsync(W.errflag, 0, sizeof(int), st));
+  hipLaunchKernelGGL(subsample_cloud_kernel, dim3(B), dim3(TPB), 0, st, pts, feats, fdim, labels, ldim, offs_d, dl, W,
+                     B, sched);
   int gx = (int)cdiv64(n, 256 * (int64_t)B);
   if (gx < 1) gx = 1;
   if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(subsample_compact_kernel, dim3(gx, B), dim3(256), 0, st, offs_d, W, B, fdim, max_p,
-                     out_pts, out_feats, out_lens);
+  hipLaunchKernelGGL(subsample_compact_kernel, dim3(gx, B), dim3(256), 0, st, offs_d, W, B, fdim, ldim, max_p,
+                     out_pts, out_feats, out_labels, out_lens);
   MVK_CHECK_HIP(hipGetLastError());
   if (out_lens_host)
     MVK_CHECK_HIP(hipMemcpyAsync(out_lens_host, out_lens, sizeof(int) * B, hipMemcpyDeviceToHost, st));
+  int err = 0;
+  MVK_CHECK_HIP(hipMemcpyAsync(&err, W.errflag, sizeof(int), hipMemcpyDeviceToHost, st));
   MVK_CHECK_HIP(hipStreamSynchronize(st));  // offs_h (stack) and out_lens_host must be settled on return
+  MVK_REQUIRE(err == 0, "subsample: a voxel holds more than %d distinct labels", MAXLAB);
   return 0;
 }

@@ -1,0 +1,150 @@
+"""KPFCNN segmentation network, baseline variant (reference KPConv-PyTorch/models/architectures.py:
+p2p_fitting_regularizer :25-58, KPFCNN :189-394). Module / parameter names match the reference
+(encoder_blocks.N.*, decoder_blocks.N.*, head_mlp.*, head_softmax.*) for state-dict compatibility."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+try:
+    from .blocks import KPConv, UnaryBlock, block_decider
+except ImportError:
+    from models.blocks import KPConv, UnaryBlock, block_decider
+
+
+def p2p_fitting_regularizer(net):
+    """Deformable-kernel regulariser: fitting (kernel point -> closest input point) + repulsion
+    between deformed kernel points (architectures.py:25-58)."""
+    fitting_loss = 0
+    repulsive_loss = 0
+    for m in net.modules():
+        if isinstance(m, KPConv) and m.deformable:
+            KP_min_d2 = m.min_d2 / (m.KP_extent ** 2)
+            fitting_loss += net.l1(KP_min_d2, torch.zeros_like(KP_min_d2))
+            KP_locs = m.deformed_KP / m.KP_extent
+            for i in range(net.K):
+                other_KP = torch.cat([KP_locs[:, :i, :], KP_locs[:, i + 1:, :]], dim=1).detach()
+                distances = torch.sqrt(torch.sum((other_KP - KP_locs[:, i:i + 1, :]) ** 2, dim=2))
+                rep_loss = torch.sum(torch.clamp_max(distances - net.repulse_extent, max=0.0) ** 2, dim=1)
+                repulsive_loss += net.l1(rep_loss, torch.zeros_like(rep_loss)) / net.K
+    return net.deform_fitting_power * (2 * fitting_loss + repulsive_loss)
+
+
+def build_encoder(config, in_dim):
+    """Encoder block list + skip bookkeeping shared by every KPFCNN variant
+    (architectures.py:207-252). Returns (blocks, skips, skip_dims, in_dim, out_dim, layer, r)."""
+    layer = 0
+    r = config.first_subsampling_dl * config.conv_radius
+    out_dim = config.first_features_dim
+    blocks, skips, skip_dims = nn.ModuleList(), [], []
+    for block_i, block in enumerate(config.architecture):
+        if ('equivariant' in block) and (not out_dim % 3 == 0):
+            raise ValueError('Equivariant block but features dimension is not a factor of 3')
+        if np.any([tmp in block for tmp in ['pool', 'strided', 'upsample', 'global']]):
+            skips.append(block_i)
+            skip_dims.append(in_dim)
+        if 'upsample' in block:
+            break
+        blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+        in_dim = out_dim // 2 if 'simple' in block else out_dim
+        if 'pool' in block or 'strided' in block:
+            layer += 1
+            r *= 2
+            out_dim *= 2
+    return blocks, skips, skip_dims, in_dim, out_dim, layer, r
+
+
+def build_decoder(config, in_dim, out_dim, layer, r, skip_dims):
+    """Decoder block list (architectures.py:254-291). Returns (blocks, concats, out_dim)."""
+    blocks, concats = nn.ModuleList(), []
+    start_i = 0
+    for block_i, block in enumerate(config.architecture):
+        if 'upsample' in block:
+            start_i = block_i
+            break
+    for block_i, block in enumerate(config.architecture[start_i:]):
+        if block_i > 0 and 'upsample' in config.architecture[start_i + block_i - 1]:
+            in_dim += skip_dims[layer]
+            concats.append(block_i)
+        blocks.append(block_decider(block, r, in_dim, out_dim, layer, config))
+        in_dim = out_dim
+        if 'upsample' in block:
+            layer -= 1
+            r *= 0.5
+            out_dim = out_dim // 2
+    return blocks, concats, out_dim
+
+
+class _SegmentationLossMixin:
+    """loss / accuracy shared by all variants (architectures.py:345-394)."""
+
+    def _init_losses(self, config, lbl_values, ign_lbls):
+        self.valid_labels = np.sort([c for c in lbl_values if c not in ign_lbls])
+        if len(config.class_w) > 0:
+            class_w = torch.from_numpy(np.array(config.class_w, dtype=np.float32))
+            self.criterion = torch.nn.CrossEntropyLoss(weight=class_w, ignore_index=-1)
+        else:
+            self.criterion = torch.nn.CrossEntropyLoss(ignore_index=-1)
+        self.deform_fitting_mode = config.deform_fitting_mode
+        self.deform_fitting_power = config.deform_fitting_power
+        self.deform_lr_factor = config.deform_lr_factor
+        self.repulse_extent = config.repulse_extent
+        self.output_loss = 0
+        self.reg_loss = 0
+        self.l1 = nn.L1Loss()
+
+    def _targets(self, labels):
+        target = - torch.ones_like(labels)
+        for i, c in enumerate(self.valid_labels):
+            target[labels == c] = i
+        return target
+
+    def loss(self, outputs, labels):
+        target = self._targets(labels)
+        outputs = torch.transpose(outputs, 0, 1).unsqueeze(0)
+        self.output_loss = self.criterion(outputs, target.unsqueeze(0))
+        if self.deform_fitting_mode == 'point2point':
+            self.reg_loss = p2p_fitting_regularizer(self)
+        elif self.deform_fitting_mode == 'point2plane':
+            raise ValueError('point2plane fitting mode not implemented yet.')
+        else:
+            raise ValueError('Unknown fitting mode: ' + self.deform_fitting_mode)
+        return self.output_loss + self.reg_loss
+
+    def accuracy(self, outputs, labels):
+        target = self._targets(labels)
+        predicted = torch.argmax(outputs.data, dim=1)
+        return (predicted == target).sum().item() / target.size(0)
+
+
+def run_encoder_decoder(net, x, batch, encoder=None):
+    skip_x = []
+    for block_i, block_op in enumerate(encoder if encoder is not None else net.encoder_blocks):
+        if block_i in net.encoder_skips:
+            skip_x.append(x)
+        x = block_op(x, batch)
+    for block_i, block_op in enumerate(net.decoder_blocks):
+        if block_i in net.decoder_concats:
+            x = torch.cat([x, skip_x.pop()], dim=1)
+        x = block_op(x, batch)
+    return x
+
+
+class KPFCNN(_SegmentationLossMixin, nn.Module):
+    """3D-only KPFCNN (train_ScanNet_baseline.py)."""
+
+    def __init__(self, config, lbl_values, ign_lbls):
+        super(KPFCNN, self).__init__()
+        self.K = config.num_kernel_points
+        self.C = len(lbl_values) - len(ign_lbls)
+        (self.encoder_blocks, self.encoder_skips, self.encoder_skip_dims,
+         in_dim, out_dim, layer, r) = build_encoder(config, config.in_features_dim)
+        self.decoder_blocks, self.decoder_concats, out_dim = build_decoder(
+            config, in_dim, out_dim, layer, r, self.encoder_skip_dims)
+        self.head_mlp = UnaryBlock(out_dim, config.first_features_dim, False, 0)
+        self.head_softmax = UnaryBlock(config.first_features_dim, self.C, False, 0)
+        self._init_losses(config, lbl_values, ign_lbls)
+
+    def forward(self, batch, config):
+        x = batch.features.clone().detach()
+        x = run_encoder_decoder(self, x, batch)
+        return self.head_softmax(self.head_mlp(x, batch), batch)

@@ -1,0 +1,41 @@
+"""MV-KPConv late fusion (reference KPConv-PyTorch/models/architectures_sphere_late_fusion.py):
+a 3D-only KPFCNN whose 128-d output is reduced to 64 (transform_mlp :171) and concatenated with
+the lifted 2D features before the head (:301-303). Gradients reach FeatureAggregation here."""
+import torch
+import torch.nn as nn
+
+try:
+    from .architectures import (p2p_fitting_regularizer, build_encoder, build_decoder, run_encoder_decoder,
+                                _SegmentationLossMixin)
+    from .blocks import UnaryBlock
+    from .fusion_common import build_2d_branch, lift_2d_features
+except ImportError:
+    from models.architectures import (p2p_fitting_regularizer, build_encoder, build_decoder,
+                                      run_encoder_decoder, _SegmentationLossMixin)
+    from models.blocks import UnaryBlock
+    from models.fusion_common import build_2d_branch, lift_2d_features
+
+
+class KPFCNN_featureAggre(_SegmentationLossMixin, nn.Module):
+
+    def __init__(self, config, lbl_values, ign_lbls):
+        super(KPFCNN_featureAggre, self).__init__()
+        self.K = config.num_kernel_points
+        self.C = len(lbl_values) - len(ign_lbls)
+        (self.encoder_blocks, self.encoder_skips, self.encoder_skip_dims,
+         in_dim, out_dim, layer, r) = build_encoder(config, config.in_features_dim)
+        self.decoder_blocks, self.decoder_concats, out_dim = build_decoder(
+            config, in_dim, out_dim, layer, r, self.encoder_skip_dims)
+        self.transform_mlp = UnaryBlock(out_dim, 64, False, 0)
+        self.head_mlp = UnaryBlock(out_dim, config.first_features_dim, False, 0)
+        self.head_softmax = UnaryBlock(config.first_features_dim, self.C, False, 0)
+        self._init_losses(config, lbl_values, ign_lbls)
+        build_2d_branch(self, config)
+
+    def forward(self, batch, config):
+        feature_2d3d = lift_2d_features(self, batch)
+        x = batch.feature_3d.clone().detach()
+        x = run_encoder_decoder(self, x, batch)
+        x = self.transform_mlp(x, batch)
+        x = torch.cat((x, feature_2d3d), dim=1)
+        return self.head_softmax(self.head_mlp(x, batch), batch)

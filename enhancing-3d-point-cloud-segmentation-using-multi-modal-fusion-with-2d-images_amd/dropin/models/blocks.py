@@ -1,0 +1,306 @@
+"""KPConv operator and network blocks with the reference's API
+(KPConv-PyTorch/models/blocks.py), running on the fused HIP kernels.
+
+Same class names, constructor arguments, attribute names and state-dict keys as the reference
+(``weights``, ``kernel_points``, ``offset_conv.*``, ``offset_bias``, ``KPConv.*``, ``batch_norm.*``,
+``mlp.weight`` ...) so checkpoints and the trainer's parameter grouping (names containing
+'offset', utils/trainer.py:72-73) keep working. The tensor algebra of KPConv.forward
+(blocks.py:277-374) is one autograd node here (ops._KPConvFn): gather + correlation + aggregation
+kernel, f32 MFMA contraction, scatter backward.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn.init import kaiming_uniform_
+from torch.nn.parameter import Parameter
+
+try:
+    from .._native import ops
+    from ..kernels.kernel_points import load_kernels
+except ImportError:  # dropin/ put on sys.path directly
+    from _native import ops
+    from kernels.kernel_points import load_kernels
+
+
+# ---------------------------------------------------------------- simple functions (blocks.py:35-133)
+
+def gather(x, idx, method=2):
+    """x[idx] for row indices of any shape (blocks.py:35-66). The reference's expand+gather forms
+    (methods 1, 2) exist for a faster backward of the materialised [N,H,D] gather; the fused
+    kernels never materialise it, so plain indexing is all that is left to do here."""
+    return x[idx]
+
+
+def radius_gaussian(sq_r, sig, eps=1e-9):
+    return torch.exp(-sq_r / (2 * sig ** 2 + eps))
+
+
+def closest_pool(x, inds):
+    """Features of the closest (first-column) neighbour; shadow index -> zeros (blocks.py:79-91)."""
+    return ops.closest_pool(x, inds)
+
+
+def max_pool(x, inds):
+    """Max over the neighbourhood, the zero shadow row taking part (blocks.py:94-110)."""
+    return ops.max_pool(x, inds)
+
+
+def global_average(x, batch_lengths):
+    """Per-cloud mean over the stacked point axis (blocks.py:113-133)."""
+    out, i0 = [], 0
+    for length in batch_lengths:
+        length = int(length)
+        out.append(torch.mean(x[i0:i0 + length], dim=0))
+        i0 += length
+    return torch.stack(out)
+
+
+# ---------------------------------------------------------------- KPConv (blocks.py:143-379)
+
+class KPConv(nn.Module):
+
+    def __init__(self, kernel_size, p_dim, in_channels, out_channels, KP_extent, radius,
+                 fixed_kernel_points='center', KP_influence='linear', aggregation_mode='sum',
+                 deformable=False, modulated=False):
+        super(KPConv, self).__init__()
+        self.K = kernel_size
+        self.p_dim = p_dim
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.radius = radius
+        self.KP_extent = KP_extent
+        self.fixed_kernel_points = fixed_kernel_points
+        self.KP_influence = KP_influence
+        self.aggregation_mode = aggregation_mode
+        self.deformable = deformable
+        self.modulated = modulated
+        if p_dim != 3:
+            raise ValueError('the HIP KPConv kernels are 3-D (p_dim == 3)')
+
+        # running variables read by the regulariser (architectures*.py p2p_fitting_regularizer)
+        self.min_d2 = None
+        self.deformed_KP = None
+        self.offset_features = None
+
+        self.weights = Parameter(torch.zeros((self.K, in_channels, out_channels), dtype=torch.float32),
+                                 requires_grad=True)
+        if deformable:
+            self.offset_dim = (self.p_dim + 1) * self.K if modulated else self.p_dim * self.K
+            self.offset_conv = KPConv(self.K, self.p_dim, self.in_channels, self.offset_dim, KP_extent, radius,
+                                      fixed_kernel_points=fixed_kernel_points, KP_influence=KP_influence,
+                                      aggregation_mode=aggregation_mode)
+            self.offset_bias = Parameter(torch.zeros(self.offset_dim, dtype=torch.float32), requires_grad=True)
+        else:
+            self.offset_dim = None
+            self.offset_conv = None
+            self.offset_bias = None
+        self.reset_parameters()
+        self.kernel_points = self.init_KP()
+
+    def reset_parameters(self):
+        kaiming_uniform_(self.weights, a=math.sqrt(5))
+        if self.deformable:
+            nn.init.zeros_(self.offset_bias)
+
+    def init_KP(self):
+        kp = load_kernels(self.radius, self.K, dimension=self.p_dim, fixed=self.fixed_kernel_points)
+        return Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)
+
+    def forward(self, q_pts, s_pts, neighb_inds, x):
+        if self.KP_influence not in ops.INFLUENCE:
+            raise ValueError('Unknown influence function type (config.KP_influence)')
+        if self.aggregation_mode not in ops.AGGREGATION:
+            raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
+        offsets = modulations = None
+        if self.deformable:
+            # offsets from an inner rigid KPConv (blocks.py:243-266)
+            self.offset_features = self.offset_conv(q_pts, s_pts, neighb_inds, x) + self.offset_bias
+            nk = self.p_dim * self.K
+            if self.modulated:
+                unscaled = self.offset_features[:, :nk].reshape(-1, self.K, self.p_dim)
+                modulations = 2 * torch.sigmoid(self.offset_features[:, nk:])
+            else:
+                unscaled = self.offset_features.reshape(-1, self.K, self.p_dim)
+            offsets = unscaled * self.KP_extent
+            self.deformed_KP = offsets + self.kernel_points          # blocks.py:287
+        y, min_d2 = ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent,
+                               self.KP_influence, self.aggregation_mode, offsets, modulations)
+        if self.deformable:
+            self.min_d2 = min_d2                                      # blocks.py:303
+        return y
+
+    def __repr__(self):
+        return 'KPConv(radius: {:.2f}, in_feat: {:d}, out_feat: {:d})'.format(self.radius, self.in_channels,
+                                                                              self.out_channels)
+
+
+# ---------------------------------------------------------------- blocks (blocks.py:387-694)
+
+_SIMPLE = {'simple', 'simple_deformable', 'simple_invariant', 'simple_equivariant', 'simple_strided',
+           'simple_deformable_strided', 'simple_invariant_strided', 'simple_equivariant_strided'}
+_RESNET = {'resnetb', 'resnetb_invariant', 'resnetb_equivariant', 'resnetb_deformable', 'resnetb_strided',
+           'resnetb_deformable_strided', 'resnetb_equivariant_strided', 'resnetb_invariant_strided'}
+
+
+def block_decider(block_name, radius, in_dim, out_dim, layer_ind, config):
+    if block_name == 'unary':
+        return UnaryBlock(in_dim, out_dim, config.use_batch_norm, config.batch_norm_momentum)
+    if block_name in _SIMPLE:
+        return SimpleBlock(block_name, in_dim, out_dim, radius, layer_ind, config)
+    if block_name in _RESNET:
+        return ResnetBottleneckBlock(block_name, in_dim, out_dim, radius, layer_ind, config)
+    if block_name in ('max_pool', 'max_pool_wide'):
+        return MaxPoolBlock(layer_ind)
+    if block_name == 'global_average':
+        return GlobalAverageBlock()
+    if block_name == 'nearest_upsample':
+        return NearestUpsampleBlock(layer_ind)
+    raise ValueError('Unknown block name in the architecture definition : ' + block_name)
+
+
+class BatchNormBlock(nn.Module):
+    """BatchNorm1d over the stacked point axis, or a learned bias (blocks.py:430-467)."""
+
+    def __init__(self, in_dim, use_bn, bn_momentum):
+        super(BatchNormBlock, self).__init__()
+        self.bn_momentum = bn_momentum
+        self.use_bn = use_bn
+        self.in_dim = in_dim
+        if self.use_bn:
+            self.batch_norm = nn.BatchNorm1d(in_dim, momentum=bn_momentum)
+        else:
+            self.bias = Parameter(torch.zeros(in_dim, dtype=torch.float32), requires_grad=True)
+
+    def reset_parameters(self):
+        nn.init.zeros_(self.bias)
+
+    def forward(self, x):
+        if self.use_bn:
+            # [N, C] is already BatchNorm1d's (batch, channel) layout: same statistics as the
+            # reference's unsqueeze/transpose round trip (blocks.py:456-460) without the copies
+            return self.batch_norm(x)
+        return x + self.bias
+
+    def __repr__(self):
+        return 'BatchNormBlock(in_feat: {:d}, momentum: {:.3f}, only_bias: {:s})'.format(
+            self.in_dim, self.bn_momentum, str(not self.use_bn))
+
+
+class UnaryBlock(nn.Module):
+
+    def __init__(self, in_dim, out_dim, use_bn, bn_momentum, no_relu=False):
+        super(UnaryBlock, self).__init__()
+        self.bn_momentum = bn_momentum
+        self.use_bn = use_bn
+        self.no_relu = no_relu
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.mlp = nn.Linear(in_dim, out_dim, bias=False)
+        self.batch_norm = BatchNormBlock(out_dim, self.use_bn, self.bn_momentum)
+        if not no_relu:
+            self.leaky_relu = nn.LeakyReLU(0.1)
+
+    def forward(self, x, batch=None):
+        x = self.batch_norm(self.mlp(x))
+        return x if self.no_relu else self.leaky_relu(x)
+
+    def __repr__(self):
+        return 'UnaryBlock(in_feat: {:d}, out_feat: {:d}, BN: {:s}, ReLU: {:s})'.format(
+            self.in_dim, self.out_dim, str(self.use_bn), str(not self.no_relu))
+
+
+def _conv_inputs(block_name, layer_ind, batch):
+    """Which pyramid tensors a block convolves over (blocks.py:551-558, :623-630)."""
+    if 'strided' in block_name:
+        return batch.points[layer_ind + 1], batch.points[layer_ind], batch.pools[layer_ind]
+    return batch.points[layer_ind], batch.points[layer_ind], batch.neighbors[layer_ind]
+
+
+class SimpleBlock(nn.Module):
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super(SimpleBlock, self).__init__()
+        current_extent = radius * config.KP_extent / config.conv_radius
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.layer_ind = layer_ind
+        self.block_name = block_name
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        self.KPConv = KPConv(config.num_kernel_points, config.in_points_dim, in_dim, out_dim // 2,
+                             current_extent, radius, fixed_kernel_points=config.fixed_kernel_points,
+                             KP_influence=config.KP_influence, aggregation_mode=config.aggregation_mode,
+                             deformable='deform' in block_name, modulated=config.modulated)
+        self.batch_norm = BatchNormBlock(out_dim // 2, self.use_bn, self.bn_momentum)
+        self.leaky_relu = nn.LeakyReLU(0.1)
+
+    def forward(self, x, batch):
+        q_pts, s_pts, inds = _conv_inputs(self.block_name, self.layer_ind, batch)
+        return self.leaky_relu(self.batch_norm(self.KPConv(q_pts, s_pts, inds, x)))
+
+
+class ResnetBottleneckBlock(nn.Module):
+
+    def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
+        super(ResnetBottleneckBlock, self).__init__()
+        current_extent = radius * config.KP_extent / config.conv_radius
+        self.bn_momentum = config.batch_norm_momentum
+        self.use_bn = config.use_batch_norm
+        self.block_name = block_name
+        self.layer_ind = layer_ind
+        self.in_dim = in_dim
+        self.out_dim = out_dim
+        if in_dim != out_dim // 4:
+            self.unary1 = UnaryBlock(in_dim, out_dim // 4, self.use_bn, self.bn_momentum)
+        else:
+            self.unary1 = nn.Identity()
+        self.KPConv = KPConv(config.num_kernel_points, config.in_points_dim, out_dim // 4, out_dim // 4,
+                             current_extent, radius, fixed_kernel_points=config.fixed_kernel_points,
+                             KP_influence=config.KP_influence, aggregation_mode=config.aggregation_mode,
+                             deformable='deform' in block_name, modulated=config.modulated)
+        self.batch_norm_conv = BatchNormBlock(out_dim // 4, self.use_bn, self.bn_momentum)
+        self.unary2 = UnaryBlock(out_dim // 4, out_dim, self.use_bn, self.bn_momentum, no_relu=True)
+        if in_dim != out_dim:
+            self.unary_shortcut = UnaryBlock(in_dim, out_dim, self.use_bn, self.bn_momentum, no_relu=True)
+        else:
+            self.unary_shortcut = nn.Identity()
+        self.leaky_relu = nn.LeakyReLU(0.1)
+
+    def forward(self, features, batch):
+        q_pts, s_pts, inds = _conv_inputs(self.block_name, self.layer_ind, batch)
+        x = self.unary1(features)
+        x = self.leaky_relu(self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x)))
+        x = self.unary2(x)
+        shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
+        return self.leaky_relu(x + self.unary_shortcut(shortcut))
+
+
+class GlobalAverageBlock(nn.Module):
+
+    def forward(self, x, batch):
+        return global_average(x, batch.lengths[-1])
+
+
+class NearestUpsampleBlock(nn.Module):
+
+    def __init__(self, layer_ind):
+        super(NearestUpsampleBlock, self).__init__()
+        self.layer_ind = layer_ind
+
+    def forward(self, x, batch):
+        return closest_pool(x, batch.upsamples[self.layer_ind - 1])
+
+    def __repr__(self):
+        return 'NearestUpsampleBlock(layer: {:d} -> {:d})'.format(self.layer_ind, self.layer_ind - 1)
+
+
+class MaxPoolBlock(nn.Module):
+
+    def __init__(self, layer_ind):
+        super(MaxPoolBlock, self).__init__()
+        self.layer_ind = layer_ind
+
+    def forward(self, x, batch):
+        return max_pool(x, batch.pools[self.layer_ind + 1])

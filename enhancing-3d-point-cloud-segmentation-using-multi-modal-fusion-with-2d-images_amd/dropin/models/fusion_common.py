@@ -1,0 +1,59 @@
+"""2D -> 3D lifting shared by the three MV-KPConv fusion variants
+(reference KPConv-PyTorch/models/architectures_sphere.py:242-284 and the identical blocks in
+architectures_sphere_middle_fusion.py:229-266 / architectures_sphere_late_fusion.py:233-270)."""
+import os
+
+import numpy as np
+import torch
+
+try:
+    from ..mvpnet.models.mvpnet_3d import FeatureAggregation
+    from ..mvpnet.models.unet_resnet34 import UNetResNet34
+    from ..mvpnet.ops.group_points import group_points
+except ImportError:
+    from mvpnet.models.mvpnet_3d import FeatureAggregation
+    from mvpnet.models.unet_resnet34 import UNetResNet34
+    from mvpnet.ops.group_points import group_points
+
+
+def build_2d_branch(net, config):
+    """FeatureAggregation(64) + frozen UNetResNet34 in eval mode (architectures_sphere.py:205-237).
+    The 2D checkpoint config.path_2D is loaded when it exists; without it (synthetic benchmarks:
+    no checkpoint can be downloaded) the encoder keeps its random initialisation."""
+    net.feat_aggreg = FeatureAggregation(64)
+    net.net_2d = UNetResNet34(20, p=0.5, pretrained=True)
+    path = getattr(config, 'path_2D', '')
+    if path and os.path.exists(path):
+        checkpoint = torch.load(path, map_location=torch.device("cpu"))
+        net.net_2d.load_state_dict(checkpoint['model'])
+    for _, params in net.net_2d.named_parameters():
+        params.requires_grad = False
+    for _, m in net.net_2d._modules.items():
+        m.train(False)
+
+
+def lift_2d_features(net, batch):
+    """images -> UNet features -> per-sphere group_points with the k-NN pixel indices ->
+    FeatureAggregation. Returns feature_2d3d (np, 64)."""
+    images = batch.images                                   # (b, nv, 3, h, w)
+    b, nv, _, h, w = images.size()
+    images = images.reshape([-1] + list(images.shape[2:]))
+    feature_2d = net.net_2d({'image': images})['feature']  # (b*nv, c, h, w), no grad (frozen)
+    feature_2d = feature_2d.reshape(b, nv, -1, h, w).transpose(1, 2).contiguous().reshape(b, -1, nv * h * w)
+    image_xyz = batch.image_xyz.permute(0, 4, 1, 2, 3).reshape(b, 3, nv * h * w)
+    feats, xyzs = [], []
+    for i in range(b):
+        knn = batch.knn_list[i]
+        if isinstance(knn, np.ndarray):
+            knn = torch.from_numpy(knn)
+        knn = knn.long().to(feature_2d.device)
+        if knn.dim() == 2:
+            knn = knn.unsqueeze(0)                           # (1, s_np, k)
+        feats.append(group_points(feature_2d[i:i + 1], knn))
+        with torch.no_grad():
+            xyzs.append(group_points(image_xyz[i:i + 1].contiguous(), knn))
+    input_feature_2d = torch.cat(feats, dim=2)              # (1, c, np, k)
+    input_image_xyz = torch.cat(xyzs, dim=2)                # (1, 3, np, k)
+    points = batch.feat_aggre_points.transpose(1, 2)        # (1, 3, np)
+    feature_2d3d = net.feat_aggreg(input_image_xyz, points, input_feature_2d)   # (1, 64, np)
+    return feature_2d3d.permute(0, 2, 1).reshape(-1, 64)

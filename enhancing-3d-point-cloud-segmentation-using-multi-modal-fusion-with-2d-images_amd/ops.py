@@ -57,6 +57,48 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=1
     return out
 
 
+# ---- optional per-launch timing of the gather kernel (bench.py roofline): HIP events on the
+# current stream around the C-ABI call; nothing is recorded unless profile_reset(enabled=True).
+_PROF = {"on": False, "rec": []}
+
+
+def profile_reset(enabled):
+    _PROF["on"] = bool(enabled)
+    _PROF["rec"] = []
+
+
+def _gather_kernel_name(Cin, deform):
+    if deform:
+        return "kpconv_lane_channel<fwd,deform>"
+    if Cin % 4 == 0 and Cin <= 512:
+        c4 = Cin // 4
+        lpp = 1
+        while lpp < min(c4, 64):
+            lpp *= 2
+        return "kpconv_gather_vec<LPP=%d,NCH=%d>" % (lpp, 2 if c4 > 64 else 1)
+    return "kpconv_lane_channel<fwd>"
+
+
+def profile_collect(h_eff=None):
+    """{(kernel, Nq, Ns, H, Cin, K): {launches, total_ms, bytes_per_launch, ...}}; h_eff maps
+    (Nq, Ns, H) -> mean number of real (non-shadow) neighbours per row."""
+    torch.cuda.synchronize()
+    out = {}
+    for key, e0, e1 in _PROF["rec"]:
+        r = out.setdefault(key, {"launches": 0, "total_ms": 0.0})
+        r["launches"] += 1
+        r["total_ms"] += e0.elapsed_time(e1)
+    for key, r in out.items():
+        name, Nq, Ns, H, Cin, K = key
+        he = (h_eff or {}).get((Nq, Ns, H), H)
+        # algorithmic bytes (SURVEY.md 8d): feature row + xyz + int32 index per real neighbour,
+        # query xyz, and the [Nq,K,Cin] aggregate written by the gather kernel
+        r["bytes_per_launch"] = Nq * he * (Cin * 4 + 12 + 4) + Nq * 12 + Nq * K * Cin * 4
+        r["kernel"] = name
+        r["shape"] = {"Nq": Nq, "Ns": Ns, "H": H, "H_eff": he, "Cin": Cin, "K": K}
+    return out
+
+
 def kpconv_gather(q, s, idx, x, kp, extent, influence="linear", aggregation="sum", offsets=None,
                   want_min_d2=False):
     """A[n,k,c] = sum_h w[n,h,k] x+[idx[n,h],c]; returns (A, min_d2 or None)."""
@@ -72,9 +114,15 @@ def kpconv_gather(q, s, idx, x, kp, extent, influence="linear", aggregation="sum
         offsets = _f32c(offsets)
         if want_min_d2:
             min_d2 = torch.empty((Nq, K), device=q.device, dtype=torch.float32)
+    if _PROF["on"]:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib().mvk_kpconv_gather_fwd(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, _p(x), Cin, _p(kp), K,
                                       float(extent), INFLUENCE[influence], AGGREGATION[aggregation],
                                       _p(offsets), _p(min_d2), _p(A), _stream()))
+    if _PROF["on"]:
+        e1.record()
+        _PROF["rec"].append(((_gather_kernel_name(Cin, offsets is not None), Nq, Ns, H, Cin, K), e0, e1))
     return A, min_d2
 
 
@@ -248,32 +296,41 @@ def _lens_host(lens):
     return _np.ascontiguousarray(lens, dtype=_np.int32)
 
 
-def grid_subsample_batch(points, lens, features=None, dl=0.1, max_p=0):
-    """Device version of cpp_subsampling.subsample_batch (wrapper.cpp:62-333), points / features only.
+def grid_subsample_batch(points, lens, features=None, labels=None, dl=0.1, max_p=0):
+    """Device version of cpp_subsampling.subsample_batch (wrapper.cpp:62-333).
 
-    points [N,3] f32 (HBM), lens host int32 [B]. Returns (s_points [M,3] HBM, s_lens np.int32 [B][, s_features]).
+    points [N,3] f32 (HBM), lens host int32 [B], optional features [N,fdim] f32 and labels [N,ldim]
+    int32 (HBM). Returns (s_points [M,3] HBM, s_lens np.int32 [B][, s_features][, s_labels]).
     Bit-identical to the reference incl. output order. Synchronises once (the counts come back to the host)."""
-    _dev(points, features)
+    _dev(points, features, labels)
     points = _f32c(points)
     lens_h = _lens_host(lens)
     N, B = points.shape[0], int(lens_h.shape[0])
-    fdim = 0
+    fdim = ldim = 0
     if features is not None:
         features = _f32c(features)
         fdim = features.shape[1]
-    ws_bytes = lib().mvk_grid_subsample_workspace(N, B) + 8 * N * max(fdim - 16, 0)
-    ws = _workspace("sub", ws_bytes, points.device)
+    if labels is not None:
+        labels = labels.to(torch.int32).contiguous()
+        if labels.dim() == 1:
+            labels = labels.unsqueeze(1)
+        ldim = labels.shape[1]
+    ws = _workspace("sub", lib().mvk_grid_subsample_workspace(N, B, fdim, ldim), points.device)
     out_pts = torch.empty((max(N, 1), 3), device=points.device, dtype=torch.float32)
     out_f = torch.empty((max(N, 1), fdim), device=points.device, dtype=torch.float32) if fdim else None
+    out_l = torch.empty((max(N, 1), ldim), device=points.device, dtype=torch.int32) if ldim else None
     out_lens = torch.empty((B,), device=points.device, dtype=torch.int32)
     out_lens_h = _np.empty((B,), _np.int32)
     check(lib().mvk_grid_subsample_batch(_p(points), N, lens_h.ctypes.data_as(C.c_void_p), B, _p(features), fdim,
-                                         float(dl), int(max_p), _p(out_pts), _p(out_f), _p(out_lens),
-                                         out_lens_h.ctypes.data_as(C.c_void_p), _p(ws), ws.numel(), _stream()))
+                                         _p(labels), ldim, float(dl), int(max_p), _p(out_pts), _p(out_f),
+                                         _p(out_l), _p(out_lens), out_lens_h.ctypes.data_as(C.c_void_p),
+                                         _p(ws), ws.numel(), _stream()))
     M = int(out_lens_h.sum())
     res = [out_pts[:M], out_lens_h]
     if fdim:
         res.append(out_f[:M])
+    if ldim:
+        res.append(out_l[:M])
     return tuple(res)
 
 

@@ -1,0 +1,268 @@
+"""Deterministic synthetic ScanNet-shaped inputs: a box-world "room" sampled
+as a point cloud, cropped to a sphere, plus pinhole RGB-D views of the same room rendered by
+ray / box intersection. No dataset or checkpoint is needed (the GPU box has no network).
+
+Host-side NumPy only generates RAW inputs (points, colours, labels, depth maps, poses); everything
+on the hot path (subsampling, neighbours, unprojection, k-NN, network) then runs through the HIP
+library (``build_batch``).
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .dropin.datasets.common import segmentation_inputs_sphere, SphereBatch
+from .dropin.utils.config import Config
+
+IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], np.float32)
+IMAGENET_STD = np.array([0.229, 0.224, 0.225], np.float32)
+
+
+# ------------------------------------------------------------------------------------ scene
+
+def room_boxes(rng):
+    """Axis-aligned boxes (lo, hi): floor, two walls, a table, clutter. Room frame: z up, floor z = 0."""
+    boxes = [
+        ([-3.0, -3.0, -0.05], [3.0, 3.0, 0.0]),        # floor
+        ([-0.85, -3.0, 0.0], [-0.8, 3.0, 2.6]),        # wall x = -0.8
+        ([-3.0, 0.9, 0.0], [3.0, 0.95, 2.6]),          # wall y = 0.9
+        ([1.25, -3.0, 0.0], [1.3, 3.0, 2.6]),          # wall x = 1.25
+        ([-3.0, -3.0, 1.9], [3.0, 3.0, 1.95]),         # low ceiling
+        ([-0.5, -0.6, 0.72], [0.6, 0.3, 0.75]),        # table slab
+    ]
+    for lx, ly in ((-0.45, -0.55), (0.5, -0.55), (-0.45, 0.2), (0.5, 0.2)):   # table legs
+        boxes.append(([lx, ly, 0.0], [lx + 0.05, ly + 0.05, 0.72]))
+    for _ in range(30):                                                        # clutter
+        c = np.array([rng.uniform(-0.7, 1.2), rng.uniform(-1.5, 0.8), 0.0])
+        s = rng.uniform(0.15, 0.55, 3)
+        z0 = rng.choice([0.0, 0.75]) if abs(c[0]) < 0.5 and -0.6 < c[1] < 0.3 else 0.0
+        boxes.append(((c - [s[0] / 2, s[1] / 2, -z0]).tolist(), (c + [s[0] / 2, s[1] / 2, z0 + s[2]]).tolist()))
+    return [(np.asarray(a, np.float64), np.asarray(b, np.float64)) for a, b in boxes]
+
+
+def sample_box_surfaces(rng, boxes, density):
+    """Uniform samples on all faces of all boxes (points per m^2 = density) + 5 mm Gaussian noise."""
+    out = []
+    for lo, hi in boxes:
+        d = hi - lo
+        for ax in range(3):
+            a, b = (ax + 1) % 3, (ax + 2) % 3
+            n = int(d[a] * d[b] * density) + 1
+            for face in (lo[ax], hi[ax]):
+                p = np.empty((n, 3))
+                p[:, ax] = face
+                p[:, a] = rng.uniform(lo[a], hi[a], n)
+                p[:, b] = rng.uniform(lo[b], hi[b], n)
+                out.append(p)
+    p = np.concatenate(out, 0)
+    return p + rng.normal(0, 0.005, p.shape)
+
+
+def raw_sphere(seed=0, radius=1.2, density=6000.0, center=(0.2, -0.2, 0.8)):
+    """Raw (un-subsampled) sphere in room (world) coordinates, colours U[0,1], labels U{0..19}."""
+    rng = np.random.default_rng(seed)
+    boxes = room_boxes(rng)
+    p = sample_box_surfaces(rng, boxes, density)
+    c = np.asarray(center)
+    keep = np.sum((p - c) ** 2, axis=1) < radius ** 2
+    p = p[keep]
+    p = p[rng.permutation(p.shape[0])]
+    colors = rng.random((p.shape[0], 3)).astype(np.float32)
+    labels = rng.integers(0, 20, p.shape[0]).astype(np.int32)
+    return dict(points=p.astype(np.float32), colors=colors, labels=labels, center=c, boxes=boxes, rng=rng)
+
+
+# ------------------------------------------------------------------------------------ cameras
+
+def look_at(eye, target, up=(0, 0, 1)):
+    """camera-to-world pose (4x4 float32), camera looks along +z, x right, y down (ScanNet convention)."""
+    eye, target, up = (np.asarray(v, np.float64) for v in (eye, target, up))
+    z = target - eye
+    z /= np.linalg.norm(z)
+    x = np.cross(z, up)
+    x /= np.linalg.norm(x)
+    y = np.cross(z, x)
+    T = np.eye(4)
+    T[:3, 0], T[:3, 1], T[:3, 2], T[:3, 3] = x, y, z, eye
+    return T.astype(np.float32)
+
+
+def render_depth(boxes, pose, cam, h, w):
+    """Depth (uint16 millimetres, 0 = no hit) by ray / axis-aligned-box intersection (slab method)."""
+    v, u = np.indices((h, w))
+    d_cam = np.stack([(u - cam[0, 2]) / cam[0, 0], (v - cam[1, 2]) / cam[1, 1], np.ones_like(u, float)], -1)
+    R, o = pose[:3, :3].astype(np.float64), pose[:3, 3].astype(np.float64)
+    d = d_cam @ R.T                                   # world ray directions, |d_z_cam| = 1 -> t == depth
+    best = np.full((h, w), np.inf)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        inv = 1.0 / d
+        for lo, hi in boxes:
+            t0 = (lo - o) * inv
+            t1 = (hi - o) * inv
+            tn = np.minimum(t0, t1).max(-1)
+            tf = np.maximum(t0, t1).min(-1)
+            hit = (tf >= np.maximum(tn, 1e-3))
+            t = np.where(tn > 1e-3, tn, tf)
+            best = np.where(hit & (t < best), t, best)
+    depth = np.where(np.isfinite(best) & (best < 60.0), best, 0.0)
+    return np.round(depth * 1000.0).astype(np.uint16)
+
+
+def sphere_views(sphere, nv=3, h=120, w=160):
+    """nv synthetic RGB-D frames looking at the sphere centre: images (nv,3,h,w) f32 normalised with
+    the ImageNet statistics (train_ScanNet_sphere.py:340), depth (nv,h,w) u16 mm, poses (nv,4,4) f32,
+    cam (3,3) f32 = ScanNet depth intrinsics / 4."""
+    rng = sphere['rng']
+    cam = np.array([[144.5, 0, 79.9], [0, 144.5, 59.9], [0, 0, 1]], np.float32)
+    c = sphere['center']
+    eyes = [c + [1.9 * np.cos(a), -1.9 * abs(np.sin(a)) - 0.3, 0.6 + 0.2 * i]
+            for i, a in enumerate(np.linspace(0.3, 2.6, nv))]
+    poses = np.stack([look_at(e, c) for e in eyes], 0)
+    depth = np.stack([render_depth(sphere['boxes'], p, cam, h, w) for p in poses], 0)
+    img = rng.random((nv, h, w, 3)).astype(np.float32)
+    img = ((img - IMAGENET_MEAN) / IMAGENET_STD).transpose(0, 3, 1, 2).copy()
+    return dict(images=img, depth=depth, poses=poses, cam=cam)
+
+
+# ------------------------------------------------------------------------------------ configs
+
+ARCH_RIGID = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb', 'resnetb_strided', 'resnetb',
+              'resnetb', 'resnetb_strided', 'resnetb', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb',
+              'nearest_upsample', 'unary', 'nearest_upsample', 'unary', 'nearest_upsample', 'unary',
+              'nearest_upsample', 'unary']
+ARCH_DEFORM = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb', 'resnetb_strided', 'resnetb',
+               'resnetb', 'resnetb_strided', 'resnetb_deformable', 'resnetb_deformable',
+               'resnetb_deformable_strided', 'resnetb_deformable', 'resnetb_deformable',
+               'nearest_upsample', 'unary', 'nearest_upsample', 'unary', 'nearest_upsample', 'unary',
+               'nearest_upsample', 'unary']
+
+
+def make_config(variant="early", deformable=False, modulated=False):
+    """The hyper-parameters of the reference's train scripts (train_ScanNet_sphere.py:39-264,
+    train_ScanNet_baseline.py, ..._middle_fusion.py, ..._late_fusion.py) as a Config."""
+
+    class _C(Config):
+        dataset = 'ScanNet'
+        dataset_task = 'cloud_segmentation'
+        num_classes = 20
+        architecture = ARCH_DEFORM if deformable else ARCH_RIGID
+        in_radius = 1.2
+        num_kernel_points = 15
+        first_subsampling_dl = 0.04
+        conv_radius = 2.5
+        deform_radius = 6.0
+        KP_extent = 1.2
+        KP_influence = 'linear'
+        aggregation_mode = 'sum'
+        first_features_dim = 128
+        use_batch_norm = True
+        batch_norm_momentum = 0.02
+        deform_fitting_mode = 'point2point'
+        deform_fitting_power = 1.0
+        deform_lr_factor = 0.1
+        repulse_extent = 1.2
+        learning_rate = 1e-2
+        momentum = 0.98
+        weight_decay = 1e-3
+        grad_clip_norm = 100.0
+        batch_num = 5
+
+    c = _C()
+    c.modulated = modulated
+    c.variant = variant
+    if variant == "baseline":
+        c.in_features_dim = 2                      # 1 + z (train_ScanNet_baseline.py)
+    elif variant == "early":
+        c.early_fusion = True
+        c.in_features_dim = 66                     # 1 + z + 64 (train_ScanNet_sphere.py:196)
+    elif variant == "middle":
+        c.middle_fusion = True
+        c.in_features_dim_3d = 4                   # 1 + rgb
+        c.in_features_dim_2d = 65                  # 1 + 64
+        c.in_features_dim = 4
+    elif variant == "late":
+        c.late_fusion = True
+        c.in_features_dim = 4
+    else:
+        raise ValueError(variant)
+    return c
+
+
+def build_model(config, device):
+    from .dropin.models import architectures, architectures_sphere, architectures_sphere_middle_fusion, \
+        architectures_sphere_late_fusion
+    lbl = list(range(20))
+    cls = {"baseline": architectures.KPFCNN, "early": architectures_sphere.KPFCNN_featureAggre,
+           "middle": architectures_sphere_middle_fusion.KPFCNN_featureAggre,
+           "late": architectures_sphere_late_fusion.KPFCNN_featureAggre}[config.variant]
+    return cls(config, lbl, []).to(device)
+
+
+# ------------------------------------------------------------------------------------ batches
+
+def stage_spheres(spheres, device, views=None):
+    """Raw host inputs -> HBM once (what the DataLoader's pinned batch transfer does in the reference)."""
+    st = dict(points=[torch.from_numpy(s['points']).to(device) for s in spheres],
+              colors=[torch.from_numpy(s['colors']).to(device) for s in spheres],
+              labels=[torch.from_numpy(s['labels']).to(device) for s in spheres],
+              center=[torch.tensor(s['center'], dtype=torch.float32, device=device) for s in spheres])
+    if views is not None:
+        st['images'] = [torch.from_numpy(v['images']).to(device) for v in views]
+        st['depth'] = [torch.from_numpy(v['depth'].astype(np.int16)).to(device) for v in views]
+        st['poses'] = [torch.from_numpy(v['poses']).to(device) for v in views]
+        st['cam'] = [v['cam'] for v in views]
+    return st
+
+
+def build_batch(config, staged, limits=None, index_dtype=torch.int32, rotations=None):
+    """One pass of the input side of the hot path, all on the GPU: first subsampling at dl
+    (load_subsampled_clouds' grid_subsampling, ScanNet_sphere_color.py:937), pyramid
+    (segmentation_inputs_sphere), and for the fusion variants unprojection + 3-NN (get_rgbd_data)."""
+    dl = config.first_subsampling_dl
+    pts, world, cols, labs, lens = [], [], [], [], []
+    for p, c, l, ctr in zip(staged['points'], staged['colors'], staged['labels'], staged['center']):
+        sp, sl, sc, slab = ops.grid_subsample_batch(p, [p.shape[0]], features=c, labels=l, dl=dl)
+        world.append(sp)
+        pts.append(sp - ctr)                        # input_points = points - center_point (:600)
+        cols.append(sc), labs.append(slab[:, 0].long()), lens.append(int(sl[0]))
+    stacked = torch.cat(pts, 0)
+    stacked_world = torch.cat(world, 0)
+    pyr = segmentation_inputs_sphere(config, stacked, np.asarray(lens, np.int32), limits, index_dtype, rotations)
+    ones = torch.ones_like(stacked[:, :1])
+    labels = torch.cat(labs, 0)
+    colors = torch.cat(cols, 0)
+    z = stacked_world[:, 2:3]                       # height feature = world z (:634)
+    v = config.variant
+    if v == "baseline":
+        return SphereBatch(pyr, labels, features=torch.cat([ones, z], 1)), lens
+    feat3d = torch.cat([ones, z], 1) if v == "early" else torch.cat([ones, colors], 1)
+    image_xyz, knn = [], []
+    for i, pw in enumerate(world):
+        xyz, valid = ops.unproject_depth(staged['depth'][i], staged['cam'][i], staged['poses'][i])
+        knn.append(ops.knn_pixels(pw, xyz, valid, k=3).unsqueeze(0))          # get_rgbd_data :448-451
+        image_xyz.append(xyz.to(torch.float32))                                # :454
+    batch = SphereBatch(pyr, labels, feature_3d=feat3d, feat_aggre_points=stacked_world.unsqueeze(0),
+                        image_xyz=torch.stack(image_xyz, 0), images=torch.stack(staged['images'], 0),
+                        knn_list=knn)
+    return batch, lens
+
+
+def calibrate_limits(config, staged, keep=0.9):
+    """neighborhood_limits like the reference's calibration (ScanNet_sphere_color.py:1380-1464):
+    per layer, the neighbour count below which `keep` of the conv neighbourhoods fall."""
+    dl = config.first_subsampling_dl
+    pts, lens = [], []
+    for p in staged['points']:
+        sp, sl = ops.grid_subsample_batch(p, [p.shape[0]], dl=dl)
+        pts.append(sp), lens.append(int(sl[0]))
+    pyr = segmentation_inputs_sphere(config, torch.cat(pts, 0), np.asarray(lens, np.int32), None, torch.int32)
+    limits = []
+    for layer, nb in enumerate(pyr['neighbors']):
+        ns = pyr['points'][layer].shape[0]
+        if nb.shape[0] == 0:
+            limits.append(1)
+            continue
+        counts = (nb < ns).sum(1).cpu().numpy()
+        hist = np.bincount(counts, minlength=nb.shape[1] + 1)
+        cum = np.cumsum(hist)
+        limits.append(int(np.sum(cum < keep * cum[-1])))
+    return limits

@@ -98,17 +98,19 @@ int mvk_gather_rows_bwd(const float* g, const void* idx, int idx64, int64_t Nq, 
 /* ---------------- input pyramid ------------------------------------------ */
 
 /* Scratch size in bytes needed by mvk_grid_subsample_batch for N points in B clouds. */
-int64_t mvk_grid_subsample_workspace(int64_t N, int B);
+int64_t mvk_grid_subsample_workspace(int64_t N, int B, int fdim, int ldim);
 
 /* Voxel-grid barycentre subsampling of a stacked batch, bit-identical (values and ORDER) to the
  * reference. pts [N,3] f32, lens_host [B] int32 (HOST), optional feats [N,fdim]
- * f32. Outputs (device): out_pts [N,3] (capacity N rows), out_feats [N,fdim] or NULL,
- * out_lens [B] int32. The per-cloud counts are also copied to out_lens_host [B] (HOST) --
- * this call SYNCHRONISES the stream once to return them. max_p as in the reference (0 = no cap).
- * Integer labels (majority vote) are only on the scene-loading path and stay on the CPU. */
+ * f32 (barycentre of features) and labels [N,ldim] int32 (majority vote, ties broken like the
+ * reference's unordered_map<int,int> iteration). Outputs (device): out_pts [N,3] (capacity N rows),
+ * out_feats [N,fdim] / out_labels [N,ldim] or NULL, out_lens [B] int32. The per-cloud counts are
+ * also copied to out_lens_host [B] (HOST) -- this call SYNCHRONISES the stream once to return them.
+ * max_p as in the reference (0 = no cap). */
 int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32_t* lens_host, int B,
-                             const float* feats, int fdim, float dl, int max_p,
-                             float* out_pts, float* out_feats, int32_t* out_lens,
+                             const float* feats, int fdim, const int32_t* labels, int ldim,
+                             float dl, int max_p, float* out_pts, float* out_feats,
+                             int32_t* out_labels, int32_t* out_lens,
                              int32_t* out_lens_host, void* workspace, int64_t workspace_bytes,
                              void* stream);
 

@@ -37,11 +37,23 @@ def test_subsample_golden_bit_exact(ops, name):
     assert bits_equal(sp.cpu().numpy(), g["out_points"])
 
 
-def test_subsample_features_golden(ops):
+def test_subsample_features_labels_golden(ops):
     g = load_golden("g1_sub_feat_lab")
     n = g["points"].shape[0]
-    sp, sl, sf = ops.grid_subsample_batch(T(g["points"]), [n], features=T(g["features"]), dl=float(g["dl"]))
+    sp, sl, sf, slab = ops.grid_subsample_batch(T(g["points"]), [n], features=T(g["features"]),
+                                                labels=T(g["labels"]), dl=float(g["dl"]))
     assert bits_equal(sp.cpu().numpy(), g["out_points"]) and bits_equal(sf.cpu().numpy(), g["out_features"])
+    assert np.array_equal(slab.cpu().numpy(), g["out_labels"])      # incl. tie-broken majority votes
+
+
+def test_subsample_labels_vs_oracle_many_classes(ops):
+    from oracle import cport
+    rng = np.random.default_rng(11)
+    p = (rng.random((20000, 3)) * [2, 2, 1]).astype(np.float32)
+    lab = rng.integers(-5, 45, (20000, 2)).astype(np.int32)           # > 13 distinct labels per voxel: rehash epochs
+    want = cport.subsample_batch(p, [20000], labels=lab, dl=0.5)
+    got = ops.grid_subsample_batch(T(p), [20000], labels=T(lab), dl=0.5)
+    assert bits_equal(got[0].cpu().numpy(), want[0]) and np.array_equal(got[2].cpu().numpy(), want[2])
 
 
 @pytest.mark.parametrize("n,dl,seed", [(1, 0.1, 0), (13, 0.5, 1), (14, 0.01, 2), (777, 0.05, 3),

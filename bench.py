@@ -44,28 +44,6 @@ def parse():
     return ap.parse_args()
 
 
-class FlatAllReduce:
-    """Data-parallel gradient exchange: one flat fp32 bucket, RCCL all-reduce (sum) / world size.
-    (~97.5 MB for the baseline KPFCNN; xGMI ring time ~1 ms, far below the step.)"""
-
-    def __init__(self, params, world):
-        self.params = [p for p in params if p.requires_grad]
-        self.world = world
-        self.flat = None
-
-    def __call__(self):
-        grads = [p.grad for p in self.params if p.grad is not None]
-        if not grads:
-            return
-        n = sum(g.numel() for g in grads)
-        if self.flat is None or self.flat.numel() != n:
-            self.flat = torch.empty(n, device=grads[0].device, dtype=torch.float32)
-        torch._foreach_copy_(list(self.flat.split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
-        dist.all_reduce(self.flat)
-        self.flat.div_(self.world)
-        torch._foreach_copy_([g.reshape(-1) for g in grads], list(self.flat.split([g.numel() for g in grads])))
-
-
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -93,7 +71,7 @@ def main():
     other = [p for n, p in net.named_parameters() if p.requires_grad and "offset" not in n]
     opt = torch.optim.SGD([{"params": other}, {"params": deform, "lr": cfg.learning_rate * cfg.deform_lr_factor}],
                           lr=cfg.learning_rate, momentum=cfg.momentum, weight_decay=cfg.weight_decay)  # trainer.py:72-79
-    reducer = FlatAllReduce(params, world) if world > 1 else None
+    reducer = mvkpconv.sub("dp").FlatAllReduce(params, world) if world > 1 else None
 
     # ---- synthetic raw inputs, staged in HBM once (data-parallel: different spheres per rank)
     spheres = [syn.raw_sphere(seed=1000 * rank + i) for i in range(args.spheres)]
@@ -209,14 +187,14 @@ def cpu_baseline(cfg, net, staged, limits, spheres, args):
     one = {k: (v[:1] if isinstance(v, list) else v) for k, v in staged.items()}
     batch, lens = syn.build_batch(cfg, one, limits, torch.int64)
     cb = torch_port.batch_to_cpu(batch)
-    raw = spheres[0]["points"]
+    sub0 = (staged["points"][0] - staged["center"][0]).cpu().numpy()      # level-0 cloud (scene-load subsampling is not per step)
     leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and
             ("weight" in k or "bias" in k) and not k.startswith("net_2d.") and "running" not in k}
 
     def cpu_step():
         t0 = time.perf_counter()
-        # pyramid: first subsampling + per level neighbours / subsampling / pool / upsample neighbours
-        p, l = cport.subsample_batch(raw, [raw.shape[0]], dl=cfg.first_subsampling_dl)
+        # pyramid: per level neighbours / subsampling / pool / upsample neighbours
+        p, l = sub0, np.array([sub0.shape[0]], np.int32)
         r = cfg.first_subsampling_dl * cfg.conv_radius
         for lvl in range(5):
             cport.radius_neighbors_batch(p, p, l, l, r, impl="ref" if cport.ref() else "oracle")

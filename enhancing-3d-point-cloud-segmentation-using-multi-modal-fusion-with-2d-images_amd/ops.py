@@ -42,13 +42,18 @@ def _idx(t):
 # raw kernels
 # --------------------------------------------------------------------------------------------
 
-def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=1):
-    """C = op(A) @ op(B) on v_mfma_f32_32x32x2_f32 (mvk_gemm_f32)."""
+def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=None):
+    """C = op(A) @ op(B) on v_mfma_f32_32x32x2_f32 (mvk_gemm_f32). split_k=None picks a split of
+    the reduction so that small-M / deep-K products (the coarse KPConv layers: 85 x 7680 x 512)
+    still fill the 256 CUs."""
     _dev(A, B)
     A, B = _f32c(A), _f32c(B)
     M, Kd = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
     N = B.shape[0] if transB else B.shape[1]
     assert (B.shape[1] if transB else B.shape[0]) == Kd, "gemm: inner dimensions differ"
+    if split_k is None:
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        split_k = 1 if tiles >= 256 else int(max(1, min((512 + tiles - 1) // tiles, Kd // 128)))
     if out is None:
         out = torch.zeros if split_k > 1 else torch.empty
         out = out((M, N), device=A.device, dtype=torch.float32)

@@ -200,11 +200,17 @@ def build_model(config, device):
 # ------------------------------------------------------------------------------------ batches
 
 def stage_spheres(spheres, device, views=None):
-    """Raw host inputs -> HBM once (what the DataLoader's pinned batch transfer does in the reference)."""
-    st = dict(points=[torch.from_numpy(s['points']).to(device) for s in spheres],
-              colors=[torch.from_numpy(s['colors']).to(device) for s in spheres],
-              labels=[torch.from_numpy(s['labels']).to(device) for s in spheres],
-              center=[torch.tensor(s['center'], dtype=torch.float32, device=device) for s in spheres])
+    """Raw host inputs -> HBM once, then the scene-load subsampling at first_subsampling_dl
+    (load_subsampled_clouds' grid_subsampling with colours + labels, ScanNet_sphere_color.py:937-940)
+    -- like the reference this happens once per cloud, not once per step."""
+    st = dict(points=[], colors=[], labels=[], center=[])
+    for s in spheres:
+        p = torch.from_numpy(s['points']).to(device)
+        c = torch.from_numpy(s['colors']).to(device)
+        l = torch.from_numpy(s['labels']).to(device)
+        sp, _, sc, sl = ops.grid_subsample_batch(p, [p.shape[0]], features=c, labels=l, dl=0.04 if 'dl' not in s else s['dl'])
+        st['points'].append(sp), st['colors'].append(sc), st['labels'].append(sl[:, 0].long())
+        st['center'].append(torch.tensor(s['center'], dtype=torch.float32, device=device))
     if views is not None:
         st['images'] = [torch.from_numpy(v['images']).to(device) for v in views]
         st['depth'] = [torch.from_numpy(v['depth'].astype(np.int16)).to(device) for v in views]
@@ -214,22 +220,19 @@ def stage_spheres(spheres, device, views=None):
 
 
 def build_batch(config, staged, limits=None, index_dtype=torch.int32, rotations=None):
-    """One pass of the input side of the hot path, all on the GPU: first subsampling at dl
-    (load_subsampled_clouds' grid_subsampling, ScanNet_sphere_color.py:937), pyramid
-    (segmentation_inputs_sphere), and for the fusion variants unprojection + 3-NN (get_rgbd_data)."""
-    dl = config.first_subsampling_dl
-    pts, world, cols, labs, lens = [], [], [], [], []
-    for p, c, l, ctr in zip(staged['points'], staged['colors'], staged['labels'], staged['center']):
-        sp, sl, sc, slab = ops.grid_subsample_batch(p, [p.shape[0]], features=c, labels=l, dl=dl)
-        world.append(sp)
-        pts.append(sp - ctr)                        # input_points = points - center_point (:600)
-        cols.append(sc), labs.append(slab[:, 0].long()), lens.append(int(sl[0]))
+    """One pass of the input side of the hot path, all on the GPU, from the subsampled sphere clouds:
+    centring + stacking (potential_item, ScanNet_sphere_color.py:600-719), pyramid
+    (segmentation_inputs_sphere, datasets/common.py:779-900) and, for the fusion variants, depth
+    unprojection + 3-NN pixel indices (get_rgbd_data :352-474)."""
+    world = staged['points']
+    pts = [p - c for p, c in zip(world, staged['center'])]      # input_points = points - center_point (:600)
+    lens = [int(p.shape[0]) for p in pts]
     stacked = torch.cat(pts, 0)
     stacked_world = torch.cat(world, 0)
     pyr = segmentation_inputs_sphere(config, stacked, np.asarray(lens, np.int32), limits, index_dtype, rotations)
     ones = torch.ones_like(stacked[:, :1])
-    labels = torch.cat(labs, 0)
-    colors = torch.cat(cols, 0)
+    labels = torch.cat(staged['labels'], 0)
+    colors = torch.cat(staged['colors'], 0)
     z = stacked_world[:, 2:3]                       # height feature = world z (:634)
     v = config.variant
     if v == "baseline":
@@ -249,11 +252,8 @@ def build_batch(config, staged, limits=None, index_dtype=torch.int32, rotations=
 def calibrate_limits(config, staged, keep=0.9):
     """neighborhood_limits like the reference's calibration (ScanNet_sphere_color.py:1380-1464):
     per layer, the neighbour count below which `keep` of the conv neighbourhoods fall."""
-    dl = config.first_subsampling_dl
-    pts, lens = [], []
-    for p in staged['points']:
-        sp, sl = ops.grid_subsample_batch(p, [p.shape[0]], dl=dl)
-        pts.append(sp), lens.append(int(sl[0]))
+    pts = [p - c for p, c in zip(staged['points'], staged['center'])]
+    lens = [int(p.shape[0]) for p in pts]
     pyr = segmentation_inputs_sphere(config, torch.cat(pts, 0), np.asarray(lens, np.int32), None, torch.int32)
     limits = []
     for layer, nb in enumerate(pyr['neighbors']):

@@ -1,24 +1,22 @@
 """The slice of the reference's ``common.nn`` the fusion path uses (common/nn/modules/mlp.py:38-75,
 common/nn/modules/conv.py:29-51, common/nn/init.py:22-26). 1x1 convolutions and BatchNorm stay
 PyTorch-ROCm library ops (plain GEMMs)."""
+import warnings
+
 import torch
 from torch import nn
 
 
 def _bn_native(bn, x):
-    """nn.BatchNorm{1,2}d.forward with the library (MIOpen) path switched off: on this ROCm stack
-    MIOpen's training-mode spatial BatchNorm is only ~1e-3 accurate on the (1, C, np, k) tensors of
-    FeatureAggregation (measured 5e-3 abs vs 1e-6 for PyTorch's native kernel), which would break
-    the 1e-4 parity bar. Same running-stat bookkeeping as torch.nn.modules.batchnorm._BatchNorm."""
-    factor = 0.0 if bn.momentum is None else bn.momentum
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-        if bn.momentum is None:
-            factor = 1.0 / float(bn.num_batches_tracked)
-    use_batch_stats = bn.training or (bn.running_mean is None and bn.running_var is None)
-    rm = bn.running_mean if (not bn.training or bn.track_running_stats) else None
-    rv = bn.running_var if (not bn.training or bn.track_running_stats) else None
-    return torch.batch_norm(x, bn.weight, bn.bias, rm, rv, use_batch_stats, factor, bn.eps, False)
+    """BatchNorm with the MIOpen path switched off (PyTorch's native kernels instead): on this ROCm
+    stack MIOpen's training-mode spatial BatchNorm is only ~1e-3 accurate on the (1, C, np, k)
+    tensors of FeatureAggregation (measured 5e-3 abs error vs 1e-6 for the native kernel), which
+    would break the 1e-4 parity bar. (Passing cudnn_enabled=False to torch.batch_norm is not enough
+    on ROCm; the backend flag is what the dispatcher consults.)"""
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        with torch.backends.cudnn.flags(enabled=False):
+            return bn(x)
 
 
 class Conv1dBNReLU(nn.Module):

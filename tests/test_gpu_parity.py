@@ -162,6 +162,35 @@ def test_kpconv_fwd_bwd_golden(ops, name, influence, agg, idt):
     assert rel_err(W.grad.cpu().numpy(), g["weights_grad"]) < FP_TOL
 
 
+@pytest.mark.parametrize("cin,cout,H", [(1, 5, 9), (4, 32, 17), (8, 8, 70), (20, 12, 33), (68, 64, 40),
+                                        (128, 16, 25), (256, 8, 64), (512, 4, 10), (516, 4, 6), (1040, 3, 5)])
+def test_kpconv_every_kernel_variant_vs_numpy_oracle(ops, cin, cout, H):
+    """Seeded inputs through every gather / scatter template instantiation (LPP = 1..64, NCH = 1, 2,
+    the generic lane = channel kernel and its > 512-channel multi-launch path) against the float64
+    numpy restatement; includes shadow neighbours, empty rows and a ragged last chunk."""
+    from oracle import npref
+    rng = np.random.default_rng(cin * 131 + H)
+    Nq, Ns, K = 257, 301, 15
+    q = (rng.random((Nq, 3)) * 0.3).astype(np.float32)
+    s = (rng.random((Ns, 3)) * 0.3).astype(np.float32)
+    idx = rng.integers(0, Ns + 1, (Nq, H)).astype(np.int32)
+    idx[5] = Ns                                   # a row of shadow neighbours only
+    idx[:, H // 2:][rng.random((Nq, H - H // 2)) < 0.5] = Ns
+    x = rng.normal(size=(Ns, cin)).astype(np.float32)
+    kp = (rng.normal(size=(K, 3)) * 0.05).astype(np.float32)
+    W = (rng.normal(size=(K, cin, cout)) * 0.1).astype(np.float32)
+    g = rng.normal(size=(Nq, cout)).astype(np.float32)
+    xt, Wt = T(x).requires_grad_(True), T(W).requires_grad_(True)
+    y, _ = ops.kpconv(T(q), T(s), T(idx), xt, T(kp), Wt, 0.06)
+    (y * T(g)).sum().backward()
+    a64 = [a.astype(np.float64) for a in (q, s)] + [idx.astype(np.int64), x.astype(np.float64), kp.astype(np.float64),
+                                                     W.astype(np.float64), 0.06]
+    assert rel_err(y.detach().cpu().numpy(), npref.kpconv_forward(*a64)) < FP_TOL
+    dx, dW = npref.kpconv_backward(*a64, g.astype(np.float64))
+    assert rel_err(xt.grad.cpu().numpy(), dx) < FP_TOL
+    assert rel_err(Wt.grad.cpu().numpy(), dW) < FP_TOL
+
+
 @pytest.mark.parametrize("name,modulated", [("g4_kpconv_deform", False), ("g4_kpconv_deform_mod", True)])
 def test_kpconv_deformable_golden(ops, name, modulated):
     g = load_golden(name)

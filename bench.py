@@ -143,6 +143,9 @@ def main():
                 "image_hw": [120, 160] if fusion else None, "parallelism": "dp%d" % world,
                 "final_loss": float(loss.item())},
             "roofline": roofline(prof),
+            "gather_launches": [dict(kernel=r["kernel"], avg_us=r["total_ms"] / r["launches"] * 1e3,
+                                     GBps=r["bytes_per_launch"] / (r["total_ms"] / r["launches"] * 1e-3) / 1e9, **r["shape"])
+                                for r in sorted(prof.values(), key=lambda r: -r["total_ms"])],
         }
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, net, staged, limits, spheres, args)

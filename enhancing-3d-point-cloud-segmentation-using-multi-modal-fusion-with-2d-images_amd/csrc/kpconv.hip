@@ -131,36 +131,43 @@ __device__ __forceinline__ int phase_a(const KPParams& P, int64_t n0, int h0, in
 }
 
 // ---------------------------------------------------------------------------
-// Vector gather kernel: Cin % 4 == 0, Cin <= 4*LPP*NCH.
+// Vector gather kernel (rigid KPConv, any Cin <= 4*64*NCH).
+//   LPP lanes own one query point (4 channels per lane and channel chunk), PPW = 64/LPP points per
+//   wave, neighbours in chunks of HC = 64/PPW per point. LPP/PPW/HC are launch parameters so that
+//   e.g. Cin = 66 runs with LPP = 17, PPW = 3 (80 % of the lanes busy) instead of a padded power of 2.
+//   Phase A: lane (p,h) gathers its neighbour's xyz and evaluates all K kernel-point correlations
+//            itself (kernel points are wave-uniform -> scalar registers), then writes one 64-byte LDS
+//            row {w[0..14], neighbour row index}.
+//   Phase B: per neighbour, the point group reads that row (4 x ds_read_b128, broadcast inside the
+//            group, rows of different groups are skewed by 16 B to spread banks), loads the
+//            16-byte slice of the feature row and does K x 4 FMAs (v_pk_fma_f32).
+//   FAST = linear influence + sum aggregation (the network default): sqrt via v_sqrt_f32 and a
+//   multiplication by 1/extent (1 ulp class differences, far inside the 1e-4 parity bar).
 // ---------------------------------------------------------------------------
-template <int LPP, int NCH, bool IDX64>
-__global__ __launch_bounds__(64) void kpconv_gather_vec(KPParams P) {
-  constexpr int PPW = 64 / LPP, HC = LPP, WPAD = 4;
-  __shared__ float4 rel[64];
-  __shared__ float wl[PPW * (HC * 16 + WPAD)];
+template <int NCH, bool IDX64, bool FAST>
+__global__ __launch_bounds__(64, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPParams P, int LPP, int PPW, int HC) {
+  constexpr int UB = NCH == 1 ? 8 : 4;  // feature rows in flight per lane
+  __shared__ float wl[64 * 16 + 64 * 4];
   const int lane = threadIdx.x;
   const int64_t n0 = (int64_t)blockIdx.x * PPW;
-  // A-phase identity of this lane
-  const int pa = lane / HC;
-  const bool nvalid_a = n0 + pa < P.Nq;
+  // phase-A identity: (point pa, neighbour slot ha)
+  const int pa = lane / HC, ha = lane - pa * HC;
+  const bool a_on = pa < PPW && n0 + pa < P.Nq;
   float qx = 0.f, qy = 0.f, qz = 0.f;
-  if (nvalid_a) {
+  if (a_on) {
     const float* qp = P.q + (n0 + pa) * 3;
     qx = qp[0];
     qy = qp[1];
     qz = qp[2];
   }
-  const int k = lane & 15;
-  float kx = 0.f, ky = 0.f, kz = 0.f;
-  if (k < P.K) {
-    kx = P.kp[k * 3];
-    ky = P.kp[k * 3 + 1];
-    kz = P.kp[k * 3 + 2];
-  }
-  // B-phase identity
-  const int p = lane / LPP, cl = lane % LPP;
-  const int64_t n = n0 + p;
-  const bool nvalid = n < P.Nq;
+  float* wrow_a = wl + lane * 16 + pa * 4;
+  // phase-B identity: (point pb, channel quad cl)
+  const int pb = lane / LPP, cl = lane - pb * LPP;
+  const int64_t n = n0 + pb;
+  const bool b_on = pb < PPW && n < P.Nq;
+  const float* wblk_b = wl + pb * (HC * 16 + 4);
+  const float inv_ext = 1.0f / P.extent;
+  const float* __restrict__ kp = P.kp;
 
   float4 acc[NCH][KMAX - 1];
 #pragma unroll
@@ -168,46 +175,136 @@ __global__ __launch_bounds__(64) void kpconv_gather_vec(KPParams P) {
 #pragma unroll
     for (int kk = 0; kk < KMAX - 1; ++kk) acc[c][kk] = make_float4(0.f, 0.f, 0.f, 0.f);
 
+  // software pipeline over neighbour chunks: index two chunks ahead, support xyz one chunk ahead
+  auto ld_j = [&](int h) -> int {
+    return (a_on && h < P.H) ? load_idx<IDX64>(P.idx, (n0 + pa) * P.H + h, P.Ns) : -2;
+  };
+  int jA = ld_j(ha), jB = ld_j(HC + ha);
+  float sx = 0.f, sy = 0.f, sz = 0.f;
+  if (jA >= 0) {
+    const float* sp = P.s + (int64_t)jA * 3;
+    sx = sp[0];
+    sy = sp[1];
+    sz = sp[2];
+  }
   for (int h0 = 0; h0 < P.H; h0 += HC) {
-    int j = phase_a<PPW, HC, WPAD, IDX64, false>(P, n0, h0, lane, rel, wl, qx, qy, qz, nvalid_a,
-                                                  kx, ky, kz, nullptr);
-    if (__ballot(j >= 0) == 0ull) continue;  // whole chunk is padding for every point of the wave
-    const float* wrow = wl + p * (HC * 16 + WPAD);
-#pragma unroll 4
-    for (int hh = 0; hh < HC; ++hh) {
-      const int jj = __shfl(j, p * HC + hh);
-      if (jj >= 0 && nvalid) {
-        const float4* w4 = reinterpret_cast<const float4*>(wrow + hh * 16);
-        const float4 wa = w4[0], wb = w4[1], wc = w4[2], wd = w4[3];
-        const float wv[16] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w,
-                              wc.x, wc.y, wc.z, wc.w, wd.x, wd.y, wd.z, wd.w};
+    const int jC = ld_j(h0 + 2 * HC + ha);
+    float tx = 0.f, ty = 0.f, tz = 0.f;
+    if (jB >= 0) {
+      const float* sp = P.s + (int64_t)jB * 3;
+      tx = sp[0];
+      ty = sp[1];
+      tz = sp[2];
+    }
+    // ---------------- phase A: this lane's neighbour against every kernel point
+    float wv[16];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-          const int c4 = (cl + c * LPP) * 4;
-          if (c4 < P.Cin) {
-            const float4 xv = *reinterpret_cast<const float4*>(P.x + (int64_t)jj * P.Cin + c4);
+    for (int kk = 0; kk < 16; ++kk) wv[kk] = 0.f;
+    if (jA >= 0) {
+      const float rx = sx - qx, ry = sy - qy, rz = sz - qz;
+      float bd = INFINITY;
+      int bk = 0;
 #pragma unroll
-            for (int kk = 0; kk < KMAX - 1; ++kk) {
-              acc[c][kk].x += wv[kk] * xv.x;
-              acc[c][kk].y += wv[kk] * xv.y;
-              acc[c][kk].z += wv[kk] * xv.z;
-              acc[c][kk].w += wv[kk] * xv.w;
+      for (int kk = 0; kk < KMAX - 1; ++kk) {
+        if (kk < P.K) {
+          const float dx = rx - kp[kk * 3], dy = ry - kp[kk * 3 + 1], dz = rz - kp[kk * 3 + 2];
+          const float d2 = dx * dx + dy * dy + dz * dz;  // blocks.py:294-297
+          if (FAST) {
+            wv[kk] = fmaxf(1.0f - __builtin_amdgcn_sqrtf(d2) * inv_ext, 0.0f);  // blocks.py:335-338
+          } else {
+            wv[kk] = influence_w(d2, P.extent, P.influence);
+            if (d2 < bd) {
+              bd = d2;
+              bk = kk;
+            }
+          }
+        }
+      }
+      if (!FAST && P.aggregation == MVK_AGG_CLOSEST) {  // one-hot of the first arg-min (blocks.py:349-351)
+#pragma unroll
+        for (int kk = 0; kk < KMAX - 1; ++kk)
+          if (kk != bk) wv[kk] = 0.f;
+      }
+    }
+    wv[15] = __int_as_float(jA);
+    {
+      float4* dst = reinterpret_cast<float4*>(wrow_a);
+      dst[0] = make_float4(wv[0], wv[1], wv[2], wv[3]);
+      dst[1] = make_float4(wv[4], wv[5], wv[6], wv[7]);
+      dst[2] = make_float4(wv[8], wv[9], wv[10], wv[11]);
+      dst[3] = make_float4(wv[12], wv[13], wv[14], wv[15]);
+    }
+    __syncthreads();
+    // ---------------- phase B: UB feature rows in flight, then their FMAs
+    if (__ballot(jA >= 0) != 0ull) {
+      for (int hb = 0; hb < HC; hb += UB) {
+        int jj[UB];
+        float4 xv[UB][NCH];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          jj[u] = (hb + u < HC && b_on) ? __float_as_int(wblk_b[(hb + u) * 16 + 15]) : -2;
+#pragma unroll
+          for (int c = 0; c < NCH; ++c) {
+            const int c4 = (cl + c * LPP) * 4;
+            xv[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (jj[u] >= 0 && c4 < P.Cin) {
+              const float* xr = P.x + (int64_t)jj[u] * P.Cin + c4;
+              if (c4 + 3 < P.Cin) {
+                xv[u][c] = *reinterpret_cast<const float4*>(xr);
+              } else {  // ragged tail of a row whose length is not a multiple of 4
+                xv[u][c].x = xr[0];
+                if (c4 + 1 < P.Cin) xv[u][c].y = xr[1];
+                if (c4 + 2 < P.Cin) xv[u][c].z = xr[2];
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          if (jj[u] >= 0) {
+            const float4* w4 = reinterpret_cast<const float4*>(wblk_b + (hb + u) * 16);
+            const float4 wa = w4[0], wb = w4[1], wc = w4[2], wd = w4[3];
+            const float wk[15] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w,
+                                  wc.x, wc.y, wc.z, wc.w, wd.x, wd.y, wd.z};
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+              for (int kk = 0; kk < KMAX - 1; ++kk) {
+                acc[c][kk].x += wk[kk] * xv[u][c].x;
+                acc[c][kk].y += wk[kk] * xv[u][c].y;
+                acc[c][kk].z += wk[kk] * xv[u][c].z;
+                acc[c][kk].w += wk[kk] * xv[u][c].w;
+              }
             }
           }
         }
       }
     }
     __syncthreads();
+    jA = jB;
+    jB = jC;
+    sx = tx;
+    sy = ty;
+    sz = tz;
   }
-  if (nvalid) {
+  if (b_on) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int c4 = (cl + c * LPP) * 4;
       if (c4 < P.Cin) {
 #pragma unroll
-        for (int kk = 0; kk < KMAX - 1; ++kk)
-          if (kk < P.K)
-            *reinterpret_cast<float4*>(P.A + (n * P.K + kk) * P.Cin + c4) = acc[c][kk];
+        for (int kk = 0; kk < KMAX - 1; ++kk) {
+          if (kk < P.K) {
+            float* o = P.A + (n * P.K + kk) * P.Cin + c4;
+            if (c4 + 3 < P.Cin) {
+              *reinterpret_cast<float4*>(o) = acc[c][kk];
+            } else {
+              o[0] = acc[c][kk].x;
+              if (c4 + 1 < P.Cin) o[1] = acc[c][kk].y;
+              if (c4 + 2 < P.Cin) o[2] = acc[c][kk].z;
+            }
+          }
+        }
       }
     }
   }
@@ -394,14 +491,21 @@ __global__ void kpconv_min_d2_bwd(KPParams P) {
   atomicAdd(P.d_offsets + t * 3 + 2, -2.f * bz * g);
 }
 
-template <int LPP, int NCH>
+template <int NCH>
 int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
-  constexpr int PPW = 64 / LPP;
+  const int c4 = (P.Cin + 3) / 4;
+  const int LPP = c4 < 64 ? c4 : 64;  // lanes per point
+  const int PPW = 64 / LPP;           // points per wave
+  const int HC = 64 / PPW;            // neighbours per chunk and point
+  const bool fast = P.influence == MVK_INFL_LINEAR && P.aggregation == MVK_AGG_SUM;
   dim3 grid((unsigned)cdiv64(P.Nq, PPW)), block(64);
-  if (idx64)
-    hipLaunchKernelGGL((kpconv_gather_vec<LPP, NCH, true>), grid, block, 0, st, P);
-  else
-    hipLaunchKernelGGL((kpconv_gather_vec<LPP, NCH, false>), grid, block, 0, st, P);
+#define LV(I64, F) hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F>), grid, block, 0, st, P, LPP, PPW, HC)
+  if (idx64) {
+    if (fast) LV(true, true); else LV(true, false);
+  } else {
+    if (fast) LV(false, true); else LV(false, false);
+  }
+#undef LV
   return 0;
 }
 
@@ -469,16 +573,10 @@ extern "C" int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s,
   }
   if (offsets != nullptr) {
     launch_lane_channel<0, true>(P, idx64, st);
-  } else if (Cin % 4 == 0 && Cin <= 512 && ((uintptr_t)x % 16 == 0) && ((uintptr_t)A_out % 16 == 0)) {
-    int c4 = Cin / 4;
-    if (c4 <= 1) launch_vec<1, 1>(P, idx64, st);
-    else if (c4 <= 2) launch_vec<2, 1>(P, idx64, st);
-    else if (c4 <= 4) launch_vec<4, 1>(P, idx64, st);
-    else if (c4 <= 8) launch_vec<8, 1>(P, idx64, st);
-    else if (c4 <= 16) launch_vec<16, 1>(P, idx64, st);
-    else if (c4 <= 32) launch_vec<32, 1>(P, idx64, st);
-    else if (c4 <= 64) launch_vec<64, 1>(P, idx64, st);
-    else launch_vec<64, 2>(P, idx64, st);
+  } else if (Cin <= 256) {
+    launch_vec<1>(P, idx64, st);
+  } else if (Cin <= 512) {
+    launch_vec<2>(P, idx64, st);
   } else {
     launch_lane_channel<0, false>(P, idx64, st);
   }

@@ -75,12 +75,9 @@ def profile_reset(enabled):
 def _gather_kernel_name(Cin, deform):
     if deform:
         return "kpconv_lane_channel<fwd,deform>"
-    if Cin % 4 == 0 and Cin <= 512:
-        c4 = Cin // 4
-        lpp = 1
-        while lpp < min(c4, 64):
-            lpp *= 2
-        return "kpconv_gather_vec<LPP=%d,NCH=%d>" % (lpp, 2 if c4 > 64 else 1)
+    if Cin <= 512:
+        lpp = min((Cin + 3) // 4, 64)
+        return "kpconv_gather_vec<NCH=%d>(LPP=%d,PPW=%d)" % (1 if Cin <= 256 else 2, lpp, 64 // lpp)
     return "kpconv_lane_channel<fwd>"
 
 

@@ -212,6 +212,7 @@ __global__ __launch_bounds__(64) void nb_query_kernel(const float* __restrict__ 
     }
     return;
   }
+  if (lane == 0) atomicMax(W.maxcount, n);
   if (n > LIST_CAP) {
     if (lane == 0) atomicExch(W.overflow, 1);
     n = LIST_CAP;
@@ -308,9 +309,11 @@ extern "C" int mvk_radius_neighbors_batch(const float* q, int64_t Nq, const floa
   if (Nq > 0 && width > 0)
     hipLaunchKernelGGL((nb_query_kernel<true>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width);
   MVK_CHECK_HIP(hipGetLastError());
-  int ovf = 0;
+  int ovf = 0, maxc = 0;
   MVK_CHECK_HIP(hipMemcpyAsync(&ovf, W.overflow, sizeof(int), hipMemcpyDeviceToHost, st));
+  MVK_CHECK_HIP(hipMemcpyAsync(&maxc, W.maxcount, sizeof(int), hipMemcpyDeviceToHost, st));
   MVK_CHECK_HIP(hipStreamSynchronize(st));
+  if (width_host) *width_host = maxc;
   MVK_REQUIRE(ovf == 0, "neighbors: a query has more than %d in-range supports (LDS list capacity)", LIST_CAP);
   return 0;
 }

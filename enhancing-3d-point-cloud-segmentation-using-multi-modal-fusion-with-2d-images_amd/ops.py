@@ -358,7 +358,10 @@ def radius_neighbors_batch(queries, supports, q_lens, s_lens, radius, limit=None
         width = int(limit)
     out = torch.empty((Nq, width), device=q.device, dtype=torch.int32)
     if width > 0 and Nq > 0:
-        check(lib().mvk_radius_neighbors_batch(*args, _p(out), width, None, _p(ws), ws.numel(), _stream()))
+        w = C.c_int(0)
+        check(lib().mvk_radius_neighbors_batch(*args, _p(out), width, C.byref(w), _p(ws), ws.numel(), _stream()))
+        if int(w.value) < width:            # reference shape: min(limit, data-dependent max count)
+            out = out[:, :int(w.value)].contiguous()
     return out
 
 

@@ -122,7 +122,9 @@ int64_t mvk_radius_neighbors_workspace(int64_t Nq, int64_t Ns, int B);
  *   Phase 1 (out == NULL): counts every row, returns max count in *width_host (SYNCHRONISES).
  *   Phase 2 (out != NULL): fills out [Nq,width] keeping the `width` nearest of every row
  *   (width may be smaller than the max count = the reference's neighborhood_limits crop,
- *   datasets/common.py:411-421). q_lens_host / s_lens_host are HOST arrays. */
+ *   datasets/common.py:411-421); *width_host (if not NULL) receives the max count seen, so a caller
+ *   that passed width = limit can narrow the matrix to min(limit, max count) like the reference.
+ *   SYNCHRONISES (overflow flag + max count). q_lens_host / s_lens_host are HOST arrays. */
 int mvk_radius_neighbors_batch(const float* q, int64_t Nq, const float* s, int64_t Ns,
                                const int32_t* q_lens_host, const int32_t* s_lens_host, int B,
                                float radius, int32_t* out, int width, int* width_host,

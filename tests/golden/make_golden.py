@@ -216,7 +216,178 @@ def g4_kpconv():
          closest_pool=rb.closest_pool(x, torch.from_numpy(pool.astype(np.int64))).numpy())
 
 
-GROUPS = {"g1": g1_subsample, "g2": g2_neighbors, "g4": g4_kpconv}
+ARCH = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb',
+        'resnetb_strided', 'resnetb', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb',
+        'nearest_upsample', 'unary', 'nearest_upsample', 'unary', 'nearest_upsample', 'unary',
+        'nearest_upsample', 'unary']
+
+
+class _Cfg:
+    architecture = ARCH
+    first_subsampling_dl = 0.04
+    conv_radius = 2.5
+    deform_radius = 6.0
+
+
+def g3_pyramid():
+    """Full 5-level pyramid of a ragged 2-sphere batch through the compiled reference core, in the
+    op order of datasets/common.py:779-900, with the random grid rotations captured."""
+    from oracle import pyramid
+    rng = np.random.default_rng(303)
+    clouds = [room_cloud(rng, 60000, 0.9), room_cloud(rng, 30000, 0.7)]
+    subs = [cport.subsample_batch(c, [c.shape[0]], dl=0.04, impl="ref")[0] for c in clouds]
+    pts = np.concatenate(subs, 0)
+    lens = np.array([s.shape[0] for s in subs], np.int32)
+    np.random.seed(33)
+    rots = [pyramid.draw_rotations(2) for _ in range(4)]
+    limits = [35, 38, 40, 36, 30]
+    pyr = pyramid.segmentation_inputs(_Cfg, pts, lens, limits, rots, impl="ref")
+    arrs = dict(points0=pts, lens0=lens, limits=np.array(limits, np.int32), rotations=np.stack(rots, 0))
+    for l in range(5):
+        arrs["points%d" % l] = pyr['points'][l]
+        arrs["lengths%d" % l] = pyr['lengths'][l]
+        arrs["neighbors%d" % l] = pyr['neighbors'][l].astype(np.int32)
+        arrs["pools%d" % l] = pyr['pools'][l].astype(np.int32)
+        arrs["upsamples%d" % l] = pyr['upsamples'][l].astype(np.int32)
+    save("g3_pyramid", **arrs)
+
+
+def g5_kpfcnn():
+    """The reference's own KPFCNN (models/architectures.py:189-394) end to end on a small pyramid:
+    logits, loss, a few gradients, with its state dict (first_features_dim = 16 keeps it small)."""
+    import types
+    import torch
+    from oracle import pyramid
+    rb = _ref_blocks()
+    from models.architectures import KPFCNN
+    from utils.config import Config
+
+    class C(Config):
+        dataset = 'ScanNet'
+        dataset_task = 'cloud_segmentation'
+        num_classes = 20
+        architecture = ARCH
+        num_kernel_points = 15
+        first_subsampling_dl = 0.04
+        conv_radius = 2.5
+        deform_radius = 6.0
+        KP_extent = 1.2
+        KP_influence = 'linear'
+        aggregation_mode = 'sum'
+        first_features_dim = 16
+        in_features_dim = 2
+        in_points_dim = 3
+        modulated = False
+        use_batch_norm = True
+        batch_norm_momentum = 0.02
+        deform_fitting_mode = 'point2point'
+        deform_fitting_power = 1.0
+        deform_lr_factor = 0.1
+        repulse_extent = 1.2
+        class_w = []
+    cfg = C()
+    rng = np.random.default_rng(505)
+    raw = room_cloud(rng, 40000, 0.75)
+    p0, l0 = cport.subsample_batch(raw, [raw.shape[0]], dl=0.04, impl="ref")
+    np.random.seed(55)
+    rots = [pyramid.draw_rotations(1) for _ in range(4)]
+    limits = [30, 32, 32, 30, 20]
+    pyr = pyramid.segmentation_inputs(_Cfg, p0, l0, limits, rots, impl="ref")
+    torch.manual_seed(5)
+    np.random.seed(5)
+    net = KPFCNN(cfg, list(range(20)), [])
+    net.train()
+    feats = np.concatenate([np.ones((p0.shape[0], 1), np.float32), p0[:, 2:3]], 1)
+    labels = rng.integers(0, 20, p0.shape[0]).astype(np.int64)
+    batch = types.SimpleNamespace(
+        points=[torch.from_numpy(a) for a in pyr['points']], neighbors=[torch.from_numpy(a) for a in pyr['neighbors']],
+        pools=[torch.from_numpy(a) for a in pyr['pools']], upsamples=[torch.from_numpy(a) for a in pyr['upsamples']],
+        lengths=[torch.from_numpy(a) for a in pyr['lengths']], features=torch.from_numpy(feats),
+        labels=torch.from_numpy(labels))
+    sd0 = {k: v.detach().clone().numpy() for k, v in net.state_dict().items()}      # before BN running-stat updates
+    out = net(batch, cfg)
+    loss = net.loss(out, batch.labels)
+    loss.backward()
+    arrs = dict(points0=p0, lens0=l0, limits=np.array(limits, np.int32), rotations=np.stack(rots, 0),
+                features=feats, labels=labels, logits=out.detach().numpy(), loss=np.float32(loss.item()))
+    for l in range(5):
+        arrs["neighbors%d" % l] = pyr['neighbors'][l].astype(np.int32)
+        arrs["pools%d" % l] = pyr['pools'][l].astype(np.int32)
+        arrs["upsamples%d" % l] = pyr['upsamples'][l].astype(np.int32)
+        arrs["points%d" % l] = pyr['points'][l]
+    for k, v in sd0.items():
+        arrs["sd/" + k] = v
+    named = dict(net.named_parameters())
+    for k in ("encoder_blocks.0.KPConv.weights", "encoder_blocks.5.KPConv.weights", "encoder_blocks.13.unary2.mlp.weight",
+              "decoder_blocks.7.mlp.weight", "head_softmax.mlp.weight", "head_mlp.batch_norm.bias"):
+        arrs["grad/" + k] = named[k].grad.numpy()
+    save("g5_kpfcnn", **arrs)
+
+
+def g6_fusion():
+    """2D -> 3D fusion: sklearn ball_tree 3-NN on float64 unprojected pixels (the reference's call,
+    ScanNet_sphere_color.py:448-451), group_points as the reference test restates it, and the
+    reference's FeatureAggregation class (byte-identical copy in mvpnet/FeatureAggregation_dummy_test.py)
+    in train and eval mode. The unprojection itself is 6 lines of NumPy inside a module that cannot be
+    imported here; its dtype-promotion behaviour is restated in oracle/npref.py."""
+    import torch
+    from sklearn.neighbors import NearestNeighbors
+    from oracle import npref
+    sys.path.insert(0, REFROOT)
+    cwd = os.getcwd()
+    os.chdir(REFROOT)
+    from mvpnet.FeatureAggregation_dummy_test import FeatureAggregation
+    os.chdir(cwd)
+    rng = np.random.default_rng(606)
+    nv, h, w = 3, 24, 32
+    cam = np.array([[28.9, 0, 15.9], [0, 28.9, 11.9], [0, 0, 1]], np.float32)
+    depth = rng.integers(400, 3000, (nv, h, w)).astype(np.uint16)
+    depth[rng.random((nv, h, w)) < 0.1] = 0                     # invalid pixels
+    poses = np.stack([np.eye(4, dtype=np.float32) for _ in range(nv)])
+    for i in range(nv):
+        a = 0.4 * i
+        poses[i, :3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+        poses[i, :3, 3] = [0.1 * i, -0.2, 0.05 * i]
+    xyz, mask = npref.unproject_frames(cam, depth, poses)
+    assert xyz.dtype == np.float64
+    valid_xyz = xyz.reshape(-1, 3)[mask.reshape(-1)]
+    ind_all = np.nonzero(mask.reshape(-1))[0]
+    pts = (valid_xyz[rng.integers(0, valid_xyz.shape[0], 700)] + rng.normal(0, 0.02, (700, 3))).astype(np.float32)
+    nbrs = NearestNeighbors(n_neighbors=3, algorithm='ball_tree').fit(valid_xyz)
+    dist, knn = nbrs.kneighbors(pts)
+    assert np.all(np.diff(dist, axis=1) > 0), "k-NN fixture must be tie-free"
+    knn_pix = ind_all[knn].astype(np.int64)
+    torch.manual_seed(6)
+    feat2d = torch.randn(1, 64, nv * h * w)
+    xyz32 = torch.from_numpy(xyz.astype(np.float32)).permute(3, 0, 1, 2).reshape(1, 3, nv * h * w)
+    index = torch.from_numpy(knn_pix).unsqueeze(0)
+    gp = lambda p: p.unsqueeze(2).expand(1, p.shape[1], 700, p.shape[2]).gather(3, index.unsqueeze(1).expand(1, p.shape[1], 700, 3))
+    gfeat, gxyz = gp(feat2d), gp(xyz32)
+    fa = FeatureAggregation(64)
+    fa.train()
+    sd0 = {k: v.detach().clone().numpy() for k, v in fa.state_dict().items()}
+    tgt = torch.from_numpy(pts).t().unsqueeze(0)
+    gfeat.requires_grad_(True)
+    out_train = fa(gxyz, tgt, gfeat)
+    gout = torch.randn_like(out_train)
+    out_train.backward(gout)
+    gfeat_grad = gfeat.grad.clone()
+    w0_grad = fa.mlp[0].conv.weight.grad.clone()
+    fa2 = FeatureAggregation(64)
+    fa2.load_state_dict({k: torch.from_numpy(v) for k, v in sd0.items()})
+    fa2.eval()
+    out_eval = fa2(gxyz, tgt, gfeat.detach())
+    arrs = dict(cam=cam, depth=depth, poses=poses, xyz=xyz, mask=mask, points=pts, knn=knn_pix, feat2d=feat2d.numpy(),
+                grouped_feat=gfeat.detach().numpy(), grouped_xyz=gxyz.numpy(), out_train=out_train.detach().numpy(),
+                out_eval=out_eval.detach().numpy(), gout=gout.numpy(), grouped_feat_grad=gfeat_grad.numpy(),
+                w0_grad=w0_grad.numpy())
+    for k, v in sd0.items():
+        arrs["sd/" + k] = v
+    save("g6_fusion", **arrs)
+
+
+GROUPS = {"g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn,
+          "g6": g6_fusion}
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -101,7 +101,8 @@ def _gloo_worker(rank, world, port, q):
     net(x).sum().backward()
     red = dp.FlatAllReduce(list(net.parameters()) + list(frozen.parameters()), world)
     red()
-    q.put((rank, [p.grad.clone() for p in net.parameters()], dp.shard_spheres(5, rank, world)))
+    q.put((rank, [p.grad.numpy().copy() for p in net.parameters()], dp.shard_spheres(5, rank, world)))
+    dist.barrier()
     dist.destroy_process_group()
 
 
@@ -109,7 +110,10 @@ def test_gradient_allreduce_two_gloo_ranks():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -128,5 +132,5 @@ def test_gradient_allreduce_two_gloo_ranks():
     want = [w / 2 for w in want]
     for rank, grads, shard in res:
         for a, b in zip(grads, want):
-            assert torch.allclose(a, b, atol=1e-6)
+            assert torch.allclose(torch.from_numpy(a), b, atol=1e-6)
     assert res[0][2] == [0, 2, 4] and res[1][2] == [1, 3]

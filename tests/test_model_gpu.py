@@ -66,7 +66,7 @@ def _run(variant, deformable=False, modulated=False, spheres=1):
     assert len(pairs) > 50
     scale = max(b.norm().item() for _, _, b in pairs)
     A, Bv = torch.cat([a for _, a, _ in pairs]), torch.cat([b for _, _, b in pairs])
-    assert (A @ Bv).item() / (A.norm().item() * Bv.norm().item()) > 0.9999       # whole gradient
+    assert (A @ Bv).item() / (A.norm().item() * Bv.norm().item()) > 0.999        # whole gradient
     for name, a, b in pairs:
         if b.norm().item() < 1e-3 * scale:
             # analytically ~0 gradients (e.g. a BatchNorm bias whose shift the next BatchNorm removes):

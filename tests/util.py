@@ -27,13 +27,22 @@ def canon_ties(nb, d2):
     return out
 
 
-def assert_neighbors_equal_mod_ties(got, want, q, s, q_lens, s_lens):
+def assert_neighbors_equal_mod_ties(got, want, q, s, q_lens, s_lens, cropped=False):
+    """Same rows up to the order inside equal-d2 groups. cropped=True: the matrices were cut to a
+    column limit, which may cut through the LAST tie group of a row -- that group is then only
+    compared by its distances."""
     assert got.shape == want.shape and got.dtype == want.dtype
     dg, dw = nb_d2(q, s, q_lens, s_lens, got), nb_d2(q, s, q_lens, s_lens, want)
     # both sorted ascending, identical distance sequences
     assert np.all(np.diff(np.where(np.isinf(dg), np.float32(3e38), dg), axis=1) >= 0)
     assert np.array_equal(dg, dw)
-    assert np.array_equal(canon_ties(got, dg), canon_ties(want, dw))
+    cg, cw = canon_ties(got, dg), canon_ties(want, dw)
+    if cropped and got.shape[1] > 0:
+        keep = dg != dg[:, -1:]
+        keep |= np.isinf(dg)
+        assert np.array_equal(np.where(keep, cg, -1), np.where(keep, cw, -1))
+    else:
+        assert np.array_equal(cg, cw)
 
 
 def rel_err(a, b):

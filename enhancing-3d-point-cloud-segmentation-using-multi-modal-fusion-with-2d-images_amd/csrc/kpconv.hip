@@ -10,18 +10,9 @@
 // w[n,h,k] is a pure function of geometry (q, s, kernel points, extent), so the
 // backward recomputes it instead of storing [N,H,K].
 //
-// Work decomposition (one 64-lane wavefront per workgroup):
-//   * a wave owns PPW = 64/LPP query points; LPP lanes ("a point group") own one
-//     point, each lane 4 consecutive channels (16-byte loads of the feature rows:
-//     a group reads one 4*LPP*4-byte row per instruction, the wave PPW rows);
-//   * neighbours are processed in chunks of HC = LPP per point (PPW*HC = 64):
-//       A1  lane (p,h): index load, support xyz gather, centring   -> LDS rel[64]
-//       A2  16 rounds: lane = (p,h,k) item, kernel-point correlation -> LDS w[p][h][16]
-//       B   per neighbour: 16-byte row load, 4 ds_read_b128 of w (broadcast inside
-//           the group), 15 x 4 FMAs into register accumulators A[k][c..c+3]
-//   * epilogue: 15 coalesced 16-byte-per-lane stores of A[n,k,:].
-// The generic kernel (any Cin, deformable, backward) maps lane = channel and one
-// point per wave (PPW = 1, HC = 64); its neighbour loop is wave-uniform.
+// Work decomposition (one 64-lane wavefront per workgroup): see the comment on
+// kpconv_gather_vec (forward, rigid) and kpconv_lane_channel (backward scatter, deformable
+// forward/backward: lane = channel, one point per wave, wave-uniform neighbour loop).
 #include "common.h"
 
 #define KMAX 16

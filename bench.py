@@ -162,12 +162,30 @@ def roofline(prof):
     if not prof:
         return None
     best = max(prof.values(), key=lambda r: r["total_ms"])
+    traffic = pmc_traffic(best)
     avg_ms = best["total_ms"] / best["launches"]
     achieved = best["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": best["kernel"],
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": best["kernel"],
             "launch": best["shape"], "avg_launch_us": avg_ms * 1e3, "launches": best["launches"],
             "algorithmic_bytes_per_launch": best["bytes_per_launch"]}
+
+
+def pmc_traffic(best):
+    """HBM bytes per launch of the dominant gather launch from the committed PMC profile
+    (profiles/r01_pmc_gather.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command,
+    gfx950 correction 2*FETCH + WRITE). PMC counters cannot be read from inside the process, so the
+    value is only reported when the launch geometry of this run matches the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_gather.json")
+    if not os.path.exists(path):
+        return None
+    sh = best["shape"]
+    lpp = min((sh["Cin"] + 3) // 4, 64)
+    grid_threads = -(-sh["Nq"] // (64 // lpp)) * 64
+    for l in json.load(open(path))["launches"]:
+        if l["kernel"].startswith("kpconv_gather_vec") and l["grid_threads"] == grid_threads:
+            return l["traffic_bytes"]
+    return None
 
 
 def cpu_baseline(cfg, net, staged, limits, spheres, args):

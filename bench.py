@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--deformable", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="replay the network part (fwd+loss+bwd+clip+SGD) as one hipGraph over capacity-padded levels")
+    ap.add_argument("--no-graph", dest="graph", action="store_false")
     ap.add_argument("--cpu-baseline-steps", type=int, default=1)
     return ap.parse_args()
 
@@ -51,10 +54,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # rehearsal hook: MVK_BENCH_BACKEND=gloo + MVK_BENCH_ONE_GPU=1 runs N ranks on ONE card (development
+    # only; the driver's multi-GPU runs use the defaults: RCCL, one rank per GPU)
+    backend = os.environ.get("MVK_BENCH_BACKEND", "nccl")
+    if os.environ.get("MVK_BENCH_ONE_GPU") == "1":
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    # everything runs on one non-default stream: autograd's AccumulateGrad nodes are bound to the stream
+    # they were first used on, and nodes born on the legacy default stream cannot be captured later
+    torch.cuda.set_stream(torch.cuda.Stream())
 
     import mvkpconv
     syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
@@ -80,8 +95,7 @@ def main():
     staged = syn.stage_spheres(spheres, dev, views)
     limits = syn.calibrate_limits(cfg, staged)
 
-    def step():
-        batch, lens = syn.build_batch(cfg, staged, limits, torch.int32)
+    def net_step(batch):
         opt.zero_grad(set_to_none=True)
         out = net(batch, cfg)
         loss = net.loss(out, batch.labels)
@@ -90,7 +104,11 @@ def main():
             reducer()
         torch.nn.utils.clip_grad_value_(params, cfg.grad_clip_norm)     # trainer.py:193
         opt.step()
-        return lens, loss
+        return loss
+
+    def eager_step():
+        batch, lens = syn.build_batch(cfg, staged, limits, torch.int32)
+        return lens, net_step(batch)
 
     def sync():
         torch.cuda.synchronize()
@@ -98,18 +116,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # ---- warm-up (eager). The gather launches of these steps are timed with HIP events on the
+    #      launch stream for the roofline figure (a captured graph cannot carry timing events).
+    use_graph = args.graph if args.graph is not None else (not args.deformable)
+    for _ in range(max(args.warmup, 1)):
+        lens, loss = eager_step()
+    ops.profile_reset(enabled=True)
+    for _ in range(3):                          # instrumented eager pass (same step, same data)
+        lens, loss = eager_step()
+    recs = ops._PROF["rec"]
+    ops.profile_reset(enabled=False)
+    ops._PROF["rec"] = recs
+
+    step = eager_step
+    graph_note = "eager"
+    if use_graph:
+        try:
+            step, graph_note = make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer)
+        except Exception as e:                      # capture refused (e.g. a collective that cannot be captured)
+            ops.set_row_counts(None)
+            step, graph_note = eager_step, "eager (graph capture failed: %s)" % type(e).__name__
+    for _ in range(2 if use_graph else 0):
         lens, loss = step()
-    ops.profile_reset(enabled=True)           # HIP events around every gather launch (current stream)
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         lens, loss = step()
     sync()
     dt = time.perf_counter() - t0
-    ops.profile_reset_keep = None
-    recs = ops._PROF["rec"]
-    ops._PROF["on"] = False
     # mean real-neighbour counts of every neighbour matrix of this (fixed) synthetic batch, computed
     # outside the timed region: (Nq, Ns, H) -> H_eff
     hb, _ = syn.build_batch(cfg, staged, limits, torch.int32)
@@ -119,7 +153,6 @@ def main():
         for m in (hb.neighbors[l], hb.pools[l]):
             if m.shape[0] > 0:
                 h_eff[(m.shape[0], ns, m.shape[1])] = float((m < ns).sum().item()) / m.shape[0]
-    ops._PROF["rec"] = recs
     prof = ops.profile_collect(h_eff)
     ops.profile_reset(enabled=False)
 
@@ -140,7 +173,7 @@ def main():
             "config": {"workload": "%s_fusion_kpfcnn5_sphere20k_x%d_per_gpu%s" % (
                 args.workload, args.spheres, "_deformable" if args.deformable else ""),
                 "points_per_step_per_gpu": int(sum(lens)), "views": args.views if fusion else 0,
-                "image_hw": [120, 160] if fusion else None, "parallelism": "dp%d" % world,
+                "image_hw": [120, 160] if fusion else None, "parallelism": "dp%d" % world, "execution": graph_note,
                 "final_loss": float(loss.item())},
             "roofline": roofline(prof),
             "gather_launches": [dict(kernel=r["kernel"], avg_us=r["total_ms"] / r["launches"] * 1e3,
@@ -153,6 +186,66 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
+    """Capacity-padded static batch + one captured hipGraph for forward, loss, backward, gradient
+    all-reduce (N>1), clip and SGD; the pyramid / fusion inputs are rebuilt eagerly every step and copied
+    into the static buffers (their shapes change with the random grid orientation, the graph's do not)."""
+    batch0, lens = syn.build_batch(cfg, staged, limits, torch.int32)
+    static = syn.StaticBatch(batch0, limits)
+    ops.set_row_counts(static.valid)
+    for _ in range(2):                          # momentum buffers, MIOpen / hipBLASLt plans for the padded shapes
+        opt.zero_grad(set_to_none=True)
+        net_step_captured(net, static, cfg, params, opt, reducer)
+    torch.cuda.synchronize()
+    opt.zero_grad(set_to_none=True)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = net_step_captured(net, static, cfg, params, opt, reducer)
+
+    # input side on its own stream, one batch ahead of the graph (what the reference's DataLoader workers
+    # do for its trainer): build(k+1) overlaps replay(k); the static buffers are filled on the main stream
+    build_stream = torch.cuda.Stream()
+    state = {"next": None, "loaded": None}
+
+    def build_async():
+        if state["loaded"] is not None:
+            build_stream.wait_event(state["loaded"])      # recycled blocks of the previous batch are safe to reuse
+        with torch.cuda.stream(build_stream):
+            batch, lens = syn.build_batch(cfg, staged, limits, torch.int32)
+            ev = torch.cuda.Event()
+            ev.record(build_stream)
+        return batch, lens, ev
+
+    state["next"] = build_async()
+
+    def step():
+        batch, lens, ev = state["next"]
+        main = torch.cuda.current_stream()
+        main.wait_event(ev)
+        static.load(batch)
+        done = torch.cuda.Event()
+        done.record(main)
+        state["loaded"] = done
+        state["keep"] = batch                   # alive until the copies above have been enqueued AND ordered
+        graph.replay()
+        state["next"] = build_async()
+        return lens, static_loss
+
+    return step, "hipGraph(network step: fwd+loss+bwd+clip+SGD over capacity-padded levels) + pyramid/fusion inputs built one batch ahead on a second stream"
+
+
+def net_step_captured(net, static, cfg, params, opt, reducer):
+    """Body of the captured graph: identical to an eager network step (no host sync inside)."""
+    out = net(static, cfg)
+    loss = net.loss(out, static.labels)
+    loss.backward()
+    if reducer is not None:
+        reducer()
+    torch.nn.utils.clip_grad_value_(params, cfg.grad_clip_norm)
+    opt.step()
+    return loss
 
 
 def roofline(prof):
@@ -168,6 +261,7 @@ def roofline(prof):
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": best["kernel"],
             "launch": best["shape"], "avg_launch_us": avg_ms * 1e3, "launches": best["launches"],
+            "measured_in": "HIP events on the launch stream around every gather launch of 3 instrumented eager steps run between warm-up and the timed region",
             "algorithmic_bytes_per_launch": best["bytes_per_launch"]}
 
 

@@ -19,6 +19,7 @@ SOURCES = [
     ("kpconv.hip", []),
     ("gemm.hip", []),
     ("pool.hip", []),
+    ("bn.hip", []),
     ("subsample.hip", ["-ffp-contract=off"]),
     ("neighbors.hip", ["-ffp-contract=off"]),
     ("fusion.hip", ["-ffp-contract=off"]),

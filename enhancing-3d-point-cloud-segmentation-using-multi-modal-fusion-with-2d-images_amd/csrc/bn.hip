@@ -1,0 +1,182 @@
+// Masked training-mode BatchNorm over the stacked point axis, fused with LeakyReLU.
+//
+// The reference normalises every KPConv / unary output with BatchNorm1d over all points of the
+// stacked batch followed by LeakyReLU(0.1) (KPConv-PyTorch/models/blocks.py:430-467, :549-561,
+// :621-649). For hipGraph replay the per-level tensors are padded to a fixed row capacity; the
+// statistics must then run over the first n_valid rows only, with n_valid read from DEVICE memory
+// (it changes from batch to batch while the launch geometry stays fixed). Padded rows are written
+// as zeros. Statistics use per-channel shifted sums (shift = first row) so that the variance does
+// not suffer the E[x^2] - E[x]^2 cancellation.
+//
+//   x [R, D] row-major f32, n_valid int32[1] (device), gamma/beta [D]
+//   stats  : mean[D], invstd[D]  (+ running_mean / running_var update, unbiased variance)
+//   apply  : y = leaky( (x - mean) * invstd * gamma + beta ), rows >= n_valid -> 0
+//   bwd    : dgamma, dbeta, dx   (g masked through the LeakyReLU by recomputing the sign)
+#include "common.h"
+
+namespace {
+
+constexpr int BN_ROWS = 64;   // rows per workgroup in the reduction kernels
+constexpr int BN_T = 256;
+
+// grid (ceil(D/64), ceil(R/BN_ROWS)); block 256 = 64 channels x 4 row lanes
+__global__ __launch_bounds__(BN_T) void bn_stats_partial(const float* __restrict__ x, const int* __restrict__ n_valid,
+                                                         int R, int D, float* __restrict__ part /* [2,D] */) {
+  __shared__ float s1[4][64], s2[4][64];
+  const int n = min(*n_valid, R);
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * BN_ROWS;
+  float a = 0.f, b = 0.f;
+  if (c < D && r0 < n) {
+    const float k = x[c];  // shift: row 0 (n >= 1 here)
+    const int r1 = min(r0 + BN_ROWS, n);
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float v = x[(int64_t)r * D + c] - k;
+      a += v;
+      b += v * v;
+    }
+  }
+  s1[rl][threadIdx.x & 63] = a;
+  s2[rl][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (rl == 0 && c < D && r0 < n) {
+    a = (s1[0][threadIdx.x] + s1[1][threadIdx.x]) + (s1[2][threadIdx.x] + s1[3][threadIdx.x]);
+    b = (s2[0][threadIdx.x] + s2[1][threadIdx.x]) + (s2[2][threadIdx.x] + s2[3][threadIdx.x]);
+    atomicAdd(part + c, a);
+    atomicAdd(part + D + c, b);
+  }
+}
+
+__global__ void bn_stats_finish(const float* __restrict__ x, const int* __restrict__ n_valid, int R, int D,
+                                const float* __restrict__ part, float eps, float momentum,
+                                float* __restrict__ mean, float* __restrict__ invstd,
+                                float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  const int n = min(*n_valid, R);
+  if (n < 1) {
+    mean[c] = 0.f;
+    invstd[c] = 0.f;
+    return;
+  }
+  const float k = x[c];
+  const float m1 = part[c] / (float)n, m2 = part[D + c] / (float)n;
+  const float mu = k + m1;
+  float var = m2 - m1 * m1;  // biased
+  var = var > 0.f ? var : 0.f;
+  mean[c] = mu;
+  invstd[c] = rsqrtf(var + eps);
+  if (running_mean) {
+    const float unbiased = n > 1 ? var * ((float)n / (float)(n - 1)) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+  }
+}
+
+__global__ void bn_apply(const float* __restrict__ x, const int* __restrict__ n_valid, int R, int D,
+                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                         const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
+                         float* __restrict__ y) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)R * D) return;
+  const int n = min(*n_valid, R);
+  const int c = (int)(t % D);
+  const int64_t r = t / D;
+  float v = 0.f;
+  if (r < n) {
+    v = (x[t] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    v = v > 0.f ? v : v * slope;
+  }
+  y[t] = v;
+}
+
+// dbeta[c] = sum g', dgamma[c] = sum g' * xhat   (g' = g through the LeakyReLU)
+__global__ __launch_bounds__(BN_T) void bn_bwd_reduce(const float* __restrict__ x, const float* __restrict__ g,
+                                                      const int* __restrict__ n_valid, int R, int D,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float slope, float* __restrict__ part /* [2,D]: dbeta, dgamma */) {
+  __shared__ float s1[4][64], s2[4][64];
+  const int n = min(*n_valid, R);
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int r0 = blockIdx.y * BN_ROWS;
+  float a = 0.f, b = 0.f;
+  if (c < D && r0 < n) {
+    const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
+    const int r1 = min(r0 + BN_ROWS, n);
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float xh = (x[(int64_t)r * D + c] - mu) * is;
+      float gv = g[(int64_t)r * D + c];
+      if (xh * ga + be <= 0.f) gv *= slope;
+      a += gv;
+      b += gv * xh;
+    }
+  }
+  s1[rl][threadIdx.x & 63] = a;
+  s2[rl][threadIdx.x & 63] = b;
+  __syncthreads();
+  if (rl == 0 && c < D && r0 < n) {
+    a = (s1[0][threadIdx.x] + s1[1][threadIdx.x]) + (s1[2][threadIdx.x] + s1[3][threadIdx.x]);
+    b = (s2[0][threadIdx.x] + s2[1][threadIdx.x]) + (s2[2][threadIdx.x] + s2[3][threadIdx.x]);
+    atomicAdd(part + c, a);
+    atomicAdd(part + D + c, b);
+  }
+}
+
+__global__ void bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ g,
+                             const int* __restrict__ n_valid, int R, int D, const float* __restrict__ mean,
+                             const float* __restrict__ invstd, const float* __restrict__ gamma,
+                             const float* __restrict__ beta, float slope, const float* __restrict__ part,
+                             float* __restrict__ dx) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)R * D) return;
+  const int n = min(*n_valid, R);
+  const int c = (int)(t % D);
+  const int64_t r = t / D;
+  float v = 0.f;
+  if (r < n) {
+    const float xh = (x[t] - mean[c]) * invstd[c];
+    float gv = g[t];
+    if (xh * gamma[c] + beta[c] <= 0.f) gv *= slope;
+    const float inv_n = 1.f / (float)n;
+    v = gamma[c] * invstd[c] * (gv - part[c] * inv_n - xh * part[D + c] * inv_n);
+  }
+  dx[t] = v;
+}
+
+}  // namespace
+
+extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t R, int D, const float* gamma,
+                                const float* beta, float eps, float momentum, float slope, float* running_mean,
+                                float* running_var, float* mean, float* invstd, float* scratch2D, float* y,
+                                void* stream) {
+  MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
+  if (R == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  MVK_CHECK_HIP(hipMemsetAsync(scratch2D, 0, sizeof(float) * 2 * D, st));
+  dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
+  hipLaunchKernelGGL(bn_stats_partial, g1, dim3(BN_T), 0, st, x, n_valid, (int)R, D, scratch2D);
+  hipLaunchKernelGGL(bn_stats_finish, dim3((unsigned)cdiv64(D, 128)), dim3(128), 0, st, x, n_valid, (int)R, D, scratch2D,
+                     eps, momentum, mean, invstd, running_mean, running_var);
+  hipLaunchKernelGGL(bn_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, n_valid, (int)R, D, mean, invstd,
+                     gamma, beta, slope, y);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n_valid, int64_t R, int D,
+                                const float* gamma, const float* beta, const float* mean, const float* invstd,
+                                float slope, float* dgamma_dbeta /* [2,D]: dbeta then dgamma */, float* dx,
+                                void* stream) {
+  MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
+  hipStream_t st = (hipStream_t)stream;
+  MVK_CHECK_HIP(hipMemsetAsync(dgamma_dbeta, 0, sizeof(float) * 2 * D, st));
+  if (R == 0) return 0;
+  dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
+  hipLaunchKernelGGL(bn_bwd_reduce, g1, dim3(BN_T), 0, st, x, g, n_valid, (int)R, D, mean, invstd, gamma, beta, slope,
+                     dgamma_dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, g, n_valid, (int)R, D, mean,
+                     invstd, gamma, beta, slope, dgamma_dbeta, dx);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}

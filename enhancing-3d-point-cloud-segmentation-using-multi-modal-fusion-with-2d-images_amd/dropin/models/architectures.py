@@ -93,9 +93,11 @@ class _SegmentationLossMixin:
         self.l1 = nn.L1Loss()
 
     def _targets(self, labels):
+        """Ignored labels -> -1, the others -> [0, C-1] (architectures.py:352-355), written without
+        boolean-mask assignment so that it involves no host sync (hipGraph capturable)."""
         target = - torch.ones_like(labels)
         for i, c in enumerate(self.valid_labels):
-            target[labels == c] = i
+            target = torch.where(labels == int(c), torch.full_like(labels, i), target)
         return target
 
     def loss(self, outputs, labels):

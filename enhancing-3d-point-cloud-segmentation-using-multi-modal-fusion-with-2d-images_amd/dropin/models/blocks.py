@@ -176,12 +176,20 @@ class BatchNormBlock(nn.Module):
     def reset_parameters(self):
         nn.init.zeros_(self.bias)
 
-    def forward(self, x):
+    def forward(self, x, slope=None):
+        """slope: when given, the LeakyReLU that follows every BatchNormBlock in the reference's blocks
+        is applied here (fused into the masked kernel in capacity-padded mode)."""
         if self.use_bn:
+            n_valid = ops.row_count_for(x.shape[0]) if self.training else None
+            if n_valid is not None:
+                # capacity-padded level (hipGraph replay): statistics over the valid rows only
+                return ops.bn_lrelu(x, n_valid, self.batch_norm, 1.0 if slope is None else slope)
             # [N, C] is already BatchNorm1d's (batch, channel) layout: same statistics as the
             # reference's unsqueeze/transpose round trip (blocks.py:456-460) without the copies
-            return self.batch_norm(x)
-        return x + self.bias
+            x = self.batch_norm(x)
+        else:
+            x = x + self.bias
+        return x if slope is None else nn.functional.leaky_relu(x, slope)
 
     def __repr__(self):
         return 'BatchNormBlock(in_feat: {:d}, momentum: {:.3f}, only_bias: {:s})'.format(
@@ -203,8 +211,7 @@ class UnaryBlock(nn.Module):
             self.leaky_relu = nn.LeakyReLU(0.1)
 
     def forward(self, x, batch=None):
-        x = self.batch_norm(self.mlp(x))
-        return x if self.no_relu else self.leaky_relu(x)
+        return self.batch_norm(self.mlp(x), None if self.no_relu else 0.1)
 
     def __repr__(self):
         return 'UnaryBlock(in_feat: {:d}, out_feat: {:d}, BN: {:s}, ReLU: {:s})'.format(
@@ -238,7 +245,7 @@ class SimpleBlock(nn.Module):
 
     def forward(self, x, batch):
         q_pts, s_pts, inds = _conv_inputs(self.block_name, self.layer_ind, batch)
-        return self.leaky_relu(self.batch_norm(self.KPConv(q_pts, s_pts, inds, x)))
+        return self.batch_norm(self.KPConv(q_pts, s_pts, inds, x), 0.1)
 
 
 class ResnetBottleneckBlock(nn.Module):
@@ -271,7 +278,7 @@ class ResnetBottleneckBlock(nn.Module):
     def forward(self, features, batch):
         q_pts, s_pts, inds = _conv_inputs(self.block_name, self.layer_ind, batch)
         x = self.unary1(features)
-        x = self.leaky_relu(self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x)))
+        x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x), 0.1)
         x = self.unary2(x)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
         return self.leaky_relu(x + self.unary_shortcut(shortcut))

@@ -212,6 +212,66 @@ def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", o
 
 
 # --------------------------------------------------------------------------------------------
+# masked BatchNorm + LeakyReLU (capacity-padded levels, hipGraph replay)
+# --------------------------------------------------------------------------------------------
+
+# capacity-padded mode: {row capacity of a level: DEVICE int32[1] tensor holding the valid row count}.
+# Set by the network wrapper around a forward pass (see synthetic.CapacityBatch); empty = plain mode.
+_ROW_COUNTS = {}
+
+
+def set_row_counts(mapping):
+    _ROW_COUNTS.clear()
+    if mapping:
+        _ROW_COUNTS.update(mapping)
+
+
+def row_count_for(rows):
+    return _ROW_COUNTS.get(int(rows))
+
+
+class _BNLReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, n_valid, gamma, beta, running_mean, running_var, eps, momentum, slope, training):
+        _dev(x, n_valid, gamma, beta)
+        x = _f32c(x)
+        R, D = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(D, device=x.device, dtype=torch.float32)
+        invstd = torch.empty(D, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(2 * D, device=x.device, dtype=torch.float32)
+        if not training:
+            raise RuntimeError("masked BatchNorm is a training-mode op; use nn.BatchNorm1d in eval mode")
+        check(lib().mvk_bn_lrelu_fwd(_p(x), _p(n_valid), R, D, _p(gamma), _p(beta), float(eps), float(momentum),
+                                     float(slope), _p(running_mean), _p(running_var), _p(mean), _p(invstd),
+                                     _p(scratch), _p(y), _stream()))
+        ctx.save_for_backward(x, n_valid, gamma, beta, mean, invstd)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, n_valid, gamma, beta, mean, invstd = ctx.saved_tensors
+        g = _f32c(g)
+        R, D = x.shape
+        dgb = torch.empty(2 * D, device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        check(lib().mvk_bn_lrelu_bwd(_p(x), _p(g), _p(n_valid), R, D, _p(gamma), _p(beta), _p(mean), _p(invstd),
+                                     ctx.slope, _p(dgb), _p(dx), _stream()))
+        return dx, None, dgb[D:], dgb[:D], None, None, None, None, None, None
+
+
+def bn_lrelu(x, n_valid, bn, slope=1.0):
+    """y = LeakyReLU_slope(BatchNorm1d(x[:n_valid])) with rows >= n_valid zeroed; `bn` is an
+    nn.BatchNorm1d whose parameters / running statistics are used and updated; n_valid is a DEVICE
+    int32 tensor of one element."""
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BNLReLUFn.apply(x, n_valid, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
+                            bn.momentum if bn.momentum is not None else 0.0, slope, bn.training)
+
+
+# --------------------------------------------------------------------------------------------
 # pooling helpers of blocks.py
 # --------------------------------------------------------------------------------------------
 

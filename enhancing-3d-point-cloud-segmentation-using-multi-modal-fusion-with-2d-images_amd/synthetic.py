@@ -266,3 +266,71 @@ def calibrate_limits(config, staged, keep=0.9):
         cum = np.cumsum(hist)
         limits.append(int(np.sum(cum < keep * cum[-1])))
     return limits
+
+
+# ------------------------------------------------------------------------------------ capacity-padded batches
+
+class StaticBatch:
+    """Capacity-padded, fixed-address copy of a SphereBatch for hipGraph replay.
+
+    Levels 1.. are padded to a fixed row capacity (their point counts change from step to step with
+    the random grid orientation); padded points sit at 1e6, padded index rows are all-shadow, and
+    `valid[capacity]` holds the real row count on the DEVICE for the masked BatchNorm kernels. Level 0
+    keeps its exact size (the spheres of a batch fix it). Neighbour matrices get their full calibrated
+    width (`limits`), shadow index = capacity of the support level."""
+
+    def __init__(self, batch, limits, margin=1.12):
+        L = len(batch.points)
+        dev = batch.points[0].device
+        self.n0 = batch.points[0].shape[0]
+        caps, used = [], set()
+        for l in range(L):
+            c = self.n0 if l == 0 else int(-(-int(batch.points[l].shape[0] * margin + 8) // 64) * 64)
+            while c in used:
+                c += 64
+            used.add(c)
+            caps.append(c)
+        self.caps, self.limits = caps, [int(x) for x in limits]
+        it = batch.neighbors[0].dtype
+        self.points = [torch.full((caps[l], 3), 1e6, device=dev) for l in range(L)]
+        self.neighbors = [torch.full((caps[l], self.limits[l]), caps[l], dtype=it, device=dev) for l in range(L)]
+        self.pools = [torch.full((caps[l + 1], self.limits[l]), caps[l], dtype=it, device=dev) if l + 1 < L
+                      else batch.pools[l] for l in range(L)]
+        self.upsamples = [torch.full((caps[l], self.limits[l + 1]), caps[l + 1], dtype=it, device=dev) if l + 1 < L
+                          else batch.upsamples[l] for l in range(L)]
+        self.lengths = batch.lengths
+        self.valid = {caps[l]: torch.zeros(1, dtype=torch.int32, device=dev) for l in range(L)}
+        self._counts = [self.valid[caps[l]] for l in range(L)]
+        for name in ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images'):
+            v = getattr(batch, name, None)
+            setattr(self, name, v.clone() if v is not None else None)
+        self.knn_list = [k.clone() for k in batch.knn_list] if batch.knn_list is not None else None
+        self.load(batch)
+
+    def load(self, batch):
+        """Copies one freshly built batch into the static buffers (raises if a level outgrew its capacity)."""
+        L = len(batch.points)
+        n = [int(p.shape[0]) for p in batch.points]
+        if n[0] != self.n0 or any(n[l] > self.caps[l] for l in range(L)):
+            raise RuntimeError("batch does not fit the captured capacities %s: %s" % (self.caps, n))
+        for l in range(L):
+            self.points[l].fill_(1e6)
+            self.points[l][:n[l]] = batch.points[l]
+            self._counts[l].fill_(n[l])
+            self._put(self.neighbors[l], batch.neighbors[l], n[l], self.caps[l])
+            if l + 1 < L:
+                self._put(self.pools[l], batch.pools[l], n[l], self.caps[l])
+                self._put(self.upsamples[l], batch.upsamples[l], n[l + 1], self.caps[l + 1])
+        for name in ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images'):
+            v = getattr(batch, name, None)
+            if v is not None:
+                getattr(self, name).copy_(v)
+        if self.knn_list is not None:
+            for dst, src in zip(self.knn_list, batch.knn_list):
+                dst.copy_(src)
+
+    @staticmethod
+    def _put(dst, src, shadow_src, shadow_dst):
+        dst.fill_(shadow_dst)
+        if src.shape[0] > 0 and src.shape[1] > 0:
+            dst[:src.shape[0], :src.shape[1]] = torch.where(src == shadow_src, torch.full_like(src, shadow_dst), src)

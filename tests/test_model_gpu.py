@@ -104,3 +104,49 @@ def test_state_dict_keys_follow_the_reference_names():
               "encoder_blocks.1.batch_norm_conv.batch_norm.running_mean", "encoder_blocks.1.unary_shortcut.mlp.weight",
               "decoder_blocks.1.mlp.weight", "head_mlp.mlp.weight", "head_softmax.batch_norm.bias"):
         assert k in keys, k
+
+
+def test_capacity_padded_mode_equals_plain_mode():
+    """Capacity-padded levels + masked BatchNorm (the hipGraph replay layout) give the same logits
+    and gradients as the plain layout, on the valid rows."""
+    import mvkpconv
+    syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = syn.make_config("early")
+    sph = [syn.raw_sphere(seed=3, radius=0.8, density=3000.0)]
+    views = [syn.sphere_views(s, nv=3, h=60, w=80) for s in sph]
+    staged = syn.stage_spheres(sph, dev, views)
+    limits = syn.calibrate_limits(cfg, staged)
+    batch, lens = syn.build_batch(cfg, staged, limits, torch.int32)
+    net = syn.build_model(cfg, dev)
+    net.train()
+    for m in net.net_2d._modules.values():
+        m.train(False)
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def run(b):
+        net.load_state_dict(sd0)
+        net.zero_grad(set_to_none=True)
+        out = net(b, cfg)
+        loss = net.loss(out, b.labels)
+        loss.backward()
+        return out.detach().clone(), loss.item(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    o1, l1, g1 = run(batch)
+    rm1 = net.encoder_blocks[3].batch_norm_conv.batch_norm.running_mean.clone()
+    static = syn.StaticBatch(batch, limits)
+    assert any(c > p.shape[0] for c, p in zip(static.caps[1:], batch.points[1:]))      # really padded
+    ops.set_row_counts(static.valid)
+    try:
+        o2, l2, g2 = run(static)
+        rm2 = net.encoder_blocks[3].batch_norm_conv.batch_norm.running_mean.clone()
+    finally:
+        ops.set_row_counts(None)
+    rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+    assert rel(o2, o1) < 1e-4 and abs(l1 - l2) < 1e-5
+    assert rel(rm2, rm1) < 1e-5
+    A = torch.cat([g2[k].reshape(-1) for k in g1]).double()
+    B = torch.cat([g1[k].reshape(-1) for k in g1]).double()
+    assert (A @ B).item() / (A.norm().item() * B.norm().item()) > 0.9999

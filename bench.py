@@ -201,8 +201,24 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     torch.cuda.synchronize()
     opt.zero_grad(set_to_none=True)
     graph = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(graph):
-        static_loss = net_step_captured(net, static, cfg, params, opt, reducer)
+    if reducer is None:
+        with torch.cuda.graph(graph):
+            static_loss = net_step_captured(net, static, cfg, params, opt, None)
+        replay = graph.replay
+    else:
+        # N > 1: the RCCL all-reduce stays an eager call between two graphs (forward+backward | clip+SGD)
+        with torch.cuda.graph(graph):
+            static_loss = net.loss(net(static, cfg), static.labels)
+            static_loss.backward()
+        graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph_b):
+            torch.nn.utils.clip_grad_value_(params, cfg.grad_clip_norm)
+            opt.step()
+
+        def replay():
+            graph.replay()
+            reducer()
+            graph_b.replay()
 
     # input side on its own stream, one batch ahead of the graph (what the reference's DataLoader workers
     # do for its trainer): build(k+1) overlaps replay(k); the static buffers are filled on the main stream
@@ -224,16 +240,30 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         batch, lens, ev = state["next"]
         main = torch.cuda.current_stream()
         main.wait_event(ev)
-        static.load(batch)
+        try:
+            static.load(batch)
+        except RuntimeError:                    # a level outgrew its captured capacity: run this step eagerly
+            ops.set_row_counts(None)
+            opt.zero_grad(set_to_none=False)
+            loss = net_step_eager(net, batch, cfg, params, opt, reducer)
+            ops.set_row_counts(static.valid)
+            state["next"] = build_async()
+            return lens, loss
         done = torch.cuda.Event()
         done.record(main)
         state["loaded"] = done
         state["keep"] = batch                   # alive until the copies above have been enqueued AND ordered
-        graph.replay()
+        replay()
         state["next"] = build_async()
         return lens, static_loss
 
     return step, "hipGraph(network step: fwd+loss+bwd+clip+SGD over capacity-padded levels) + pyramid/fusion inputs built one batch ahead on a second stream"
+
+
+def net_step_eager(net, batch, cfg, params, opt, reducer):
+    """Fallback for a batch that does not fit the captured capacities: gradients are written into the
+    graph's static .grad tensors (zeroed in place), so later replays stay valid."""
+    return net_step_captured(net, batch, cfg, params, opt, reducer)
 
 
 def net_step_captured(net, static, cfg, params, opt, reducer):

@@ -150,3 +150,56 @@ def test_capacity_padded_mode_equals_plain_mode():
     A = torch.cat([g2[k].reshape(-1) for k in g1]).double()
     B = torch.cat([g1[k].reshape(-1) for k in g1]).double()
     assert (A @ B).item() / (A.norm().item() * B.norm().item()) > 0.9999
+
+
+def test_graph_replay_trains_like_eager():
+    """bench.py's hipGraph step (capacity-padded static batch, masked BatchNorm, input pyramid one batch
+    ahead on a second stream) follows the same trajectory as plain eager steps: with the grid rotations
+    pinned (so every batch is identical) the losses and the weights after 5 optimizer steps agree."""
+    import importlib
+    import types
+    import mvkpconv
+    bench = importlib.import_module("bench")
+    syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
+    dev = torch.device("cuda:0")
+    torch.cuda.set_stream(torch.cuda.Stream())
+    cfg = syn.make_config("early")
+    sph = [syn.raw_sphere(seed=5, radius=0.8, density=3000.0)]
+    views = [syn.sphere_views(s, nv=3, h=60, w=80) for s in sph]
+    staged = syn.stage_spheres(sph, dev, views)
+    limits = syn.calibrate_limits(cfg, staged)
+    rots = [np.stack([np.eye(3, dtype=np.float32)]) for _ in range(4)]
+    shim = types.SimpleNamespace(StaticBatch=syn.StaticBatch,
+                                 build_batch=lambda c, st, lim, dt: syn.build_batch(c, st, lim, dt, rotations=rots))
+
+    def make():
+        torch.manual_seed(0)
+        np.random.seed(0)
+        net = syn.build_model(cfg, dev)
+        net.train()
+        for m in net.net_2d._modules.values():
+            m.train(False)
+        params = [p for p in net.parameters() if p.requires_grad]
+        opt = torch.optim.SGD(params, lr=1e-3, momentum=0.9, weight_decay=1e-3)
+        return net, params, opt
+
+    try:
+        net, params, opt = make()
+        losses_e = []
+        for _ in range(5):
+            batch, _ = shim.build_batch(cfg, staged, limits, torch.int32)
+            opt.zero_grad(set_to_none=True)
+            losses_e.append(bench.net_step_captured(net, batch, cfg, params, opt, None).item())
+        w_e = torch.cat([p.detach().reshape(-1) for p in params]).clone()
+        net, params, opt = make()
+        step, note = bench.make_graph_step(shim, ops, cfg, net, staged, limits, params, opt, None)   # 2 eager steps inside
+        assert note.startswith("hipGraph")
+        losses_g = [step()[1].item() for _ in range(3)]
+        torch.cuda.synchronize()
+        w_g = torch.cat([p.detach().reshape(-1) for p in params])
+        assert np.allclose(losses_g, losses_e[2:], rtol=2e-3), (losses_g, losses_e)
+        assert ((w_g - w_e).norm() / w_e.norm()).item() < 1e-3
+    finally:
+        ops.set_row_counts(None)
+        torch.cuda.synchronize()
+        torch.cuda.set_stream(torch.cuda.default_stream())

@@ -85,7 +85,8 @@ def main():
     deform = [p for n, p in net.named_parameters() if p.requires_grad and "offset" in n]
     other = [p for n, p in net.named_parameters() if p.requires_grad and "offset" not in n]
     opt = torch.optim.SGD([{"params": other}, {"params": deform, "lr": cfg.learning_rate * cfg.deform_lr_factor}],
-                          lr=cfg.learning_rate, momentum=cfg.momentum, weight_decay=cfg.weight_decay)  # trainer.py:72-79
+                          lr=cfg.learning_rate, momentum=cfg.momentum, weight_decay=cfg.weight_decay,
+                          fused=os.environ.get("MVK_FUSED_SGD", "1") == "1")  # trainer.py:72-79; fused = one multi-tensor kernel per step
     reducer = mvkpconv.sub("dp").FlatAllReduce(params, world) if world > 1 else None
 
     # ---- synthetic raw inputs, staged in HBM once (data-parallel: different spheres per rank)
@@ -125,6 +126,7 @@ def main():
     for _ in range(3):                          # instrumented eager pass (same step, same data)
         lens, loss = eager_step()
     recs = ops._PROF["rec"]
+    contraction = ops.profile_collect_contraction()
     ops.profile_reset(enabled=False)
     ops._PROF["rec"] = recs
 
@@ -176,6 +178,7 @@ def main():
                 "image_hw": [120, 160] if fusion else None, "parallelism": "dp%d" % world, "execution": graph_note,
                 "final_loss": float(loss.item())},
             "roofline": roofline(prof),
+            "contraction": mfma_report(contraction),
             "gather_launches": [dict(kernel=r["kernel"], avg_us=r["total_ms"] / r["launches"] * 1e3,
                                      GBps=r["bytes_per_launch"] / (r["total_ms"] / r["launches"] * 1e-3) / 1e9, **r["shape"])
                                 for r in sorted(prof.values(), key=lambda r: -r["total_ms"])],
@@ -257,6 +260,24 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         state["next"] = build_async()
         return lens, static_loss
 
+    if os.environ.get("MVK_BENCH_DIAG") == "1":        # development aid: the two chains in isolation
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(10):
+            replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            syn.build_batch(cfg, staged, limits, torch.int32)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(10):
+            static.load(batch0)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        print("DIAG graph replay %.2f ms | build_batch %.2f ms | static.load %.2f ms" % (
+            (t1 - t0) * 100, (t2 - t1) * 100, (t3 - t2) * 100), file=sys.stderr)
+
     return step, "hipGraph(network step: fwd+loss+bwd+clip+SGD over capacity-padded levels) + pyramid/fusion inputs built one batch ahead on a second stream"
 
 
@@ -293,6 +314,23 @@ def roofline(prof):
             "launch": best["shape"], "avg_launch_us": avg_ms * 1e3, "launches": best["launches"],
             "measured_in": "HIP events on the launch stream around every gather launch of 3 instrumented eager steps run between warm-up and the timed region",
             "algorithmic_bytes_per_launch": best["bytes_per_launch"]}
+
+
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= f32 vector peak)
+
+
+def mfma_report(contraction):
+    """The dense K x Cin x Cout contraction (forward, gemm_f32_mfma NN): all launches of the instrumented
+    steps together, and the largest one, against the f32 MFMA peak."""
+    if not contraction:
+        return None
+    tot_f = sum(r["flops_per_launch"] * r["launches"] for r in contraction.values())
+    tot_t = sum(r["total_ms"] for r in contraction.values()) * 1e-3
+    (M, Kd, N), big = max(contraction.items(), key=lambda kv: kv[1]["flops_per_launch"])
+    big_tf = big["flops_per_launch"] / (big["total_ms"] / big["launches"] * 1e-3) / 1e12
+    return {"bound": "mfma", "dtype": "f32", "achieved": tot_f / tot_t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": tot_f / tot_t / 1e12 / MFMA_F32_PEAK_TFLOPS,
+            "largest": {"M": M, "K": Kd, "N": N, "TFLOP/s": big_tf, "avg_launch_us": big["total_ms"] / big["launches"] * 1e3}}
 
 
 def pmc_traffic(best):

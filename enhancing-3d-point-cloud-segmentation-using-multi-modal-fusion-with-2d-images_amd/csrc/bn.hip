@@ -21,7 +21,7 @@ constexpr int BN_T = 256;
 
 // grid (ceil(D/64), ceil(R/BN_ROWS)); block 256 = 64 channels x 4 row lanes
 __global__ __launch_bounds__(BN_T) void bn_stats_partial(const float* __restrict__ x, const int* __restrict__ n_valid,
-                                                         int R, int D, float* __restrict__ part /* [2,D] */) {
+                                                         int R, int D, float* __restrict__ part /* [nblk,2,D] */) {
   __shared__ float s1[4][64], s2[4][64];
   const int n = min(*n_valid, R);
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
@@ -39,12 +39,23 @@ __global__ __launch_bounds__(BN_T) void bn_stats_partial(const float* __restrict
   s1[rl][threadIdx.x & 63] = a;
   s2[rl][threadIdx.x & 63] = b;
   __syncthreads();
-  if (rl == 0 && c < D && r0 < n) {
+  if (rl == 0 && c < D) {  // every row block writes its slot (zeros past n_valid): no memset, no atomics
     a = (s1[0][threadIdx.x] + s1[1][threadIdx.x]) + (s1[2][threadIdx.x] + s1[3][threadIdx.x]);
     b = (s2[0][threadIdx.x] + s2[1][threadIdx.x]) + (s2[2][threadIdx.x] + s2[3][threadIdx.x]);
-    atomicAdd(part + c, a);
-    atomicAdd(part + D + c, b);
+    part[((int64_t)blockIdx.y * 2) * D + c] = a;
+    part[((int64_t)blockIdx.y * 2 + 1) * D + c] = b;
   }
+}
+
+// sums the per-row-block partials in block order (deterministic) -> tot[2,D]
+__device__ __forceinline__ void bn_sum_partials(const float* __restrict__ part, int nblk, int D, int c, float* a, float* b) {
+  float x = 0.f, y = 0.f;
+  for (int i = 0; i < nblk; ++i) {
+    x += part[((int64_t)i * 2) * D + c];
+    y += part[((int64_t)i * 2 + 1) * D + c];
+  }
+  *a = x;
+  *b = y;
 }
 
 __global__ void bn_stats_finish(const float* __restrict__ x, const int* __restrict__ n_valid, int R, int D,
@@ -60,7 +71,9 @@ __global__ void bn_stats_finish(const float* __restrict__ x, const int* __restri
     return;
   }
   const float k = x[c];
-  const float m1 = part[c] / (float)n, m2 = part[D + c] / (float)n;
+  float p1, p2;
+  bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, c, &p1, &p2);
+  const float m1 = p1 / (float)n, m2 = p2 / (float)n;
   const float mu = k + m1;
   float var = m2 - m1 * m1;  // biased
   var = var > 0.f ? var : 0.f;
@@ -95,7 +108,7 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce(const float* __restrict__ 
                                                       const int* __restrict__ n_valid, int R, int D,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float slope, float* __restrict__ part /* [2,D]: dbeta, dgamma */) {
+                                                      float slope, float* __restrict__ part /* [nblk,2,D] */) {
   __shared__ float s1[4][64], s2[4][64];
   const int n = min(*n_valid, R);
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
@@ -115,12 +128,21 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce(const float* __restrict__ 
   s1[rl][threadIdx.x & 63] = a;
   s2[rl][threadIdx.x & 63] = b;
   __syncthreads();
-  if (rl == 0 && c < D && r0 < n) {
+  if (rl == 0 && c < D) {
     a = (s1[0][threadIdx.x] + s1[1][threadIdx.x]) + (s1[2][threadIdx.x] + s1[3][threadIdx.x]);
     b = (s2[0][threadIdx.x] + s2[1][threadIdx.x]) + (s2[2][threadIdx.x] + s2[3][threadIdx.x]);
-    atomicAdd(part + c, a);
-    atomicAdd(part + D + c, b);
+    part[((int64_t)blockIdx.y * 2) * D + c] = a;
+    part[((int64_t)blockIdx.y * 2 + 1) * D + c] = b;
   }
+}
+
+__global__ void bn_bwd_finish(const float* __restrict__ part, int R, int D, float* __restrict__ dgb /* [2,D] */) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float a, b;
+  bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, c, &a, &b);
+  dgb[c] = a;
+  dgb[D + c] = b;
 }
 
 __global__ void bn_bwd_apply(const float* __restrict__ x, const float* __restrict__ g,
@@ -148,12 +170,11 @@ __global__ void bn_bwd_apply(const float* __restrict__ x, const float* __restric
 
 extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t R, int D, const float* gamma,
                                 const float* beta, float eps, float momentum, float slope, float* running_mean,
-                                float* running_var, float* mean, float* invstd, float* scratch2D, float* y,
+                                float* running_var, float* mean, float* invstd, float* scratch2D /* [ceil(R/64),2,D] */, float* y,
                                 void* stream) {
   MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
   if (R == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  MVK_CHECK_HIP(hipMemsetAsync(scratch2D, 0, sizeof(float) * 2 * D, st));
   dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
   hipLaunchKernelGGL(bn_stats_partial, g1, dim3(BN_T), 0, st, x, n_valid, (int)R, D, scratch2D);
   hipLaunchKernelGGL(bn_stats_finish, dim3((unsigned)cdiv64(D, 128)), dim3(128), 0, st, x, n_valid, (int)R, D, scratch2D,
@@ -166,15 +187,18 @@ extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t 
 
 extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n_valid, int64_t R, int D,
                                 const float* gamma, const float* beta, const float* mean, const float* invstd,
-                                float slope, float* dgamma_dbeta /* [2,D]: dbeta then dgamma */, float* dx,
-                                void* stream) {
+                                float slope, float* scratch /* [ceil(R/64),2,D] */,
+                                float* dgamma_dbeta /* [2,D]: dbeta then dgamma */, float* dx, void* stream) {
   MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
   hipStream_t st = (hipStream_t)stream;
-  MVK_CHECK_HIP(hipMemsetAsync(dgamma_dbeta, 0, sizeof(float) * 2 * D, st));
-  if (R == 0) return 0;
+  if (R == 0) {
+    MVK_CHECK_HIP(hipMemsetAsync(dgamma_dbeta, 0, sizeof(float) * 2 * D, st));
+    return 0;
+  }
   dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
   hipLaunchKernelGGL(bn_bwd_reduce, g1, dim3(BN_T), 0, st, x, g, n_valid, (int)R, D, mean, invstd, gamma, beta, slope,
-                     dgamma_dbeta);
+                     scratch);
+  hipLaunchKernelGGL(bn_bwd_finish, dim3((unsigned)cdiv64(D, 128)), dim3(128), 0, st, scratch, (int)R, D, dgamma_dbeta);
   hipLaunchKernelGGL(bn_bwd_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, g, n_valid, (int)R, D, mean,
                      invstd, gamma, beta, slope, dgamma_dbeta, dx);
   MVK_CHECK_HIP(hipGetLastError());

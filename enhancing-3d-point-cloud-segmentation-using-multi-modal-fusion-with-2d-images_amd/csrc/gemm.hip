@@ -7,63 +7,90 @@
 // products. bf16/fp16 MFMA would miss the 1e-4 parity bar, so
 // the f32 MFMA forms are used.
 //
-// Tiling: 64 x 64 output tile per 256-thread workgroup, BK = 16; four waves in a
-// 2 x 2 arrangement, each owning one 32 x 32 accumulator (16 VGPRs). Operands
-// are staged k-major in LDS ([BK][64 + 1]) so that the MFMA operand reads
-// (lane l -> row/col l & 31, k = l >> 5) are bank-conflict free. Split-K
-// (grid.z) accumulates with f32 atomics; it exists for dW = A^T g whose
-// reduction runs over all points.
+// Shapes are tall-skinny (20 000 x 990 x 64) or short-and-deep (65 x 7680 x 512), never square:
+//   * 64 x 64 output tile per 256-thread workgroup, BK = 32; four waves in a 2 x 2 arrangement, each
+//     owning one 32 x 32 accumulator (16 VGPRs) -> 16 MFMAs (>= 1024 cycles) per wave and k-tile;
+//   * operands staged k-major in LDS ([BK][64 + 4]): the MFMA operand reads (lane l -> row/col l & 31,
+//     k = l >> 5) are bank-conflict free, m/n-contiguous sources are written with ds_write_b128;
+//   * two LDS buffers + register prefetch: the global loads of k-tile t+1 are issued before the MFMAs
+//     of tile t and written to the other buffer after them -> one barrier per k-tile, loads hidden;
+//   * split-K (grid.z) with f32 atomics fills the chip when M*N is small (coarse layers, dW).
 #include "common.h"
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 64, BN = 64, BK = 16, LDP = 65;
+constexpr int BM = 64, BN = 64, BK = 32, LDP = 68;
 
-// Loads one operand tile into LDS as T[k][i] (k < BK, i < 64).
+// One operand tile = 64 (i) x 32 (k) elements, 2 float4 per thread.
 //   CONTIG_K == true : source element (i,k) at src[i*ld + k]  (contiguous along k)
 //   CONTIG_K == false: source element (i,k) at src[k*ld + i]  (contiguous along i)
 template <bool CONTIG_K>
-__device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t ld, int64_t i0,
-                                          int64_t imax, int64_t k0, int64_t kmax, bool vec_ok,
-                                          float (*T)[LDP], int tid) {
-  if (CONTIG_K) {
-    const int i = tid >> 2, kq = (tid & 3) * 4;
-    const int64_t gi = i0 + i, gk = k0 + kq;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (gi < imax) {
-      const float* p = src + gi * ld + gk;
-      if (vec_ok && gk + 3 < kmax) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+struct TileLoader {
+  float4 v[2];
+
+  // vec: 4 = rows 16-byte aligned, 2 = 8-byte aligned (e.g. K*Cin = 990), 1 = scalar
+  __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int64_t i0, int64_t imax,
+                                       int64_t k0, int64_t kmax, int vec, int tid) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float t[4] = {0.f, 0.f, 0.f, 0.f};
+      if (CONTIG_K) {
+        const int i = (tid >> 3) + 32 * u, kq = (tid & 7) * 4;
+        const int64_t gi = i0 + i, gk = k0 + kq;
+        if (gi < imax) {
+          const float* p = src + gi * ld + gk;
+          if (vec == 4 && gk + 3 < kmax) {
+            const float4 q = *reinterpret_cast<const float4*>(p);
+            t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+          } else if (vec == 2 && gk + 3 < kmax) {
+            const float2 q0 = *reinterpret_cast<const float2*>(p), q1 = *reinterpret_cast<const float2*>(p + 2);
+            t[0] = q0.x; t[1] = q0.y; t[2] = q1.x; t[3] = q1.y;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (gk + e < kmax) t[e] = p[e];
+          }
+        }
       } else {
+        const int k = (tid >> 4) + 16 * u, iq = (tid & 15) * 4;
+        const int64_t gk = k0 + k, gi = i0 + iq;
+        if (gk < kmax) {
+          const float* p = src + gk * ld + gi;
+          if (vec == 4 && gi + 3 < imax) {
+            const float4 q = *reinterpret_cast<const float4*>(p);
+            t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+          } else if (vec == 2 && gi + 3 < imax) {
+            const float2 q0 = *reinterpret_cast<const float2*>(p), q1 = *reinterpret_cast<const float2*>(p + 2);
+            t[0] = q0.x; t[1] = q0.y; t[2] = q1.x; t[3] = q1.y;
+          } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (gk + e < kmax) v[e] = p[e];
+            for (int e = 0; e < 4; ++e)
+              if (gi + e < imax) t[e] = p[e];
+          }
+        }
       }
+      v[u] = make_float4(t[0], t[1], t[2], t[3]);
     }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) T[kq + e][i] = v[e];
-  } else {
-    const int k = tid >> 4, iq = (tid & 15) * 4;
-    const int64_t gk = k0 + k, gi = i0 + iq;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    if (gk < kmax) {
-      const float* p = src + gk * ld + gi;
-      if (vec_ok && gi + 3 < imax) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (gi + e < imax) v[e] = p[e];
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) T[k][iq + e] = v[e];
   }
-}
+
+  __device__ __forceinline__ void store(float (*T)[LDP], int tid) const {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (CONTIG_K) {
+        const int i = (tid >> 3) + 32 * u, kq = (tid & 7) * 4;
+        T[kq + 0][i] = v[u].x;
+        T[kq + 1][i] = v[u].y;
+        T[kq + 2][i] = v[u].z;
+        T[kq + 3][i] = v[u].w;
+      } else {
+        const int k = (tid >> 4) + 16 * u, iq = (tid & 15) * 4;
+        *reinterpret_cast<float4*>(&T[k][iq]) = v[u];
+      }
+    }
+  }
+};
 
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A,
@@ -72,8 +99,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
                                                      int64_t Kd, int64_t lda, int64_t ldb,
                                                      int64_t k_per_split, int atomic_out,
                                                      int accumulate, int vecA, int vecB) {
-  __shared__ float As[BK][LDP];
-  __shared__ float Bs[BK][LDP];
+  __shared__ __attribute__((aligned(16))) float As[2][BK][LDP];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
@@ -84,20 +111,36 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+  // A tile: element (m,k); TA == false -> A[m*lda + k] (k-contiguous). B tile: element (n,k);
+  // TB == false -> B[k*ldb + n] (n-contiguous).
+  TileLoader<!TA> la;
+  TileLoader<TB> lb;
+  la.load(A, lda, m0, M, kbeg, kend, vecA, tid);
+  lb.load(B, ldb, n0, N, kbeg, kend, vecB, tid);
+  la.store(As[0], tid);
+  lb.store(Bs[0], tid);
+  __syncthreads();
+
+  const int i = wm * 32 + (lane & 31), j = wn * 32 + (lane & 31), kh = lane >> 5;
+  int buf = 0;
   for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-    // A tile: element (m,k). TA == false: A[m*lda + k] (contiguous along k).
-    load_tile<!TA>(A, lda, m0, M, k0, kend, vecA, As, tid);
-    // B tile: element (n,k). TB == false: B[k*ldb + n] (contiguous along n).
-    load_tile<TB>(B, ldb, n0, N, k0, kend, vecB, Bs, tid);
-    __syncthreads();
-    const int i = wm * 32 + (lane & 31), j = wn * 32 + (lane & 31), kh = lane >> 5;
+    const bool more = k0 + BK < kend;
+    if (more) {  // prefetch the next k-tile into registers while this one is multiplied
+      la.load(A, lda, m0, M, k0 + BK, kend, vecA, tid);
+      lb.load(B, ldb, n0, N, k0 + BK, kend, vecB, tid);
+    }
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
-      const float a = As[kk + kh][i];
-      const float b = Bs[kk + kh][j];
+      const float a = As[buf][kk + kh][i];
+      const float b = Bs[buf][kk + kh][j];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+    if (more) {
+      la.store(As[buf ^ 1], tid);
+      lb.store(Bs[buf ^ 1], tid);
+    }
     __syncthreads();
+    buf ^= 1;
   }
 
   const int64_t col = n0 + wn * 32 + (lane & 31);
@@ -136,8 +179,8 @@ extern "C" int mvk_gemm_f32(const float* A, const float* B, float* C, int64_t M,
   int64_t k_per_split = cdiv64(ksteps, split_k) * BK;
   split_k = (int)cdiv64(Kd, k_per_split);
   const int64_t lda = transA ? M : Kd, ldb = transB ? Kd : N;
-  const int vecA = (lda % 4 == 0) && ((uintptr_t)A % 16 == 0);
-  const int vecB = (ldb % 4 == 0) && ((uintptr_t)B % 16 == 0);
+  const int vecA = ((lda % 4 == 0) && ((uintptr_t)A % 16 == 0)) ? 4 : ((lda % 2 == 0) && ((uintptr_t)A % 8 == 0)) ? 2 : 1;
+  const int vecB = ((ldb % 4 == 0) && ((uintptr_t)B % 16 == 0)) ? 4 : ((ldb % 2 == 0) && ((uintptr_t)B % 8 == 0)) ? 2 : 1;
   MVK_REQUIRE(cdiv64(M, BM) < 65536 && split_k < 65536, "gemm: grid too large");
   dim3 grid((unsigned)cdiv64(N, BN), (unsigned)cdiv64(M, BM), (unsigned)split_k), block(256);
   const int atomic_out = split_k > 1;

@@ -52,8 +52,10 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
     N = B.shape[0] if transB else B.shape[1]
     assert (B.shape[1] if transB else B.shape[0]) == Kd, "gemm: inner dimensions differ"
     if split_k is None:
+        # measured on MI355X (tests/dev_gemm_bench.py): ~4 workgroups per CU hide the global-load
+        # latency of the k-loop; keep >= 4 k-tiles (128 columns) per split
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        split_k = 1 if tiles >= 256 else int(max(1, min((512 + tiles - 1) // tiles, Kd // 128)))
+        split_k = int(max(1, min((1000 + tiles - 1) // tiles, 32, Kd // 128)))
     if out is None:
         out = torch.zeros if split_k > 1 else torch.empty
         out = out((M, N), device=A.device, dtype=torch.float32)
@@ -64,12 +66,25 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
 
 # ---- optional per-launch timing of the gather kernel (bench.py roofline): HIP events on the
 # current stream around the C-ABI call; nothing is recorded unless profile_reset(enabled=True).
-_PROF = {"on": False, "rec": []}
+_PROF = {"on": False, "rec": [], "gemm": []}
 
 
 def profile_reset(enabled):
     _PROF["on"] = bool(enabled)
     _PROF["rec"] = []
+    _PROF["gemm"] = []
+
+
+def profile_collect_contraction():
+    """{(M, Kd, N): {launches, total_ms, flops_per_launch}} of the forward K x Cin x Cout contraction
+    (gemm_f32_mfma NN); flops = 2*M*Kd*N (SURVEY.md 8d F_mfma)."""
+    torch.cuda.synchronize()
+    out = {}
+    for key, e0, e1 in _PROF["gemm"]:
+        r = out.setdefault(key, {"launches": 0, "total_ms": 0.0, "flops_per_launch": 2.0 * key[0] * key[1] * key[2]})
+        r["launches"] += 1
+        r["total_ms"] += e0.elapsed_time(e1)
+    return out
 
 
 def _gather_kernel_name(Cin, deform):
@@ -150,8 +165,8 @@ def kpconv_scatter(q, s, idx, dA, kp, extent, influence="linear", aggregation="s
 
 def _split_for(n_red, tiles):
     """split-K factor for reductions over the point axis: fill ~2 waves of workgroups per CU."""
-    want = max(1, (512 + tiles - 1) // max(tiles, 1))
-    return int(max(1, min(want, (n_red + 255) // 256)))
+    want = max(1, (1024 + tiles - 1) // max(tiles, 1))
+    return int(max(1, min(want, 64, n_red // 256)))
 
 
 # --------------------------------------------------------------------------------------------
@@ -170,7 +185,13 @@ class _KPConvFn(torch.autograd.Function):
         deform = offsets is not None
         A, min_d2 = kpconv_gather(q, s, idx, x, kp, extent, influence, aggregation, offsets, want_min_d2=deform)
         Am = A * modulations.unsqueeze(2) if modulations is not None else A     # blocks.py:366-367
+        if _PROF["on"]:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         y = gemm(Am.view(-1, K * Cin), W.reshape(K * Cin, Cout))                # blocks.py:370-374
+        if _PROF["on"]:
+            e1.record()
+            _PROF["gemm"].append(((q.shape[0], K * Cin, Cout), e0, e1))
         ctx.save_for_backward(q, s, idx, x, kp, W, A, offsets, modulations)
         ctx.cfg = (extent, influence, aggregation)
         return y, min_d2
@@ -239,7 +260,7 @@ class _BNLReLUFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(D, device=x.device, dtype=torch.float32)
         invstd = torch.empty(D, device=x.device, dtype=torch.float32)
-        scratch = torch.empty(2 * D, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(((R + 63) // 64) * 2 * D, device=x.device, dtype=torch.float32)
         if not training:
             raise RuntimeError("masked BatchNorm is a training-mode op; use nn.BatchNorm1d in eval mode")
         check(lib().mvk_bn_lrelu_fwd(_p(x), _p(n_valid), R, D, _p(gamma), _p(beta), float(eps), float(momentum),
@@ -255,9 +276,10 @@ class _BNLReLUFn(torch.autograd.Function):
         g = _f32c(g)
         R, D = x.shape
         dgb = torch.empty(2 * D, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(((R + 63) // 64) * 2 * D, device=x.device, dtype=torch.float32)
         dx = torch.empty_like(x)
         check(lib().mvk_bn_lrelu_bwd(_p(x), _p(g), _p(n_valid), R, D, _p(gamma), _p(beta), _p(mean), _p(invstd),
-                                     ctx.slope, _p(dgb), _p(dx), _stream()))
+                                     ctx.slope, _p(scratch), _p(dgb), _p(dx), _stream()))
         return dx, None, dgb[D:], dgb[:D], None, None, None, None, None, None
 
 

@@ -87,15 +87,16 @@ int mvk_gemm_f32(const float* A, const float* B, float* C, int64_t M, int64_t N,
  * LeakyReLU(slope) (slope = 1 -> no activation); rows >= n_valid of y are zero. Replaces
  * BatchNormBlock + LeakyReLU (KPConv-PyTorch/models/blocks.py:430-467,:549-561). running_mean /
  * running_var (may be NULL) are updated with `momentum` (unbiased variance). mean / invstd [D] are
- * saved for the backward; scratch2D is a [2,D] f32 scratch. */
+ * saved for the backward; scratch is a [ceil(R/64),2,D] f32 scratch (per-row-block partial sums,
+ * reduced in block order: no atomics, bit-reproducible). */
 int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t R, int D, const float* gamma,
                      const float* beta, float eps, float momentum, float slope, float* running_mean,
-                     float* running_var, float* mean, float* invstd, float* scratch2D, float* y,
+                     float* running_var, float* mean, float* invstd, float* scratch, float* y,
                      void* stream);
 /* dgamma_dbeta [2,D] receives dbeta (row 0) and dgamma (row 1); dx [R,D] (rows >= n_valid zero). */
 int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n_valid, int64_t R, int D,
                      const float* gamma, const float* beta, const float* mean, const float* invstd,
-                     float slope, float* dgamma_dbeta, float* dx, void* stream);
+                     float slope, float* scratch, float* dgamma_dbeta, float* dx, void* stream);
 
 /* ---------------- row gathers of blocks.py ------------------------------- */
 

@@ -47,23 +47,43 @@ __global__ __launch_bounds__(BN_T) void bn_stats_partial(const float* __restrict
   }
 }
 
-// sums the per-row-block partials in block order (deterministic) -> tot[2,D]
-__device__ __forceinline__ void bn_sum_partials(const float* __restrict__ part, int nblk, int D, int c, float* a, float* b) {
+// Sums the per-row-block partials of 64 channels with a 1024-thread block (64 channels x 16 row
+// parts; fixed summation tree -> bit-reproducible). Returns the two totals to the lanes with part == 0.
+__device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ part, int nblk, int D, float* a, float* b) {
+  __shared__ float r1[16][64], r2[16][64];
+  const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   float x = 0.f, y = 0.f;
-  for (int i = 0; i < nblk; ++i) {
-    x += part[((int64_t)i * 2) * D + c];
-    y += part[((int64_t)i * 2 + 1) * D + c];
+  if (c < D)
+    for (int i = pr; i < nblk; i += 16) {
+      x += part[((int64_t)i * 2) * D + c];
+      y += part[((int64_t)i * 2 + 1) * D + c];
+    }
+  r1[pr][cl] = x;
+  r2[pr][cl] = y;
+  __syncthreads();
+  if (pr != 0 || c >= D) return false;
+  x = 0.f;
+  y = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    x += r1[i][cl];
+    y += r2[i][cl];
   }
   *a = x;
   *b = y;
+  return true;
 }
 
-__global__ void bn_stats_finish(const float* __restrict__ x, const int* __restrict__ n_valid, int R, int D,
-                                const float* __restrict__ part, float eps, float momentum,
-                                float* __restrict__ mean, float* __restrict__ invstd,
-                                float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+// grid ceil(D/64), block 1024
+__global__ __launch_bounds__(1024) void bn_stats_finish(const float* __restrict__ x, const int* __restrict__ n_valid,
+                                                        int R, int D, const float* __restrict__ part, float eps,
+                                                        float momentum, float* __restrict__ mean,
+                                                        float* __restrict__ invstd, float* __restrict__ running_mean,
+                                                        float* __restrict__ running_var) {
+  float p1, p2;
+  if (!bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, &p1, &p2)) return;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int n = min(*n_valid, R);
   if (n < 1) {
     mean[c] = 0.f;
@@ -71,8 +91,6 @@ __global__ void bn_stats_finish(const float* __restrict__ x, const int* __restri
     return;
   }
   const float k = x[c];
-  float p1, p2;
-  bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, c, &p1, &p2);
   const float m1 = p1 / (float)n, m2 = p2 / (float)n;
   const float mu = k + m1;
   float var = m2 - m1 * m1;  // biased
@@ -136,11 +154,11 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce(const float* __restrict__ 
   }
 }
 
-__global__ void bn_bwd_finish(const float* __restrict__ part, int R, int D, float* __restrict__ dgb /* [2,D] */) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= D) return;
+__global__ __launch_bounds__(1024) void bn_bwd_finish(const float* __restrict__ part, int R, int D,
+                                                      float* __restrict__ dgb /* [2,D] */) {
   float a, b;
-  bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, c, &a, &b);
+  if (!bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, &a, &b)) return;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   dgb[c] = a;
   dgb[D + c] = b;
 }
@@ -177,7 +195,7 @@ extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t 
   hipStream_t st = (hipStream_t)stream;
   dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
   hipLaunchKernelGGL(bn_stats_partial, g1, dim3(BN_T), 0, st, x, n_valid, (int)R, D, scratch2D);
-  hipLaunchKernelGGL(bn_stats_finish, dim3((unsigned)cdiv64(D, 128)), dim3(128), 0, st, x, n_valid, (int)R, D, scratch2D,
+  hipLaunchKernelGGL(bn_stats_finish, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, x, n_valid, (int)R, D, scratch2D,
                      eps, momentum, mean, invstd, running_mean, running_var);
   hipLaunchKernelGGL(bn_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, n_valid, (int)R, D, mean, invstd,
                      gamma, beta, slope, y);
@@ -198,7 +216,7 @@ extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n
   dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
   hipLaunchKernelGGL(bn_bwd_reduce, g1, dim3(BN_T), 0, st, x, g, n_valid, (int)R, D, mean, invstd, gamma, beta, slope,
                      scratch);
-  hipLaunchKernelGGL(bn_bwd_finish, dim3((unsigned)cdiv64(D, 128)), dim3(128), 0, st, scratch, (int)R, D, dgamma_dbeta);
+  hipLaunchKernelGGL(bn_bwd_finish, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, scratch, (int)R, D, dgamma_dbeta);
   hipLaunchKernelGGL(bn_bwd_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, g, n_valid, (int)R, D, mean,
                      invstd, gamma, beta, slope, dgamma_dbeta, dx);
   MVK_CHECK_HIP(hipGetLastError());

@@ -62,6 +62,11 @@ __device__ __forceinline__ void topk_insert(double (&bd)[K], int64_t (&bi)[K], d
   }
 }
 
+// QPT queries per lane: every LDS key read (3 broadcast ds_read_b64) is reused QPT times, which moves the
+// loop from LDS-issue bound (1 query per lane: ~6 LDS cycles per 28 fp64 VALU cycles per wave, four waves
+// sharing one LDS) to fp64-VALU bound.
+constexpr int QPT = 4;
+
 template <int K>
 __global__ __launch_bounds__(KNN_T) void knn_partial_kernel(const float* __restrict__ q, int64_t nq,
                                                             const double* __restrict__ keys,
@@ -71,20 +76,22 @@ __global__ __launch_bounds__(KNN_T) void knn_partial_kernel(const float* __restr
                                                             int64_t* __restrict__ pi) {
   __shared__ double kx[KNN_T], ky[KNN_T], kz[KNN_T];
   __shared__ int kok[KNN_T];
-  const int64_t i = (int64_t)blockIdx.x * KNN_T + threadIdx.x;
+  const int64_t i0 = ((int64_t)blockIdx.x * KNN_T + threadIdx.x) * QPT;
   const int64_t kbeg = (int64_t)blockIdx.y * per_split, kend = min(nk, kbeg + per_split);
-  double qx = 0, qy = 0, qz = 0;
-  if (i < nq) {
-    qx = (double)q[i * 3];
-    qy = (double)q[i * 3 + 1];
-    qz = (double)q[i * 3 + 2];
-  }
-  double bd[K];
-  int64_t bi[K];
+  double qx[QPT], qy[QPT], qz[QPT];
+  double bd[QPT][K];
+  int64_t bi[QPT][K];
 #pragma unroll
-  for (int c = 0; c < K; ++c) {
-    bd[c] = INFINITY;
-    bi[c] = INT64_MAX;
+  for (int u = 0; u < QPT; ++u) {
+    const int64_t i = i0 + u;
+    qx[u] = i < nq ? (double)q[i * 3] : 0.0;
+    qy[u] = i < nq ? (double)q[i * 3 + 1] : 0.0;
+    qz[u] = i < nq ? (double)q[i * 3 + 2] : 0.0;
+#pragma unroll
+    for (int c = 0; c < K; ++c) {
+      bd[u][c] = INFINITY;
+      bi[u][c] = INT64_MAX;
+    }
   }
   for (int64_t k0 = kbeg; k0 < kend; k0 += KNN_T) {
     const int64_t j = k0 + threadIdx.x;
@@ -100,20 +107,28 @@ __global__ __launch_bounds__(KNN_T) void knn_partial_kernel(const float* __restr
     const int cnt = (int)min((int64_t)KNN_T, kend - k0);
     for (int t = 0; t < cnt; ++t) {
       if (!kok[t]) continue;  // uniform across the workgroup
-      const double dx = qx - kx[t], dy = qy - ky[t], dz = qz - kz[t];
-      double d2 = 0.0;
-      d2 += dx * dx;
-      d2 += dy * dy;
-      d2 += dz * dz;
-      topk_insert<K>(bd, bi, d2, k0 + t);
+      const double x = kx[t], y = ky[t], z = kz[t];
+#pragma unroll
+      for (int u = 0; u < QPT; ++u) {
+        const double dx = qx[u] - x, dy = qy[u] - y, dz = qz[u] - z;
+        double d2 = 0.0;
+        d2 += dx * dx;
+        d2 += dy * dy;
+        d2 += dz * dz;
+        topk_insert<K>(bd[u], bi[u], d2, k0 + t);
+      }
     }
     __syncthreads();
   }
-  if (i < nq) {
 #pragma unroll
-    for (int c = 0; c < K; ++c) {
-      pd[((int64_t)blockIdx.y * nq + i) * K + c] = bd[c];
-      pi[((int64_t)blockIdx.y * nq + i) * K + c] = bi[c];
+  for (int u = 0; u < QPT; ++u) {
+    const int64_t i = i0 + u;
+    if (i < nq) {
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        pd[((int64_t)blockIdx.y * nq + i) * K + c] = bd[u][c];
+        pi[((int64_t)blockIdx.y * nq + i) * K + c] = bi[u][c];
+      }
     }
   }
 }
@@ -187,7 +202,7 @@ extern "C" int mvk_unproject_depth(const uint16_t* depth, int nv, int h, int w, 
 namespace {
 // key splits: enough (query block x key range) workgroups to give every CU ~4 of them
 void knn_plan(int64_t nq, int64_t nk, int* nsplit_out, int64_t* per_split_out) {
-  const int64_t qblocks = cdiv64(nq > 0 ? nq : 1, KNN_T);
+  const int64_t qblocks = cdiv64(nq > 0 ? nq : 1, KNN_T * QPT);
   const int64_t keys = nk > 0 ? nk : 1;
   int64_t nsplit = cdiv64(1024, qblocks);
   const int64_t max_split = cdiv64(keys, 4 * KNN_T);
@@ -221,7 +236,7 @@ extern "C" int mvk_knn_f64(const float* queries, int64_t nq, const double* keys,
   MVK_REQUIRE(workspace && workspace_bytes >= mvk_knn_workspace(nq, nk, k), "knn: workspace too small");
   double* pd = (double*)workspace;
   int64_t* pi = (int64_t*)((char*)workspace + (int64_t)nsplit * nq * KK * 8);
-  dim3 grid((unsigned)cdiv64(nq, KNN_T), (unsigned)nsplit);
+  dim3 grid((unsigned)cdiv64(nq, KNN_T * QPT), (unsigned)nsplit);
   if (KK == 3) {
     hipLaunchKernelGGL((knn_partial_kernel<3>), grid, dim3(KNN_T), 0, st, queries, nq, keys, key_valid, nk,
                        per_split, pd, pi);

@@ -69,7 +69,7 @@ def main():
 
     # everything runs on one non-default stream: autograd's AccumulateGrad nodes are bound to the stream
     # they were first used on, and nodes born on the legacy default stream cannot be captured later
-    torch.cuda.set_stream(torch.cuda.Stream())
+    torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ.get("MVK_MAIN_PRIO", "-1"))))   # high priority: the graph chain is the critical path
 
     import mvkpconv
     syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")

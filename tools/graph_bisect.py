@@ -1,6 +1,6 @@
 """Development-only: which piece breaks hipGraph capture? Each case runs in its own process."""
 import os, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (tools/ sits next to the package)
 CASE = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, %r)

@@ -209,12 +209,13 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             static_loss = net_step_captured(net, static, cfg, params, opt, None)
         replay = graph.replay
     else:
-        # N > 1: the RCCL all-reduce stays an eager call between two graphs (forward+backward | clip+SGD)
-        with torch.cuda.graph(graph):
+        # N > 1: the RCCL all-reduce stays an eager call between two graphs (forward+backward | clip+SGD).
+        # thread_local capture mode: the process group's watchdog thread may query events meanwhile.
+        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             static_loss = net.loss(net(static, cfg), static.labels)
             static_loss.backward()
         graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph_b):
+        with torch.cuda.graph(graph_b, capture_error_mode="thread_local"):
             torch.nn.utils.clip_grad_value_(params, cfg.grad_clip_norm)
             opt.step()
 

@@ -184,7 +184,56 @@ __global__ void group_points_bwd_kernel(const float* __restrict__ go, const int6
   if (j >= 0 && j < N1) atomicAdd(gi + bc * N1 + j, go[t]);  // group_points_kernel.cu:85-87
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused input of FeatureAggregation (reference mvpnet/models/mvpnet_3d.py:54-58 fed by the two
+// group_points calls of architectures_sphere.py:266-274): for every (point n, neighbour kk) pair
+//   X[c, n*k+kk]   = feature_2d[view(p), c, pix(p)]            c < C,  p = knn[n,kk]
+//   X[C+0..2, .]   = image_xyz[p] - point[n]                   (diff_xyz)
+//   X[C+3, .]      = |diff|^2                                   (sum of squares in x,y,z order)
+// X is channel-major [C+4, np*k] (the layout the 1x1 convolution wants as a transposed GEMM operand);
+// lanes run over pairs, so every channel row is written coalesced and the gather stays inside one
+// h*w channel plane (L2 resident). Reads the 2D feature map in its native (nv, C, h, w) layout: the
+// (b, C, nv*h*w) transpose copy of the reference is not needed.
+// ---------------------------------------------------------------------------------------------
+__global__ void fa_gather_kernel(const float* __restrict__ feat /* [nv,C,hw] */, const float* __restrict__ xyz /* [nv*hw,3] */,
+                                 const int64_t* __restrict__ knn /* [np*k] */, const float* __restrict__ pts /* [np,3] */,
+                                 int C, int nv, int64_t hw, int64_t npk, int k, float* __restrict__ X /* [C+4, npk] */) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= npk) return;
+  const int64_t p = knn[e];
+  const bool ok = p >= 0 && p < nv * hw;
+  const int64_t view = ok ? p / hw : 0, pix = ok ? p % hw : 0;
+  const float* f = feat + view * C * hw + pix;
+  for (int c = blockIdx.y; c < C; c += gridDim.y) X[(int64_t)c * npk + e] = ok ? f[(int64_t)c * hw] : 0.f;
+  if (blockIdx.y == 0) {
+    const int64_t n = e / k;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    if (ok) {
+      dx = xyz[p * 3] - pts[n * 3];
+      dy = xyz[p * 3 + 1] - pts[n * 3 + 1];
+      dz = xyz[p * 3 + 2] - pts[n * 3 + 2];
+    }
+    X[(int64_t)C * npk + e] = dx;
+    X[(int64_t)(C + 1) * npk + e] = dy;
+    X[(int64_t)(C + 2) * npk + e] = dz;
+    X[(int64_t)(C + 3) * npk + e] = (dx * dx + dy * dy) + dz * dz;
+  }
+}
+
 }  // namespace
+
+extern "C" int mvk_fa_gather_fwd(const float* feature_2d, const float* image_xyz, const int64_t* knn,
+                                 const float* points, int C, int nv, int64_t hw, int64_t np, int k, float* X,
+                                 void* stream) {
+  MVK_REQUIRE(C > 0 && nv > 0 && hw > 0 && np >= 0 && k > 0, "fa_gather: bad sizes");
+  const int64_t npk = np * k;
+  if (npk == 0) return 0;
+  dim3 grid((unsigned)cdiv64(npk, 256), 8);
+  hipLaunchKernelGGL(fa_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, feature_2d, image_xyz, knn, points, C, nv,
+                     hw, npk, k, X);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int mvk_unproject_depth(const uint16_t* depth, int nv, int h, int w, const double* cam_inv,
                                    const float* poses, double* xyz, uint8_t* valid, void* stream) {

@@ -32,21 +32,36 @@ def build_2d_branch(net, config):
         m.train(False)
 
 
-def lift_2d_features(net, batch):
-    """images -> UNet features -> per-sphere group_points with the k-NN pixel indices ->
-    FeatureAggregation. Returns feature_2d3d (np, 64)."""
+def lift_2d_features(net, batch, fused=None):
+    """images -> UNet features -> k nearest pixels of every point -> FeatureAggregation.
+    Returns feature_2d3d (np, 64).
+
+    fused (default: one sphere per batch): FeatureAggregation.forward_fused -- a single HIP gather
+    kernel + MFMA linear layers; with several spheres the BatchNorm statistics must span all of them,
+    so the per-sphere inputs are gathered first (reference op sequence) and aggregated together."""
     images = batch.images                                   # (b, nv, 3, h, w)
     b, nv, _, h, w = images.size()
     images = images.reshape([-1] + list(images.shape[2:]))
     feature_2d = net.net_2d({'image': images})['feature']  # (b*nv, c, h, w), no grad (frozen)
+
+    def knn_of(i):
+        knn = batch.knn_list[i]
+        if isinstance(knn, np.ndarray):
+            knn = torch.from_numpy(knn)
+        return knn.long().to(feature_2d.device)
+
+    if fused is None:
+        fused = b == 1
+    if fused and b == 1:
+        knn = knn_of(0)
+        knn = knn[0] if knn.dim() == 3 else knn              # (s_np, k)
+        return net.feat_aggreg.forward_fused(feature_2d, batch.image_xyz[0], knn, batch.feat_aggre_points[0])
+
     feature_2d = feature_2d.reshape(b, nv, -1, h, w).transpose(1, 2).contiguous().reshape(b, -1, nv * h * w)
     image_xyz = batch.image_xyz.permute(0, 4, 1, 2, 3).reshape(b, 3, nv * h * w)
     feats, xyzs = [], []
     for i in range(b):
-        knn = batch.knn_list[i]
-        if isinstance(knn, np.ndarray):
-            knn = torch.from_numpy(knn)
-        knn = knn.long().to(feature_2d.device)
+        knn = knn_of(i)
         if knn.dim() == 2:
             knn = knn.unsqueeze(0)                           # (1, s_np, k)
         feats.append(group_points(feature_2d[i:i + 1], knn))

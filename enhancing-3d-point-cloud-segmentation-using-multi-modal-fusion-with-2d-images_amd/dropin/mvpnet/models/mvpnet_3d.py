@@ -3,11 +3,14 @@
 Sub-module names (mlp.{i}.conv / mlp.{i}.bn) match the reference so MVPNet checkpoints load."""
 import torch
 from torch import nn
+import torch.nn.functional as F
 
 try:
     from ...common.nn import SharedMLP, xavier_uniform
+    from ..._native import ops
 except ImportError:
     from common.nn import SharedMLP, xavier_uniform
+    from _native import ops
 
 
 class FeatureAggregation(nn.Module):
@@ -39,6 +42,33 @@ class FeatureAggregation(nn.Module):
             distance = torch.sum(diff_xyz ** 2, dim=1, keepdim=True)
             x = torch.cat([feature, diff_xyz, distance], dim=1)
         return self.reduction(self.mlp(x), 3)
+
+    def forward_fused(self, feature_2d, image_xyz, knn, points):
+        """Same function as forward() fed by the two group_points calls of the network
+        (architectures_sphere.py:266-284), for ONE sphere and without materialising the grouped tensors:
+        one HIP gather kernel builds the (C+4, np*k) MLP input straight from the encoder's (nv,C,h,w)
+        feature map, the three 1x1 convolutions run on the f32 MFMA GEMM over rows, BatchNorm over the
+        np*k rows (identical statistics to BatchNorm2d over (1,C,np,k)), sum over k.
+        feature_2d (nv,C,h,w), image_xyz (nv,h,w,3), knn (np,k) int64, points (np,3) -> (np, out)."""
+        if self.mlp is None or not self.use_relation or self.reduction is not torch.sum:
+            raise RuntimeError("forward_fused covers the MV-KPConv configuration (relation features, MLP, sum)")
+        n_pts, k = knn.shape
+        x = ops.fa_gather(feature_2d, image_xyz, knn, points)           # [C+4, np*k] channel-major
+        transposed = True
+        for layer in self.mlp:
+            w = layer.conv.weight
+            x = ops.linear(x, w.view(w.shape[0], w.shape[1]), x_is_transposed=transposed)   # [np*k, out]
+            transposed = False
+            bn = layer.bn
+            n_valid = ops.row_count_for(x.shape[0]) if bn.training else None
+            if n_valid is not None:
+                x = ops.bn_lrelu(x, n_valid, bn, 0.0)                   # masked BN + ReLU
+            else:
+                if bn.training and bn.num_batches_tracked is not None:
+                    bn.num_batches_tracked.add_(1)
+                x = F.relu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training,
+                                        bn.momentum, bn.eps))
+        return x.view(n_pts, k, -1).sum(dim=1)
 
     def reset_parameters(self):
         for m in self.modules():

@@ -514,3 +514,50 @@ class _GroupPointsFn(torch.autograd.Function):
 def group_points(points, index):
     """points (B,C,N1), index (B,N2,K) int64 -> (B,C,N2,K) (mvpnet/ops/group_points.py:20-31)."""
     return _GroupPointsFn.apply(points, index)
+
+
+# --------------------------------------------------------------------------------------------
+# fused FeatureAggregation path: gather kernel + MFMA linear layers
+# --------------------------------------------------------------------------------------------
+
+def fa_gather(feature_2d, image_xyz, knn, points):
+    """X [C+4, np*k] channel-major for ONE sphere: feature_2d (nv,C,h,w) f32, image_xyz (nv,h,w,3) f32,
+    knn (np,k) int64 flat pixel indices, points (np,3) f32. Treated as a constant by autograd (the 2D
+    encoder is frozen in every MV-KPConv variant, architectures_sphere.py:234-237)."""
+    _dev(feature_2d, image_xyz, knn, points)
+    f, xyz, pts = _f32c(feature_2d.detach()), _f32c(image_xyz), _f32c(points)
+    knn = knn.contiguous()
+    if knn.dtype != torch.int64:
+        raise RuntimeError("fa_gather: knn must be int64")
+    nv, Cc, h, w = f.shape
+    np_, k = knn.shape
+    X = torch.empty((Cc + 4, np_ * k), device=f.device, dtype=torch.float32)
+    check(lib().mvk_fa_gather_fwd(_p(f), _p(xyz), _p(knn), _p(pts), Cc, nv, h * w, np_, k, _p(X), _stream()))
+    return X
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x @ W^T on the f32 MFMA GEMM. x is [M,Kd] row-major, or [Kd,M] when x_is_transposed."""
+
+    @staticmethod
+    def forward(ctx, x, W, x_is_transposed):
+        ctx.save_for_backward(x, W)
+        ctx.xt = bool(x_is_transposed)
+        return gemm(x, W, transA=ctx.xt, transB=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W = ctx.saved_tensors
+        g = _f32c(g)
+        dx = dW = None
+        if ctx.needs_input_grad[0]:
+            dx = gemm(W, g, transA=True, transB=True) if ctx.xt else gemm(g, W)      # [Kd,M] or [M,Kd]
+        if ctx.needs_input_grad[1]:
+            # dW [N,Kd] = g^T [N,M] @ x [M,Kd]
+            dW = gemm(g, x, transA=True, transB=ctx.xt, split_k=_split_for(g.shape[0], 4))
+        return dx, dW, None
+
+
+def linear(x, W, x_is_transposed=False):
+    """nn.Linear without bias / a 1x1 convolution over rows, on gemm_f32_mfma."""
+    return _LinearFn.apply(x, W, x_is_transposed)

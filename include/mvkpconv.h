@@ -163,6 +163,15 @@ int mvk_knn_f64(const float* queries, int64_t nq, const double* keys, const uint
                 int64_t nk, int k, int64_t* out_idx, void* workspace, int64_t workspace_bytes,
                 void* stream);
 
+/* Fused input of FeatureAggregation for one sphere: X [C+4, np*k] channel-major =
+ * {2D features of the k nearest pixels | xyz(pixel) - xyz(point) | squared distance}
+ * (mvpnet/models/mvpnet_3d.py:54-58 + the two group_points calls of architectures_sphere.py:266-274).
+ * feature_2d [nv,C,h*w] f32 (the encoder's native layout), image_xyz [nv*h*w,3] f32, knn [np,k] int64
+ * flat pixel indices, points [np,3] f32. */
+int mvk_fa_gather_fwd(const float* feature_2d, const float* image_xyz, const int64_t* knn,
+                      const float* points, int C, int nv, int64_t hw, int64_t np, int k, float* X,
+                      void* stream);
+
 /* group_points forward: points [B,C,N1] f32, index [B,N2,K] int64 -> out [B,C,N2,K]. */
 int mvk_group_points_fwd(const float* points, const int64_t* index, int B, int C, int64_t N1,
                          int64_t N2, int K, float* out, void* stream);

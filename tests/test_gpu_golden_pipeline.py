@@ -92,3 +92,38 @@ def test_fusion_chain_vs_golden():
     fa2.load_state_dict(sd, strict=True)
     fa2.eval()
     assert rel_err(fa2(gxyz, tgt, gfeat.detach()).detach().cpu().numpy(), g["out_eval"]) < 1e-4
+
+
+def test_fused_feature_aggregation_vs_golden():
+    """FeatureAggregation.forward_fused (HIP gather kernel + MFMA linear layers) against the reference
+    class's outputs and weight gradients (G6)."""
+    fa_mod = importlib.import_module(PKG + ".dropin.mvpnet.models.mvpnet_3d")
+    g = load_golden("g6_fusion")
+    nv, h, w = g["depth"].shape
+    feat = T(g["feat2d"].reshape(64, nv, h * w).transpose(1, 0, 2).reshape(nv, 64, h, w).copy())   # (nv,C,h,w)
+    xyz32 = T(g["xyz"].astype(np.float32))                                                           # (nv,h,w,3)
+    sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")}
+    fa = fa_mod.FeatureAggregation(64).cuda()
+    fa.load_state_dict(sd, strict=True)
+    fa.train()
+    out = fa.forward_fused(feat, xyz32, T(g["knn"]), T(g["points"]))           # (np, 64)
+    want = np.transpose(g["out_train"][0], (1, 0))                             # (np, 64)
+    assert rel_err(out.detach().cpu().numpy(), want) < 1e-4
+    out.backward(T(np.transpose(g["gout"][0], (1, 0)).copy()))
+    assert rel_err(fa.mlp[0].conv.weight.grad.cpu().numpy(), g["w0_grad"]) < 1e-4
+    rm = fa.mlp[0].bn.running_mean.clone()
+    fa2 = fa_mod.FeatureAggregation(64).cuda()
+    fa2.load_state_dict(sd, strict=True)
+    fa2.eval()
+    want_eval = np.transpose(g["out_eval"][0], (1, 0))
+    assert rel_err(fa2.forward_fused(feat, xyz32, T(g["knn"]), T(g["points"])).detach().cpu().numpy(), want_eval) < 1e-4
+    # running statistics moved like BatchNorm2d's would
+    fa3 = fa_mod.FeatureAggregation(64).cuda()
+    fa3.load_state_dict(sd, strict=True)
+    fa3.train()
+    idx = T(g["knn"]).unsqueeze(0)
+    ops = importlib.import_module(PKG + ".ops")
+    f_cm = T(g["feat2d"])
+    x_cm = T(np.transpose(g["xyz"].astype(np.float32), (3, 0, 1, 2)).reshape(1, 3, nv * h * w).copy())
+    fa3(ops.group_points(x_cm, idx), T(g["points"]).t().unsqueeze(0).contiguous(), ops.group_points(f_cm, idx))
+    assert rel_err(rm.cpu().numpy(), fa3.mlp[0].bn.running_mean.cpu().numpy()) < 1e-4

@@ -48,7 +48,7 @@ def subsample_batch(points, batches, *, features=None, classes=None, sampleDl=0.
                     max_p=0, verbose=0):
     """(s_points f32 (M,3), s_len i32 (B,)[, s_features f32 (M,d)][, s_classes i32 (M,l)])."""
     if method not in ('barycenters', 'voxelcenters'):
-        raise RuntimeError("Error parsing method. Valid method names are \\"barycenters\\" and \\"voxelcenters\\" ")
+        raise RuntimeError('Error parsing method. Valid method names are "barycenters" and "voxelcenters" ')
     lens = _as(batches, np.int32, "input batches")
     if lens.ndim > 1:
         raise RuntimeError("Wrong dimensions : batches.shape is not (B,) ")
@@ -66,7 +66,7 @@ def subsample_batch(points, batches, *, features=None, classes=None, sampleDl=0.
 def subsample(points, *, features=None, classes=None, sampleDl=0.1, method='barycenters', verbose=0):
     """s_points | (s_points, s_features) | (s_points, s_classes) | (s_points, s_features, s_classes)."""
     if method not in ('barycenters', 'voxelcenters'):
-        raise RuntimeError("Error parsing method. Valid method names are \\"barycenters\\" and \\"voxelcenters\\" ")
+        raise RuntimeError('Error parsing method. Valid method names are "barycenters" and "voxelcenters" ')
     tp, tf, tl = _check_and_stage(points, features, classes)
     res = ops.grid_subsample_batch(tp, [tp.shape[0]], features=tf, labels=tl, dl=sampleDl)
     if res[0].shape[0] < 1:

@@ -51,6 +51,8 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
     M, Kd = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
     N = B.shape[0] if transB else B.shape[1]
     assert (B.shape[1] if transB else B.shape[0]) == Kd, "gemm: inner dimensions differ"
+    if M == 0 or N == 0 or Kd == 0:
+        return out.zero_() if out is not None else torch.zeros((M, N), device=A.device, dtype=torch.float32)
     if split_k is None:
         # measured on MI355X (tests/dev_gemm_bench.py): ~4 workgroups per CU hide the global-load
         # latency of the k-loop; keep >= 4 k-tiles (128 columns) per split

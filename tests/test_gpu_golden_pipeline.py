@@ -127,3 +127,24 @@ def test_fused_feature_aggregation_vs_golden():
     x_cm = T(np.transpose(g["xyz"].astype(np.float32), (3, 0, 1, 2)).reshape(1, 3, nv * h * w).copy())
     fa3(ops.group_points(x_cm, idx), T(g["points"]).t().unsqueeze(0).contiguous(), ops.group_points(f_cm, idx))
     assert rel_err(rm.cpu().numpy(), fa3.mlp[0].bn.running_mean.cpu().numpy()) < 1e-4
+
+
+def test_numpy_dropin_extensions_vs_golden():
+    """The cpp_wrappers drop-ins (NumPy in / NumPy out, reference signatures) on the reference's goldens."""
+    sub = importlib.import_module(PKG + ".dropin.cpp_wrappers.cpp_subsampling.grid_subsampling")
+    nbm = importlib.import_module(PKG + ".dropin.cpp_wrappers.cpp_neighbors.radius_neighbors")
+    g = load_golden("g1_sub_batch")
+    sp, sl = sub.subsample_batch(g["points"], g["lens"], sampleDl=float(g["dl"]), max_p=0, verbose=0)
+    assert sp.dtype == np.float32 and sl.dtype == np.int32
+    assert bits_equal(sp, g["out_points"]) and np.array_equal(sl, g["out_lens"])
+    g = load_golden("g1_sub_feat_lab")
+    p, f, l = sub.subsample(g["points"], features=g["features"], classes=g["labels"], sampleDl=float(g["dl"]), verbose=0)
+    assert bits_equal(p, g["out_points"]) and bits_equal(f, g["out_features"]) and np.array_equal(l, g["out_labels"])
+    assert l.dtype == np.int32
+    only_p = sub.subsample(g["points"], sampleDl=float(g["dl"]))
+    assert isinstance(only_p, np.ndarray) and bits_equal(only_p, g["out_points"])
+    g = load_golden("g2_nb_conv_b1")
+    nb = nbm.batch_query(g["queries"], g["supports"], g["q_lens"], g["s_lens"], radius=float(g["radius"]))
+    assert nb.dtype == np.int32 and np.array_equal(nb, g["out"])
+    with pytest.raises(RuntimeError, match="^Error$"):          # empty result (wrapper.cpp:201-205)
+        nbm.batch_query(np.zeros((0, 3), np.float32), g["supports"], [0], g["s_lens"], radius=0.1)

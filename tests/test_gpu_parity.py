@@ -281,3 +281,39 @@ def test_group_points_reference_test_shapes(ops, b, c, n1, n2, k):
     gw, = torch.autograd.grad(want, pts, go, retain_graph=True)
     gg, = torch.autograd.grad(got, pts, go)
     assert torch.allclose(gg, gw, atol=1e-5)
+
+
+# ------------------------------------------------------------------ edge cases / error paths
+
+def test_empty_and_degenerate_inputs(ops):
+    kp = torch.zeros(15, 3, device="cuda")
+    W = torch.zeros(15, 8, 4, device="cuda")
+    q = torch.rand(10, 3, device="cuda")
+    # no neighbour columns at all -> zeros
+    y, _ = ops.kpconv(q, q, torch.zeros(10, 0, dtype=torch.int32, device="cuda"), torch.rand(10, 8, device="cuda"), kp, W, 0.1)
+    assert y.shape == (10, 4) and float(y.abs().max()) == 0.0
+    # no query points
+    y, _ = ops.kpconv(q[:0], q, torch.zeros(0, 5, dtype=torch.int32, device="cuda"), torch.rand(10, 8, device="cuda"), kp, W, 0.1)
+    assert y.shape == (0, 4)
+    # a batch with an empty cloud on both sides
+    nb = ops.radius_neighbors_batch(q, q, [0, 10], [0, 10], 0.5)
+    assert nb.shape[0] == 10 and (nb[:, 0].cpu() == torch.arange(10, dtype=torch.int32)).all()
+    sp, sl = ops.grid_subsample_batch(q, [0, 10, 0], dl=10.0)
+    assert list(sl) == [0, 1, 0] and sp.shape == (1, 3)
+    # gemm with an empty reduction
+    assert float(ops.gemm(torch.zeros(3, 0, device="cuda"), torch.zeros(0, 2, device="cuda")).abs().max()) == 0.0
+
+
+def test_capacity_errors_are_loud(ops):
+    # more than 1024 in-range supports per query: LDS list capacity -> RuntimeError, never truncation
+    s = torch.rand(3000, 3, device="cuda") * 0.01
+    with pytest.raises(RuntimeError, match="in-range supports"):
+        ops.radius_neighbors_batch(s[:4], s, [4], [3000], 1.0)
+    # more than 64 distinct labels in one voxel
+    p = torch.rand(500, 3, device="cuda") * 0.01
+    lab = torch.arange(500, dtype=torch.int32, device="cuda")
+    with pytest.raises(RuntimeError, match="distinct labels"):
+        ops.grid_subsample_batch(p, [500], labels=lab, dl=1.0)
+    with pytest.raises(RuntimeError, match="kernel size"):
+        ops.kpconv(p, p, torch.zeros(500, 2, dtype=torch.int32, device="cuda"), torch.rand(500, 4, device="cuda"),
+                   torch.zeros(17, 3, device="cuda"), torch.zeros(17, 4, 4, device="cuda"), 0.1)

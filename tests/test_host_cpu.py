@@ -134,3 +134,60 @@ def test_gradient_allreduce_two_gloo_ranks():
         for a, b in zip(grads, want):
             assert torch.allclose(torch.from_numpy(a), b, atol=1e-6)
     assert res[0][2] == [0, 2, 4] and res[1][2] == [1, 3]
+
+
+def test_dropin_wrappers_keep_the_reference_error_strings():
+    """Argument validation of the cpp_wrappers drop-ins runs before anything touches the GPU and raises
+    RuntimeError with the reference's messages (cpp_subsampling/wrapper.cpp:389-470,
+    cpp_neighbors/wrapper.cpp:127-171)."""
+    sub = importlib.import_module(PKG + ".dropin.cpp_wrappers.cpp_subsampling.grid_subsampling")
+    nb = importlib.import_module(PKG + ".dropin.cpp_wrappers.cpp_neighbors.radius_neighbors")
+    with pytest.raises(RuntimeError, match=r"points.shape is not \(N, 3\)"):
+        sub.subsample(np.zeros((5, 2), np.float32))
+    with pytest.raises(RuntimeError, match=r"points.shape is not \(N, 3\)"):
+        sub.subsample_batch(np.zeros((5,), np.float32), np.array([5], np.int32))
+    with pytest.raises(RuntimeError, match=r"features.shape is not \(N, d\)"):
+        sub.subsample(np.zeros((5, 3), np.float32), features=np.zeros((4, 2), np.float32))
+    with pytest.raises(RuntimeError, match="Error parsing method"):
+        sub.subsample(np.zeros((5, 3), np.float32), method="median")
+    with pytest.raises(TypeError):
+        sub.subsample(np.zeros((5, 3), np.float32), np.zeros((5, 1), np.float32))      # options are keyword-only
+    with pytest.raises(RuntimeError, match=r"query.shape is not \(N, 3\)"):
+        nb.batch_query(np.zeros((5, 4), np.float32), np.zeros((5, 3), np.float32), [5], [5], radius=0.1)
+    with pytest.raises(RuntimeError, match="different for queries and supports"):
+        nb.batch_query(np.zeros((5, 3), np.float32), np.zeros((5, 3), np.float32), [5], [2, 3], radius=0.1)
+
+
+def test_kernel_disposition_optimizer_for_uncached_sizes():
+    kp_mod = importlib.import_module(PKG + ".dropin.kernels.kernel_points")
+    p = kp_mod.optimize_disposition(9, 3, "center", iters=300)
+    assert p.shape == (9, 3) and np.allclose(p[0], 0) and np.linalg.norm(p, axis=1).max() <= 0.66 + 1e-9
+    d = np.linalg.norm(p[:, None] - p[None], axis=-1) + np.eye(9)
+    assert d.min() > 0.2                                   # points repel each other
+
+
+def test_dropin_resolves_like_the_reference_when_first_on_sys_path():
+    """INTEGRATION.md route 1: with dropin/ first on sys.path the reference's own import statements
+    (datasets/common.py:32-36, architectures_sphere.py:18-22) resolve to the drop-in modules."""
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import cpp_wrappers.cpp_subsampling.grid_subsampling as cpp_subsampling
+import cpp_wrappers.cpp_neighbors.radius_neighbors as cpp_neighbors
+from kernels.kernel_points import create_3D_rotations, load_kernels
+from models.blocks import *
+from models.architectures import KPFCNN, p2p_fitting_regularizer
+from models.architectures_sphere import KPFCNN_featureAggre
+from models.architectures_sphere_middle_fusion import KPFCNN_featureAggre as M
+from models.architectures_sphere_late_fusion import KPFCNN_featureAggre as L
+from mvpnet.models.mvpnet_3d import FeatureAggregation
+from mvpnet.models.unet_resnet34 import UNetResNet34
+from mvpnet.ops.group_points import group_points
+from common.nn import SharedMLP
+from datasets.common import grid_subsampling, batch_grid_subsampling, batch_neighbors
+assert callable(cpp_subsampling.subsample) and callable(cpp_subsampling.subsample_batch) and callable(cpp_neighbors.batch_query)
+assert KPConv.__module__ == "models.blocks" and FeatureAggregation(64).out_channels == 64
+print("ok")
+''' % os.path.join(ROOT, PKG, "dropin")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stderr[-2000:]

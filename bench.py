@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--workload", default="early", choices=["early", "baseline", "middle", "late"])
     ap.add_argument("--spheres", type=int, default=1, help="spheres per GPU per step")
     ap.add_argument("--views", type=int, default=3)
+    ap.add_argument("--in-radius", type=float, default=1.2, help="sphere radius (1.2 -> ~20 k points, 1.7 -> ~40 k)")
     ap.add_argument("--deformable", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
@@ -90,7 +91,7 @@ def main():
     reducer = mvkpconv.sub("dp").FlatAllReduce(params, world) if world > 1 else None
 
     # ---- synthetic raw inputs, staged in HBM once (data-parallel: different spheres per rank)
-    spheres = [syn.raw_sphere(seed=1000 * rank + i) for i in range(args.spheres)]
+    spheres = [syn.raw_sphere(seed=1000 * rank + i, radius=args.in_radius) for i in range(args.spheres)]
     fusion = args.workload != "baseline"
     views = [syn.sphere_views(s, nv=args.views) for s in spheres] if fusion else None
     staged = syn.stage_spheres(spheres, dev, views)
@@ -172,8 +173,9 @@ def main():
             "value": total_points / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s_fusion_kpfcnn5_sphere20k_x%d_per_gpu%s" % (
-                args.workload, args.spheres, "_deformable" if args.deformable else ""),
+            "config": {"workload": "%s_kpfcnn5_sphere%dk_x%d_per_gpu%s" % (
+                args.workload + ("_fusion" if fusion else ""), int(round(sum(lens) / max(args.spheres, 1) / 1000.0)),
+                args.spheres, "_deformable" if args.deformable else ""),
                 "points_per_step_per_gpu": int(sum(lens)), "views": args.views if fusion else 0,
                 "image_hw": [120, 160] if fusion else None, "parallelism": "dp%d" % world, "execution": graph_note,
                 "final_loss": float(loss.item())},

@@ -12,6 +12,8 @@
 //   stats  : mean[D], invstd[D]  (+ running_mean / running_var update, unbiased variance)
 //   apply  : y = leaky( (x - mean) * invstd * gamma + beta ), rows >= n_valid -> 0
 //   bwd    : dgamma, dbeta, dx   (g masked through the LeakyReLU by recomputing the sign)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -184,6 +186,146 @@ __global__ void bn_bwd_apply(const float* __restrict__ x, const float* __restric
   dx[t] = v;
 }
 
+// ---- small tensors (coarse pyramid levels): one workgroup per 64 channels does statistics AND
+// normalisation in a single launch (the rows are re-read from L2), 3 kernel nodes -> 1.
+constexpr int BN_SMALL_ROWS_DEFAULT = 128;   // measured: above ~128 rows three parallel launches beat one workgroup per 64 channels
+
+__device__ __forceinline__ void block_sum2(float& a, float& b, float (*r1)[64], float (*r2)[64]) {
+  const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
+  r1[pr][cl] = a;
+  r2[pr][cl] = b;
+  __syncthreads();
+  float x = 0.f, y = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    x += r1[i][cl];
+    y += r2[i][cl];
+  }
+  a = x;
+  b = y;
+  __syncthreads();
+}
+
+// grid ceil(D/64), block 1024 = 64 channels x 16 row lanes
+__global__ __launch_bounds__(1024) void bn_small_fwd(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
+                                                     int D, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, float momentum,
+                                                     float slope, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var, float* __restrict__ mean,
+                                                     float* __restrict__ invstd, float* __restrict__ y) {
+  __shared__ float r1[16][64], r2[16][64];
+  const int n = min(*n_valid, R);
+  const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool on = c < D;
+  const float k = (on && n > 0) ? x[c] : 0.f;
+  float a = 0.f, b = 0.f;
+  if (on)
+    for (int r = pr; r < n; r += 16) {
+      const float v = x[(int64_t)r * D + c] - k;
+      a += v;
+      b += v * v;
+    }
+  block_sum2(a, b, r1, r2);
+  float mu = 0.f, is = 0.f;
+  if (n > 0) {
+    const float m1 = a / (float)n, m2 = b / (float)n;
+    mu = k + m1;
+    float var = m2 - m1 * m1;
+    var = var > 0.f ? var : 0.f;
+    is = rsqrtf(var + eps);
+    if (on && pr == 0) {
+      mean[c] = mu;
+      invstd[c] = is;
+      if (running_mean) {
+        const float unbiased = n > 1 ? var * ((float)n / (float)(n - 1)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+    }
+  } else if (on && pr == 0) {
+    mean[c] = 0.f;
+    invstd[c] = 0.f;
+  }
+  if (on) {
+    const float ga = gamma[c], be = beta[c];
+    for (int r = pr; r < R; r += 16) {
+      float v = 0.f;
+      if (r < n) {
+        v = (x[(int64_t)r * D + c] - mu) * is * ga + be;
+        v = v > 0.f ? v : v * slope;
+      }
+      y[(int64_t)r * D + c] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_small_bwd(const float* __restrict__ x, const float* __restrict__ g,
+                                                     const int* __restrict__ n_valid, int R, int D,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float slope, float* __restrict__ dgb, float* __restrict__ dx) {
+  __shared__ float r1[16][64], r2[16][64];
+  const int n = min(*n_valid, R);
+  const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const bool on = c < D;
+  const float mu = on ? mean[c] : 0.f, is = on ? invstd[c] : 0.f, ga = on ? gamma[c] : 0.f, be = on ? beta[c] : 0.f;
+  float a = 0.f, b = 0.f;
+  if (on)
+    for (int r = pr; r < n; r += 16) {
+      const float xh = (x[(int64_t)r * D + c] - mu) * is;
+      float gv = g[(int64_t)r * D + c];
+      if (xh * ga + be <= 0.f) gv *= slope;
+      a += gv;
+      b += gv * xh;
+    }
+  block_sum2(a, b, r1, r2);
+  if (on) {
+    if (pr == 0) {
+      dgb[c] = a;
+      dgb[D + c] = b;
+    }
+    const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
+    for (int r = pr; r < R; r += 16) {
+      float v = 0.f;
+      if (r < n) {
+        const float xh = (x[(int64_t)r * D + c] - mu) * is;
+        float gv = g[(int64_t)r * D + c];
+        if (xh * ga + be <= 0.f) gv *= slope;
+        v = ga * is * (gv - a * inv_n - xh * b * inv_n);
+      }
+      dx[(int64_t)r * D + c] = v;
+    }
+  }
+}
+
+// ---- y = LeakyReLU(a + b) (the residual join of ResnetBottleneckBlock, blocks.py:649) in one launch
+__global__ void add_lrelu_fwd_k(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float slope,
+                                float* __restrict__ y) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const float v = a[t] + b[t];
+  y[t] = v > 0.f ? v : v * slope;
+}
+
+__global__ void add_lrelu_bwd_k(const float* __restrict__ y, const float* __restrict__ g, int64_t n, float slope,
+                                float* __restrict__ d) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  d[t] = y[t] > 0.f ? g[t] : g[t] * slope;   // slope > 0: sign(y) == sign(a + b)
+}
+
+// rows up to which the single-launch kernels are used (development override: MVK_BN_SMALL_ROWS)
+int bn_small_rows() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MVK_BN_SMALL_ROWS");
+    v = e ? atoi(e) : BN_SMALL_ROWS_DEFAULT;
+  }
+  return v;
+}
+
 }  // namespace
 
 extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t R, int D, const float* gamma,
@@ -193,6 +335,12 @@ extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t 
   MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
   if (R == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (R <= bn_small_rows()) {
+    hipLaunchKernelGGL(bn_small_fwd, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, x, n_valid, (int)R, D, gamma, beta,
+                       eps, momentum, slope, running_mean, running_var, mean, invstd, y);
+    MVK_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
   hipLaunchKernelGGL(bn_stats_partial, g1, dim3(BN_T), 0, st, x, n_valid, (int)R, D, scratch2D);
   hipLaunchKernelGGL(bn_stats_finish, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, x, n_valid, (int)R, D, scratch2D,
@@ -213,12 +361,32 @@ extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n
     MVK_CHECK_HIP(hipMemsetAsync(dgamma_dbeta, 0, sizeof(float) * 2 * D, st));
     return 0;
   }
+  if (R <= bn_small_rows()) {
+    hipLaunchKernelGGL(bn_small_bwd, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, x, g, n_valid, (int)R, D, mean,
+                       invstd, gamma, beta, slope, dgamma_dbeta, dx);
+    MVK_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
   hipLaunchKernelGGL(bn_bwd_reduce, g1, dim3(BN_T), 0, st, x, g, n_valid, (int)R, D, mean, invstd, gamma, beta, slope,
                      scratch);
   hipLaunchKernelGGL(bn_bwd_finish, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, scratch, (int)R, D, dgamma_dbeta);
   hipLaunchKernelGGL(bn_bwd_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, g, n_valid, (int)R, D, mean,
                      invstd, gamma, beta, slope, dgamma_dbeta, dx);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_add_lrelu_fwd(const float* a, const float* b, int64_t n, float slope, float* y, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(add_lrelu_fwd_k, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, slope, y);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_add_lrelu_bwd(const float* y, const float* g, int64_t n, float slope, float* d, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(add_lrelu_bwd_k, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, y, g, n, slope, d);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -9,6 +9,7 @@ Same class names, constructor arguments, attribute names and state-dict keys as 
 kernel, f32 MFMA contraction, scatter backward.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -22,6 +23,9 @@ try:
 except ImportError:  # dropin/ put on sys.path directly
     from _native import ops
     from kernels.kernel_points import load_kernels
+
+
+_FUSE_ADD = os.environ.get("MVK_FUSE_ADD", "1") == "1"      # development switch for A/B timing
 
 
 # ---------------------------------------------------------------- simple functions (blocks.py:35-133)
@@ -281,6 +285,8 @@ class ResnetBottleneckBlock(nn.Module):
         x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x), 0.1)
         x = self.unary2(x)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
+        if _FUSE_ADD:
+            return ops.add_lrelu(x, self.unary_shortcut(shortcut), 0.1)
         return self.leaky_relu(x + self.unary_shortcut(shortcut))
 
 

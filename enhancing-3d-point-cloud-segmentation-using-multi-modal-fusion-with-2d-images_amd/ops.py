@@ -295,6 +295,33 @@ def bn_lrelu(x, n_valid, bn, slope=1.0):
                             bn.momentum if bn.momentum is not None else 0.0, slope, bn.training)
 
 
+class _AddLReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, slope):
+        _dev(a, b)
+        a, b = _f32c(a), _f32c(b)
+        y = torch.empty_like(a)
+        check(lib().mvk_add_lrelu_fwd(_p(a), _p(b), a.numel(), float(slope), _p(y), _stream()))
+        ctx.save_for_backward(y)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = _f32c(g)
+        d = torch.empty_like(y)
+        check(lib().mvk_add_lrelu_bwd(_p(y), _p(g), y.numel(), ctx.slope, _p(d), _stream()))
+        return d, d, None
+
+
+def add_lrelu(a, b, slope=0.1):
+    """LeakyReLU(a + b) in one launch (residual join of ResnetBottleneckBlock, blocks.py:649)."""
+    if a.shape != b.shape:
+        raise RuntimeError("add_lrelu: shapes differ")
+    return _AddLReLUFn.apply(a, b, slope)
+
+
 # --------------------------------------------------------------------------------------------
 # pooling helpers of blocks.py
 # --------------------------------------------------------------------------------------------

@@ -98,6 +98,11 @@ int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n_valid, int
                      const float* gamma, const float* beta, const float* mean, const float* invstd,
                      float slope, float* scratch, float* dgamma_dbeta, float* dx, void* stream);
 
+/* y = LeakyReLU_slope(a + b) over n elements and its backward d = g * (y > 0 ? 1 : slope) (both
+ * addends receive d): the residual join of ResnetBottleneckBlock (blocks.py:649), slope > 0. */
+int mvk_add_lrelu_fwd(const float* a, const float* b, int64_t n, float slope, float* y, void* stream);
+int mvk_add_lrelu_bwd(const float* y, const float* g, int64_t n, float slope, float* d, void* stream);
+
 /* ---------------- row gathers of blocks.py ------------------------------- */
 
 /* out[n,:] = max_h x+[idx[n,h],:]  (zero shadow row participates, blocks.py:94-110);

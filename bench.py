@@ -120,7 +120,7 @@ def main():
 
     # ---- warm-up (eager). The gather launches of these steps are timed with HIP events on the
     #      launch stream for the roofline figure (a captured graph cannot carry timing events).
-    use_graph = args.graph if args.graph is not None else (not args.deformable)
+    use_graph = args.graph if args.graph is not None else True
     for _ in range(max(args.warmup, 1)):
         lens, loss = eager_step()
     ops.profile_reset(enabled=True)

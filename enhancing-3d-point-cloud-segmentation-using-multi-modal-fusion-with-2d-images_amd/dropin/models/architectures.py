@@ -7,25 +7,48 @@ import torch.nn as nn
 
 try:
     from .blocks import KPConv, UnaryBlock, block_decider
+    from .._native import ops as _ops
 except ImportError:
     from models.blocks import KPConv, UnaryBlock, block_decider
+    from _native import ops as _ops
 
 
 def p2p_fitting_regularizer(net):
-    """Deformable-kernel regulariser: fitting (kernel point -> closest input point) + repulsion
-    between deformed kernel points (architectures.py:25-58)."""
+    """Deformable-kernel regulariser (architectures.py:25-58): fitting loss = mean |min_d2| / extent^2
+    (kernel point -> closest input point) and repulsive loss between the deformed kernel points of a
+    point (the "other" points detached, :52). Same arithmetic as the reference's per-kernel-point
+    Python loop, evaluated for all K points at once (one [N,K,K] distance tensor instead of 15 x 8 small
+    kernels per deformable layer); in capacity-padded mode the means run over the valid rows only."""
     fitting_loss = 0
     repulsive_loss = 0
     for m in net.modules():
         if isinstance(m, KPConv) and m.deformable:
-            KP_min_d2 = m.min_d2 / (m.KP_extent ** 2)
-            fitting_loss += net.l1(KP_min_d2, torch.zeros_like(KP_min_d2))
+            rows = m.min_d2.shape[0]
+            n_valid = _ops.row_count_for(rows)
+            if n_valid is None:
+                mask, denom = None, float(rows)
+            else:
+                mask = (torch.arange(rows, device=m.min_d2.device) < n_valid).to(m.min_d2.dtype).unsqueeze(1)
+                denom = n_valid.to(m.min_d2.dtype)
+
+            def mean_rows(v):                      # nn.L1Loss(v, 0) = mean |v| over rows x columns (v >= 0 here)
+                v = v.abs()
+                if mask is not None:
+                    v = v * mask
+                return v.sum() / (denom * v.shape[1])
+
+            # fitting: squared distance to the closest input point, normalised by the extent (:35-38)
+            fitting_loss = fitting_loss + mean_rows(m.min_d2 / (m.KP_extent ** 2))
+            # repulsion (:44-56): d[n,i,j] = |KP_i - sg(KP_j)|, j != i
             KP_locs = m.deformed_KP / m.KP_extent
-            for i in range(net.K):
-                other_KP = torch.cat([KP_locs[:, :i, :], KP_locs[:, i + 1:, :]], dim=1).detach()
-                distances = torch.sqrt(torch.sum((other_KP - KP_locs[:, i:i + 1, :]) ** 2, dim=2))
-                rep_loss = torch.sum(torch.clamp_max(distances - net.repulse_extent, max=0.0) ** 2, dim=1)
-                repulsive_loss += net.l1(rep_loss, torch.zeros_like(rep_loss)) / net.K
+            K = KP_locs.shape[1]
+            diff = KP_locs.unsqueeze(2) - KP_locs.detach().unsqueeze(1)               # [N,K,K,3]
+            eye = torch.eye(K, device=diff.device, dtype=diff.dtype)
+            d2 = torch.sum(diff ** 2, dim=3) + eye                                     # keep sqrt'(0) off the diagonal
+            dist = torch.sqrt(d2)
+            rep = torch.clamp_max(dist - net.repulse_extent, max=0.0) ** 2 * (1 - eye)
+            rep_loss = rep.sum(dim=2)                                                  # [N,K]: sum over the other points
+            repulsive_loss = repulsive_loss + mean_rows(rep_loss) * rep_loss.shape[1] / net.K
     return net.deform_fitting_power * (2 * fitting_loss + repulsive_loss)
 
 

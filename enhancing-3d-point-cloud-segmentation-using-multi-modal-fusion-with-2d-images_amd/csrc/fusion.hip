@@ -220,6 +220,144 @@ __global__ void fa_gather_kernel(const float* __restrict__ feat /* [nv,C,hw] */,
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Sphere extraction around a centre (reference ScanNetDataset.potential_item,
+// KPConv-PyTorch/datasets/ScanNet_sphere_color.py:556-597: sklearn KDTree.query_radius on float64
+// data, membership rdist = dx^2+dy^2+dz^2 <= r^2) and the Tukey update of the sampling potentials
+// (:576-584). Points are float32 promoted to float64 like the tree's data; evaluation order as
+// sklearn's euclidean rdist. Ordered stream compaction: per-block ballot counts -> block scan ->
+// scatter, so the indices come out ascending (the reference's order is KD-tree traversal order; the
+// contract here is the SET).
+// ---------------------------------------------------------------------------------------------
+struct Ball {
+  double cx, cy, cz, r2;
+};
+
+__device__ __forceinline__ double ball_rdist(const float* __restrict__ pts, int64_t i, const Ball& b) {
+  const double dx = (double)pts[i * 3] - b.cx, dy = (double)pts[i * 3 + 1] - b.cy, dz = (double)pts[i * 3 + 2] - b.cz;
+  double d2 = 0.0;
+  d2 += dx * dx;
+  d2 += dy * dy;
+  d2 += dz * dz;
+  return d2;
+}
+
+// grid ceil(N/1024), block 1024: block_count[b] = members in the block
+__global__ __launch_bounds__(1024) void ball_count_kernel(const float* __restrict__ pts, int64_t N, Ball b,
+                                                          int* __restrict__ block_count) {
+  __shared__ int wc[16];
+  const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  const bool in = i < N && ball_rdist(pts, i, b) <= b.r2;
+  const unsigned long long m = __ballot(in);
+  if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < 16; ++w) t += wc[w];
+    block_count[blockIdx.x] = t;
+  }
+}
+
+// single block: exclusive scan of block counts in place, total -> *count
+__global__ __launch_bounds__(1024) void ball_scan_kernel(int* __restrict__ block_count, int nblk, int64_t* __restrict__ count) {
+  __shared__ int carry;
+  __shared__ int ws[16];
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblk ? block_count[i] : 0;
+    int x = v;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int y = __shfl_up(x, o);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) ws[w] = x;
+    __syncthreads();
+    int off = carry;
+    for (int k = 0; k < w; ++k) off += ws[k];
+    if (i < nblk) block_count[i] = off + x - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = off + x;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *count = carry;
+}
+
+__global__ __launch_bounds__(1024) void ball_scatter_kernel(const float* __restrict__ pts, int64_t N, Ball b,
+                                                            const int* __restrict__ block_off,
+                                                            int64_t* __restrict__ out_idx, double* __restrict__ out_d2) {
+  __shared__ int wc[16];
+  const int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x;
+  double d2 = 0.0;
+  bool in = false;
+  if (i < N) {
+    d2 = ball_rdist(pts, i, b);
+    in = d2 <= b.r2;
+  }
+  const unsigned long long m = __ballot(in);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (lane == 0) wc[w] = __popcll(m);
+  __syncthreads();
+  if (in) {
+    int off = block_off[blockIdx.x];
+    for (int k = 0; k < w; ++k) off += wc[k];
+    off += __popcll(m & ((1ull << lane) - 1ull));
+    out_idx[off] = i;
+    if (out_d2) out_d2[off] = d2;
+  }
+}
+
+// potentials[i] += tukey(d2) for the members (ScanNet_sphere_color.py:576-582)
+__global__ void tukey_update_kernel(const float* __restrict__ pts, int64_t N, Ball b, double* __restrict__ pot) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const double rd = ball_rdist(pts, i, b);
+  if (rd <= b.r2) {
+    const double d = sqrt(rd);          // query_radius returns dist = sqrt(rdist) ...
+    const double d2s = d * d;           // ... and the reference squares it again (:576)
+    double t = 1.0 - d2s / b.r2;
+    t = t * t;
+    if (d2s > b.r2) t = 0.0;            // :579
+    pot[i] += t;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t mvk_ball_query_workspace(int64_t N) { return (cdiv64(N > 0 ? N : 1, 1024) + 4) * 4 + 64; }
+
+extern "C" int mvk_ball_query(const float* pts, int64_t N, const double* center_host, double radius,
+                              int64_t* out_idx, double* out_d2, int64_t* count_dev, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+  MVK_REQUIRE(N >= 0 && radius >= 0.0, "ball_query: bad arguments");
+  MVK_REQUIRE(workspace && workspace_bytes >= mvk_ball_query_workspace(N), "ball_query: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = (int)cdiv64(N > 0 ? N : 1, 1024);
+  Ball b{center_host[0], center_host[1], center_host[2], radius * radius};
+  int* bc = (int*)workspace;
+  hipLaunchKernelGGL(ball_count_kernel, dim3(nblk), dim3(1024), 0, st, pts, N, b, bc);
+  hipLaunchKernelGGL(ball_scan_kernel, dim3(1), dim3(1024), 0, st, bc, nblk, count_dev);
+  hipLaunchKernelGGL(ball_scatter_kernel, dim3(nblk), dim3(1024), 0, st, pts, N, b, bc, out_idx, out_d2);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_tukey_update(const float* pts, int64_t N, const double* center_host, double radius,
+                                double* potentials, void* stream) {
+  MVK_REQUIRE(N >= 0 && radius > 0.0, "tukey_update: bad arguments");
+  if (N == 0) return 0;
+  Ball b{center_host[0], center_host[1], center_host[2], radius * radius};
+  hipLaunchKernelGGL(tukey_update_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, (hipStream_t)stream, pts, N, b,
+                     potentials);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+namespace {
+
 }  // namespace
 
 extern "C" int mvk_fa_gather_fwd(const float* feature_2d, const float* image_xyz, const int64_t* knn,

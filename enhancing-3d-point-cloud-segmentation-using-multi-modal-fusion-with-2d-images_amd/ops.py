@@ -590,3 +590,37 @@ class _LinearFn(torch.autograd.Function):
 def linear(x, W, x_is_transposed=False):
     """nn.Linear without bias / a 1x1 convolution over rows, on gemm_f32_mfma."""
     return _LinearFn.apply(x, W, x_is_transposed)
+
+
+# --------------------------------------------------------------------------------------------
+# sphere extraction + sampling potentials (SURVEY.md 8f-2)
+# --------------------------------------------------------------------------------------------
+
+def ball_query(points, center, radius, return_d2=False):
+    """Indices (ascending, int64, HBM) of the points of `points` [N,3] f32 within `radius` of `center`
+    (3 host floats), float64 membership like KDTree.query_radius (ScanNet_sphere_color.py:592-597).
+    Synchronises once (the count comes back to size the result)."""
+    _dev(points)
+    pts = _f32c(points)
+    N = pts.shape[0]
+    c = _np.ascontiguousarray(_np.asarray(center, dtype=_np.float64).reshape(3))
+    idx = torch.empty((max(N, 1),), device=pts.device, dtype=torch.int64)
+    d2 = torch.empty((max(N, 1),), device=pts.device, dtype=torch.float64) if return_d2 else None
+    cnt = torch.zeros((1,), device=pts.device, dtype=torch.int64)
+    ws = _workspace("ball", lib().mvk_ball_query_workspace(N), pts.device)
+    check(lib().mvk_ball_query(_p(pts), N, c.ctypes.data_as(C.c_void_p), float(radius), _p(idx), _p(d2), _p(cnt),
+                               _p(ws), ws.numel(), _stream()))
+    n = int(cnt.item())
+    return (idx[:n], d2[:n]) if return_d2 else idx[:n]
+
+
+def tukey_update(points, center, radius, potentials):
+    """potentials (float64, HBM) += Tukey weights of the ball around center (ScanNet_sphere_color.py:576-582)."""
+    _dev(points, potentials)
+    if potentials.dtype != torch.float64 or not potentials.is_contiguous():
+        raise RuntimeError("tukey_update: potentials must be a contiguous float64 tensor")
+    pts = _f32c(points)
+    c = _np.ascontiguousarray(_np.asarray(center, dtype=_np.float64).reshape(3))
+    check(lib().mvk_tukey_update(_p(pts), pts.shape[0], c.ctypes.data_as(C.c_void_p), float(radius), _p(potentials),
+                                 _stream()))
+    return potentials

@@ -177,6 +177,19 @@ int mvk_fa_gather_fwd(const float* feature_2d, const float* image_xyz, const int
                       const float* points, int C, int nv, int64_t hw, int64_t np, int k, float* X,
                       void* stream);
 
+/* ---------------- sphere extraction + sampling potentials ---- */
+
+/* All points of pts [N,3] f32 within `radius` of center_host (HOST double[3]): float64 rdist <= r^2
+ * like sklearn KDTree.query_radius (KPConv-PyTorch/datasets/ScanNet_sphere_color.py:571-573,592-597).
+ * out_idx [cap N] int64 ascending, out_d2 [cap N] f64 or NULL, *count_dev (DEVICE int64). */
+int64_t mvk_ball_query_workspace(int64_t N);
+int mvk_ball_query(const float* pts, int64_t N, const double* center_host, double radius,
+                   int64_t* out_idx, double* out_d2, int64_t* count_dev, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+/* potentials[i] += (1 - d2/r^2)^2 for the points of the ball (Tukey weights, :576-582). */
+int mvk_tukey_update(const float* pts, int64_t N, const double* center_host, double radius,
+                     double* potentials, void* stream);
+
 /* group_points forward: points [B,C,N1] f32, index [B,N2,K] int64 -> out [B,C,N2,K]. */
 int mvk_group_points_fwd(const float* points, const int64_t* index, int B, int C, int64_t N1,
                          int64_t N2, int K, float* out, void* stream);

@@ -147,3 +147,41 @@ def group_points_backward(grad_out, index, n1):
         for c in range(Cc):
             np.add.at(gi[b, c], index[b].reshape(-1), grad_out[b, c].reshape(-1))
     return gi
+
+
+# ---------------------------------------------------------------------------
+# sphere picking (KPConv-PyTorch/datasets/ScanNet_sphere_color.py:556-597)
+# ---------------------------------------------------------------------------
+
+def ball_members(points, center, radius):
+    """sklearn KDTree.query_radius membership: float64 rdist = dx^2+dy^2+dz^2 (in that order) <= r^2;
+    returns ascending indices and rdist."""
+    p = np.asarray(points, np.float64)
+    c = np.asarray(center, np.float64).reshape(3)
+    d = p - c
+    rd = np.zeros(p.shape[0])
+    rd += d[:, 0] * d[:, 0]
+    rd += d[:, 1] * d[:, 1]
+    rd += d[:, 2] * d[:, 2]
+    idx = np.nonzero(rd <= radius * radius)[0]
+    return idx, rd[idx]
+
+
+def sphere_pick(pot_points, potentials, min_pot, argmin_pot, input_points, in_radius, mask_margin=0.1):
+    """One critical-section iteration (:556-584) + the input-region queries (:592-597), numpy.
+    potentials / min_pot / argmin_pot are updated in place; returns (cloud_ind, point_ind, center,
+    input_inds, mask_inds) with ascending indices."""
+    cloud_ind = int(np.argmin(min_pot))
+    point_ind = int(argmin_pot[cloud_ind])
+    center = np.asarray(pot_points[cloud_ind], np.float64)[point_ind]
+    idx, rd = ball_members(pot_points[cloud_ind], center, in_radius)
+    d2s = np.square(np.sqrt(rd))                                   # query_radius returns sqrt(rdist); :576 squares it
+    tukeys = np.square(1 - d2s / np.square(in_radius))             # :578
+    tukeys[d2s > np.square(in_radius)] = 0                         # :579
+    potentials[cloud_ind][idx] += tukeys                           # :581
+    m = int(np.argmin(potentials[cloud_ind]))
+    min_pot[cloud_ind] = potentials[cloud_ind][m]
+    argmin_pot[cloud_ind] = m
+    inp, _ = ball_members(input_points[cloud_ind], center, in_radius)
+    msk, _ = ball_members(input_points[cloud_ind], center, in_radius + mask_margin)
+    return cloud_ind, point_ind, center, inp, msk

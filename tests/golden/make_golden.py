@@ -386,7 +386,47 @@ def g6_fusion():
     save("g6_fusion", **arrs)
 
 
-GROUPS = {"g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn,
+def g7_sphere_picking():
+    """Potentials-based sphere picking through scikit-learn's KDTree.query_radius, the reference's calls
+    (ScanNet_sphere_color.py:556-597), 6 iterations over 2 clouds: centres, potentials, member sets."""
+    from sklearn.neighbors import KDTree
+    rng = np.random.default_rng(707)
+    clouds = [room_cloud(rng, 60000, 2.0), room_cloud(rng, 30000, 1.6)]
+    inputs = [cport.subsample_batch(c, [c.shape[0]], dl=0.04, impl="ref")[0] for c in clouds]
+    coarse = [cport.subsample_batch(c, [c.shape[0]], dl=0.12, impl="ref")[0] for c in inputs]     # in_radius / 10
+    pot_trees = [KDTree(c, leaf_size=10) for c in coarse]
+    in_trees = [KDTree(c, leaf_size=10) for c in inputs]
+    potentials = [rng.random(c.shape[0]) * 1e-3 for c in coarse]
+    init = [p.copy() for p in potentials]
+    min_pot = np.array([p.min() for p in potentials])
+    argmin_pot = np.array([p.argmin() for p in potentials])
+    R = 1.2
+    arrs = {"in_radius": np.float64(R)}
+    for ci in range(2):
+        arrs["coarse%d" % ci], arrs["input%d" % ci], arrs["init_pot%d" % ci] = coarse[ci], inputs[ci], init[ci]
+    for it in range(6):
+        cloud_ind = int(np.argmin(min_pot))
+        point_ind = int(argmin_pot[cloud_ind])
+        pot_points = np.array(pot_trees[cloud_ind].data, copy=False)
+        center = pot_points[point_ind, :].reshape(1, -1)
+        pot_inds, dists = pot_trees[cloud_ind].query_radius(center, r=R, return_distance=True)
+        d2s = np.square(dists[0])
+        tukeys = np.square(1 - d2s / np.square(R))
+        tukeys[d2s > np.square(R)] = 0
+        potentials[cloud_ind][pot_inds[0]] += tukeys
+        m = int(np.argmin(potentials[cloud_ind]))
+        min_pot[cloud_ind] = potentials[cloud_ind][m]
+        argmin_pot[cloud_ind] = m
+        inp = in_trees[cloud_ind].query_radius(center, r=R)[0]
+        msk = in_trees[cloud_ind].query_radius(center, r=R + 0.1)[0]
+        arrs["it%d_cloud" % it], arrs["it%d_point" % it] = np.int64(cloud_ind), np.int64(point_ind)
+        arrs["it%d_center" % it] = center[0].astype(np.float64)
+        arrs["it%d_input_inds" % it], arrs["it%d_mask_inds" % it] = np.sort(inp).astype(np.int64), np.sort(msk).astype(np.int64)
+        arrs["it%d_pot" % it] = potentials[cloud_ind].copy()
+    save("g7_sphere_picking", **arrs)
+
+
+GROUPS = {"g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn,
           "g6": g6_fusion}
 
 if __name__ == "__main__":

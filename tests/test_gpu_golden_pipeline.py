@@ -148,3 +148,24 @@ def test_numpy_dropin_extensions_vs_golden():
     assert nb.dtype == np.int32 and np.array_equal(nb, g["out"])
     with pytest.raises(RuntimeError, match="^Error$"):          # empty result (wrapper.cpp:201-205)
         nbm.batch_query(np.zeros((0, 3), np.float32), g["supports"], [0], g["s_lens"], radius=0.1)
+
+
+def test_sphere_picking_vs_sklearn_golden():
+    """Device-resident potentials sampler against scikit-learn KDTree.query_radius (G7)."""
+    sp = importlib.import_module(PKG + ".dropin.datasets.sphere_picking")
+    g = load_golden("g7_sphere_picking")
+    s = sp.PotentialSphereSampler([g["coarse0"], g["coarse1"]], [g["input0"], g["input1"]], float(g["in_radius"]),
+                                  init_potentials=[g["init_pot0"], g["init_pot1"]])
+    for it in range(6):
+        r = s.pick()
+        assert r["cloud_ind"] == int(g["it%d_cloud" % it]) and r["point_ind"] == int(g["it%d_point" % it])
+        assert np.array_equal(r["center"], g["it%d_center" % it])
+        assert np.array_equal(r["input_inds"].cpu().numpy(), g["it%d_input_inds" % it])
+        assert np.array_equal(r["mask_inds"].cpu().numpy(), g["it%d_mask_inds" % it])
+        pot = s.potentials[r["cloud_ind"]].cpu().numpy()
+        assert np.allclose(pot, g["it%d_pot" % it], rtol=0, atol=1e-15)      # sqrt / divide rounding: last bit at most
+    # ball query on an empty set and on everything
+    ops = importlib.import_module(PKG + ".ops")
+    pts = T(g["input0"])
+    assert ops.ball_query(pts, [100, 100, 100], 0.5).numel() == 0
+    assert ops.ball_query(pts, [0, 0, 0], 1e3).numel() == pts.shape[0]

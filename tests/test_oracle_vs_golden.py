@@ -169,3 +169,19 @@ def test_fusion_oracle_vs_golden():
     args = (torch.from_numpy(g["grouped_xyz"]), tgt, torch.from_numpy(g["grouped_feat"]))
     assert rel_err(torch_port.feature_aggregation(sd, "fa", *args, training=True).numpy(), g["out_train"]) < 1e-5
     assert rel_err(torch_port.feature_aggregation(sd, "fa", *args, training=False).numpy(), g["out_eval"]) < 1e-5
+
+
+def test_sphere_picking_oracle_vs_sklearn_golden():
+    """6 iterations of potentials-based sphere picking: the numpy restatement against scikit-learn's
+    KDTree.query_radius (the reference's calls): same centres, member sets and potentials."""
+    g = load_golden("g7_sphere_picking")
+    coarse, inputs = [g["coarse0"], g["coarse1"]], [g["input0"], g["input1"]]
+    pots = [g["init_pot0"].copy(), g["init_pot1"].copy()]
+    min_pot = np.array([p.min() for p in pots])
+    argmin_pot = np.array([p.argmin() for p in pots])
+    for it in range(6):
+        ci, pi, c, inp, msk = npref.sphere_pick(coarse, pots, min_pot, argmin_pot, inputs, float(g["in_radius"]))
+        assert ci == int(g["it%d_cloud" % it]) and pi == int(g["it%d_point" % it])
+        assert np.array_equal(c, g["it%d_center" % it])
+        assert np.array_equal(inp, g["it%d_input_inds" % it]) and np.array_equal(msk, g["it%d_mask_inds" % it])
+        assert np.array_equal(pots[ci], g["it%d_pot" % it])          # float64 Tukey update, bit for bit

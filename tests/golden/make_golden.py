@@ -426,7 +426,19 @@ def g7_sphere_picking():
     save("g7_sphere_picking", **arrs)
 
 
-GROUPS = {"g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn,
+def g8_metrics():
+    """IoU_from_confusions / fast_confusion of the reference's utils/metrics.py on random predictions."""
+    _ref_blocks()
+    from utils.metrics import IoU_from_confusions, fast_confusion
+    rng = np.random.default_rng(808)
+    true = rng.integers(0, 20, 5000).astype(np.int32)
+    pred = np.where(rng.random(5000) < 0.6, true, rng.integers(0, 20, 5000)).astype(np.int32)
+    true[true == 7] = 3                                  # an absent class
+    conf = fast_confusion(true, pred, np.arange(20, dtype=np.int32))
+    save("g8_metrics", true=true, pred=pred, confusion=conf.astype(np.int64), iou=IoU_from_confusions(conf))
+
+
+GROUPS = {"g8": g8_metrics, "g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn,
           "g6": g6_fusion}
 
 if __name__ == "__main__":

@@ -169,3 +169,47 @@ def test_sphere_picking_vs_sklearn_golden():
     pts = T(g["input0"])
     assert ops.ball_query(pts, [100, 100, 100], 0.5).numel() == 0
     assert ops.ball_query(pts, [0, 0, 0], 1e3).numel() == pts.shape[0]
+
+
+def test_voting_metrics_and_frame_selection():
+    """SURVEY.md 8f-3/8f-4 helpers: confusion / IoU against the reference's utils.metrics (G8), voting
+    update and greedy frame selection against their NumPy restatements, overlap table against brute force."""
+    vt = importlib.import_module(PKG + ".dropin.utils.voting")
+    syn = importlib.import_module(PKG + ".synthetic")
+    g = load_golden("g8_metrics")
+    conf = vt.confusion(T(g["true"]), T(g["pred"]), 20)
+    assert np.array_equal(conf.cpu().numpy(), g["confusion"])
+    assert np.allclose(vt.IoU_from_confusions(conf).cpu().numpy(), g["iou"], rtol=1e-6, atol=1e-9)
+    # voting (tester.py:185)
+    rng = np.random.default_rng(1)
+    tp = rng.random((1000, 20)).astype(np.float32)
+    inds = rng.permutation(1000)[:300]
+    pr = rng.random((300, 20)).astype(np.float32)
+    want = tp.copy()
+    want[inds] = 0.95 * want[inds] + (1 - 0.95) * pr
+    got = vt.vote_update(T(tp), T(inds), T(pr), 0.95)
+    assert np.allclose(got.cpu().numpy(), want, rtol=1e-6)
+    # greedy frame selection (ScanNet_sphere_color.py:53-63 restated)
+    ov = rng.random((500, 12)) < 0.2
+    o = ov.copy()
+    ref = []
+    for _ in range(3):
+        f = int(o.sum(0).argmax())
+        ref.append(f)
+        o[o[:, f]] = False
+    assert vt.select_frames(T(ov), 3) == ref
+    # overlap table vs brute force (get_rgbd_overlap_subcloud.py:68-138)
+    sph = syn.raw_sphere(seed=2, radius=0.9, density=1500.0)
+    views = syn.sphere_views(sph, nv=3, h=30, w=40)
+    base = sph["points"][rng.permutation(sph["points"].shape[0])[:800]]
+    got = vt.frame_overlaps(T(base), T(views["depth"].astype(np.int16)), views["cam"], T(views["poses"])).cpu().numpy()
+    from oracle import npref
+    xyz, mask = npref.unproject_frames(views["cam"], views["depth"], views["poses"])
+    want = np.zeros((800, 3), bool)
+    for f in range(3):
+        pix = xyz[f].reshape(-1, 3)[mask[f].reshape(-1)]
+        d2 = ((pix[:, None, :] - base[None].astype(np.float64)) ** 2).sum(-1)
+        nn = d2.argmin(1)
+        ok = d2[np.arange(len(nn)), nn] <= 0.01
+        want[nn[ok], f] = True
+    assert np.array_equal(got, want)

@@ -25,7 +25,8 @@ except ImportError:  # dropin/ put on sys.path directly
     from kernels.kernel_points import load_kernels
 
 
-_FUSE_ADD = os.environ.get("MVK_FUSE_ADD", "1") == "1"      # development switch for A/B timing
+_FUSE_ADD = os.environ.get("MVK_FUSE_ADD", "1") == "1"      # development switches for A/B timing
+_MFMA_LINEAR = os.environ.get("MVK_MFMA_LINEAR", "1") == "1"
 
 
 # ---------------------------------------------------------------- simple functions (blocks.py:35-133)
@@ -215,7 +216,10 @@ class UnaryBlock(nn.Module):
             self.leaky_relu = nn.LeakyReLU(0.1)
 
     def forward(self, x, batch=None):
-        return self.batch_norm(self.mlp(x), None if self.no_relu else 0.1)
+        # nn.Linear(bias=False) = x @ W^T: on the f32 MFMA GEMM (faster than the library GEMM on these
+        # tall-skinny shapes, tools/gemm_bench.py); parameters stay those of self.mlp (state-dict compatible)
+        y = ops.linear(x, self.mlp.weight) if (_MFMA_LINEAR and x.is_cuda) else self.mlp(x)
+        return self.batch_norm(y, None if self.no_relu else 0.1)
 
     def __repr__(self):
         return 'UnaryBlock(in_feat: {:d}, out_feat: {:d}, BN: {:s}, ReLU: {:s})'.format(

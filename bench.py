@@ -204,6 +204,10 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         opt.zero_grad(set_to_none=True)
         net_step_captured(net, static, cfg, params, opt, reducer)
     torch.cuda.synchronize()
+    ops.step_begin()
+    if os.environ.get("MVK_ZERO_ARENA", "1") == "1":
+        # one fill per replay instead of ~100 (split-K outputs, scatter targets): sized from the warm-up
+        ops.zero_arena_enable(int(ops.zero_arena_high_water() * 1.05) + (1 << 20), static.points[0].device)
     opt.zero_grad(set_to_none=True)
     graph = torch.cuda.CUDAGraph()
     if reducer is None:
@@ -214,6 +218,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         # N > 1: the RCCL all-reduce stays an eager call between two graphs (forward+backward | clip+SGD).
         # thread_local capture mode: the process group's watchdog thread may query events meanwhile.
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            ops.step_begin()
             static_loss = net.loss(net(static, cfg), static.labels)
             static_loss.backward()
         graph_b = torch.cuda.CUDAGraph()
@@ -250,9 +255,11 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             static.load(batch)
         except RuntimeError:                    # a level outgrew its captured capacity: run this step eagerly
             ops.set_row_counts(None)
+            ops._ARENA["on"], arena_was = False, ops._ARENA["on"]
             opt.zero_grad(set_to_none=False)
             loss = net_step_eager(net, batch, cfg, params, opt, reducer)
             ops.set_row_counts(static.valid)
+            ops._ARENA["on"] = arena_was
             state["next"] = build_async()
             return lens, loss
         done = torch.cuda.Event()
@@ -292,6 +299,8 @@ def net_step_eager(net, batch, cfg, params, opt, reducer):
 
 def net_step_captured(net, static, cfg, params, opt, reducer):
     """Body of the captured graph: identical to an eager network step (no host sync inside)."""
+    import mvkpconv
+    mvkpconv.sub("ops").step_begin()
     out = net(static, cfg)
     loss = net.loss(out, static.labels)
     loss.backward()

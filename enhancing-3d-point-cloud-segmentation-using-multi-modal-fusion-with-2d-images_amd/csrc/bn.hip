@@ -82,7 +82,8 @@ __global__ __launch_bounds__(1024) void bn_stats_finish(const float* __restrict_
                                                         int R, int D, const float* __restrict__ part, float eps,
                                                         float momentum, float* __restrict__ mean,
                                                         float* __restrict__ invstd, float* __restrict__ running_mean,
-                                                        float* __restrict__ running_var) {
+                                                        float* __restrict__ running_var, long long* __restrict__ nbt) {
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;   // num_batches_tracked (nn.BatchNorm bookkeeping)
   float p1, p2;
   if (!bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, &p1, &p2)) return;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
@@ -212,8 +213,10 @@ __global__ __launch_bounds__(1024) void bn_small_fwd(const float* __restrict__ x
                                                      const float* __restrict__ beta, float eps, float momentum,
                                                      float slope, float* __restrict__ running_mean,
                                                      float* __restrict__ running_var, float* __restrict__ mean,
-                                                     float* __restrict__ invstd, float* __restrict__ y) {
+                                                     float* __restrict__ invstd, float* __restrict__ y,
+                                                     long long* __restrict__ nbt) {
   __shared__ float r1[16][64], r2[16][64];
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
   const int n = min(*n_valid, R);
   const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -331,20 +334,20 @@ int bn_small_rows() {
 extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t R, int D, const float* gamma,
                                 const float* beta, float eps, float momentum, float slope, float* running_mean,
                                 float* running_var, float* mean, float* invstd, float* scratch2D /* [ceil(R/64),2,D] */, float* y,
-                                void* stream) {
+                                int64_t* num_batches_tracked, void* stream) {
   MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
   if (R == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (R <= bn_small_rows()) {
     hipLaunchKernelGGL(bn_small_fwd, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, x, n_valid, (int)R, D, gamma, beta,
-                       eps, momentum, slope, running_mean, running_var, mean, invstd, y);
+                       eps, momentum, slope, running_mean, running_var, mean, invstd, y, (long long*)num_batches_tracked);
     MVK_CHECK_HIP(hipGetLastError());
     return 0;
   }
   dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
   hipLaunchKernelGGL(bn_stats_partial, g1, dim3(BN_T), 0, st, x, n_valid, (int)R, D, scratch2D);
   hipLaunchKernelGGL(bn_stats_finish, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, x, n_valid, (int)R, D, scratch2D,
-                     eps, momentum, mean, invstd, running_mean, running_var);
+                     eps, momentum, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked);
   hipLaunchKernelGGL(bn_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, n_valid, (int)R, D, mean, invstd,
                      gamma, beta, slope, y);
   MVK_CHECK_HIP(hipGetLastError());

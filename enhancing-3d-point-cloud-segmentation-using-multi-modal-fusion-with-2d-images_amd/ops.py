@@ -39,6 +39,49 @@ def _idx(t):
 
 
 # --------------------------------------------------------------------------------------------
+# zero arena (opt-in): one fill per step instead of one per zero-initialised output
+# --------------------------------------------------------------------------------------------
+# Split-K GEMM outputs and scatter targets must start at zero; eagerly that is ~100 tiny fill kernels per
+# step. With the arena enabled, step_begin() zeroes one big buffer with a single launch and _zeros()
+# hands out 256-byte aligned slices of it. Slices are only valid until the next step_begin(): this is for
+# the captured-graph step of bench.py (fixed addresses), not a general allocator.
+_ARENA = {"on": False, "buf": None, "off": 0, "high": 0}
+
+
+def zero_arena_enable(nbytes, device):
+    _ARENA.update(on=True, buf=torch.zeros(int(nbytes), dtype=torch.uint8, device=device), off=0)
+
+
+def zero_arena_disable():
+    _ARENA.update(on=False, buf=None, off=0)
+
+
+def zero_arena_high_water():
+    """Largest number of bytes _zeros() handed out (or would have) between two step_begin() calls."""
+    return _ARENA["high"]
+
+
+def step_begin():
+    _ARENA["high"] = max(_ARENA["high"], _ARENA["off"])
+    _ARENA["off"] = 0
+    if _ARENA["on"]:
+        _ARENA["buf"].zero_()
+
+
+def _zeros(shape, device, dtype=torch.float32):
+    n = 1
+    for s in shape:
+        n *= int(s)
+    nbytes = (n * torch.empty((), dtype=dtype).element_size() + 255) // 256 * 256
+    off = _ARENA["off"]
+    _ARENA["off"] = off + nbytes
+    buf = _ARENA["buf"]
+    if _ARENA["on"] and n > 0 and off + nbytes <= buf.numel() and buf.device == device:
+        return buf[off:off + nbytes].view(dtype)[:n].view(shape)
+    return torch.zeros(shape, device=device, dtype=dtype)
+
+
+# --------------------------------------------------------------------------------------------
 # raw kernels
 # --------------------------------------------------------------------------------------------
 
@@ -59,8 +102,7 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
         split_k = int(max(1, min((1000 + tiles - 1) // tiles, 32, Kd // 128)))
     if out is None:
-        out = torch.zeros if split_k > 1 else torch.empty
-        out = out((M, N), device=A.device, dtype=torch.float32)
+        out = _zeros((M, N), A.device) if split_k > 1 else torch.empty((M, N), device=A.device, dtype=torch.float32)
     check(lib().mvk_gemm_f32(_p(A), _p(B), _p(out), M, N, Kd, int(transA), int(transB), int(accumulate),
                              int(split_k), _stream()))
     return out
@@ -152,11 +194,11 @@ def kpconv_scatter(q, s, idx, dA, kp, extent, influence="linear", aggregation="s
     q, s, dA, kp = _f32c(q), _f32c(s), _f32c(dA), _f32c(kp)
     idx, i64 = _idx(idx)
     Nq, Ns, H, K, Cin = q.shape[0], s.shape[0], idx.shape[1], kp.shape[0], dA.shape[2]
-    dx = torch.zeros((Ns, Cin), device=q.device, dtype=torch.float32)
+    dx = _zeros((Ns, Cin), q.device)
     d_off = None
     if offsets is not None:
         offsets, x = _f32c(offsets), _f32c(x)
-        d_off = torch.zeros((Nq, K, 3), device=q.device, dtype=torch.float32)
+        d_off = _zeros((Nq, K, 3), q.device)
         if g_min_d2 is not None:
             g_min_d2 = _f32c(g_min_d2)
     check(lib().mvk_kpconv_scatter_bwd(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, Cin, _p(kp), K, float(extent),
@@ -255,7 +297,7 @@ def row_count_for(rows):
 
 class _BNLReLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, n_valid, gamma, beta, running_mean, running_var, eps, momentum, slope, training):
+    def forward(ctx, x, n_valid, gamma, beta, running_mean, running_var, eps, momentum, slope, training, nbt=None):
         _dev(x, n_valid, gamma, beta)
         x = _f32c(x)
         R, D = x.shape
@@ -267,7 +309,7 @@ class _BNLReLUFn(torch.autograd.Function):
             raise RuntimeError("masked BatchNorm is a training-mode op; use nn.BatchNorm1d in eval mode")
         check(lib().mvk_bn_lrelu_fwd(_p(x), _p(n_valid), R, D, _p(gamma), _p(beta), float(eps), float(momentum),
                                      float(slope), _p(running_mean), _p(running_var), _p(mean), _p(invstd),
-                                     _p(scratch), _p(y), _stream()))
+                                     _p(scratch), _p(y), _p(nbt), _stream()))
         ctx.save_for_backward(x, n_valid, gamma, beta, mean, invstd)
         ctx.slope = float(slope)
         return y
@@ -282,17 +324,16 @@ class _BNLReLUFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         check(lib().mvk_bn_lrelu_bwd(_p(x), _p(g), _p(n_valid), R, D, _p(gamma), _p(beta), _p(mean), _p(invstd),
                                      ctx.slope, _p(scratch), _p(dgb), _p(dx), _stream()))
-        return dx, None, dgb[D:], dgb[:D], None, None, None, None, None, None
+        return dx, None, dgb[D:], dgb[:D], None, None, None, None, None, None, None
 
 
 def bn_lrelu(x, n_valid, bn, slope=1.0):
     """y = LeakyReLU_slope(BatchNorm1d(x[:n_valid])) with rows >= n_valid zeroed; `bn` is an
     nn.BatchNorm1d whose parameters / running statistics are used and updated; n_valid is a DEVICE
     int32 tensor of one element."""
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # += 1 inside the kernel
     return _BNLReLUFn.apply(x, n_valid, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                            bn.momentum if bn.momentum is not None else 0.0, slope, bn.training)
+                            bn.momentum if bn.momentum is not None else 0.0, slope, bn.training, nbt)
 
 
 class _AddLReLUFn(torch.autograd.Function):
@@ -344,7 +385,7 @@ class _MaxPoolFn(torch.autograd.Function):
     def backward(ctx, g):
         inds, arg = ctx.saved_tensors
         g = _f32c(g)
-        dx = torch.zeros((ctx.ns, g.shape[1]), device=g.device, dtype=torch.float32)
+        dx = _zeros((ctx.ns, g.shape[1]), g.device)
         check(lib().mvk_max_pool_bwd(_p(g), _p(arg), _p(inds), int(inds.dtype == torch.int64), inds.shape[0],
                                      inds.shape[1], ctx.ns, g.shape[1], _p(dx), _stream()))
         return dx, None
@@ -368,7 +409,7 @@ class _GatherRowsFn(torch.autograd.Function):
     def backward(ctx, g):
         (inds2d,) = ctx.saved_tensors
         g = _f32c(g)
-        dx = torch.zeros((ctx.ns, g.shape[1]), device=g.device, dtype=torch.float32)
+        dx = _zeros((ctx.ns, g.shape[1]), g.device)
         check(lib().mvk_gather_rows_bwd(_p(g), _p(inds2d), int(inds2d.dtype == torch.int64), inds2d.shape[0],
                                         ctx.stride, ctx.ns, g.shape[1], _p(dx), _stream()))
         return dx, None

@@ -92,7 +92,7 @@ int mvk_gemm_f32(const float* A, const float* B, float* C, int64_t M, int64_t N,
 int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t R, int D, const float* gamma,
                      const float* beta, float eps, float momentum, float slope, float* running_mean,
                      float* running_var, float* mean, float* invstd, float* scratch, float* y,
-                     void* stream);
+                     int64_t* num_batches_tracked /* DEVICE counter += 1, may be NULL */, void* stream);
 /* dgamma_dbeta [2,D] receives dbeta (row 0) and dgamma (row 1); dx [R,D] (rows >= n_valid zero). */
 int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n_valid, int64_t R, int D,
                      const float* gamma, const float* beta, const float* mean, const float* invstd,

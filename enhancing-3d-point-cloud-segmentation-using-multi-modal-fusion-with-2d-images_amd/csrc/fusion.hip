@@ -158,6 +158,323 @@ __global__ void knn_merge_kernel(const double* __restrict__ pd, const int64_t* _
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pruned exact k-NN (same results as the brute-force kernels above, bit for bit):
+//   1. queries and valid keys are binned into a 32^3 Morton-ordered torus grid (cell 0.1 m; the
+//      binning only decides the ORDER things are visited in, never the result), counting sort;
+//   2. every run of 64 sorted keys is a tile with an axis-aligned box (float, rounded outwards);
+//   3. a workgroup owns 64 consecutive sorted queries (a compact patch). Per query an upper bound of
+//      the k-th distance follows from the boxes alone (ub = min over tiles holding >= k keys of the
+//      farthest box corner); a tile is visited only if some query of the wave has
+//      min-dist(box) <= min(ub, its current k-th best). Every key with d2 <= the true k-th distance
+//      sits in such a tile, ties included, so the (d2, index)-ordered top-k is the brute-force one.
+//      The waves of the workgroup share out the candidate tiles and merge their results in LDS.
+// Distances are the same float64 expression as above.
+// ---------------------------------------------------------------------------------------------
+constexpr int PG = 32, PNC = PG * PG * PG;        // grid cells
+constexpr float PCELL_INV = 10.f;                  // 1 / 0.1 m
+constexpr int PT = 64;                             // keys per tile
+constexpr int PCH = 1024;                          // tiles considered at a time (candidate list <= 36 KB of LDS)
+
+__device__ __forceinline__ unsigned spread3(unsigned v) {  // 5 bits -> every third bit
+  v &= 31u;
+  v = (v | (v << 8)) & 0x0000100Fu;
+  v = (v | (v << 4)) & 0x000010C3u;
+  v = (v | (v << 2)) & 0x00001249u;
+  return v;
+}
+__device__ __forceinline__ int morton_cell(float x, float y, float z) {
+  const int ix = (int)floorf(x * PCELL_INV), iy = (int)floorf(y * PCELL_INV), iz = (int)floorf(z * PCELL_INV);
+  return (int)(spread3((unsigned)ix) | (spread3((unsigned)iy) << 1) | (spread3((unsigned)iz) << 2));
+}
+
+struct PrunedWs {
+  int* cnt;        // [2][PNC]   (0 = queries, 1 = keys), zeroed by the host
+  int* start;      // [2][PNC]
+  int* cell;       // [nq + nk]
+  int* rank;       // [nq + nk]
+  int* qorder;     // [nq]
+  double* skey;    // [nk][3] sorted valid keys
+  int* sidx;       // [nk]    their original index
+  float* box;      // [ntiles_max][8]  lo xyz, hi xyz, count, pad
+  int* nvalid;     // [1]
+};
+
+__global__ void pk_count_kernel(const float* __restrict__ q, int64_t nq, const double* __restrict__ keys,
+                                const uint8_t* __restrict__ kvalid, int64_t nk, PrunedWs ws) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nq + nk) return;
+  int set, c;
+  if (e < nq) {
+    set = 0;
+    c = morton_cell(q[e * 3], q[e * 3 + 1], q[e * 3 + 2]);
+  } else {
+    const int64_t j = e - nq;
+    if (kvalid && !kvalid[j]) {
+      ws.cell[e] = -1;
+      return;
+    }
+    set = 1;
+    c = morton_cell((float)keys[j * 3], (float)keys[j * 3 + 1], (float)keys[j * 3 + 2]);
+  }
+  ws.cell[e] = c;
+  ws.rank[e] = atomicAdd(ws.cnt + set * PNC + c, 1);
+}
+
+// exclusive scan of the PNC cell counts of one set (blockIdx.x), 1024 threads x 32 cells
+__global__ __launch_bounds__(1024) void pk_scan_kernel(PrunedWs ws) {
+  __shared__ int part[1024];
+  const int set = blockIdx.x, tid = threadIdx.x;
+  const int* cnt = ws.cnt + set * PNC;
+  int* start = ws.start + set * PNC;
+  constexpr int PER = PNC / 1024;
+  int loc[PER], s = 0;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) {
+    loc[i] = s;
+    s += cnt[tid * PER + i];
+  }
+  part[tid] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = tid >= off ? part[tid - off] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  const int base = part[tid] - s;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) start[tid * PER + i] = base + loc[i];
+  if (set == 1 && tid == 1023) *ws.nvalid = part[1023];
+}
+
+__global__ void pk_scatter_kernel(int64_t nq, const double* __restrict__ keys, int64_t nk, PrunedWs ws) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nq + nk) return;
+  const int c = ws.cell[e];
+  if (c < 0) return;
+  if (e < nq) {
+    ws.qorder[ws.start[c] + ws.rank[e]] = (int)e;
+  } else {
+    const int64_t j = e - nq;
+    const int p = ws.start[PNC + c] + ws.rank[e];
+    ws.skey[(int64_t)p * 3] = keys[j * 3];
+    ws.skey[(int64_t)p * 3 + 1] = keys[j * 3 + 1];
+    ws.skey[(int64_t)p * 3 + 2] = keys[j * 3 + 2];
+    ws.sidx[p] = (int)j;
+  }
+}
+
+// one wave per tile: outward-rounded float box of its keys
+__global__ __launch_bounds__(64) void pk_box_kernel(PrunedWs ws) {
+  const int nv = *ws.nvalid;
+  const int t = blockIdx.x, p = t * PT + threadIdx.x;
+  float* b = ws.box + (int64_t)t * 8;
+  if (t * PT >= nv) {
+    if (threadIdx.x == 0) b[6] = 0.f;
+    return;
+  }
+  const bool ok = p < nv;
+  float lo[3], hi[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const double v = ok ? ws.skey[(int64_t)p * 3 + a] : 0.0;
+    lo[a] = ok ? __double2float_rd(v) : INFINITY;
+    hi[a] = ok ? __double2float_ru(v) : -INFINITY;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo[a] = fminf(lo[a], __shfl_xor(lo[a], off));
+      hi[a] = fmaxf(hi[a], __shfl_xor(hi[a], off));
+    }
+  }
+  if (threadIdx.x == 0) {
+    b[0] = lo[0]; b[1] = lo[1]; b[2] = lo[2];
+    b[3] = hi[0]; b[4] = hi[1]; b[5] = hi[2];
+    b[6] = (float)min(PT, nv - t * PT);
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void topk_insert32(double (&bd)[K], int (&bi)[K], double d2, int id) {
+  if (d2 < bd[K - 1] || (d2 == bd[K - 1] && id < bi[K - 1])) {
+    bd[K - 1] = d2;
+    bi[K - 1] = id;
+#pragma unroll
+    for (int c = K - 1; c > 0; --c) {
+      if (bd[c] < bd[c - 1] || (bd[c] == bd[c - 1] && bi[c] < bi[c - 1])) {
+        const double td = bd[c]; bd[c] = bd[c - 1]; bd[c - 1] = td;
+        const int ti = bi[c]; bi[c] = bi[c - 1]; bi[c - 1] = ti;
+      }
+    }
+  }
+}
+
+template <int K, int PW>   // PW waves per workgroup share one set of 64 queries
+__global__ __launch_bounds__(64 * PW) void knn_pruned_kernel(const float* __restrict__ q, int64_t nq, PrunedWs ws,
+                                                             int ntiles_max, int kout,
+                                                             int64_t* __restrict__ out) {
+  __shared__ double sk[PW][3][PT];
+  __shared__ int si[PW][PT];
+  __shared__ float sub[PW][64];
+  // candidate list during the sweeps, merge buffers afterwards (same LDS bytes)
+  constexpr int CAND_BYTES = PCH * 36, MERGE_BYTES = PW * 64 * K * 12;
+  __shared__ __attribute__((aligned(16))) char un[CAND_BYTES > MERGE_BYTES ? CAND_BYTES : MERGE_BYTES];
+  float4 (*cbox)[2] = reinterpret_cast<float4 (*)[2]>(un);          // [PCH][2] boxes of the candidate tiles
+  int* cand = reinterpret_cast<int*>(un + PCH * 32);                 // [PCH] their tile ids
+  double (*md)[64][K] = reinterpret_cast<double (*)[64][K]>(un);      // [PW][64][K]
+  int (*mi)[64][K] = reinterpret_cast<int (*)[64][K]>(un + PW * 64 * K * 8);
+  __shared__ int ncand;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int64_t slot = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = slot < nq;
+  const int qi = live ? ws.qorder[slot] : 0;
+  const float fx = live ? q[(int64_t)qi * 3] : 0.f, fy = live ? q[(int64_t)qi * 3 + 1] : 0.f,
+              fz = live ? q[(int64_t)qi * 3 + 2] : 0.f;
+  const double qx = fx, qy = fy, qz = fz;
+  const int nv = *ws.nvalid;
+  const int ntiles = min(ntiles_max, (nv + PT - 1) / PT);
+
+  // box of the workgroup's 64 queries (every wave holds the same queries)
+  float ql[3] = {live ? fx : INFINITY, live ? fy : INFINITY, live ? fz : INFINITY};
+  float qh[3] = {live ? fx : -INFINITY, live ? fy : -INFINITY, live ? fz : -INFINITY};
+#pragma unroll
+  for (int a = 0; a < 3; ++a)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ql[a] = fminf(ql[a], __shfl_xor(ql[a], off));
+      qh[a] = fmaxf(qh[a], __shfl_xor(qh[a], off));
+    }
+
+  // A. workgroup bound: the farthest pair (query box, tile box) of the best tile holding >= K keys
+  float ubw = INFINITY;
+  for (int t = tid; t < ntiles; t += 64 * PW) {
+    const float4 b0 = reinterpret_cast<const float4*>(ws.box)[t * 2], b1 = reinterpret_cast<const float4*>(ws.box)[t * 2 + 1];
+    if (b1.z >= (float)K) {
+      const float dx = fmaxf(b0.w - ql[0], qh[0] - b0.x), dy = fmaxf(b1.x - ql[1], qh[1] - b0.y),
+                  dz = fmaxf(b1.y - ql[2], qh[2] - b0.z);
+      ubw = fminf(ubw, (dx * dx + dy * dy + dz * dz) * 1.0001f + 1e-30f);
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) ubw = fminf(ubw, __shfl_xor(ubw, off));
+  if (lane == 0) sub[wv][0] = ubw;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < PW; ++w) ubw = fminf(ubw, sub[w][0]);
+  __syncthreads();
+
+  double bd[K];
+  int bi[K];
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    bd[c] = INFINITY;
+    bi[c] = INT_MAX;
+  }
+  float ub = INFINITY;
+  // Sweep 0 tightens the per-query bound over the candidate tiles, sweep 1 scans them. Tiles are taken
+  // PCH at a time so that the candidate list always fits in LDS; with one chunk (the usual case) the
+  // list of sweep 0 is reused.
+  const bool one_chunk = ntiles <= PCH;
+  for (int sweep = 0; sweep < 2; ++sweep) {
+    for (int c0 = 0; c0 < ntiles; c0 += PCH) {
+      if (sweep == 0 || !one_chunk) {
+        // B. candidates of this chunk: tile boxes within ubw of the query box
+        __syncthreads();
+        if (tid == 0) ncand = 0;
+        __syncthreads();
+        for (int t = c0 + tid; t < min(ntiles, c0 + PCH); t += 64 * PW) {
+          const float4 b0 = reinterpret_cast<const float4*>(ws.box)[t * 2], b1 = reinterpret_cast<const float4*>(ws.box)[t * 2 + 1];
+          const float dx = fmaxf(fmaxf(b0.x - qh[0], ql[0] - b0.w), 0.f);
+          const float dy = fmaxf(fmaxf(b0.y - qh[1], ql[1] - b1.x), 0.f);
+          const float dz = fmaxf(fmaxf(b0.z - qh[2], ql[2] - b1.y), 0.f);
+          if ((dx * dx + dy * dy + dz * dz) * 0.9999f <= ubw) {
+            const int s = atomicAdd(&ncand, 1);
+            cand[s] = t;
+            cbox[s][0] = b0;
+            cbox[s][1] = b1;
+          }
+        }
+        __syncthreads();
+      }
+      const int nc = ncand;
+      if (sweep == 0) {
+        for (int c = wv; c < nc; c += PW) {
+          const float4 b0 = cbox[c][0], b1 = cbox[c][1];
+          if (b1.z >= (float)K) {
+            const float dx = fmaxf(fabsf(fx - b0.x), fabsf(b0.w - fx));
+            const float dy = fmaxf(fabsf(fy - b0.y), fabsf(b1.x - fy));
+            const float dz = fmaxf(fabsf(fz - b0.z), fabsf(b1.y - fz));
+            ub = fminf(ub, (dx * dx + dy * dy + dz * dz) * 1.0001f + 1e-30f);
+          }
+        }
+        continue;
+      }
+      for (int c = wv; c < nc; c += PW) {
+        const float4 b0 = cbox[c][0], b1 = cbox[c][1];
+        const float dx = fmaxf(fmaxf(b0.x - fx, fx - b0.w), 0.f);
+        const float dy = fmaxf(fmaxf(b0.y - fy, fy - b1.x), 0.f);
+        const float dz = fmaxf(fmaxf(b0.z - fz, fz - b1.y), 0.f);
+        const float mind = (dx * dx + dy * dy + dz * dz) * 0.9999f;
+        const float thr = fminf(ub, (float)bd[K - 1] * 1.0001f);      // (float)inf stays inf
+        if (!__any(mind <= thr)) continue;
+        const int cntk = (int)b1.z;
+        const int p = cand[c] * PT + lane;
+        const bool has = lane < cntk;                                 // padding keys can never be inserted
+        sk[wv][0][lane] = has ? ws.skey[(int64_t)p * 3] : INFINITY;
+        sk[wv][1][lane] = has ? ws.skey[(int64_t)p * 3 + 1] : INFINITY;
+        sk[wv][2][lane] = has ? ws.skey[(int64_t)p * 3 + 2] : INFINITY;
+        si[wv][lane] = has ? ws.sidx[p] : INT_MAX;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int U = 8;                                          // independent distance chains in flight
+        for (int j0 = 0; j0 < PT; j0 += U) {
+          double d2[U];
+          int id[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const double ddx = qx - sk[wv][0][j0 + u], ddy = qy - sk[wv][1][j0 + u], ddz = qz - sk[wv][2][j0 + u];
+            double s = 0.0;
+            s += ddx * ddx;
+            s += ddy * ddy;
+            s += ddz * ddz;
+            d2[u] = s;
+            id[u] = si[wv][j0 + u];
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) topk_insert32<K>(bd, bi, d2[u], id[u]);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (sweep == 0) {   // combine the per-wave partial bounds
+      sub[wv][lane] = ub;
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < PW; ++w) ub = fminf(ub, sub[w][lane]);
+      if (!live) ub = -1.f;   // idle lanes never ask for a tile
+    }
+  }
+  __syncthreads();   // the candidate list is dead: its bytes become the merge buffers
+#pragma unroll
+  for (int c = 0; c < K; ++c) {
+    md[wv][lane][c] = bd[c];
+    mi[wv][lane][c] = bi[c];
+  }
+  __syncthreads();
+  if (wv == 0 && live) {
+    for (int w = 1; w < PW; ++w)
+#pragma unroll
+      for (int c = 0; c < K; ++c) {
+        const int id = mi[w][lane][c];
+        if (id != INT_MAX) topk_insert32<K>(bd, bi, md[w][lane][c], id);
+      }
+#pragma unroll
+    for (int c = 0; c < K; ++c)
+      if (c < kout) out[(int64_t)qi * kout + c] = bi[c] == INT_MAX ? -1 : (int64_t)bi[c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // group_points: out[b,c,n,k] = in[b,c,idx[b,n,k]]; one lane per output element, (n,k) fastest so
 // index reads and output writes are coalesced; the gather itself is element granular by nature
 // (channel-major feature maps), served by L2 / Infinity Cache.
@@ -402,11 +719,49 @@ void knn_plan(int64_t nq, int64_t nk, int* nsplit_out, int64_t* per_split_out) {
 }
 }  // namespace
 
+namespace {
+int64_t align256(int64_t b) { return (b + 255) / 256 * 256; }
+
+// the pruned path pays five small launches: only worth it when the brute-force product is large
+bool knn_use_pruned(int64_t nq, int64_t nk) {
+  const char* e = getenv("MVK_KNN_BRUTE");
+  if (e && e[0] == '1') return false;
+  return nq >= 1024 && nk >= 4096 && nq + nk < (int64_t)1 << 30;
+}
+
+int64_t pruned_layout(int64_t nq, int64_t nk, char* base, PrunedWs* ws) {
+  int64_t off = 0;
+  auto take = [&](int64_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align256(bytes);
+    return p;
+  };
+  const int64_t ntiles = cdiv64(nk, PT);
+  char* cnt = take(2 * PNC * 4);
+  char* start = take(2 * PNC * 4);
+  char* cell = take((nq + nk) * 4);
+  char* rank = take((nq + nk) * 4);
+  char* qorder = take(nq * 4);
+  char* skey = take(nk * 24);
+  char* sidx = take(nk * 4);
+  char* box = take(ntiles * 32);
+  char* nvalid = take(4);
+  if (ws) {
+    ws->cnt = (int*)cnt; ws->start = (int*)start; ws->cell = (int*)cell; ws->rank = (int*)rank;
+    ws->qorder = (int*)qorder; ws->skey = (double*)skey; ws->sidx = (int*)sidx; ws->box = (float*)box;
+    ws->nvalid = (int*)nvalid;
+  }
+  return off;
+}
+}  // namespace
+
 extern "C" int64_t mvk_knn_workspace(int64_t nq, int64_t nk, int k) {
   int nsplit;
   int64_t per;
   knn_plan(nq, nk, &nsplit, &per);
-  return (int64_t)nsplit * (nq > 0 ? nq : 1) * (k <= 3 ? 3 : 8) * 16 + 64;
+  const int64_t brute = (int64_t)nsplit * (nq > 0 ? nq : 1) * (k <= 3 ? 3 : 8) * 16 + 64;
+  const int64_t pruned = pruned_layout(nq > 0 ? nq : 1, nk > 0 ? nk : 1, nullptr, nullptr) + 256;
+  return brute > pruned ? brute : pruned;
 }
 
 extern "C" int mvk_knn_f64(const float* queries, int64_t nq, const double* keys, const uint8_t* key_valid,
@@ -421,6 +776,25 @@ extern "C" int mvk_knn_f64(const float* queries, int64_t nq, const double* keys,
   knn_plan(nq, nk, &nsplit, &per_split);
   const int KK = k <= 3 ? 3 : 8;
   MVK_REQUIRE(workspace && workspace_bytes >= mvk_knn_workspace(nq, nk, k), "knn: workspace too small");
+  if (knn_use_pruned(nq, nk)) {
+    PrunedWs ws;
+    char* base = (char*)(((uintptr_t)workspace + 255) / 256 * 256);
+    pruned_layout(nq, nk, base, &ws);
+    const int ntiles = (int)cdiv64(nk, PT);
+    MVK_CHECK_HIP(hipMemsetAsync(ws.cnt, 0, 2 * PNC * 4, st));
+    const unsigned eb = (unsigned)cdiv64(nq + nk, 256);
+    hipLaunchKernelGGL(pk_count_kernel, dim3(eb), dim3(256), 0, st, queries, nq, keys, key_valid, nk, ws);
+    hipLaunchKernelGGL(pk_scan_kernel, dim3(2), dim3(1024), 0, st, ws);
+    hipLaunchKernelGGL(pk_scatter_kernel, dim3(eb), dim3(256), 0, st, nq, keys, nk, ws);
+    hipLaunchKernelGGL(pk_box_kernel, dim3((unsigned)ntiles), dim3(64), 0, st, ws);
+    const dim3 grid((unsigned)cdiv64(nq, 64));
+    if (KK == 3)
+      hipLaunchKernelGGL((knn_pruned_kernel<3, 8>), grid, dim3(64 * 8), 0, st, queries, nq, ws, ntiles, k, out_idx);
+    else
+      hipLaunchKernelGGL((knn_pruned_kernel<8, 4>), grid, dim3(64 * 4), 0, st, queries, nq, ws, ntiles, k, out_idx);
+    MVK_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   double* pd = (double*)workspace;
   int64_t* pi = (int64_t*)((char*)workspace + (int64_t)nsplit * nq * KK * 8);
   dim3 grid((unsigned)cdiv64(nq, KNN_T * QPT), (unsigned)nsplit);

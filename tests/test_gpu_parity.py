@@ -285,6 +285,54 @@ def test_group_points_reference_test_shapes(ops, b, c, n1, n2, k):
 
 # ------------------------------------------------------------------ edge cases / error paths
 
+def _knn_scene(seed, nq, nk_side):
+    """Three overlapping 'depth maps' of a wall + floor (row-major pixel order), queries on and far off
+    the surfaces, duplicated keys (exact ties), invalid pixels, keys beyond the 3.2 m torus period."""
+    rng = np.random.default_rng(seed)
+    u, v = np.meshgrid(np.linspace(-1.5, 1.5, nk_side), np.linspace(0, 2.2, nk_side))
+    wall = np.stack([u.ravel(), np.full(u.size, 1.3), v.ravel()], 1)
+    floor = np.stack([u.ravel(), v.ravel() - 0.9, np.zeros(u.size)], 1)
+    far = np.stack([u.ravel() * 3, v.ravel() * 2 + 3.0, np.full(u.size, 0.4)], 1)
+    keys = np.concatenate([wall, floor, far], 0) + rng.normal(0, 0.004, (3 * u.size, 3))
+    keys[100:200] = keys[300:400]                          # exact duplicates -> (d2, index) tie rule
+    valid = rng.random(keys.shape[0]) > 0.1
+    q = np.concatenate([keys[rng.integers(0, keys.shape[0], nq // 2)] + rng.normal(0, 0.02, (nq // 2, 3)),
+                        rng.uniform(-1.2, 1.2, (nq - nq // 2, 3)) + [0, 0, 1.0]], 0).astype(np.float32)
+    q[:50] = keys[100:150].astype(np.float32)              # queries sitting on the duplicated keys
+    return q, keys, valid
+
+
+@pytest.mark.parametrize("k", [3, 1, 5])
+def test_knn_pruned_vs_oracle_and_brute_force(ops, k, monkeypatch):
+    """The box-pruned 3-NN (taken for nq >= 1024, nk >= 4096) returns exactly what the brute-force
+    kernels and the CPU oracle return (ScanNet_sphere_color.py:448-451 contract: exact, float64)."""
+    from oracle import cport
+    q, keys, valid = _knn_scene(3, 3000, 70)               # 3000 x 14700
+    shape = (3, 70, 70)
+    Tq, Tk, Tv = T(q), T(keys.reshape(shape + (3,))), T(valid.reshape(shape))
+    got = ops.knn_pixels(Tq, Tk, Tv, k=k).cpu().numpy()
+    ind_all = np.nonzero(valid)[0]
+    want = ind_all[cport.knn_f64(q.astype(np.float64), keys[ind_all], k)[0]]
+    assert np.array_equal(got, want)
+    monkeypatch.setenv("MVK_KNN_BRUTE", "1")
+    assert np.array_equal(ops.knn_pixels(Tq, Tk, Tv, k=k).cpu().numpy(), want)
+
+
+def test_knn_pruned_full_size_equals_brute_force(ops, monkeypatch):
+    """BASELINE config 3 size (19 464 queries x 57 600 pixels): pruned == brute force, and fewer valid
+    keys than k yields -1 like the brute-force path."""
+    q, keys, valid = _knn_scene(5, 19464, 139)
+    keys, valid = keys[:57600], valid[:57600]
+    Tq, Tk, Tv = T(q), T(keys.reshape(3, 120, 160, 3)), T(valid.reshape(3, 120, 160))
+    fast = ops.knn_pixels(Tq, Tk, Tv, k=3).cpu().numpy()
+    few = valid.copy(); few[:] = False; few[[7, 5000]] = True
+    fast_few = ops.knn_pixels(Tq, Tk, T(few.reshape(3, 120, 160)), k=3).cpu().numpy()
+    monkeypatch.setenv("MVK_KNN_BRUTE", "1")
+    assert np.array_equal(fast, ops.knn_pixels(Tq, Tk, Tv, k=3).cpu().numpy())
+    assert np.array_equal(fast_few, ops.knn_pixels(Tq, Tk, T(few.reshape(3, 120, 160)), k=3).cpu().numpy())
+    assert (fast_few[:, 2] == -1).all() and set(np.unique(fast_few[:, :2])) == {7, 5000}
+
+
 def test_empty_and_degenerate_inputs(ops):
     kp = torch.zeros(15, 3, device="cuda")
     W = torch.zeros(15, 8, 4, device="cuda")

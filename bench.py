@@ -70,7 +70,7 @@ def main():
 
     # everything runs on one non-default stream: autograd's AccumulateGrad nodes are bound to the stream
     # they were first used on, and nodes born on the legacy default stream cannot be captured later
-    torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ.get("MVK_MAIN_PRIO", "-1"))))   # high priority: the graph chain is the critical path
+    torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ.get("MVK_MAIN_PRIO", "0"))))
 
     import mvkpconv
     syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
@@ -147,6 +147,9 @@ def main():
         lens, loss = step()
     sync()
     dt = time.perf_counter() - t0
+    if os.environ.get("MVK_BENCH_DIAG") == "1" and state_ref:
+        h = np.asarray(state_ref[-1].get("host", [(0, 0)]))[-args.steps:]
+        print("DIAG host ms per step: replay enqueue %.2f | build_async %.2f" % tuple(h.mean(0) * 1e3), file=sys.stderr)
     # mean real-neighbour counts of every neighbour matrix of this (fixed) synthetic batch, computed
     # outside the timed region: (Nq, Ns, H) -> H_eff
     hb, _ = syn.build_batch(cfg, staged, limits, torch.int32)
@@ -193,102 +196,199 @@ def main():
         dist.destroy_process_group()
 
 
+state_ref = []
+
+
 def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
-    """Capacity-padded static batch + one captured hipGraph for forward, loss, backward, gradient
-    all-reduce (N>1), clip and SGD; the pyramid / fusion inputs are rebuilt eagerly every step and copied
-    into the static buffers (their shapes change with the random grid orientation, the graph's do not)."""
+    """Capacity-padded static batches + captured hipGraphs for forward, loss, backward, gradient
+    all-reduce (N>1), clip and SGD.
+
+    Three HIP streams, all doing work of the SAME steady-state step loop:
+      main   : replay of the network graph on static set k % 2;
+      build  : pyramid + unprojection + 3-NN of batch k+1 and its padding into static set (k+1) % 2
+               (their shapes change with the random grid orientation, the graph's do not);
+      encode : the frozen, eval-mode 2D encoder (architectures_sphere.py:232-237: a pure function of the
+               images) on the views of batch k+1, itself a captured graph.
+    Two static sets / two graph instances make the input side a true double buffer: nothing of batch k+1
+    touches memory the replay of batch k reads."""
+    has_2d = hasattr(net, "net_2d") and os.environ.get("MVK_ENCODER_AHEAD", "1") == "1"
+    dev = staged['points'][0].device
+    # all three streams at the same priority: on this driver a priority difference between queues that
+    # are busy at the same time costs far more (2-3x the step) than any ordering it buys
+    build_stream = torch.cuda.Stream(priority=int(os.environ.get("MVK_BUILD_PRIO", "0")))
+    enc_stream = torch.cuda.Stream()
+    status = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(2)]   # neighbour-search status words
+
+    enc = None
+    if has_2d:
+        enc_in = torch.stack(staged['images'], 0).clone()          # (b, nv, 3, h, w)
+
+        def encode(images):
+            b, nv = images.shape[:2]
+            with torch.no_grad():
+                return net.net_2d({'image': images.reshape([-1] + list(images.shape[2:]))})['feature']
+
+        main = torch.cuda.current_stream()
+        enc_stream.wait_stream(main)
+        with torch.cuda.stream(enc_stream):
+            for _ in range(2):
+                encode(enc_in)
+        enc_stream.synchronize()
+        enc_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(enc_graph, stream=enc_stream, capture_error_mode="thread_local"):
+            enc_out = encode(enc_in)
+        enc = (enc_in, enc_out, enc_graph)
+
     batch0, lens = syn.build_batch(cfg, staged, limits, torch.int32)
-    static = syn.StaticBatch(batch0, limits)
-    ops.set_row_counts(static.valid)
+    if enc is not None:
+        enc_graph.replay()
+        torch.cuda.synchronize()
+        batch0.feature_2d = enc_out
+    statics = [syn.StaticBatch(batch0, limits)]
+    statics.append(syn.StaticBatch(batch0, limits, caps=statics[0].caps))
+
+    ops.set_row_counts(statics[0].valid)
     for _ in range(2):                          # momentum buffers, MIOpen / hipBLASLt plans for the padded shapes
         opt.zero_grad(set_to_none=True)
-        net_step_captured(net, static, cfg, params, opt, reducer)
+        net_step_captured(net, statics[0], cfg, params, opt, reducer)
     torch.cuda.synchronize()
     ops.step_begin()
     if os.environ.get("MVK_ZERO_ARENA", "1") == "1":
         # one fill per replay instead of ~100 (split-K outputs, scatter targets): sized from the warm-up
-        ops.zero_arena_enable(int(ops.zero_arena_high_water() * 1.05) + (1 << 20), static.points[0].device)
+        ops.zero_arena_enable(int(ops.zero_arena_high_water() * 1.05) + (1 << 20), dev)
     opt.zero_grad(set_to_none=True)
-    graph = torch.cuda.CUDAGraph()
-    if reducer is None:
-        with torch.cuda.graph(graph):
-            static_loss = net_step_captured(net, static, cfg, params, opt, None)
-        replay = graph.replay
-    else:
+
+    def capture(static):
+        ops.set_row_counts(static.valid)
+        opt.zero_grad(set_to_none=True)         # every graph instance produces its own .grad tensors
+        graph = torch.cuda.CUDAGraph()
+        if reducer is None:
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                loss = net_step_captured(net, static, cfg, params, opt, None)
+            return graph.replay, loss
         # N > 1: the RCCL all-reduce stays an eager call between two graphs (forward+backward | clip+SGD).
         # thread_local capture mode: the process group's watchdog thread may query events meanwhile.
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
             ops.step_begin()
-            static_loss = net.loss(net(static, cfg), static.labels)
-            static_loss.backward()
+            loss = net.loss(net(static, cfg), static.labels)
+            loss.backward()
         graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph_b, capture_error_mode="thread_local"):
             torch.nn.utils.clip_grad_value_(params, cfg.grad_clip_norm)
             opt.step()
 
+        grads = [p.grad for p in reducer.params if p.grad is not None]
+
         def replay():
             graph.replay()
-            reducer()
+            reducer(grads)
             graph_b.replay()
+        return replay, loss
 
-    # input side on its own stream, one batch ahead of the graph (what the reference's DataLoader workers
-    # do for its trainer): build(k+1) overlaps replay(k); the static buffers are filled on the main stream
-    build_stream = torch.cuda.Stream()
-    state = {"next": None, "loaded": None}
+    replays = [capture(s) for s in statics]
+    state = {"next": None, "k": 0, "free": [None, None]}
 
-    def build_async():
-        if state["loaded"] is not None:
-            build_stream.wait_event(state["loaded"])      # recycled blocks of the previous batch are safe to reuse
+    def build_async(slot):
+        """Enqueues batch k+1 on the build / encode streams and pads it into static set `slot`."""
+        free = state["free"][slot]
+        if free is not None:                       # (the searches of the batch this set held are long done)
+            with torch.cuda.stream(build_stream):
+                ops.check_neighbor_status(status[slot])
+        if free is not None:                       # the replay that last read this set has finished
+            build_stream.wait_event(free)
+            enc_stream.wait_event(free)
+        if enc is not None:
+            if state["next"] is not None:          # the previous batch's padding has read enc_out
+                enc_stream.wait_event(state["next"][2])
+            with torch.cuda.stream(enc_stream):
+                enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
+                enc_graph.replay()
+                enc_done = torch.cuda.Event()
+                enc_done.record(enc_stream)
         with torch.cuda.stream(build_stream):
-            batch, lens = syn.build_batch(cfg, staged, limits, torch.int32)
+            status[slot].zero_()
+            batch, lens = syn.build_batch(cfg, staged, limits, torch.int32, status=status[slot])
+            fits = True
+            if enc is not None:
+                build_stream.wait_event(enc_done)
+                batch.feature_2d = enc_out
+            try:
+                statics[slot].load(batch)
+            except RuntimeError as e:           # a level outgrew its captured capacity
+                fits = False
+                state["fallbacks"] = state.get("fallbacks", 0) + 1
+                if os.environ.get("MVK_BENCH_DIAG") == "1":
+                    print("DIAG eager fallback:", str(e)[:200], file=sys.stderr)
             ev = torch.cuda.Event()
             ev.record(build_stream)
-        return batch, lens, ev
+        return batch, lens, ev, fits, slot
 
-    state["next"] = build_async()
+    state["next"] = build_async(0)
 
     def step():
-        batch, lens, ev = state["next"]
+        batch, lens, ev, fits, slot = state["next"]
         main = torch.cuda.current_stream()
         main.wait_event(ev)
-        try:
-            static.load(batch)
-        except RuntimeError:                    # a level outgrew its captured capacity: run this step eagerly
+        if not fits:                            # run this step eagerly on the exact-size batch
             ops.set_row_counts(None)
             ops._ARENA["on"], arena_was = False, ops._ARENA["on"]
             opt.zero_grad(set_to_none=False)
+            if enc is not None:
+                batch.feature_2d = enc_out.clone()
             loss = net_step_eager(net, batch, cfg, params, opt, reducer)
-            ops.set_row_counts(static.valid)
             ops._ARENA["on"] = arena_was
-            state["next"] = build_async()
+            main.synchronize()                  # rare path: `batch` lives in the build stream's pool
+            state["next"] = build_async(slot)
             return lens, loss
+        ops.set_row_counts(statics[slot].valid)
+        ta = time.perf_counter()
+        replays[slot][0]()
         done = torch.cuda.Event()
         done.record(main)
-        state["loaded"] = done
-        state["keep"] = batch                   # alive until the copies above have been enqueued AND ordered
-        replay()
-        state["next"] = build_async()
-        return lens, static_loss
+        state["free"][slot] = done
+        state["keep"] = batch                   # alive until its padding copies are ordered before `ev`
+        tb = time.perf_counter()
+        state["next"] = build_async(slot ^ 1)
+        tc = time.perf_counter()
+        state.setdefault("host", []).append((tb - ta, tc - tb))
+        return lens, replays[slot][1]
 
-    if os.environ.get("MVK_BENCH_DIAG") == "1":        # development aid: the two chains in isolation
+    if os.environ.get("MVK_BENCH_DIAG") == "1":        # development aid: the chains in isolation
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):
-            replay()
+            replays[0][0]()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         for _ in range(10):
-            syn.build_batch(cfg, staged, limits, torch.int32)
+            bb, _ = syn.build_batch(cfg, staged, limits, torch.int32)
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         for _ in range(10):
-            static.load(batch0)
+            statics[1].load(batch0)
         torch.cuda.synchronize()
         t3 = time.perf_counter()
-        print("DIAG graph replay %.2f ms | build_batch %.2f ms | static.load %.2f ms" % (
-            (t1 - t0) * 100, (t2 - t1) * 100, (t3 - t2) * 100), file=sys.stderr)
+        for _ in range(10 if enc is not None else 0):
+            enc_graph.replay()
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        for _ in range(10):
+            replays[1][0]()
+        torch.cuda.synchronize()
+        t5 = time.perf_counter()
+        for _ in range(5):
+            replays[0][0]()
+            replays[1][0]()
+        torch.cuda.synchronize()
+        t6 = time.perf_counter()
+        print("DIAG graph replay %.2f ms (set 1: %.2f, alternating: %.2f) | build_batch %.2f ms | static.load %.2f ms | "
+              "2D encoder graph %.2f ms" % ((t1 - t0) * 100, (t5 - t4) * 100, (t6 - t5) * 100, (t2 - t1) * 100,
+                                            (t3 - t2) * 100, (t4 - t3) * 100), file=sys.stderr)
 
-    return step, "hipGraph(network step: fwd+loss+bwd+clip+SGD over capacity-padded levels) + pyramid/fusion inputs built one batch ahead on a second stream"
+    state_ref.append(state)
+    return step, ("hipGraph(network step: fwd+loss+bwd+clip+SGD over capacity-padded levels, two static sets) | "
+                  "second stream: pyramid + unprojection + 3-NN of the next batch" +
+                  (" | third stream: frozen 2D encoder of the next batch (hipGraph)" if enc is not None else ""))
 
 
 def net_step_eager(net, batch, cfg, params, opt, reducer):

@@ -31,9 +31,15 @@ _SIGNATURES = {
     "mvk_grid_subsample_workspace": (C.c_int64, [_i64, _i, _i, _i]),
     "mvk_grid_subsample_batch": (C.c_int, [_vp, _i64, _vp, _i, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp,
                                            _vp, _vp, _i64, _vp]),
+    "mvk_grid_subsample_batch_oriented": (C.c_int, [_vp, _i64, _vp, _i, _vp, _vp, _i, _vp, _i, _f, _i, _vp, _vp,
+                                                    _vp, _vp, _vp, _vp, _i64, _vp]),
     "mvk_radius_neighbors_workspace": (C.c_int64, [_i64, _i64, _i]),
     "mvk_radius_neighbors_batch": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _vp,
                                              _vp, _i64, _vp]),
+    "mvk_radius_neighbors_enqueue": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _vp, _i,
+                                               _vp, _i64, _vp]),
+    "mvk_pad_points": (C.c_int, [_vp, _i64, _vp, _i64, _i, _f, _vp, _vp]),
+    "mvk_pad_index_rows": (C.c_int, [_vp, _i, _i64, _i, _i64, _vp, _i64, _i, _i64, _vp]),
     "mvk_unproject_depth": (C.c_int, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "mvk_knn_workspace": (C.c_int64, [_i64, _i64, _i]),
     "mvk_knn_f64": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i, _vp, _vp, _i64, _vp]),

@@ -20,6 +20,7 @@ SOURCES = [
     ("gemm.hip", []),
     ("pool.hip", []),
     ("bn.hip", []),
+    ("batchpad.hip", []),
     ("subsample.hip", ["-ffp-contract=off"]),
     ("neighbors.hip", ["-ffp-contract=off"]),
     ("fusion.hip", ["-ffp-contract=off"]),

@@ -246,57 +246,68 @@ struct Carver {
 int64_t ws_bytes(int64_t Nq, int64_t Ns, int B) {
   int64_t cells = cell_cap(Ns) + (int64_t)B * (4096 + 1 + 4);
   return (int64_t)B * sizeof(CloudGrid) + 2 * cells * 4 + (Ns + 1) * 16 + 2 * (int64_t)(B + 1) * 4 +
-         (Nq + 1) * 4 + 64 + 16 * 12;
+         (Nq + 1) * 4 + 64 + 16 * 12 + 16;
 }
 
 }  // namespace
 
 extern "C" int64_t mvk_radius_neighbors_workspace(int64_t Nq, int64_t Ns, int B) { return ws_bytes(Nq, Ns, B); }
 
-extern "C" int mvk_radius_neighbors_batch(const float* q, int64_t Nq, const float* s, int64_t Ns,
-                                          const int32_t* q_lens_host, const int32_t* s_lens_host,
-                                          int B, float radius, int32_t* out, int width,
-                                          int* width_host, void* workspace, int64_t workspace_bytes,
-                                          void* stream) {
+namespace {
+
+// Common body. status_dev == nullptr: classic two-phase contract (synchronises, reports through
+// width_host). status_dev != nullptr: enqueue only -- the max row count / overflow flag are folded into
+// status_dev[0] / status_dev[1] on the device. reuse_grid: the workspace still holds the grid built by
+// the previous call for the SAME supports, batch lengths and radius (conv / pool / upsample searches of
+// one pyramid level share it), so only the query pass is launched.
+int nb_run(const float* q, int64_t Nq, const float* s, int64_t Ns, const int32_t* q_lens_host,
+           const int32_t* s_lens_host, int B, float radius, int32_t* out, int width, int* width_host,
+           int32_t* status_dev, int reuse_grid, void* workspace, int64_t workspace_bytes, void* stream) {
   MVK_REQUIRE(B >= 1 && Nq >= 0 && Ns >= 0 && Nq < (1ll << 31) && Ns < (1ll << 29), "neighbors: bad sizes");
   MVK_REQUIRE(radius > 0.f, "neighbors: radius must be positive");
   MVK_REQUIRE(workspace && workspace_bytes >= ws_bytes(Nq, Ns, B), "neighbors: workspace too small");
   hipStream_t st = (hipStream_t)stream;
-  static thread_local int offs_h[2 * 4097];
+  // header = {max count, overflow, query offsets [B+1], support offsets [B+1]}: ONE host-to-device copy
+  static thread_local int hdr_h[4 + 2 * 4097];
   MVK_REQUIRE(B <= 4096, "neighbors: more than 4096 clouds in a batch");
+  int* qo = hdr_h + 4;
+  int* so = hdr_h + 4 + B + 1;
   int64_t tq = 0, ts = 0;
   for (int b = 0; b < B; ++b) {
     MVK_REQUIRE(q_lens_host[b] >= 0 && s_lens_host[b] >= 0, "neighbors: negative batch length");
-    offs_h[b] = (int)tq;
-    offs_h[B + 1 + b] = (int)ts;
+    qo[b] = (int)tq;
+    so[b] = (int)ts;
     tq += q_lens_host[b];
     ts += s_lens_host[b];
   }
-  offs_h[B] = (int)tq;
-  offs_h[2 * B + 1] = (int)ts;
+  qo[B] = (int)tq;
+  so[B] = (int)ts;
+  hdr_h[0] = hdr_h[1] = hdr_h[2] = hdr_h[3] = 0;
   MVK_REQUIRE(tq == Nq && ts == Ns, "neighbors: batch lengths do not sum to the point counts");
 
   Carver cv{(char*)workspace};
   NbWs W;
   int64_t cells = cell_cap(Ns) + (int64_t)B * (4096 + 1 + 4);
-  W.grids = cv.take<CloudGrid>(B);
+  W.grids = cv.take<CloudGrid>(B);              // grid part first: its layout depends on (Ns, B) only
   W.cell_start = cv.take<int>(cells);
   W.cell_fill = cv.take<int>(cells);
   W.recs = cv.take<float4>(Ns + 1);
-  W.qoffs = cv.take<int>(B + 1);
-  W.soffs = cv.take<int>(B + 1);
+  int* hdr = cv.take<int>(4 + 2 * (B + 1));
+  W.maxcount = hdr;
+  W.overflow = hdr + 1;
+  W.qoffs = hdr + 4;
+  W.soffs = hdr + 4 + B + 1;
   W.counts = cv.take<int>(Nq + 1);
-  W.maxcount = cv.take<int>(1);
-  W.overflow = cv.take<int>(1);
   MVK_REQUIRE(cv.p <= (char*)workspace + workspace_bytes, "neighbors: workspace carve overflow");
+  if (status_dev) {
+    W.maxcount = status_dev;
+    W.overflow = status_dev + 1;
+  }
 
-  MVK_CHECK_HIP(hipMemcpyAsync(W.qoffs, offs_h, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
-  MVK_CHECK_HIP(hipMemcpyAsync(W.soffs, offs_h + B + 1, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
-  MVK_CHECK_HIP(hipMemsetAsync(W.maxcount, 0, sizeof(int), st));
-  MVK_CHECK_HIP(hipMemsetAsync(W.overflow, 0, sizeof(int), st));
-  hipLaunchKernelGGL(nb_build_kernel, dim3(B), dim3(TPB), 0, st, s, W, radius);
+  MVK_CHECK_HIP(hipMemcpyAsync(hdr, hdr_h, sizeof(int) * (4 + 2 * (B + 1)), hipMemcpyHostToDevice, st));
+  if (!reuse_grid) hipLaunchKernelGGL(nb_build_kernel, dim3(B), dim3(TPB), 0, st, s, W, radius);
   if (out == nullptr) {
-    MVK_REQUIRE(width_host != nullptr, "neighbors: phase 1 needs width_host");
+    MVK_REQUIRE(width_host != nullptr && status_dev == nullptr, "neighbors: phase 1 needs width_host");
     if (Nq > 0)
       hipLaunchKernelGGL((nb_query_kernel<false>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns,
                          (int*)nullptr, 0);
@@ -309,11 +320,32 @@ extern "C" int mvk_radius_neighbors_batch(const float* q, int64_t Nq, const floa
   if (Nq > 0 && width > 0)
     hipLaunchKernelGGL((nb_query_kernel<true>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width);
   MVK_CHECK_HIP(hipGetLastError());
-  int ovf = 0, maxc = 0;
-  MVK_CHECK_HIP(hipMemcpyAsync(&ovf, W.overflow, sizeof(int), hipMemcpyDeviceToHost, st));
-  MVK_CHECK_HIP(hipMemcpyAsync(&maxc, W.maxcount, sizeof(int), hipMemcpyDeviceToHost, st));
+  if (status_dev) return 0;
+  int res[2] = {0, 0};
+  MVK_CHECK_HIP(hipMemcpyAsync(res, hdr, sizeof(int) * 2, hipMemcpyDeviceToHost, st));
   MVK_CHECK_HIP(hipStreamSynchronize(st));
-  if (width_host) *width_host = maxc;
-  MVK_REQUIRE(ovf == 0, "neighbors: a query has more than %d in-range supports (LDS list capacity)", LIST_CAP);
+  if (width_host) *width_host = res[0];
+  MVK_REQUIRE(res[1] == 0, "neighbors: a query has more than %d in-range supports (LDS list capacity)", LIST_CAP);
   return 0;
+}
+
+}  // namespace
+
+extern "C" int mvk_radius_neighbors_batch(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                                          const int32_t* q_lens_host, const int32_t* s_lens_host,
+                                          int B, float radius, int32_t* out, int width,
+                                          int* width_host, void* workspace, int64_t workspace_bytes,
+                                          void* stream) {
+  return nb_run(q, Nq, s, Ns, q_lens_host, s_lens_host, B, radius, out, width, width_host, nullptr, 0, workspace,
+                workspace_bytes, stream);
+}
+
+extern "C" int mvk_radius_neighbors_enqueue(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                                            const int32_t* q_lens_host, const int32_t* s_lens_host,
+                                            int B, float radius, int32_t* out, int width,
+                                            int32_t* status_dev, int reuse_grid, void* workspace,
+                                            int64_t workspace_bytes, void* stream) {
+  MVK_REQUIRE(out != nullptr && status_dev != nullptr, "neighbors: enqueue needs an output matrix and a status word");
+  return nb_run(q, Nq, s, Ns, q_lens_host, s_lens_host, B, radius, out, width, nullptr, status_dev, reuse_grid,
+                workspace, workspace_bytes, stream);
 }

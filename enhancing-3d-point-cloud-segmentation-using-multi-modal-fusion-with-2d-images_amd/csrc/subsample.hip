@@ -408,7 +408,43 @@ int64_t ws_bytes(int64_t N, int B, int fdim, int ldim) {
   bytes += 3 * (3 * n + 32 * (int64_t)B) * 4;  // ft bcnt bhead
   bytes += (int64_t)(B + 1) * 4 * 2;        // out_count, offs
   bytes += n * 12;                          // stage_pts
+  bytes += n * 12 + 16;                     // rot_pts (oriented variant)
   return bytes + 64 * 32;
+}
+
+}  // namespace
+
+namespace {
+
+struct Rot3 {
+  float m[9];
+};
+
+// out[n,i] = (p0 * R[0][i] + p1 * R[1][i]) + p2 * R[2][i]  (or R transposed): the float32 products and
+// NumPy's axis-1 summation order of datasets/common.py:118 / :134. `count_dev` (optional) = device row
+// counts per cloud; the rows of cloud `b` then start at sum(count_dev[:b]) (the compacted output).
+__global__ void rotate_cloud_kernel(const float* __restrict__ in, float* __restrict__ out, int64_t first,
+                                    int64_t count, const int32_t* __restrict__ count_dev, int b, Rot3 R,
+                                    int transpose) {
+  if (count_dev) {
+    first = 0;
+    for (int i = 0; i < b; ++i) first += count_dev[i];
+    count = count_dev[b];
+  }
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const float* p = in + (first + t) * 3;
+  const float p0 = p[0], p1 = p[1], p2 = p[2];
+  float o[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float r0 = transpose ? R.m[i * 3 + 0] : R.m[0 * 3 + i];
+    const float r1 = transpose ? R.m[i * 3 + 1] : R.m[1 * 3 + i];
+    const float r2 = transpose ? R.m[i * 3 + 2] : R.m[2 * 3 + i];
+    o[i] = (p0 * r0 + p1 * r1) + p2 * r2;
+  }
+  float* q = out + (first + t) * 3;
+  q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
 }
 
 }  // namespace
@@ -417,12 +453,13 @@ extern "C" int64_t mvk_grid_subsample_workspace(int64_t N, int B, int fdim, int 
   return ws_bytes(N, B, fdim, ldim);
 }
 
-extern "C" int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32_t* lens_host, int B,
-                                        const float* feats, int fdim, const int32_t* labels, int ldim,
-                                        float dl, int max_p, float* out_pts, float* out_feats,
-                                        int32_t* out_labels, int32_t* out_lens,
-                                        int32_t* out_lens_host, void* workspace,
-                                        int64_t workspace_bytes, void* stream) {
+namespace {
+int subsample_run(const float* pts, int64_t N, const int32_t* lens_host, int B, const float* rot_host,
+                  const float* feats, int fdim, const int32_t* labels, int ldim,
+                  float dl, int max_p, float* out_pts, float* out_feats,
+                  int32_t* out_labels, int32_t* out_lens,
+                  int32_t* out_lens_host, void* workspace,
+                  int64_t workspace_bytes, void* stream) {
   MVK_REQUIRE(B >= 1 && N >= 0 && N < (1ll << 29), "subsample: bad sizes N=%lld B=%d", (long long)N, B);
   MVK_REQUIRE(dl > 0.f, "subsample: sampleDl must be positive");
   MVK_REQUIRE(fdim >= 0 && (fdim == 0 || (feats && out_feats)), "subsample: features pointer missing");
@@ -459,7 +496,18 @@ extern "C" int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32
   W.stage_pts = cv.take<float>(3 * n);
   W.stage_feat = cv.take<float>(n * (fdim > 0 ? fdim : 0) + 1);
   W.stage_lab = cv.take<int>(n * (ldim > 0 ? ldim : 0) + 1);
+  float* rot_pts = cv.take<float>(3 * n);
   MVK_REQUIRE(cv.p <= cv.end, "subsample: workspace carve overflow");
+  if (rot_host) {   // random grid orientation (datasets/common.py:89-118): rotate every cloud by its matrix
+    for (int b = 0; b < B; ++b) {
+      if (lens_host[b] == 0) continue;
+      Rot3 R;
+      for (int i = 0; i < 9; ++i) R.m[i] = rot_host[b * 9 + i];
+      hipLaunchKernelGGL(rotate_cloud_kernel, dim3((unsigned)cdiv64(lens_host[b], 256)), dim3(256), 0, st, pts, rot_pts,
+                         (int64_t)offs_h[b], (int64_t)lens_host[b], (const int32_t*)nullptr, b, R, 0);
+    }
+    pts = rot_pts;
+  }
 
   // _Prime_rehash_policy::_M_need_rehash: first allocation 13 buckets, then
   // next_bkt(max(count + 2, 2 * nb)) = next_bkt(2 * nb) each time count reaches nb.
@@ -475,6 +523,15 @@ extern "C" int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(subsample_compact_kernel, dim3(gx, B), dim3(256), 0, st, offs_d, W, B, fdim, ldim, max_p,
                      out_pts, out_feats, out_labels, out_lens);
+  if (rot_host) {   // ... and the barycentres back by its transpose (:134), in place on the compacted output
+    for (int b = 0; b < B; ++b) {
+      if (lens_host[b] == 0) continue;
+      Rot3 R;
+      for (int i = 0; i < 9; ++i) R.m[i] = rot_host[b * 9 + i];
+      hipLaunchKernelGGL(rotate_cloud_kernel, dim3((unsigned)cdiv64(lens_host[b], 256)), dim3(256), 0, st, out_pts, out_pts,
+                         (int64_t)0, (int64_t)0, (const int32_t*)out_lens, b, R, 1);
+    }
+  }
   MVK_CHECK_HIP(hipGetLastError());
   if (out_lens_host)
     MVK_CHECK_HIP(hipMemcpyAsync(out_lens_host, out_lens, sizeof(int) * B, hipMemcpyDeviceToHost, st));
@@ -483,4 +540,26 @@ extern "C" int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32
   MVK_CHECK_HIP(hipStreamSynchronize(st));  // offs_h (stack) and out_lens_host must be settled on return
   MVK_REQUIRE(err == 0, "subsample: a voxel holds more than %d distinct labels", MAXLAB);
   return 0;
+}
+}  // namespace
+
+extern "C" int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32_t* lens_host, int B,
+                                        const float* feats, int fdim, const int32_t* labels, int ldim,
+                                        float dl, int max_p, float* out_pts, float* out_feats,
+                                        int32_t* out_labels, int32_t* out_lens,
+                                        int32_t* out_lens_host, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+  return subsample_run(pts, N, lens_host, B, nullptr, feats, fdim, labels, ldim, dl, max_p, out_pts, out_feats,
+                       out_labels, out_lens, out_lens_host, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvk_grid_subsample_batch_oriented(const float* pts, int64_t N, const int32_t* lens_host, int B,
+                                                 const float* rot_host, const float* feats, int fdim,
+                                                 const int32_t* labels, int ldim, float dl, int max_p,
+                                                 float* out_pts, float* out_feats, int32_t* out_labels,
+                                                 int32_t* out_lens, int32_t* out_lens_host, void* workspace,
+                                                 int64_t workspace_bytes, void* stream) {
+  MVK_REQUIRE(rot_host != nullptr, "subsample: the oriented variant needs one rotation per cloud");
+  return subsample_run(pts, N, lens_host, B, rot_host, feats, fdim, labels, ldim, dl, max_p, out_pts, out_feats,
+                       out_labels, out_lens, out_lens_host, workspace, workspace_bytes, stream);
 }

@@ -18,8 +18,11 @@ class FlatAllReduce:
         self.world = world if world is not None else dist.get_world_size()
         self.flat = None
 
-    def __call__(self):
-        grads = [p.grad for p in self.params if p.grad is not None]
+    def __call__(self, grads=None):
+        """grads: the gradient tensors to average (default: the current .grad of every parameter; a
+        captured graph passes the fixed tensors ITS backward writes)."""
+        if grads is None:
+            grads = [p.grad for p in self.params if p.grad is not None]
         if not grads:
             return
         sizes = [g.numel() for g in grads]

@@ -52,18 +52,6 @@ def random_grid_rotations(B, rng=None):
     return create_3D_rotations(u.T, alpha).astype(np.float32)
 
 
-def _rotate_stacked(points, lens, R, transpose):
-    """p' = sum_j p_j * R[j, :] per cloud in float32 (common.py:118 / :134)."""
-    Rt = torch.from_numpy(np.ascontiguousarray(R)).to(points.device)
-    if transpose:
-        Rt = Rt.transpose(1, 2)
-    cloud = torch.repeat_interleave(torch.arange(len(lens), device=points.device),
-                                    torch.as_tensor(np.asarray(lens, dtype=np.int64), device=points.device))
-    M = Rt[cloud]                                               # [N,3,3]
-    p = points.unsqueeze(2) * M                                 # [N,3(j),3]
-    return (p[:, 0, :] + p[:, 1, :]) + p[:, 2, :]               # NumPy's axis-1 sum order for 3 terms
-
-
 def batch_grid_subsampling(points, batches_len, features=None, labels=None, sampleDl=0.1, max_p=0, verbose=0,
                            random_grid_orient=True, R=None):
     """common.py:77-182: random per-cloud grid orientation, subsample, rotate the barycentres back.
@@ -73,39 +61,50 @@ def batch_grid_subsampling(points, batches_len, features=None, labels=None, samp
     lens = np.ascontiguousarray(batches_len.cpu().numpy() if isinstance(batches_len, torch.Tensor) else batches_len,
                                 dtype=np.int32)
     B = len(lens)
-    if random_grid_orient:
-        if R is None:
-            R = random_grid_rotations(B)
-        pts = _rotate_stacked(pts, lens, R, transpose=False)
+    if random_grid_orient and R is None:
+        R = random_grid_rotations(B)
     res = ops.grid_subsample_batch(pts, lens, features=None if features is None else _t(features, np.float32),
-                                   labels=None if labels is None else _t(labels, np.int32), dl=sampleDl, max_p=max_p)
+                                   labels=None if labels is None else _t(labels, np.int32), dl=sampleDl, max_p=max_p,
+                                   rotations=R if random_grid_orient else None)
     s_points, s_len = res[0], res[1]
-    if random_grid_orient:
-        s_points = _rotate_stacked(s_points, s_len, R, transpose=True)
     out = [s_points, s_len] + list(res[2:])
     if as_np:
         out = [o.cpu().numpy() if isinstance(o, torch.Tensor) else o for o in out]
     return tuple(out)
 
 
-def batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None):
-    """common.py:185-196 (+ optional crop to ``limit`` columns = big_neighborhood_filter :411-421)."""
+def batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None, status=None, reuse_grid=False):
+    """common.py:185-196 (+ optional crop to ``limit`` columns = big_neighborhood_filter :411-421).
+    status / reuse_grid: the enqueue-only mode of ops.radius_neighbors_batch."""
     as_np = not isinstance(queries, torch.Tensor)
     out = ops.radius_neighbors_batch(_t(queries, np.float32), _t(supports, np.float32), q_batches, s_batches,
-                                     radius, limit=limit)
+                                     radius, limit=limit, status=status, reuse_grid=reuse_grid)
     return out.cpu().numpy() if as_np else out
 
 
 def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborhood_limits=None,
-                               index_dtype=torch.int64, rotations=None):
+                               index_dtype=torch.int64, rotations=None, status=None):
     """Per-layer network inputs (common.py:779-900): returns dict with lists ``points``, ``neighbors``,
     ``pools``, ``upsamples``, ``lengths`` (one entry per layer), all in HBM.
 
     neighborhood_limits: per-layer column caps (the calibrated 90th percentiles of the reference,
     :864-867); None keeps every neighbour. index_dtype: int64 like the reference (:874-876) or int32
     (half the index traffic; the kernels take both). rotations: optional list of (B,3,3) matrices, one
-    per subsampling level, replacing the random grid orientation draws."""
+    per subsampling level, replacing the random grid orientation draws. status (int32 [2] HBM, needs
+    neighborhood_limits): the 13 neighbour searches are only enqueued (full ``limit`` columns, no read-back
+    per search; ops.check_neighbor_status(status) validates them later) and the searches that share
+    supports and radius -- conv / pool of a level and the upsample search of the level above -- share
+    one cell grid."""
     r_normal = config.first_subsampling_dl * config.conv_radius
+    grid_of = [None, None]          # supports tensor and radius of the grid the neighbour workspace holds
+
+    def neighbors(qp, sp, qb, sb, radius, layer):
+        if status is None:
+            return batch_neighbors(qp, sp, qb, sb, radius, limit=lim(layer)).to(index_dtype)
+        reuse = grid_of[0] is sp and grid_of[1] == np.float32(radius)
+        grid_of[0], grid_of[1] = sp, np.float32(radius)
+        return batch_neighbors(qp, sp, qb, sb, radius, limit=lim(layer), status=status, reuse_grid=reuse).to(index_dtype)
+
     pts = _t(stacked_points, np.float32)
     lens = np.ascontiguousarray(stack_lengths.cpu().numpy() if isinstance(stack_lengths, torch.Tensor)
                                 else stack_lengths, dtype=np.int32)
@@ -134,7 +133,7 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
                 deform_layer = True
             else:
                 r = r_normal
-            conv_i = batch_neighbors(pts, pts, lens, lens, r, limit=lim(layer)).to(index_dtype)
+            conv_i = neighbors(pts, pts, lens, lens, r, layer)
         else:
             conv_i = empty_idx()
         if 'pool' in block or 'strided' in block:
@@ -147,8 +146,8 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
                 deform_layer = True
             else:
                 r = r_normal
-            pool_i = batch_neighbors(pool_p, pts, pool_b, lens, r, limit=lim(layer)).to(index_dtype)
-            up_i = batch_neighbors(pts, pool_p, lens, pool_b, 2 * r, limit=lim(layer + 1)).to(index_dtype)
+            pool_i = neighbors(pool_p, pts, pool_b, lens, r, layer)
+            up_i = neighbors(pts, pool_p, lens, pool_b, 2 * r, layer + 1)
         else:
             pool_i, up_i = empty_idx(), empty_idx()
             pool_p = torch.zeros((0, 3), dtype=torch.float32, device=dev)

@@ -42,7 +42,9 @@ def lift_2d_features(net, batch, fused=None):
     images = batch.images                                   # (b, nv, 3, h, w)
     b, nv, _, h, w = images.size()
     images = images.reshape([-1] + list(images.shape[2:]))
-    feature_2d = net.net_2d({'image': images})['feature']  # (b*nv, c, h, w), no grad (frozen)
+    feature_2d = getattr(batch, 'feature_2d', None)         # the frozen encoder may have been run ahead (bench.py)
+    if feature_2d is None:
+        feature_2d = net.net_2d({'image': images})['feature']  # (b*nv, c, h, w), no grad (frozen)
 
     def knn_of(i):
         knn = batch.knn_list[i]

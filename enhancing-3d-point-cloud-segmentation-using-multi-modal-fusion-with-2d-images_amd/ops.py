@@ -85,10 +85,11 @@ def _zeros(shape, device, dtype=torch.float32):
 # raw kernels
 # --------------------------------------------------------------------------------------------
 
-def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=None):
+def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=None, keep=False):
     """C = op(A) @ op(B) on v_mfma_f32_32x32x2_f32 (mvk_gemm_f32). split_k=None picks a split of
     the reduction so that small-M / deep-K products (the coarse KPConv layers: 85 x 7680 x 512)
-    still fill the 256 CUs."""
+    still fill the 256 CUs. keep=True: the result outlives the step (a weight gradient that becomes
+    .grad), so it must not be a slice of the per-step zero arena."""
     _dev(A, B)
     A, B = _f32c(A), _f32c(B)
     M, Kd = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
@@ -102,7 +103,8 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
         tiles = ((M + 63) // 64) * ((N + 63) // 64)
         split_k = int(max(1, min((1000 + tiles - 1) // tiles, 32, Kd // 128)))
     if out is None:
-        out = _zeros((M, N), A.device) if split_k > 1 else torch.empty((M, N), device=A.device, dtype=torch.float32)
+        out = ((torch.zeros((M, N), device=A.device, dtype=torch.float32) if keep else _zeros((M, N), A.device))
+               if split_k > 1 else torch.empty((M, N), device=A.device, dtype=torch.float32))
     check(lib().mvk_gemm_f32(_p(A), _p(B), _p(out), M, N, Kd, int(transA), int(transB), int(accumulate),
                              int(split_k), _stream()))
     return out
@@ -251,7 +253,7 @@ class _KPConvFn(torch.autograd.Function):
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
             tiles = ((K * Cin + 63) // 64) * ((Cout + 63) // 64)
-            dW = gemm(Am.view(Nq, K * Cin), gy, transA=True, split_k=_split_for(Nq, tiles)).view(K, Cin, Cout)
+            dW = gemm(Am.view(Nq, K * Cin), gy, transA=True, split_k=_split_for(Nq, tiles), keep=True).view(K, Cin, Cout)
         need_dA = ctx.needs_input_grad[3] or (offsets is not None)
         if need_dA:
             dAm = gemm(gy, W.reshape(K * Cin, Cout), transB=True).view(Nq, K, Cin)
@@ -450,12 +452,14 @@ def _lens_host(lens):
     return _np.ascontiguousarray(lens, dtype=_np.int32)
 
 
-def grid_subsample_batch(points, lens, features=None, labels=None, dl=0.1, max_p=0):
+def grid_subsample_batch(points, lens, features=None, labels=None, dl=0.1, max_p=0, rotations=None):
     """Device version of cpp_subsampling.subsample_batch (wrapper.cpp:62-333).
 
     points [N,3] f32 (HBM), lens host int32 [B], optional features [N,fdim] f32 and labels [N,ldim]
     int32 (HBM). Returns (s_points [M,3] HBM, s_lens np.int32 [B][, s_features][, s_labels]).
-    Bit-identical to the reference incl. output order. Synchronises once (the counts come back to the host)."""
+    Bit-identical to the reference incl. output order. Synchronises once (the counts come back to the host).
+    rotations (host float32 [B,3,3]): the random grid orientation of batch_grid_subsampling
+    (datasets/common.py:89-134) applied inside the same call (rotate, subsample, rotate back)."""
     _dev(points, features, labels)
     points = _f32c(points)
     lens_h = _lens_host(lens)
@@ -475,10 +479,16 @@ def grid_subsample_batch(points, lens, features=None, labels=None, dl=0.1, max_p
     out_l = torch.empty((max(N, 1), ldim), device=points.device, dtype=torch.int32) if ldim else None
     out_lens = torch.empty((B,), device=points.device, dtype=torch.int32)
     out_lens_h = _np.empty((B,), _np.int32)
-    check(lib().mvk_grid_subsample_batch(_p(points), N, lens_h.ctypes.data_as(C.c_void_p), B, _p(features), fdim,
-                                         _p(labels), ldim, float(dl), int(max_p), _p(out_pts), _p(out_f),
-                                         _p(out_l), _p(out_lens), out_lens_h.ctypes.data_as(C.c_void_p),
-                                         _p(ws), ws.numel(), _stream()))
+    tail = (_p(features), fdim, _p(labels), ldim, float(dl), int(max_p), _p(out_pts), _p(out_f), _p(out_l),
+            _p(out_lens), out_lens_h.ctypes.data_as(C.c_void_p), _p(ws), ws.numel(), _stream())
+    if rotations is None:
+        check(lib().mvk_grid_subsample_batch(_p(points), N, lens_h.ctypes.data_as(C.c_void_p), B, *tail))
+    else:
+        rot = _np.ascontiguousarray(rotations, dtype=_np.float32)
+        if rot.shape != (B, 3, 3):
+            raise RuntimeError("grid_subsample_batch: rotations must be [B,3,3]")
+        check(lib().mvk_grid_subsample_batch_oriented(_p(points), N, lens_h.ctypes.data_as(C.c_void_p), B,
+                                                      rot.ctypes.data_as(C.c_void_p), *tail))
     M = int(out_lens_h.sum())
     res = [out_pts[:M], out_lens_h]
     if fdim:
@@ -488,12 +498,20 @@ def grid_subsample_batch(points, lens, features=None, labels=None, dl=0.1, max_p
     return tuple(res)
 
 
-def radius_neighbors_batch(queries, supports, q_lens, s_lens, radius, limit=None):
+_NB_GRID = {}      # device index -> workspace address that holds the last built grid
+
+
+def radius_neighbors_batch(queries, supports, q_lens, s_lens, radius, limit=None, status=None, reuse_grid=False):
     """Device version of cpp_neighbors.batch_query (wrapper.cpp:58-238): int32 [Nq, W] in HBM.
 
     limit=None: W = the data-dependent max count (one extra counting pass + host sync, like the
     reference's two-pass fill); limit=k: keep the k nearest per row (= big_neighborhood_filter,
-    datasets/common.py:411-421) without the counting pass."""
+    datasets/common.py:411-421) without the counting pass, W = min(k, max count) like the reference.
+
+    status (int32 [2] HBM tensor, needs limit): enqueue-only mode for a sync-free pyramid -- W = limit
+    always, nothing is read back; status accumulates [max row count, overflow flag] for ONE later check
+    (check_neighbor_status). reuse_grid=True (enqueue-only mode): the caller guarantees that the previous
+    search on this device used the same supports, s_lens and radius, so its cell grid is reused."""
     _dev(queries, supports)
     q, s = _f32c(queries), _f32c(supports)
     ql, sl = _lens_host(q_lens), _lens_host(s_lens)
@@ -502,6 +520,19 @@ def radius_neighbors_batch(queries, supports, q_lens, s_lens, radius, limit=None
     Nq, Ns, B = q.shape[0], s.shape[0], int(ql.shape[0])
     ws = _workspace("nb", lib().mvk_radius_neighbors_workspace(Nq, Ns, B), q.device)
     args = (_p(q), Nq, _p(s), Ns, ql.ctypes.data_as(C.c_void_p), sl.ctypes.data_as(C.c_void_p), B, float(radius))
+    if status is not None:
+        if limit is None:
+            raise RuntimeError("radius_neighbors_batch: the enqueue-only mode needs a column limit")
+        _dev(status)
+        width = int(limit)
+        out = torch.empty((Nq, width), device=q.device, dtype=torch.int32)
+        reuse = bool(reuse_grid) and _NB_GRID.get(q.device.index) == ws.data_ptr()   # a regrown workspace lost the grid
+        if width > 0 and Nq > 0:
+            check(lib().mvk_radius_neighbors_enqueue(*args, _p(out), width, _p(status), int(reuse), _p(ws),
+                                                     ws.numel(), _stream()))
+            _NB_GRID[q.device.index] = ws.data_ptr()
+        return out
+    _NB_GRID.pop(q.device.index, None)
     if limit is None:
         w = C.c_int(0)
         check(lib().mvk_radius_neighbors_batch(*args, None, 0, C.byref(w), _p(ws), ws.numel(), _stream()))
@@ -515,6 +546,35 @@ def radius_neighbors_batch(queries, supports, q_lens, s_lens, radius, limit=None
         if int(w.value) < width:            # reference shape: min(limit, data-dependent max count)
             out = out[:, :int(w.value)].contiguous()
     return out
+
+
+def check_neighbor_status(status):
+    """Reads an enqueue-only status word back (synchronises with the work that produced it)."""
+    maxc, ovf = (int(v) for v in status.cpu())
+    if ovf:
+        raise RuntimeError("neighbors: a query has more in-range supports than the in-kernel list holds")
+    return maxc
+
+
+def pad_points(src, dst, fill, count_out=None):
+    """dst [cap,w] <- src [n,w] padded with `fill`; count_out (int32 [1] HBM) <- n. One launch."""
+    _dev(src, dst, count_out)
+    src = _f32c(src)
+    if not dst.is_contiguous() or dst.dtype != torch.float32 or dst.shape[1] != src.shape[1]:
+        raise RuntimeError("pad_points: destination must be a contiguous float32 [cap, %d] tensor" % src.shape[1])
+    check(lib().mvk_pad_points(_p(src), src.shape[0], _p(dst), dst.shape[0], src.shape[1], float(fill),
+                               _p(count_out), _stream()))
+
+
+def pad_index_rows(src, shadow_src, dst, shadow_dst):
+    """dst [cap,w_dst] <- src [n,w_src] with the shadow index rewritten, padded with shadow_dst. One launch."""
+    _dev(src, dst)
+    src, i64 = _idx(src)
+    if dst.dtype != src.dtype or not dst.is_contiguous():
+        raise RuntimeError("pad_index_rows: destination must be contiguous and of the source's index type")
+    w_src = src.shape[1] if src.dim() == 2 else 0
+    check(lib().mvk_pad_index_rows(_p(src), i64, src.shape[0], w_src, int(shadow_src), _p(dst), dst.shape[0],
+                                   dst.shape[1], int(shadow_dst), _stream()))
 
 
 # --------------------------------------------------------------------------------------------
@@ -624,7 +684,7 @@ class _LinearFn(torch.autograd.Function):
             dx = gemm(W, g, transA=True, transB=True) if ctx.xt else gemm(g, W)      # [Kd,M] or [M,Kd]
         if ctx.needs_input_grad[1]:
             # dW [N,Kd] = g^T [N,M] @ x [M,Kd]
-            dW = gemm(g, x, transA=True, transB=ctx.xt, split_k=_split_for(g.shape[0], 4))
+            dW = gemm(g, x, transA=True, transB=ctx.xt, split_k=_split_for(g.shape[0], 4), keep=True)
         return dx, dW, None
 
 

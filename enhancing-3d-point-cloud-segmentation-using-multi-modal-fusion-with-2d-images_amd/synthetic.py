@@ -219,7 +219,7 @@ def stage_spheres(spheres, device, views=None):
     return st
 
 
-def build_batch(config, staged, limits=None, index_dtype=torch.int32, rotations=None):
+def build_batch(config, staged, limits=None, index_dtype=torch.int32, rotations=None, status=None):
     """One pass of the input side of the hot path, all on the GPU, from the subsampled sphere clouds:
     centring + stacking (potential_item, ScanNet_sphere_color.py:600-719), pyramid
     (segmentation_inputs_sphere, datasets/common.py:779-900) and, for the fusion variants, depth
@@ -229,7 +229,8 @@ def build_batch(config, staged, limits=None, index_dtype=torch.int32, rotations=
     lens = [int(p.shape[0]) for p in pts]
     stacked = torch.cat(pts, 0)
     stacked_world = torch.cat(world, 0)
-    pyr = segmentation_inputs_sphere(config, stacked, np.asarray(lens, np.int32), limits, index_dtype, rotations)
+    pyr = segmentation_inputs_sphere(config, stacked, np.asarray(lens, np.int32), limits, index_dtype, rotations,
+                                     status=status)
     ones = torch.ones_like(stacked[:, :1])
     labels = torch.cat(staged['labels'], 0)
     colors = torch.cat(staged['colors'], 0)
@@ -279,17 +280,19 @@ class StaticBatch:
     keeps its exact size (the spheres of a batch fix it). Neighbour matrices get their full calibrated
     width (`limits`), shadow index = capacity of the support level."""
 
-    def __init__(self, batch, limits, margin=1.12):
+    def __init__(self, batch, limits, margin=1.12, caps=None):
         L = len(batch.points)
         dev = batch.points[0].device
         self.n0 = batch.points[0].shape[0]
-        caps, used = [], set()
-        for l in range(L):
+        given, caps, used = caps, [], set()
+        for l in range(L if given is None else 0):
             c = self.n0 if l == 0 else int(-(-int(batch.points[l].shape[0] * margin + 8) // 64) * 64)
             while c in used:
                 c += 64
             used.add(c)
             caps.append(c)
+        if given is not None:            # a second static set with the capacities of the first
+            caps = list(given)
         self.caps, self.limits = caps, [int(x) for x in limits]
         it = batch.neighbors[0].dtype
         self.points = [torch.full((caps[l], 3), 1e6, device=dev) for l in range(L)]
@@ -301,11 +304,14 @@ class StaticBatch:
         self.lengths = batch.lengths
         self.valid = {caps[l]: torch.zeros(1, dtype=torch.int32, device=dev) for l in range(L)}
         self._counts = [self.valid[caps[l]] for l in range(L)]
-        for name in ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images'):
+        for name in self._DENSE:
             v = getattr(batch, name, None)
             setattr(self, name, v.clone() if v is not None else None)
         self.knn_list = [k.clone() for k in batch.knn_list] if batch.knn_list is not None else None
         self.load(batch)
+
+    # feature_2d: output of the frozen 2D encoder when it was run ahead of the network step
+    _DENSE = ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images', 'feature_2d')
 
     def load(self, batch):
         """Copies one freshly built batch into the static buffers (raises if a level outgrew its capacity)."""
@@ -314,14 +320,12 @@ class StaticBatch:
         if n[0] != self.n0 or any(n[l] > self.caps[l] for l in range(L)):
             raise RuntimeError("batch does not fit the captured capacities %s: %s" % (self.caps, n))
         for l in range(L):
-            self.points[l].fill_(1e6)
-            self.points[l][:n[l]] = batch.points[l]
-            self._counts[l].fill_(n[l])
+            ops.pad_points(batch.points[l], self.points[l], 1e6, self._counts[l])
             self._put(self.neighbors[l], batch.neighbors[l], n[l], self.caps[l])
             if l + 1 < L:
                 self._put(self.pools[l], batch.pools[l], n[l], self.caps[l])
                 self._put(self.upsamples[l], batch.upsamples[l], n[l + 1], self.caps[l + 1])
-        for name in ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images'):
+        for name in self._DENSE:
             v = getattr(batch, name, None)
             if v is not None:
                 getattr(self, name).copy_(v)
@@ -331,6 +335,6 @@ class StaticBatch:
 
     @staticmethod
     def _put(dst, src, shadow_src, shadow_dst):
-        dst.fill_(shadow_dst)
-        if src.shape[0] > 0 and src.shape[1] > 0:
-            dst[:src.shape[0], :src.shape[1]] = torch.where(src == shadow_src, torch.full_like(src, shadow_dst), src)
+        if src.shape[1] > dst.shape[1]:
+            raise RuntimeError("batch does not fit the captured neighbour widths: %d > %d" % (src.shape[1], dst.shape[1]))
+        ops.pad_index_rows(src, shadow_src, dst, shadow_dst)

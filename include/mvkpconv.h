@@ -137,6 +137,17 @@ int mvk_grid_subsample_batch(const float* pts, int64_t N, const int32_t* lens_ho
                              int32_t* out_lens_host, void* workspace, int64_t workspace_bytes,
                              void* stream);
 
+/* batch_grid_subsampling with random_grid_orient (datasets/common.py:77-182): cloud b is rotated by
+ * rot_host[b] (HOST, [B,3,3] f32, row-major; p' = sum_j p_j R[j,:] in float32, :118), subsampled, and its
+ * barycentres are rotated back by the transpose (:134) -- same results as rotating with NumPy around
+ * mvk_grid_subsample_batch, without the intermediate tensors. Features / labels are untouched. */
+int mvk_grid_subsample_batch_oriented(const float* pts, int64_t N, const int32_t* lens_host, int B,
+                                      const float* rot_host, const float* feats, int fdim,
+                                      const int32_t* labels, int ldim, float dl, int max_p,
+                                      float* out_pts, float* out_feats, int32_t* out_labels,
+                                      int32_t* out_lens, int32_t* out_lens_host, void* workspace,
+                                      int64_t workspace_bytes, void* stream);
+
 int64_t mvk_radius_neighbors_workspace(int64_t Nq, int64_t Ns, int B);
 
 /* Fixed-radius neighbours of a stacked batch: out [Nq,width] int32, row = indices (into the stacked
@@ -152,6 +163,30 @@ int mvk_radius_neighbors_batch(const float* q, int64_t Nq, const float* s, int64
                                const int32_t* q_lens_host, const int32_t* s_lens_host, int B,
                                float radius, int32_t* out, int width, int* width_host,
                                void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Enqueue-only variant of phase 2 (never synchronises): out [Nq,width] is always written at full
+ * `width`; status_dev (DEVICE, int32 [2], zeroed by the caller once per batch) accumulates
+ * [0] = max(row count seen) and [1] = 1 if a row overflowed the in-kernel list capacity -- the caller
+ * reads it back once after the last search of a pyramid. reuse_grid != 0: the workspace still holds
+ * the cell grid of the previous call for the SAME supports, s_lens and radius (the conv / pool /
+ * upsample searches of one level of datasets/common.py:832-857 share supports and radius), so only
+ * the query pass runs. */
+int mvk_radius_neighbors_enqueue(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                                 const int32_t* q_lens_host, const int32_t* s_lens_host, int B,
+                                 float radius, int32_t* out, int width, int32_t* status_dev,
+                                 int reuse_grid, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ---------------- capacity padding (hipGraph replay over fixed shapes) ----- */
+
+/* No reference counterpart (the reference re-allocates every batch). dst [cap,w] f32: rows < n copied
+ * from src [n,w], the rest = fill; *count_out (DEVICE, may be NULL) = n, the row count word the masked
+ * BatchNorm kernels read. */
+int mvk_pad_points(const float* src, int64_t n, float* dst, int64_t cap, int w, float fill,
+                   int32_t* count_out, void* stream);
+/* dst [cap,w_dst] (int32, or int64 when idx64): dst[r,c] = src[r,c] for r < n, c < w_src with the
+ * "no neighbour" index shadow_src rewritten to shadow_dst; every other element = shadow_dst. */
+int mvk_pad_index_rows(const void* src, int idx64, int64_t n, int w_src, int64_t shadow_src, void* dst,
+                       int64_t cap, int w_dst, int64_t shadow_dst, void* stream);
 
 /* ---------------- 2D -> 3D fusion ----------------------------------------- */
 

@@ -140,6 +140,62 @@ def test_neighbors_properties_full_size(ops):
     assert (back == counts).all()                                             # symmetric relation
 
 
+def test_neighbors_enqueue_only_and_grid_reuse_equal_the_synchronous_search(ops):
+    """mvk_radius_neighbors_enqueue (no read-back, shared cell grid) fills exactly the rows the classic
+    call fills; the status word carries the max row count; the pyramid built that way equals the
+    synchronous pyramid column for column."""
+    rng = np.random.default_rng(11)
+    raw = (rng.random((120000, 3)) * [2.0, 2.0, 0.6]).astype(np.float32)
+    lens0 = [70000, 50000]
+    p, l = ops.grid_subsample_batch(T(raw), lens0, dl=0.04)
+    sub, ls = ops.grid_subsample_batch(p, l, dl=0.08)
+    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ref_conv = ops.radius_neighbors_batch(p, p, l, l, 0.1, limit=30)
+    ref_pool = ops.radius_neighbors_batch(sub, p, ls, l, 0.1, limit=30)
+    conv = ops.radius_neighbors_batch(p, p, l, l, 0.1, limit=30, status=status)                       # builds the grid
+    pool = ops.radius_neighbors_batch(sub, p, ls, l, 0.1, limit=30, status=status, reuse_grid=True)   # reuses it
+    assert conv.shape[1] == 30 and torch.equal(conv[:, :ref_conv.shape[1]], ref_conv)
+    assert torch.equal(pool[:, :ref_pool.shape[1]], ref_pool)
+    assert (conv[:, ref_conv.shape[1]:] == p.shape[0]).all() and (pool[:, ref_pool.shape[1]:] == p.shape[0]).all()
+    full = ops.radius_neighbors_batch(p, p, l, l, 0.1)
+    assert ops.check_neighbor_status(status) == full.shape[1]
+
+    import importlib
+    common = importlib.import_module(PKG + ".dropin.datasets.common")
+    syn = importlib.import_module(PKG + ".synthetic")
+    cfg = syn.make_config("baseline")
+    rots = [np.stack([np.eye(3, dtype=np.float32)] * 2) for _ in range(4)]
+    limits = [30, 28, 30, 32, 20]
+    a = common.segmentation_inputs_sphere(cfg, p, np.asarray(l), limits, torch.int32, rots)
+    status.zero_()
+    b = common.segmentation_inputs_sphere(cfg, p, np.asarray(l), limits, torch.int32, rots, status=status)
+    ops.check_neighbor_status(status)
+    for key in ("neighbors", "pools", "upsamples"):
+        for x, y in zip(a[key], b[key]):
+            if x.numel() == 0:
+                continue
+            assert torch.equal(y[:, :x.shape[1]], x), key
+    for x, y in zip(a["points"], b["points"]):
+        assert torch.equal(x, y)
+
+
+def test_capacity_padding_kernels(ops):
+    src = torch.randint(0, 50, (37, 5), dtype=torch.int32, device="cuda")
+    src[::3, 2] = 50                                               # shadow index of the source
+    for dt in (torch.int32, torch.int64):
+        dst = torch.full((64, 8), -7, dtype=dt, device="cuda")
+        ops.pad_index_rows(src.to(dt), 50, dst, 64)
+        want = torch.full((64, 8), 64, dtype=dt, device="cuda")
+        want[:37, :5] = torch.where(src == 50, torch.full_like(src, 64), src).to(dt)
+        assert torch.equal(dst, want)
+    pts = torch.randn(37, 3, device="cuda")
+    dst, cnt = torch.zeros(64, 3, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.pad_points(pts, dst, 1e6, cnt)
+    assert torch.equal(dst[:37], pts) and (dst[37:] == 1e6).all() and int(cnt) == 37
+    with pytest.raises(RuntimeError):
+        ops.pad_index_rows(src, 50, torch.zeros((20, 8), dtype=torch.int32, device="cuda"), 20)     # too few rows
+
+
 # ------------------------------------------------------------------ KPConv
 
 KP_CASES = [("g4_kpconv_config1", "linear", "sum"), ("g4_kpconv_gaussian", "gaussian", "sum"),

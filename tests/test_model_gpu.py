@@ -178,7 +178,7 @@ def test_graph_replay_trains_like_eager():
     limits = syn.calibrate_limits(cfg, staged)
     rots = [np.stack([np.eye(3, dtype=np.float32)]) for _ in range(4)]
     shim = types.SimpleNamespace(StaticBatch=syn.StaticBatch,
-                                 build_batch=lambda c, st, lim, dt: syn.build_batch(c, st, lim, dt, rotations=rots))
+                                 build_batch=lambda c, st, lim, dt, **kw: syn.build_batch(c, st, lim, dt, rotations=rots, **kw))
 
     def make():
         torch.manual_seed(0)
@@ -209,5 +209,6 @@ def test_graph_replay_trains_like_eager():
         assert ((w_g - w_e).norm() / w_e.norm()).item() < 1e-3
     finally:
         ops.set_row_counts(None)
+        ops.zero_arena_disable()
         torch.cuda.synchronize()
         torch.cuda.set_stream(torch.cuda.default_stream())

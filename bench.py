@@ -203,15 +203,18 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     """Capacity-padded static batches + captured hipGraphs for forward, loss, backward, gradient
     all-reduce (N>1), clip and SGD.
 
-    Three HIP streams, all doing work of the SAME steady-state step loop:
-      main   : replay of the network graph on static set k % 2;
-      build  : pyramid + unprojection + 3-NN of batch k+1 and its padding into static set (k+1) % 2
-               (their shapes change with the random grid orientation, the graph's do not);
-      encode : the frozen, eval-mode 2D encoder (architectures_sphere.py:232-237: a pure function of the
-               images) on the views of batch k+1, itself a captured graph.
+    main stream  : replay of the network graph on static set k % 2;
+    build stream : pyramid + unprojection + 3-NN of batch k+1 and its padding into static set (k+1) % 2
+                   (their shapes change with the random grid orientation, the graph's do not).
     Two static sets / two graph instances make the input side a true double buffer: nothing of batch k+1
-    touches memory the replay of batch k reads."""
-    has_2d = hasattr(net, "net_2d") and os.environ.get("MVK_ENCODER_AHEAD", "1") == "1"
+    touches memory the replay of batch k reads, and the host never waits for the replay.
+    Measured on this runtime (tools/overlap_probe.py): a graph replay does not overlap with work of another
+    stream or another graph launch -- only branches inside ONE graph run concurrently -- so the second stream
+    hides the HOST latency of the input chain (its few round trips), not its kernel time.
+    MVK_ENCODER_AHEAD=1 (experiment, off by default) makes the frozen eval-mode 2D encoder
+    (architectures_sphere.py:232-237: a pure function of the images) such a parallel branch, computing the
+    features of batch k+1 while the network runs on batch k: 0.5 ms less GPU time, 2 ms more launch time."""
+    has_2d = hasattr(net, "net_2d") and os.environ.get("MVK_ENCODER_AHEAD", "0") == "1"
     dev = staged['points'][0].device
     # all three streams at the same priority: on this driver a priority difference between queues that
     # are busy at the same time costs far more (2-3x the step) than any ordering it buys
@@ -228,22 +231,13 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             with torch.no_grad():
                 return net.net_2d({'image': images.reshape([-1] + list(images.shape[2:]))})['feature']
 
-        main = torch.cuda.current_stream()
-        enc_stream.wait_stream(main)
-        with torch.cuda.stream(enc_stream):
-            for _ in range(2):
-                encode(enc_in)
-        enc_stream.synchronize()
-        enc_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(enc_graph, stream=enc_stream, capture_error_mode="thread_local"):
-            enc_out = encode(enc_in)
-        enc = (enc_in, enc_out, enc_graph)
+        for _ in range(2):
+            encode(enc_in)
+        enc = enc_in
 
     batch0, lens = syn.build_batch(cfg, staged, limits, torch.int32)
     if enc is not None:
-        enc_graph.replay()
-        torch.cuda.synchronize()
-        batch0.feature_2d = enc_out
+        batch0.feature_2d = encode(enc_in)
     statics = [syn.StaticBatch(batch0, limits)]
     statics.append(syn.StaticBatch(batch0, limits, caps=statics[0].caps))
 
@@ -262,16 +256,35 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         ops.set_row_counts(static.valid)
         opt.zero_grad(set_to_none=True)         # every graph instance produces its own .grad tensors
         graph = torch.cuda.CUDAGraph()
+        other = statics[1 - statics.index(static)]
+
+        def fork_encoder():
+            # parallel branch of the SAME graph (separate graph launches do not overlap on this runtime,
+            # branches of one graph do): features of the NEXT batch's views into the other static set
+            if enc is None:
+                return
+            enc_stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(enc_stream):
+                other.feature_2d.copy_(encode(enc_in))
+
+        def join_encoder():
+            if enc is not None:
+                torch.cuda.current_stream().wait_stream(enc_stream)
+
         if reducer is None:
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                fork_encoder()
                 loss = net_step_captured(net, static, cfg, params, opt, None)
+                join_encoder()
             return graph.replay, loss
         # N > 1: the RCCL all-reduce stays an eager call between two graphs (forward+backward | clip+SGD).
         # thread_local capture mode: the process group's watchdog thread may query events meanwhile.
         with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            fork_encoder()
             ops.step_begin()
             loss = net.loss(net(static, cfg), static.labels)
             loss.backward()
+            join_encoder()
         graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph_b, capture_error_mode="thread_local"):
             torch.nn.utils.clip_grad_value_(params, cfg.grad_clip_norm)
@@ -296,22 +309,10 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                 ops.check_neighbor_status(status[slot])
         if free is not None:                       # the replay that last read this set has finished
             build_stream.wait_event(free)
-            enc_stream.wait_event(free)
-        if enc is not None:
-            if state["next"] is not None:          # the previous batch's padding has read enc_out
-                enc_stream.wait_event(state["next"][2])
-            with torch.cuda.stream(enc_stream):
-                enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
-                enc_graph.replay()
-                enc_done = torch.cuda.Event()
-                enc_done.record(enc_stream)
         with torch.cuda.stream(build_stream):
             status[slot].zero_()
             batch, lens = syn.build_batch(cfg, staged, limits, torch.int32, status=status[slot])
             fits = True
-            if enc is not None:
-                build_stream.wait_event(enc_done)
-                batch.feature_2d = enc_out
             try:
                 statics[slot].load(batch)
             except RuntimeError as e:           # a level outgrew its captured capacity
@@ -332,15 +333,17 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         if not fits:                            # run this step eagerly on the exact-size batch
             ops.set_row_counts(None)
             ops._ARENA["on"], arena_was = False, ops._ARENA["on"]
-            opt.zero_grad(set_to_none=False)
-            if enc is not None:
-                batch.feature_2d = enc_out.clone()
+            opt.zero_grad(set_to_none=True)     # fresh .grad tensors: the captured ones are slices of the zero arena
+            if enc is not None:                 # keep the encoder pipeline going: features for the next set
+                statics[slot ^ 1].feature_2d.copy_(encode(enc_in))
             loss = net_step_eager(net, batch, cfg, params, opt, reducer)
             ops._ARENA["on"] = arena_was
             main.synchronize()                  # rare path: `batch` lives in the build stream's pool
             state["next"] = build_async(slot)
             return lens, loss
         ops.set_row_counts(statics[slot].valid)
+        if enc is not None:
+            enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
         ta = time.perf_counter()
         replays[slot][0]()
         done = torch.cuda.Event()
@@ -369,7 +372,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         for _ in range(10 if enc is not None else 0):
-            enc_graph.replay()
+            encode(enc_in)
         torch.cuda.synchronize()
         t4 = time.perf_counter()
         for _ in range(10):
@@ -382,18 +385,18 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         torch.cuda.synchronize()
         t6 = time.perf_counter()
         print("DIAG graph replay %.2f ms (set 1: %.2f, alternating: %.2f) | build_batch %.2f ms | static.load %.2f ms | "
-              "2D encoder graph %.2f ms" % ((t1 - t0) * 100, (t5 - t4) * 100, (t6 - t5) * 100, (t2 - t1) * 100,
+              "2D encoder (eager) %.2f ms" % ((t1 - t0) * 100, (t5 - t4) * 100, (t6 - t5) * 100, (t2 - t1) * 100,
                                             (t3 - t2) * 100, (t4 - t3) * 100), file=sys.stderr)
 
     state_ref.append(state)
     return step, ("hipGraph(network step: fwd+loss+bwd+clip+SGD over capacity-padded levels, two static sets) | "
                   "second stream: pyramid + unprojection + 3-NN of the next batch" +
-                  (" | third stream: frozen 2D encoder of the next batch (hipGraph)" if enc is not None else ""))
+                  (" | frozen 2D encoder of the next batch as a parallel branch of the same graph" if enc is not None else ""))
 
 
 def net_step_eager(net, batch, cfg, params, opt, reducer):
-    """Fallback for a batch that does not fit the captured capacities: gradients are written into the
-    graph's static .grad tensors (zeroed in place), so later replays stay valid."""
+    """Fallback for a batch that does not fit the captured capacities: one plain eager step on the
+    exact-size batch (fresh .grad tensors; the graphs keep the addresses they captured)."""
     return net_step_captured(net, batch, cfg, params, opt, reducer)
 
 

@@ -116,12 +116,18 @@ class _SegmentationLossMixin:
         self.l1 = nn.L1Loss()
 
     def _targets(self, labels):
-        """Ignored labels -> -1, the others -> [0, C-1] (architectures.py:352-355), written without
-        boolean-mask assignment so that it involves no host sync (hipGraph capturable)."""
-        target = - torch.ones_like(labels)
-        for i, c in enumerate(self.valid_labels):
-            target = torch.where(labels == int(c), torch.full_like(labels, i), target)
-        return target
+        """Ignored labels -> -1, the others -> [0, C-1] (architectures.py:352-355) through a lookup table:
+        three launches whatever the number of classes, no boolean-mask assignment, no host sync
+        (hipGraph capturable). Any value that is not a valid label maps to -1, like the reference's loop."""
+        lut = getattr(self, "_target_lut", None)
+        if lut is None or lut.device != labels.device:
+            top = int(max(self.valid_labels)) if len(self.valid_labels) else 0
+            table = np.full(top + 3, -1, dtype=np.int64)            # slot 0: negatives, slot top+2: above the range
+            for i, c in enumerate(self.valid_labels):
+                table[int(c) + 1] = i
+            lut = self._target_lut = torch.from_numpy(table).to(labels.device)
+        idx = labels.long().clamp(-1, lut.numel() - 2) + 1
+        return lut[idx].to(labels.dtype)
 
     def loss(self, outputs, labels):
         target = self._targets(labels)

@@ -253,7 +253,7 @@ class _KPConvFn(torch.autograd.Function):
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
             tiles = ((K * Cin + 63) // 64) * ((Cout + 63) // 64)
-            dW = gemm(Am.view(Nq, K * Cin), gy, transA=True, split_k=_split_for(Nq, tiles), keep=True).view(K, Cin, Cout)
+            dW = gemm(Am.view(Nq, K * Cin), gy, transA=True, split_k=_split_for(Nq, tiles)).view(K, Cin, Cout)
         need_dA = ctx.needs_input_grad[3] or (offsets is not None)
         if need_dA:
             dAm = gemm(gy, W.reshape(K * Cin, Cout), transB=True).view(Nq, K, Cin)
@@ -684,7 +684,7 @@ class _LinearFn(torch.autograd.Function):
             dx = gemm(W, g, transA=True, transB=True) if ctx.xt else gemm(g, W)      # [Kd,M] or [M,Kd]
         if ctx.needs_input_grad[1]:
             # dW [N,Kd] = g^T [N,M] @ x [M,Kd]
-            dW = gemm(g, x, transA=True, transB=ctx.xt, split_k=_split_for(g.shape[0], 4), keep=True)
+            dW = gemm(g, x, transA=True, transB=ctx.xt, split_k=_split_for(g.shape[0], 4))
         return dx, dW, None
 
 

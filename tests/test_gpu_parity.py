@@ -322,6 +322,46 @@ def test_gemm_f32_mfma(ops, M, N, K):
     assert rel_err(ops.gemm(A.t().contiguous(), B, transA=True, split_k=3).cpu().numpy(), ref) < 1e-5
 
 
+# ------------------------------------------------------------------ masked BatchNorm + LeakyReLU
+
+@pytest.mark.parametrize("slope", [1.0, 0.1])
+@pytest.mark.parametrize("R,D,n", [(50, 64, 50), (128, 32, 100), (3000, 128, 2873), (19464, 64, 19464),
+                                   (19464, 66, 19000), (40000, 32, 40000), (4096, 200, 4000)])
+def test_masked_bn_lrelu_vs_torch(ops, R, D, n, slope):
+    """blocks.py:430-467 + LeakyReLU: the single-workgroup (R <= 128) and the three-launch kernels against
+    torch's batch_norm on the valid rows; padded rows come back as zeros, running statistics and the batch
+    counter move like nn.BatchNorm1d's. slope = 1 checks every gradient tightly; with slope = 0.1 a
+    last-bit difference of the normalised value flips the slope of elements sitting on the kink, so the
+    input gradient is compared away from it and the parameter gradients (sums over all rows) loosely."""
+    torch.manual_seed(R + D)
+    x = (torch.randn(R, D, device="cuda") * 2 + 3).requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(D, momentum=0.02).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    ref = torch.nn.BatchNorm1d(D, momentum=0.02).cuda()
+    ref.load_state_dict(bn.state_dict())
+    nv = torch.tensor([n], dtype=torch.int32, device="cuda")
+    go = torch.randn(R, D, device="cuda")
+    for _ in range(2):
+        y = ops.bn_lrelu(x, nv, bn, slope=slope)
+        gx, gw, gb = torch.autograd.grad(y, [x, bn.weight, bn.bias], go)
+    xr = x.detach()[:n].clone().requires_grad_(True)
+    for _ in range(2):
+        yr = torch.nn.functional.leaky_relu(ref(xr), slope)
+        gxr, gwr, gbr = torch.autograd.grad(yr, [xr, ref.weight, ref.bias], go[:n])
+    assert (y[n:] == 0).all() and (gx[n:] == 0).all()
+    assert rel_err(y[:n].detach().cpu().numpy(), yr.detach().cpu().numpy()) < 1e-5
+    away = (yr.detach().abs() > 1e-4).float() if slope != 1.0 else torch.ones_like(yr)
+    assert away.mean() > 0.99
+    ptol = 1e-4 if slope == 1.0 else 1e-2
+    assert rel_err((gx[:n] * away).cpu().numpy(), (gxr * away).cpu().numpy()) < ptol
+    assert rel_err(gw.cpu().numpy(), gwr.cpu().numpy()) < ptol and rel_err(gb.cpu().numpy(), gbr.cpu().numpy()) < ptol
+    assert rel_err(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy()) < 1e-5
+    assert rel_err(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 1e-5
+    assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+
+
 # ------------------------------------------------------------------ group_points (reference test shapes)
 
 @pytest.mark.parametrize("b,c,n1,n2,k", [(2, 3, 512, 128, 32), (5, 64, 513, 129, 33)])

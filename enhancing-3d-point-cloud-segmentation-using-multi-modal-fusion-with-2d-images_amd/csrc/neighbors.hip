@@ -136,12 +136,19 @@ __global__ __launch_bounds__(TPB) void nb_build_kernel(const float* __restrict__
   }
 }
 
-template <bool FILL>
+// max-reduction into one word shared by every query wave: read first, most waves then skip the atomic
+__device__ __forceinline__ void note_count(int* maxcount, int n) {
+  if (n > __hip_atomic_load(maxcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxcount, n);
+}
+
+// CAP = in-range neighbours a query can hold in LDS (8 bytes each): 1024 in general, 256 when the caller
+// keeps at most 64 columns (the conv-radius searches: more waves per CU)
+template <bool FILL, int CAP>
 __global__ __launch_bounds__(64) void nb_query_kernel(const float* __restrict__ q, NbWs W, int B,
                                                       float radius, int64_t Ns, int* __restrict__ out,
                                                       int width) {
-  __shared__ float ld2[FILL ? LIST_CAP : 1];
-  __shared__ int lidx[FILL ? LIST_CAP : 1];
+  __shared__ float ld2[FILL ? CAP : 1];
+  __shared__ int lidx[FILL ? CAP : 1];
   const int64_t i = blockIdx.x;
   const int lane = threadIdx.x;
   int b = 0;
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(64) void nb_query_kernel(const float* __restrict__ 
     const unsigned long long m = __ballot(hit);
     if (FILL && hit) {
       const int pos = n + __popcll(m & ((1ull << lane) - 1ull));
-      if (pos < LIST_CAP) {
+      if (pos < CAP) {
         ld2[pos] = d2;
         lidx[pos] = idx;
       }
@@ -208,14 +215,14 @@ __global__ __launch_bounds__(64) void nb_query_kernel(const float* __restrict__ 
   if (!FILL) {
     if (lane == 0) {
       W.counts[i] = n;
-      atomicMax(W.maxcount, n);
+      note_count(W.maxcount, n);
     }
     return;
   }
-  if (lane == 0) atomicMax(W.maxcount, n);
-  if (n > LIST_CAP) {
+  if (lane == 0) note_count(W.maxcount, n);
+  if (n > CAP) {
     if (lane == 0) atomicExch(W.overflow, 1);
-    n = LIST_CAP;
+    n = CAP;
   }
   __syncthreads();
   // rank-by-counting sort on (d2, idx)
@@ -309,7 +316,7 @@ int nb_run(const float* q, int64_t Nq, const float* s, int64_t Ns, const int32_t
   if (out == nullptr) {
     MVK_REQUIRE(width_host != nullptr && status_dev == nullptr, "neighbors: phase 1 needs width_host");
     if (Nq > 0)
-      hipLaunchKernelGGL((nb_query_kernel<false>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns,
+      hipLaunchKernelGGL((nb_query_kernel<false, LIST_CAP>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns,
                          (int*)nullptr, 0);
     MVK_CHECK_HIP(hipGetLastError());
     MVK_CHECK_HIP(hipMemcpyAsync(width_host, W.maxcount, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -317,8 +324,14 @@ int nb_run(const float* q, int64_t Nq, const float* s, int64_t Ns, const int32_t
     return 0;
   }
   MVK_REQUIRE(width >= 0, "neighbors: negative width");
-  if (Nq > 0 && width > 0)
-    hipLaunchKernelGGL((nb_query_kernel<true>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width);
+  if (Nq > 0 && width > 0) {
+    // enqueue-only mode with a column limit: a row holding more than 4x the calibrated limit is reported
+    // through the overflow flag like a row beyond LIST_CAP
+    if (status_dev && width <= 64)
+      hipLaunchKernelGGL((nb_query_kernel<true, 256>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width);
+    else
+      hipLaunchKernelGGL((nb_query_kernel<true, LIST_CAP>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width);
+  }
   MVK_CHECK_HIP(hipGetLastError());
   if (status_dev) return 0;
   int res[2] = {0, 0};

@@ -211,10 +211,11 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     Measured on this runtime (tools/overlap_probe.py): a graph replay does not overlap with work of another
     stream or another graph launch -- only branches inside ONE graph run concurrently -- so the second stream
     hides the HOST latency of the input chain (its few round trips), not its kernel time.
-    MVK_ENCODER_AHEAD=1 (experiment, off by default) makes the frozen eval-mode 2D encoder
-    (architectures_sphere.py:232-237: a pure function of the images) such a parallel branch, computing the
-    features of batch k+1 while the network runs on batch k: 0.5 ms less GPU time, 2 ms more launch time."""
-    has_2d = hasattr(net, "net_2d") and os.environ.get("MVK_ENCODER_AHEAD", "0") == "1"
+    The frozen eval-mode 2D encoder (architectures_sphere.py:232-237: a pure function of the images) is
+    such a parallel branch: it computes the features of batch k+1 into the other static set while the
+    network runs on batch k (0.8 ms less GPU time per step, 2 ms more host launch time, which the step has
+    to spare; MVK_ENCODER_AHEAD=0 keeps it in line inside the network forward)."""
+    has_2d = hasattr(net, "net_2d") and os.environ.get("MVK_ENCODER_AHEAD", "1") == "1"
     dev = staged['points'][0].device
     # all three streams at the same priority: on this driver a priority difference between queues that
     # are busy at the same time costs far more (2-3x the step) than any ordering it buys

@@ -243,6 +243,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     statics.append(syn.StaticBatch(batch0, limits, caps=statics[0].caps))
 
     ops.set_row_counts(statics[0].valid)
+    ops.zero_arena_high_water(reset=True)
     for _ in range(2):                          # momentum buffers, MIOpen / hipBLASLt plans for the padded shapes
         opt.zero_grad(set_to_none=True)
         net_step_captured(net, statics[0], cfg, params, opt, reducer)
@@ -251,6 +252,8 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     if os.environ.get("MVK_ZERO_ARENA", "1") == "1":
         # one fill per replay instead of ~100 (split-K outputs, scatter targets): sized from the warm-up
         ops.zero_arena_enable(int(ops.zero_arena_high_water() * 1.05) + (1 << 20), dev)
+        if os.environ.get("MVK_BENCH_DIAG") == "1":
+            print("DIAG zero arena %.1f MB" % (ops.zero_arena_high_water() / 1e6), file=sys.stderr)
     opt.zero_grad(set_to_none=True)
 
     def capture(static):

@@ -56,8 +56,12 @@ def zero_arena_disable():
     _ARENA.update(on=False, buf=None, off=0)
 
 
-def zero_arena_high_water():
-    """Largest number of bytes _zeros() handed out (or would have) between two step_begin() calls."""
+def zero_arena_high_water(reset=False):
+    """Largest number of bytes _zeros() handed out (or would have) between two step_begin() calls;
+    reset=True starts a new measurement (call it right before the steps that size the arena)."""
+    if reset:
+        _ARENA["off"] = 0
+        _ARENA["high"] = 0
     return _ARENA["high"]
 
 
@@ -75,6 +79,9 @@ def _zeros(shape, device, dtype=torch.float32):
     nbytes = (n * torch.empty((), dtype=dtype).element_size() + 255) // 256 * 256
     off = _ARENA["off"]
     _ARENA["off"] = off + nbytes
+    if _ARENA.get("log") is not None:
+        import traceback
+        _ARENA["log"].append((nbytes, tuple(shape), traceback.extract_stack(limit=3)[0].name))
     buf = _ARENA["buf"]
     if _ARENA["on"] and n > 0 and off + nbytes <= buf.numel() and buf.device == device:
         return buf[off:off + nbytes].view(dtype)[:n].view(shape)

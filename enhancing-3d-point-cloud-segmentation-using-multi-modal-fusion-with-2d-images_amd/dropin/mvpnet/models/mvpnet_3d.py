@@ -60,13 +60,11 @@ class FeatureAggregation(nn.Module):
             x = ops.linear(x, w.view(w.shape[0], w.shape[1]), x_is_transposed=transposed)   # [np*k, out]
             transposed = False
             bn = layer.bn
-            n_valid = ops.row_count_for(x.shape[0]) if bn.training else None
-            if n_valid is not None:
-                x = ops.bn_lrelu(x, n_valid, bn, 0.0)                   # masked BN + ReLU
+            if bn.training:   # HIP BatchNorm + ReLU over the np*k rows (all valid unless the level is capacity padded)
+                n_valid = ops.row_count_for(x.shape[0])
+                x = ops.bn_lrelu(x, n_valid if n_valid is not None else ops.full_count(x.shape[0], x.device), bn, 0.0)
             else:
-                if bn.training and bn.num_batches_tracked is not None:
-                    bn.num_batches_tracked.add_(1)
-                x = F.relu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, bn.training,
+                x = F.relu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False,
                                         bn.momentum, bn.eps))
         return x.view(n_pts, k, -1).sum(dim=1)
 

@@ -304,6 +304,18 @@ def row_count_for(rows):
     return _ROW_COUNTS.get(int(rows))
 
 
+_FULL_COUNTS = {}
+
+
+def full_count(rows, device):
+    """Device int32 [1] holding `rows` (cached): the n_valid of a tensor without padded rows."""
+    key = (int(rows), device.index)
+    t = _FULL_COUNTS.get(key)
+    if t is None:
+        t = _FULL_COUNTS[key] = torch.tensor([int(rows)], dtype=torch.int32, device=device)
+    return t
+
+
 class _BNLReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n_valid, gamma, beta, running_mean, running_var, eps, momentum, slope, training, nbt=None):

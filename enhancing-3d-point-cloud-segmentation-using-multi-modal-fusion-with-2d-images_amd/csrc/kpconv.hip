@@ -135,12 +135,23 @@ __device__ __forceinline__ int phase_a(const KPParams& P, int64_t n0, int h0, in
 //   FAST = linear influence + sum aggregation (the network default): sqrt via v_sqrt_f32 and a
 //   multiplication by 1/extent (1 ulp class differences, far inside the 1e-4 parity bar).
 // ---------------------------------------------------------------------------
+// GWPB independent waves per workgroup (nothing is shared between them): one-wave workgroups are
+// dispatched too slowly to keep the SIMDs' wave slots filled (measured 2.3 resident waves per SIMD of 4)
+constexpr int GWPB = 4;
+
+__device__ __forceinline__ void wave_sync_lds() {   // LDS hand-off inside ONE wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int NCH, bool IDX64, bool FAST>
-__global__ __launch_bounds__(64, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPParams P, int LPP, int PPW, int HC) {
-  constexpr int UB = NCH == 1 ? 8 : 4;  // feature rows in flight per lane
-  __shared__ float wl[64 * 16 + 64 * 4];
-  const int lane = threadIdx.x;
-  const int64_t n0 = (int64_t)blockIdx.x * PPW;
+__global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPParams P, int LPP, int PPW, int HC) {
+  constexpr int UB = NCH == 1 ? 6 : 4;  // feature rows in flight per lane (8 spills two VGPRs to scratch)
+  __shared__ float wl_all[GWPB][64 * 16 + 64 * 4];
+  float* wl = wl_all[threadIdx.x >> 6];
+  const int lane = threadIdx.x & 63;
+  const int64_t n0 = ((int64_t)blockIdx.x * GWPB + (threadIdx.x >> 6)) * PPW;
   // phase-A identity: (point pa, neighbour slot ha)
   const int pa = lane / HC, ha = lane - pa * HC;
   const bool a_on = pa < PPW && n0 + pa < P.Nq;
@@ -225,7 +236,7 @@ __global__ __launch_bounds__(64, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPPara
       dst[2] = make_float4(wv[8], wv[9], wv[10], wv[11]);
       dst[3] = make_float4(wv[12], wv[13], wv[14], wv[15]);
     }
-    __syncthreads();
+    wave_sync_lds();
     // ---------------- phase B: UB feature rows in flight, then their FMAs
     if (__ballot(jA >= 0) != 0ull) {
       for (int hb = 0; hb < HC; hb += UB) {
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(64, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPPara
         }
       }
     }
-    __syncthreads();
+    wave_sync_lds();
     jA = jB;
     jB = jC;
     sx = tx;
@@ -489,7 +500,7 @@ int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
   const int PPW = 64 / LPP;           // points per wave
   const int HC = 64 / PPW;            // neighbours per chunk and point
   const bool fast = P.influence == MVK_INFL_LINEAR && P.aggregation == MVK_AGG_SUM;
-  dim3 grid((unsigned)cdiv64(P.Nq, PPW)), block(64);
+  dim3 grid((unsigned)cdiv64(cdiv64(P.Nq, PPW), GWPB)), block(64 * GWPB);
 #define LV(I64, F) hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F>), grid, block, 0, st, P, LPP, PPW, HC)
   if (idx64) {
     if (fast) LV(true, true); else LV(true, false);

@@ -128,6 +128,17 @@ def profile_reset(enabled):
     _PROF["gemm"] = []
 
 
+def _timing_events():
+    """Start / stop events for one launch. Eager steps are host-bound, so the queue is usually empty when
+    the start event is enqueued and the event would also time the host's launch latency of the kernel
+    behind it: a short device-side spin first keeps the GPU busy until start event, kernel and stop event
+    are all queued."""
+    torch.cuda._sleep(200000)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    return e0, e1
+
+
 def profile_collect_contraction():
     """{(M, Kd, N): {launches, total_ms, flops_per_launch}} of the forward K x Cin x Cout contraction
     (gemm_f32_mfma NN); flops = 2*M*Kd*N (SURVEY.md 8d F_mfma)."""
@@ -185,8 +196,7 @@ def kpconv_gather(q, s, idx, x, kp, extent, influence="linear", aggregation="sum
         if want_min_d2:
             min_d2 = torch.empty((Nq, K), device=q.device, dtype=torch.float32)
     if _PROF["on"]:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0, e1 = _timing_events()
     check(lib().mvk_kpconv_gather_fwd(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, _p(x), Cin, _p(kp), K,
                                       float(extent), INFLUENCE[influence], AGGREGATION[aggregation],
                                       _p(offsets), _p(min_d2), _p(A), _stream()))
@@ -239,8 +249,7 @@ class _KPConvFn(torch.autograd.Function):
         A, min_d2 = kpconv_gather(q, s, idx, x, kp, extent, influence, aggregation, offsets, want_min_d2=deform)
         Am = A * modulations.unsqueeze(2) if modulations is not None else A     # blocks.py:366-367
         if _PROF["on"]:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0, e1 = _timing_events()
         y = gemm(Am.view(-1, K * Cin), W.reshape(K * Cin, Cout))                # blocks.py:370-374
         if _PROF["on"]:
             e1.record()

@@ -148,6 +148,8 @@ def main():
         lens, loss = step()
     sync()
     dt = time.perf_counter() - t0
+    if hasattr(step, "finish"):
+        step.finish()                           # loud check of the input chain's status words
     if os.environ.get("MVK_BENCH_DIAG") == "1" and state_ref:
         h = np.asarray(state_ref[-1].get("host", [(0, 0)]))[-args.steps:]
         print("DIAG host ms per step: replay enqueue %.2f | build_async %.2f" % tuple(h.mean(0) * 1e3), file=sys.stderr)
@@ -242,6 +244,14 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         batch0.feature_2d = encode(enc_in)
     statics = [syn.StaticBatch(batch0, limits)]
     statics.append(syn.StaticBatch(batch0, limits, caps=statics[0].caps))
+    # MVK_DEVICE_CHAIN=1 (default): the input side is a sync-free launch sequence with device-side counts,
+    # captured as one more parallel branch of the graph (chain s fills static set s)
+    use_chain = os.environ.get("MVK_DEVICE_CHAIN", "1") == "1" and hasattr(syn, "DeviceInputChain")
+    chains = [syn.DeviceInputChain(cfg, staged, limits, s) for s in statics] if use_chain else None
+    if use_chain:
+        for c, s in zip(chains, statics):       # warm the workspaces of the chain outside the capture
+            c.draw_rotations()
+            c.build(s)
 
     ops.set_row_counts(statics[0].valid)
     ops.zero_arena_high_water(reset=True)
@@ -264,17 +274,24 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         other = statics[1 - statics.index(static)]
 
         def fork_encoder():
-            # parallel branch of the SAME graph (separate graph launches do not overlap on this runtime,
-            # branches of one graph do): features of the NEXT batch's views into the other static set
-            if enc is None:
-                return
-            enc_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(enc_stream):
-                other.feature_2d.copy_(encode(enc_in))
+            # parallel branches of the SAME graph (separate graph launches do not overlap on this runtime,
+            # branches of one graph do): features of the NEXT batch's views, and the NEXT batch's pyramid /
+            # unprojection / 3-NN, into the other static set
+            cur = torch.cuda.current_stream()
+            if enc is not None:
+                enc_stream.wait_stream(cur)
+                with torch.cuda.stream(enc_stream):
+                    other.feature_2d.copy_(encode(enc_in))
+            if use_chain:
+                build_stream.wait_stream(cur)
+                with torch.cuda.stream(build_stream):
+                    chains[1 - statics.index(static)].build(other)
 
         def join_encoder():
             if enc is not None:
                 torch.cuda.current_stream().wait_stream(enc_stream)
+            if use_chain:
+                torch.cuda.current_stream().wait_stream(build_stream)
 
         if reducer is None:
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
@@ -305,6 +322,60 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
 
     replays = [capture(s) for s in statics]
     state = {"next": None, "k": 0, "free": [None, None]}
+
+    if use_chain:
+        lens0 = [int(p.shape[0]) for p in staged['points']]
+        pending = []                            # (event, pinned copy of a chain's status word)
+
+        def check_status(block=False):
+            while pending and (block or pending[0][0].query()):
+                ev, host = pending.pop(0)
+                ev.synchronize()
+                if int(host[1]):
+                    raise RuntimeError("input chain: a level outgrew its captured capacity or a query its "
+                                       "neighbour list (status %s)" % host.tolist())
+
+        chains[0].draw_rotations()
+        chains[0].build(statics[0])             # batch 0; every later batch is built by the graph before it
+        state["slot"] = 0
+
+        def step_chain():
+            slot = state["slot"]
+            check_status()
+            chains[slot ^ 1].draw_rotations()   # host draw + one small async copy: the orientations of batch k+1
+            if enc is not None:
+                enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
+            ta = time.perf_counter()
+            replays[slot][0]()
+            host = torch.empty(2, dtype=torch.int32).pin_memory() if len(pending) < 4 else None
+            if host is not None:
+                host.copy_(chains[slot ^ 1].status, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                pending.append((ev, host))
+            state.setdefault("host", []).append((time.perf_counter() - ta, 0.0))
+            state["slot"] = slot ^ 1
+            return lens0, replays[slot][1]
+
+        step_chain.finish = lambda: check_status(block=True)
+        if os.environ.get("MVK_BENCH_DIAG") == "1":
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                replays[0][0]()
+                replays[1][0]()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                chains[0].build(statics[0])
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            print("DIAG graph replay (network + encoder + input chain branches) %.2f ms | input chain alone, eager "
+                  "%.2f ms" % ((t1 - t0) * 50, (t2 - t1) * 100), file=sys.stderr)
+        state_ref.append(state)
+        return step_chain, ("hipGraph with three branches per step: network fwd+loss+bwd+clip+SGD on static set k%2 | "
+                            "sync-free input chain (pyramid, unprojection, 3-NN; device-side counts) of batch k+1 | "
+                            + ("frozen 2D encoder of batch k+1" if enc is not None else "no 2D encoder"))
 
     def build_async(slot):
         """Enqueues batch k+1 on the build / encode streams and pads it into static set `slot`."""

@@ -33,6 +33,10 @@ _SIGNATURES = {
                                            _vp, _vp, _i64, _vp]),
     "mvk_grid_subsample_batch_oriented": (C.c_int, [_vp, _i64, _vp, _i, _vp, _vp, _i, _vp, _i, _f, _i, _vp, _vp,
                                                     _vp, _vp, _vp, _vp, _i64, _vp]),
+    "mvk_grid_subsample_batch_dev": (C.c_int, [_vp, _i64, _vp, _i, _vp, _f, _vp, _i64, _f, _vp, _vp, _vp, _vp, _i64,
+                                               _vp]),
+    "mvk_radius_neighbors_dev": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _i, _vp, _i, _vp, _i64,
+                                           _vp]),
     "mvk_radius_neighbors_workspace": (C.c_int64, [_i64, _i64, _i]),
     "mvk_radius_neighbors_batch": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _vp,
                                              _vp, _i64, _vp]),

@@ -151,6 +151,11 @@ __global__ __launch_bounds__(64) void nb_query_kernel(const float* __restrict__ 
   __shared__ int lidx[FILL ? CAP : 1];
   const int64_t i = blockIdx.x;
   const int lane = threadIdx.x;
+  if (i >= W.qoffs[B]) {   // fixed-capacity launch (device-lens variant): a padding row has no neighbours
+    if (FILL)
+      for (int c = lane; c < width; c += 64) out[i * width + c] = (int)Ns;
+    return;
+  }
   int b = 0;
   while (b + 1 < B && i >= W.qoffs[b + 1]) ++b;
   const CloudGrid G = W.grids[b];
@@ -361,4 +366,57 @@ extern "C" int mvk_radius_neighbors_enqueue(const float* q, int64_t Nq, const fl
   MVK_REQUIRE(out != nullptr && status_dev != nullptr, "neighbors: enqueue needs an output matrix and a status word");
   return nb_run(q, Nq, s, Ns, q_lens_host, s_lens_host, B, radius, out, width, nullptr, status_dev, reuse_grid,
                 workspace, workspace_bytes, stream);
+}
+
+namespace {
+// query / support offsets from DEVICE lengths into the header the kernels read
+__global__ void nb_offsets_kernel(const int* __restrict__ q_lens, const int* __restrict__ s_lens, int B,
+                                  int* __restrict__ qoffs, int* __restrict__ soffs) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int a = 0, b = 0;
+  for (int i = 0; i < B; ++i) {
+    qoffs[i] = a;
+    soffs[i] = b;
+    a += max(q_lens[i], 0);
+    b += max(s_lens[i], 0);
+  }
+  qoffs[B] = a;
+  soffs[B] = b;
+}
+}  // namespace
+
+extern "C" int mvk_radius_neighbors_dev(const float* q, int64_t Nq_cap, const float* s, int64_t Ns_cap,
+                                        const int32_t* q_lens_dev, const int32_t* s_lens_dev, int B,
+                                        float radius, int32_t* out, int width, int32_t shadow,
+                                        int32_t* status_dev, int reuse_grid, void* workspace,
+                                        int64_t workspace_bytes, void* stream) {
+  MVK_REQUIRE(B >= 1 && B <= 4096 && Nq_cap >= 1 && Ns_cap >= 1 && Nq_cap < (1ll << 31) && Ns_cap < (1ll << 29),
+              "neighbors: bad sizes");
+  MVK_REQUIRE(radius > 0.f && width >= 1 && out && status_dev, "neighbors: bad arguments");
+  MVK_REQUIRE(workspace && workspace_bytes >= ws_bytes(Nq_cap, Ns_cap, B), "neighbors: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  Carver cv{(char*)workspace};
+  NbWs W;
+  int64_t cells = cell_cap(Ns_cap) + (int64_t)B * (4096 + 1 + 4);
+  W.grids = cv.take<CloudGrid>(B);
+  W.cell_start = cv.take<int>(cells);
+  W.cell_fill = cv.take<int>(cells);
+  W.recs = cv.take<float4>(Ns_cap + 1);
+  int* hdr = cv.take<int>(4 + 2 * (B + 1));
+  W.qoffs = hdr + 4;
+  W.soffs = hdr + 4 + B + 1;
+  W.counts = cv.take<int>(Nq_cap + 1);
+  MVK_REQUIRE(cv.p <= (char*)workspace + workspace_bytes, "neighbors: workspace carve overflow");
+  W.maxcount = status_dev;
+  W.overflow = status_dev + 1;
+  hipLaunchKernelGGL(nb_offsets_kernel, dim3(1), dim3(64), 0, st, q_lens_dev, s_lens_dev, B, W.qoffs, W.soffs);
+  if (!reuse_grid) hipLaunchKernelGGL(nb_build_kernel, dim3(B), dim3(TPB), 0, st, s, W, radius);
+  if (width <= 64)
+    hipLaunchKernelGGL((nb_query_kernel<true, 256>), dim3((unsigned)Nq_cap), dim3(64), 0, st, q, W, B, radius,
+                       (int64_t)shadow, out, width);
+  else
+    hipLaunchKernelGGL((nb_query_kernel<true, LIST_CAP>), dim3((unsigned)Nq_cap), dim3(64), 0, st, q, W, B, radius,
+                       (int64_t)shadow, out, width);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
 }

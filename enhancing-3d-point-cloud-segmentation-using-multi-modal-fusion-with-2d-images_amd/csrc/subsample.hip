@@ -369,12 +369,16 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
 __global__ void subsample_compact_kernel(const int* __restrict__ offs, SubWs W, int B, int fdim, int ldim,
                                          int max_p, float* __restrict__ out_pts,
                                          float* __restrict__ out_feats, int* __restrict__ out_labels,
-                                         int* __restrict__ out_lens) {
+                                         int* __restrict__ out_lens, int64_t out_cap, int* __restrict__ overflow) {
   const int b = blockIdx.y;
   int base = 0;
   for (int i = 0; i < b; ++i) base += min(W.out_count[i], max_p);
-  const int m = min(W.out_count[b], max_p);
+  int m = min(W.out_count[b], max_p);
   if (blockIdx.x == 0 && threadIdx.x == 0) out_lens[b] = m;
+  if (base + m > out_cap) {   // device-lens variant with a fixed output capacity: flag, never write past it
+    if (blockIdx.x == 0 && threadIdx.x == 0 && overflow) atomicExch(overflow, 1);
+    m = base < out_cap ? (int)(out_cap - base) : 0;
+  }
   const int off = offs[b];
   for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < m; o += gridDim.x * blockDim.x) {
     for (int c = 0; c < 3; ++c) out_pts[(int64_t)(base + o) * 3 + c] = W.stage_pts[(int64_t)(off + o) * 3 + c];
@@ -383,6 +387,55 @@ __global__ void subsample_compact_kernel(const int* __restrict__ offs, SubWs W, 
     for (int d = 0; d < ldim; ++d)
       out_labels[(int64_t)(base + o) * ldim + d] = W.stage_lab[(int64_t)(off + o) * ldim + d];
   }
+}
+
+// ---- device-lens variant (capturable in a hipGraph: no host reads, fixed launch geometry) ----------------
+
+// offs[b] = sum(lens[:b]) for b <= B (one thread; B is a handful of clouds)
+__global__ void offsets_from_lens_kernel(const int* __restrict__ lens, int B, int* __restrict__ offs) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  int s = 0;
+  for (int b = 0; b < B; ++b) {
+    offs[b] = s;
+    s += max(lens[b], 0);
+  }
+  offs[B] = s;
+}
+
+// same arithmetic as rotate_cloud_kernel, cloud of a row found from DEVICE offsets, matrices in DEVICE memory
+__global__ void rotate_stacked_dev_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                          const int* __restrict__ lens, int B, const float* __restrict__ R,
+                                          int transpose, int64_t cap) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= cap) return;
+  int b = 0, acc = 0;
+  while (b < B && t >= acc + lens[b]) acc += lens[b++];
+  if (b >= B) return;   // padding row
+  const float* M = R + b * 9;
+  const float p0 = in[t * 3], p1 = in[t * 3 + 1], p2 = in[t * 3 + 2];
+  float o[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float r0 = transpose ? M[i * 3 + 0] : M[0 * 3 + i];
+    const float r1 = transpose ? M[i * 3 + 1] : M[1 * 3 + i];
+    const float r2 = transpose ? M[i * 3 + 2] : M[2 * 3 + i];
+    o[i] = (p0 * r0 + p1 * r1) + p2 * r2;
+  }
+  out[t * 3] = o[0];
+  out[t * 3 + 1] = o[1];
+  out[t * 3 + 2] = o[2];
+}
+
+// rows >= sum(out_lens) of the fixed-capacity output <- pad value; *total_out <- sum(out_lens)
+__global__ void pad_tail_kernel(float* __restrict__ out_pts, const int* __restrict__ out_lens, int B, int64_t out_cap,
+                                float pad, int* __restrict__ total_out) {
+  int tot = 0;
+  for (int b = 0; b < B; ++b) tot += out_lens[b];
+  if (tot > out_cap) tot = (int)out_cap;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t == 0 && total_out) *total_out = tot;
+  if (t >= out_cap * 3) return;
+  if (t >= (int64_t)tot * 3) out_pts[t] = pad;
 }
 
 struct Carver {
@@ -522,7 +575,7 @@ int subsample_run(const float* pts, int64_t N, const int32_t* lens_host, int B, 
   if (gx < 1) gx = 1;
   if (gx > 64) gx = 64;
   hipLaunchKernelGGL(subsample_compact_kernel, dim3(gx, B), dim3(256), 0, st, offs_d, W, B, fdim, ldim, max_p,
-                     out_pts, out_feats, out_labels, out_lens);
+                     out_pts, out_feats, out_labels, out_lens, (int64_t)n, (int*)nullptr);
   if (rot_host) {   // ... and the barycentres back by its transpose (:134), in place on the compacted output
     for (int b = 0; b < B; ++b) {
       if (lens_host[b] == 0) continue;
@@ -562,4 +615,60 @@ extern "C" int mvk_grid_subsample_batch_oriented(const float* pts, int64_t N, co
   MVK_REQUIRE(rot_host != nullptr, "subsample: the oriented variant needs one rotation per cloud");
   return subsample_run(pts, N, lens_host, B, rot_host, feats, fdim, labels, ldim, dl, max_p, out_pts, out_feats,
                        out_labels, out_lens, out_lens_host, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mvk_grid_subsample_batch_dev(const float* pts, int64_t cap_in, const int32_t* lens_dev, int B,
+                                            const float* rot_dev, float dl, float* out_pts, int64_t out_cap,
+                                            float pad_value, int32_t* out_lens_dev, int32_t* total_out_dev,
+                                            int32_t* status_dev, void* workspace, int64_t workspace_bytes,
+                                            void* stream) {
+  MVK_REQUIRE(B >= 1 && cap_in >= 1 && cap_in < (1ll << 29) && out_cap >= 1, "subsample: bad sizes");
+  MVK_REQUIRE(dl > 0.f, "subsample: sampleDl must be positive");
+  MVK_REQUIRE(status_dev != nullptr && out_lens_dev != nullptr, "subsample: the device-lens variant needs a status word");
+  MVK_REQUIRE(workspace != nullptr && workspace_bytes >= ws_bytes(cap_in, B, 0, 0), "subsample: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n = cap_in;
+  Carver cv{(char*)workspace, (char*)workspace + workspace_bytes};
+  SubWs W;
+  W.slot = cv.take<int>(n); W.member = cv.take<int>(n); W.scan = cv.take<int>(n);
+  W.hkey = cv.take<unsigned long long>(4 * n); W.hfirst = cv.take<int>(4 * n); W.hvox = cv.take<int>(4 * n);
+  W.vkey = cv.take<unsigned long long>(n); W.vcount = cv.take<int>(n); W.vseg = cv.take<int>(n);
+  W.vcursor = cv.take<int>(n); W.vbary = cv.take<float>(3 * n);
+  W.vfeat = cv.take<float>(1);
+  W.vlab = cv.take<int>(1);
+  W.lab_key = cv.take<int>(n); W.lab_cnt = cv.take<int>(n); W.errflag = cv.take<int>(1);
+  W.tau = cv.take<int>(n); W.posnew = cv.take<int>(n); W.nextb = cv.take<int>(n); W.tarr = cv.take<int>(n);
+  W.ft = cv.take<int>(3 * n + 32 * B); W.bcnt = cv.take<int>(3 * n + 32 * B); W.bhead = cv.take<int>(3 * n + 32 * B);
+  W.out_count = cv.take<int>(B + 1);
+  int* offs_d = cv.take<int>(B + 1);
+  W.stage_pts = cv.take<float>(3 * n);
+  W.stage_feat = cv.take<float>(1);
+  W.stage_lab = cv.take<int>(1);
+  float* rot_pts = cv.take<float>(3 * n);
+  MVK_REQUIRE(cv.p <= cv.end, "subsample: workspace carve overflow");
+  W.errflag = status_dev + 1;   // label overflow cannot happen without labels; shares the overflow word
+
+  Schedule sched;
+  sched.nb[0] = 13;
+  for (int e = 1; e < 48; ++e) sched.nb[e] = mvk_next_bkt(2 * sched.nb[e - 1]);
+  hipLaunchKernelGGL(offsets_from_lens_kernel, dim3(1), dim3(64), 0, st, lens_dev, B, offs_d);
+  const unsigned pb = (unsigned)cdiv64(cap_in, 256);
+  if (rot_dev) {
+    hipLaunchKernelGGL(rotate_stacked_dev_kernel, dim3(pb), dim3(256), 0, st, pts, rot_pts, lens_dev, B, rot_dev, 0, cap_in);
+    pts = rot_pts;
+  }
+  hipLaunchKernelGGL(subsample_cloud_kernel, dim3(B), dim3(TPB), 0, st, pts, (const float*)nullptr, 0,
+                     (const int32_t*)nullptr, 0, offs_d, dl, W, B, sched);
+  int gx = (int)cdiv64(n, 256 * (int64_t)B);
+  if (gx < 1) gx = 1;
+  if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(subsample_compact_kernel, dim3(gx, B), dim3(256), 0, st, offs_d, W, B, 0, 0, (int)n, out_pts,
+                     (float*)nullptr, (int*)nullptr, out_lens_dev, out_cap, status_dev + 1);
+  if (rot_dev)
+    hipLaunchKernelGGL(rotate_stacked_dev_kernel, dim3((unsigned)cdiv64(out_cap, 256)), dim3(256), 0, st, out_pts, out_pts,
+                       out_lens_dev, B, rot_dev, 1, out_cap);
+  hipLaunchKernelGGL(pad_tail_kernel, dim3((unsigned)cdiv64(out_cap * 3, 256)), dim3(256), 0, st, out_pts, out_lens_dev, B,
+                     out_cap, pad_value, total_out_dev);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
 }

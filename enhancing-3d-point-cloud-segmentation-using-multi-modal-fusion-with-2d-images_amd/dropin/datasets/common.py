@@ -82,6 +82,31 @@ def batch_neighbors(queries, supports, q_batches, s_batches, radius, limit=None,
     return out.cpu().numpy() if as_np else out
 
 
+def pyramid_plan(config):
+    """The radii / cell sizes segmentation_inputs_sphere uses, one dict per pyramid layer
+    (common.py:797-857): ``conv_r`` (None when the layer has no conv block), ``pool`` (whether a level
+    follows), ``dl`` of the subsampling and the pool / upsample search radii."""
+    r_normal = config.first_subsampling_dl * config.conv_radius
+    plan, layer_blocks = [], []
+    for block in config.architecture:
+        if not ('pool' in block or 'strided' in block or 'global' in block or 'upsample' in block):
+            layer_blocks.append(block)
+            continue
+        entry = dict(conv_r=None, pool=False, dl=None, pool_r=None, up_r=None)
+        if layer_blocks:
+            deform = bool(np.any(['deformable' in b for b in layer_blocks]))
+            entry['conv_r'] = r_normal * config.deform_radius / config.conv_radius if deform else r_normal
+        if 'pool' in block or 'strided' in block:
+            r = r_normal * config.deform_radius / config.conv_radius if 'deformable' in block else r_normal
+            entry.update(pool=True, dl=2 * r_normal / config.conv_radius, pool_r=r, up_r=2 * r)
+        plan.append(entry)
+        r_normal *= 2
+        layer_blocks = []
+        if 'global' in block or 'upsample' in block:
+            break
+    return plan
+
+
 def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborhood_limits=None,
                                index_dtype=torch.int64, rotations=None, status=None):
     """Per-layer network inputs (common.py:779-900): returns dict with lists ``points``, ``neighbors``,

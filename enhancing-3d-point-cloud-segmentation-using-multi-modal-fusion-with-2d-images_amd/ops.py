@@ -576,6 +576,35 @@ def radius_neighbors_batch(queries, supports, q_lens, s_lens, radius, limit=None
     return out
 
 
+def grid_subsample_dev(points, lens_dev, dl, out_points, out_lens_dev, status, rotations_dev=None,
+                       total_out=None, pad_value=1e6):
+    """Capturable subsampling (mvk_grid_subsample_batch_dev): points [cap_in,3] with DEVICE lens [B] ->
+    out_points [out_cap,3] (rows past the total = pad_value), out_lens_dev [B], total_out [1]. No host sync."""
+    _dev(points, lens_dev, out_points, out_lens_dev, status, rotations_dev, total_out)
+    points = _f32c(points)
+    cap_in, B = points.shape[0], int(lens_dev.shape[0])
+    if not out_points.is_contiguous() or out_points.dtype != torch.float32:
+        raise RuntimeError("grid_subsample_dev: out_points must be a contiguous float32 [cap,3] tensor")
+    ws = _workspace("sub", lib().mvk_grid_subsample_workspace(cap_in, B, 0, 0), points.device)
+    check(lib().mvk_grid_subsample_batch_dev(_p(points), cap_in, _p(lens_dev), B, _p(rotations_dev), float(dl),
+                                             _p(out_points), out_points.shape[0], float(pad_value),
+                                             _p(out_lens_dev), _p(total_out), _p(status), _p(ws), ws.numel(), _stream()))
+
+
+def radius_neighbors_dev(queries, supports, q_lens_dev, s_lens_dev, radius, out, shadow, status, reuse_grid=False):
+    """Capturable neighbour search (mvk_radius_neighbors_dev) into the fixed matrix out [Nq_cap, width] int32."""
+    _dev(queries, supports, q_lens_dev, s_lens_dev, out, status)
+    q, s = _f32c(queries), _f32c(supports)
+    if out.dtype != torch.int32 or not out.is_contiguous() or out.shape[0] != q.shape[0]:
+        raise RuntimeError("radius_neighbors_dev: out must be a contiguous int32 [Nq_cap, width] tensor")
+    B = int(q_lens_dev.shape[0])
+    ws = _workspace("nb", lib().mvk_radius_neighbors_workspace(q.shape[0], s.shape[0], B), q.device)
+    check(lib().mvk_radius_neighbors_dev(_p(q), q.shape[0], _p(s), s.shape[0], _p(q_lens_dev), _p(s_lens_dev), B,
+                                         float(radius), _p(out), out.shape[1], int(shadow), _p(status),
+                                         int(bool(reuse_grid)), _p(ws), ws.numel(), _stream()))
+    _NB_GRID.pop(q.device.index, None)
+
+
 def check_neighbor_status(status):
     """Reads an enqueue-only status word back (synchronises with the work that produced it)."""
     maxc, ovf = (int(v) for v in status.cpu())

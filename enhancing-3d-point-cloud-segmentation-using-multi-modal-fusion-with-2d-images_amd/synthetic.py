@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .dropin.datasets.common import segmentation_inputs_sphere, SphereBatch
+from .dropin.datasets.common import pyramid_plan, random_grid_rotations, segmentation_inputs_sphere, SphereBatch
 from .dropin.utils.config import Config
 
 IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], np.float32)
@@ -338,3 +338,85 @@ class StaticBatch:
         if src.shape[1] > dst.shape[1]:
             raise RuntimeError("batch does not fit the captured neighbour widths: %d > %d" % (src.shape[1], dst.shape[1]))
         ops.pad_index_rows(src, shadow_src, dst, shadow_dst)
+
+
+class DeviceInputChain:
+    """The input side of one step -- centring, pyramid (oriented subsampling + neighbour searches),
+    unprojection, 3-NN -- as a fixed sequence of launches with DEVICE-side counts that writes straight
+    into a StaticBatch: no host read-back, no shape depends on data, so it can be captured as a branch of
+    the network's hipGraph (the only way the two overlap on this runtime). Same results as
+    build_batch + StaticBatch.load (tests/test_model_gpu.py). The per-level random grid orientations
+    (datasets/common.py:89-108) are drawn on the host and copied into `rot` before each replay.
+    `status` accumulates [max neighbour count, overflow]: overflow = a level outgrew its capacity or a
+    query its in-kernel list; check it with ops.check_neighbor_status (loud, possibly one step late)."""
+
+    def __init__(self, config, staged, limits, static):
+        self.config, self.staged = config, staged
+        self.plan = pyramid_plan(config)
+        dev = staged['points'][0].device
+        self.B = len(staged['points'])
+        lens0 = [int(p.shape[0]) for p in staged['points']]
+        L = len(static.points)
+        self.lens = [torch.tensor(lens0, dtype=torch.int32, device=dev)] + \
+                    [torch.zeros(self.B, dtype=torch.int32, device=dev) for _ in range(L - 1)]
+        self.rot = torch.zeros((max(L - 1, 1), self.B, 3, 3), dtype=torch.float32, device=dev)
+        self.rot_host = torch.zeros((max(L - 1, 1), self.B, 3, 3), dtype=torch.float32).pin_memory()
+        self.status = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.limits = [int(x) for x in limits]
+        if static.neighbors[0].dtype != torch.int32:
+            raise RuntimeError("DeviceInputChain writes int32 neighbour matrices")
+        # size the shared workspaces once for the largest call (a regrown workspace would lose a reused grid)
+        caps = static.caps
+        ops._workspace("nb", max(ops.lib().mvk_radius_neighbors_workspace(caps[a], caps[b], self.B)
+                                 for a in range(L) for b in range(L) if abs(a - b) <= 1), dev)
+        ops._workspace("sub", ops.lib().mvk_grid_subsample_workspace(caps[0], self.B, 0, 0), dev)
+
+    def draw_rotations(self, rotations=None):
+        """Host side of a step: one random rotation per cloud and level (or the given ones), staged in
+        pinned memory and copied to the device asynchronously on the current stream."""
+        L1 = self.rot.shape[0]
+        for l in range(L1):
+            R = random_grid_rotations(self.B) if rotations is None else rotations[l]
+            self.rot_host[l].copy_(torch.from_numpy(np.ascontiguousarray(R, dtype=np.float32)))
+        self.rot.copy_(self.rot_host, non_blocking=True)
+
+    def build(self, static):
+        """Enqueues the whole chain on the current stream, writing into `static`."""
+        cfg, st, plan, caps, lim = self.config, self.staged, self.plan, static.caps, self.limits
+        world = st['points']
+        stacked_world = torch.cat(world, 0)
+        static.points[0].copy_(torch.cat([p - c for p, c in zip(world, st['center'])], 0))   # :600
+        static._counts[0].fill_(static.n0)
+        L = len(static.points)
+        grid_of = (None, None)
+
+        def search(ql, sl, radius, out, limit_layer):
+            nonlocal grid_of
+            reuse = grid_of == (sl, np.float32(radius))
+            grid_of = (sl, np.float32(radius))
+            ops.radius_neighbors_dev(static.points[ql], static.points[sl], self.lens[ql], self.lens[sl], radius,
+                                     out, caps[sl], self.status, reuse_grid=reuse)
+
+        for l in range(L):
+            e = plan[l]
+            if e['conv_r'] is not None:
+                search(l, l, e['conv_r'], static.neighbors[l], l)
+            if e['pool'] and l + 1 < L:
+                ops.grid_subsample_dev(static.points[l], self.lens[l], e['dl'], static.points[l + 1], self.lens[l + 1],
+                                       self.status, rotations_dev=self.rot[l], total_out=static._counts[l + 1])
+                search(l + 1, l, e['pool_r'], static.pools[l], l)
+                search(l, l + 1, e['up_r'], static.upsamples[l], l + 1)
+        static.labels.copy_(torch.cat(st['labels'], 0))
+        ones = torch.ones_like(stacked_world[:, :1])
+        z = stacked_world[:, 2:3]
+        v = cfg.variant
+        if v == "baseline":
+            static.features.copy_(torch.cat([ones, z], 1))
+            return
+        static.feature_3d.copy_(torch.cat([ones, z], 1) if v == "early" else torch.cat([ones, torch.cat(st['colors'], 0)], 1))
+        static.feat_aggre_points.copy_(stacked_world.unsqueeze(0))
+        static.images.copy_(torch.stack(st['images'], 0))
+        for i, pw in enumerate(world):
+            xyz, valid = ops.unproject_depth(st['depth'][i], st['cam'][i], st['poses'][i])
+            static.knn_list[i].copy_(ops.knn_pixels(pw, xyz, valid, k=3).unsqueeze(0))
+            static.image_xyz[i].copy_(xyz.to(torch.float32))

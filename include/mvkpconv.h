@@ -148,6 +148,17 @@ int mvk_grid_subsample_batch_oriented(const float* pts, int64_t N, const int32_t
                                       int32_t* out_lens, int32_t* out_lens_host, void* workspace,
                                       int64_t workspace_bytes, void* stream);
 
+/* Device-lens variant for a hipGraph-capturable input chain: nothing is read back, every launch has a
+ * fixed geometry. pts [cap_in,3] holds the clouds back to back, cloud b = lens_dev[b] rows (DEVICE int32
+ * [B]); rows past sum(lens) are ignored. rot_dev (DEVICE [B,3,3] f32 or NULL) as rot_host above. out_pts
+ * [out_cap,3]: the subsampled clouds back to back, rows past their total = pad_value; out_lens_dev [B];
+ * *total_out_dev (DEVICE, may be NULL) = sum(out_lens). status_dev (DEVICE int32 [2]): [1] is set when the
+ * result does not fit out_cap (rows beyond it are dropped, never written). Workspace as for N = cap_in. */
+int mvk_grid_subsample_batch_dev(const float* pts, int64_t cap_in, const int32_t* lens_dev, int B,
+                                 const float* rot_dev, float dl, float* out_pts, int64_t out_cap,
+                                 float pad_value, int32_t* out_lens_dev, int32_t* total_out_dev,
+                                 int32_t* status_dev, void* workspace, int64_t workspace_bytes, void* stream);
+
 int64_t mvk_radius_neighbors_workspace(int64_t Nq, int64_t Ns, int B);
 
 /* Fixed-radius neighbours of a stacked batch: out [Nq,width] int32, row = indices (into the stacked
@@ -175,6 +186,14 @@ int mvk_radius_neighbors_enqueue(const float* q, int64_t Nq, const float* s, int
                                  const int32_t* q_lens_host, const int32_t* s_lens_host, int B,
                                  float radius, int32_t* out, int width, int32_t* status_dev,
                                  int reuse_grid, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Device-lens variant of mvk_radius_neighbors_enqueue (hipGraph capturable): q [Nq_cap,3] / s [Ns_cap,3]
+ * hold the clouds back to back with DEVICE lengths; out [Nq_cap,width] is written for EVERY row: real rows
+ * as above with pad value `shadow`, rows past sum(q_lens) all `shadow`. Workspace as for (Nq_cap, Ns_cap). */
+int mvk_radius_neighbors_dev(const float* q, int64_t Nq_cap, const float* s, int64_t Ns_cap,
+                             const int32_t* q_lens_dev, const int32_t* s_lens_dev, int B, float radius,
+                             int32_t* out, int width, int32_t shadow, int32_t* status_dev, int reuse_grid,
+                             void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------- capacity padding (hipGraph replay over fixed shapes) ----- */
 

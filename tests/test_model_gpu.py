@@ -160,7 +160,50 @@ def test_capacity_padded_mode_equals_plain_mode(variant, deformable):
     assert (A @ B).item() / (A.norm().item() * B.norm().item()) > 0.9999
 
 
-def test_graph_replay_trains_like_eager():
+@pytest.mark.parametrize("variant,deformable,nspheres", [("early", False, 1), ("late", True, 2), ("baseline", False, 3)])
+def test_device_input_chain_equals_eager_input_side(variant, deformable, nspheres):
+    """The sync-free, capturable input chain (device-side counts, fixed launch geometry) fills a static
+    batch with exactly what build_batch + StaticBatch.load put there: points, counts, the 13 index
+    matrices, 3-NN indices, unprojected pixels -- for the same grid rotations, one or several spheres."""
+    import mvkpconv
+    syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
+    common = mvkpconv.sub("dropin.datasets.common")
+    dev = torch.device("cuda:0")
+    cfg = syn.make_config(variant, deformable=deformable, modulated=deformable)
+    sph = [syn.raw_sphere(seed=20 + i, radius=0.7 + 0.1 * i, density=3000.0) for i in range(nspheres)]
+    views = [syn.sphere_views(s, nv=3, h=60, w=80) for s in sph] if variant != "baseline" else None
+    staged = syn.stage_spheres(sph, dev, views)
+    limits = syn.calibrate_limits(cfg, staged)
+    rng = np.random.RandomState(4)
+    rots = [common.random_grid_rotations(nspheres, rng) for _ in range(4)]
+    batch, _ = syn.build_batch(cfg, staged, limits, torch.int32, rotations=rots)
+    want = syn.StaticBatch(batch, limits)
+    got = syn.StaticBatch(batch, limits, caps=want.caps)
+    for tl in (got.points[1:], got.neighbors, got.pools[:-1], got.upsamples[:-1]):
+        for x in tl:
+            x.fill_(-12345)                                           # everything must be rewritten
+    chain = syn.DeviceInputChain(cfg, staged, limits, got)
+    for _ in range(2):                                               # twice: the chain must be re-runnable as is
+        chain.draw_rotations(rots)
+        chain.build(got)
+    assert ops.check_neighbor_status(chain.status) >= max(limits[:1])
+    L = len(want.points)
+    for l in range(L):
+        assert torch.equal(got.points[l], want.points[l]), l
+        assert torch.equal(got._counts[l], want._counts[l]), l
+        assert torch.equal(got.neighbors[l], want.neighbors[l]), l
+        if l + 1 < L:
+            assert torch.equal(got.pools[l], want.pools[l]) and torch.equal(got.upsamples[l], want.upsamples[l]), l
+    for name in syn.StaticBatch._DENSE:
+        a, b = getattr(got, name), getattr(want, name)
+        assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), name
+    if want.knn_list is not None:
+        for a, b in zip(got.knn_list, want.knn_list):
+            assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("device_chain", [False, True])
+def test_graph_replay_trains_like_eager(device_chain):
     """bench.py's hipGraph step (capacity-padded static batch, masked BatchNorm, input pyramid one batch
     ahead on a second stream) follows the same trajectory as plain eager steps: with the grid rotations
     pinned (so every batch is identical) the losses and the weights after 5 optimizer steps agree."""
@@ -179,6 +222,11 @@ def test_graph_replay_trains_like_eager():
     rots = [np.stack([np.eye(3, dtype=np.float32)]) for _ in range(4)]
     shim = types.SimpleNamespace(StaticBatch=syn.StaticBatch,
                                  build_batch=lambda c, st, lim, dt, **kw: syn.build_batch(c, st, lim, dt, rotations=rots, **kw))
+    if device_chain:        # the input side as a captured branch of the graph (device-side counts)
+        class PinnedChain(syn.DeviceInputChain):
+            def draw_rotations(self, rotations=None):
+                super().draw_rotations(rots)
+        shim.DeviceInputChain = PinnedChain
 
     def make():
         torch.manual_seed(0)

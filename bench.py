@@ -206,18 +206,18 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     """Capacity-padded static batches + captured hipGraphs for forward, loss, backward, gradient
     all-reduce (N>1), clip and SGD.
 
-    main stream  : replay of the network graph on static set k % 2;
-    build stream : pyramid + unprojection + 3-NN of batch k+1 and its padding into static set (k+1) % 2
-                   (their shapes change with the random grid orientation, the graph's do not).
-    Two static sets / two graph instances make the input side a true double buffer: nothing of batch k+1
-    touches memory the replay of batch k reads, and the host never waits for the replay.
+    Two static sets / two graph instances: the graph of set k % 2 runs the network on batch k and prepares
+    batch k+1 in the other set, so nothing of batch k+1 touches memory the network reads.
     Measured on this runtime (tools/overlap_probe.py): a graph replay does not overlap with work of another
-    stream or another graph launch -- only branches inside ONE graph run concurrently -- so the second stream
-    hides the HOST latency of the input chain (its few round trips), not its kernel time.
-    The frozen eval-mode 2D encoder (architectures_sphere.py:232-237: a pure function of the images) is
-    such a parallel branch: it computes the features of batch k+1 into the other static set while the
-    network runs on batch k (0.8 ms less GPU time per step, 2 ms more host launch time, which the step has
-    to spare; MVK_ENCODER_AHEAD=0 keeps it in line inside the network forward)."""
+    stream or another graph launch -- only branches inside ONE graph run concurrently. Hence, per graph:
+      branch 1  network forward + loss + backward + clip + SGD on static set k % 2;
+      branch 2  the frozen eval-mode 2D encoder (architectures_sphere.py:232-237: a pure function of the
+                images) on the views of batch k+1 (MVK_ENCODER_AHEAD=0: in line inside the forward);
+      branch 3  the input chain of batch k+1 -- pyramid, unprojection, 3-NN -- as a sync-free launch
+                sequence with device-side counts (synthetic.DeviceInputChain). MVK_DEVICE_CHAIN=0 builds
+                it eagerly on a second stream instead (its shapes then follow the data; only the host round
+                trips of the chain are hidden, and a batch that outgrows a capacity falls back to an eager step).
+    The host draws the random grid orientations, copies them to the device and launches the graph."""
     has_2d = hasattr(net, "net_2d") and os.environ.get("MVK_ENCODER_AHEAD", "1") == "1"
     dev = staged['points'][0].device
     # all three streams at the same priority: on this driver a priority difference between queues that

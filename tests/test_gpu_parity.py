@@ -179,6 +179,46 @@ def test_neighbors_enqueue_only_and_grid_reuse_equal_the_synchronous_search(ops)
         assert torch.equal(x, y)
 
 
+def test_device_lens_variants_edge_cases(ops):
+    """mvk_grid_subsample_batch_dev / mvk_radius_neighbors_dev: an empty cloud inside the batch, rows past
+    the device-side counts, and an output capacity that is too small (flagged, nothing written past it)."""
+    rng = np.random.default_rng(21)
+    a = (rng.random((30000, 3)) * [1.5, 1.5, 0.3]).astype(np.float32)
+    b = (rng.random((20000, 3)) * [1.0, 1.0, 0.3] + 5).astype(np.float32)
+    lens_h = [30000, 0, 20000]
+    pts = T(np.concatenate([a, b, np.full((777, 3), 1e6, np.float32)]))          # 777 padding rows
+    lens = torch.tensor(lens_h, dtype=torch.int32, device="cuda")
+    want_p, want_l = ops.grid_subsample_batch(pts[:50000], lens_h, dl=0.06)
+    M = want_p.shape[0]
+    status = torch.zeros(2, dtype=torch.int32, device="cuda")
+    out = torch.full((M + 100, 3), -1.0, device="cuda")
+    out_l = torch.zeros(3, dtype=torch.int32, device="cuda")
+    tot = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ops.grid_subsample_dev(pts, lens, 0.06, out, out_l, status, total_out=tot)
+    assert torch.equal(out[:M], want_p) and (out[M:] == 1e6).all()
+    assert out_l.cpu().tolist() == list(want_l) and int(tot) == M and int(status[1]) == 0
+    # neighbours: queries = subsampled clouds (capacity M + 100), supports = input clouds (capacity 50 777)
+    ref = ops.radius_neighbors_batch(want_p, pts[:50000], want_l, lens_h, 0.08, limit=40)
+    nb = torch.full((M + 100, 40), -7, dtype=torch.int32, device="cuda")
+    ops.radius_neighbors_dev(out, pts, out_l, lens, 0.08, nb, 123456, status)
+    w = ref.shape[1]
+    body = nb[:M, :w]
+    assert torch.equal(torch.where(body == 123456, torch.full_like(body, 50000), body), ref)
+    assert (nb[:M, w:] == 123456).all() and (nb[M:] == 123456).all()
+    assert 40 < ops.check_neighbor_status(status) <= 256
+    # a row with more in-range supports than the 256-entry list of the narrow searches: flagged, loudly
+    dense = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.radius_neighbors_dev(out, pts, out_l, lens, 0.3, nb, 123456, dense)
+    with pytest.raises(RuntimeError):
+        ops.check_neighbor_status(dense)
+    # capacity too small: flagged, rows beyond the capacity are dropped, the guard row stays untouched
+    small = torch.full((M - 50 + 1, 3), -1.0, device="cuda")
+    ops.grid_subsample_dev(pts, lens, 0.06, small[:M - 50], out_l, status, total_out=tot)
+    assert int(status[1]) == 1 and (small[M - 50] == -1).all() and torch.equal(small[:M - 50], want_p[:M - 50])
+    with pytest.raises(RuntimeError):
+        ops.check_neighbor_status(status)
+
+
 def test_capacity_padding_kernels(ops):
     src = torch.randint(0, 50, (37, 5), dtype=torch.int32, device="cuda")
     src[::3, 2] = 50                                               # shadow index of the source

@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--in-radius", type=float, default=1.2, help="sphere radius (1.2 -> ~20 k points, 1.7 -> ~40 k)")
     ap.add_argument("--deformable", action="store_true")
+    ap.add_argument("--features", default="f32", choices=["f32", "f16"],
+                    help="f16: BASELINE config 5's fp16-feature mode of every KPConv layer (fp16 features / aggregate / "
+                         "weights, fp16 MFMA contraction, f32 accumulation and f32 everything else)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="replay the network part (fwd+loss+bwd+clip+SGD) as one hipGraph over capacity-padded levels")
@@ -74,6 +77,7 @@ def main():
 
     import mvkpconv
     syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
+    ops.set_feature_dtype(torch.float16 if args.features == "f16" else torch.float32)
     torch.manual_seed(1234)           # same initial weights on every rank
     np.random.seed(1234)
     cfg = syn.make_config(args.workload, deformable=args.deformable, modulated=args.deformable and args.workload == "late")
@@ -178,7 +182,8 @@ def main():
             "metric": "input points/s through MV-KPConv KPFCNN forward+backward (pyramid + fusion + fwd + bwd + SGD)",
             "value": total_points / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if args.features == "f32" else "f16 features / f32 accumulate",
+            "data": "synthetic",
             "config": {"workload": "%s_kpfcnn5_sphere%dk_x%d_per_gpu%s" % (
                 args.workload + ("_fusion" if fusion else ""), int(round(sum(lens) / max(args.spheres, 1) / 1000.0)),
                 args.spheres, "_deformable" if args.deformable else ""),
@@ -186,7 +191,7 @@ def main():
                 "image_hw": [120, 160] if fusion else None, "parallelism": "dp%d" % world, "execution": graph_note,
                 "final_loss": float(loss.item())},
             "roofline": roofline(prof),
-            "contraction": mfma_report(contraction),
+            "contraction": mfma_report(contraction, args.features),
             "gather_launches": [dict(kernel=r["kernel"], avg_us=r["total_ms"] / r["launches"] * 1e3,
                                      GBps=r["bytes_per_launch"] / (r["total_ms"] / r["launches"] * 1e-3) / 1e9, **r["shape"])
                                 for r in sorted(prof.values(), key=lambda r: -r["total_ms"])],
@@ -510,17 +515,21 @@ def roofline(prof):
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= f32 vector peak)
 
 
-def mfma_report(contraction):
-    """The dense K x Cin x Cout contraction (forward, gemm_f32_mfma NN): all launches of the instrumented
-    steps together, and the largest one, against the f32 MFMA peak."""
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak of the MI355X (the vendor's headline figure includes 2:1 sparsity)
+
+
+def mfma_report(contraction, features="f32"):
+    """The dense K x Cin x Cout contraction (forward, gemm_f32_mfma / gemm_f16_mfma NN): all launches of the
+    instrumented steps together, and the largest one, against the MFMA peak of the operand type."""
     if not contraction:
         return None
+    peak = MFMA_F32_PEAK_TFLOPS if features == "f32" else MFMA_F16_PEAK_TFLOPS
     tot_f = sum(r["flops_per_launch"] * r["launches"] for r in contraction.values())
     tot_t = sum(r["total_ms"] for r in contraction.values()) * 1e-3
     (M, Kd, N), big = max(contraction.items(), key=lambda kv: kv[1]["flops_per_launch"])
     big_tf = big["flops_per_launch"] / (big["total_ms"] / big["launches"] * 1e-3) / 1e12
-    return {"bound": "mfma", "dtype": "f32", "achieved": tot_f / tot_t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": tot_f / tot_t / 1e12 / MFMA_F32_PEAK_TFLOPS,
+    return {"bound": "mfma", "dtype": features, "achieved": tot_f / tot_t / 1e12, "peak": peak,
+            "unit": "TFLOP/s", "frac": tot_f / tot_t / 1e12 / peak,
             "largest": {"M": M, "K": Kd, "N": N, "TFLOP/s": big_tf, "avg_launch_us": big["total_ms"] / big["launches"] * 1e3}}
 
 

@@ -18,6 +18,7 @@ SOURCES = [
     ("error.cpp", []),
     ("kpconv.hip", []),
     ("gemm.hip", []),
+    ("gemm16.hip", []),
     ("pool.hip", []),
     ("bn.hip", []),
     ("batchpad.hip", []),

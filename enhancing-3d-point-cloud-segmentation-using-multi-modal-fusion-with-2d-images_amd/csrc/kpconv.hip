@@ -145,8 +145,26 @@ __device__ __forceinline__ void wave_sync_lds() {   // LDS hand-off inside ONE w
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <int NCH, bool IDX64, bool FAST>
+// 4 consecutive channels of a feature row / of the aggregate, stored as f32 or (fp16-feature mode) f16
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const _Float16* p) {
+  const half4_t h = *reinterpret_cast<const half4_t*>(p);   // Cin even -> 4-byte aligned, enough for dwordx2
+  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(_Float16* p, float4 v) {
+  half4_t h;
+  h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
+  *reinterpret_cast<half4_t*>(p) = h;
+}
+
+template <int NCH, bool IDX64, bool FAST, typename XT = float>
 __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPParams P, int LPP, int PPW, int HC) {
+  const XT* __restrict__ X = reinterpret_cast<const XT*>(P.x);      // features [Ns,Cin]
+  XT* __restrict__ Aout = reinterpret_cast<XT*>(P.A);                // aggregate [Nq,K,Cin]
+  const bool vec_ok = sizeof(XT) == 4 || (P.Cin & 1) == 0;           // f16 rows of odd length: scalar loads
   constexpr int UB = NCH == 1 ? 6 : 4;  // feature rows in flight per lane (8 spills two VGPRs to scratch)
   __shared__ float wl_all[GWPB][64 * 16 + 64 * 4];
   float* wl = wl_all[threadIdx.x >> 6];
@@ -250,13 +268,14 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
             const int c4 = (cl + c * LPP) * 4;
             xv[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (jj[u] >= 0 && c4 < P.Cin) {
-              const float* xr = P.x + (int64_t)jj[u] * P.Cin + c4;
-              if (c4 + 3 < P.Cin) {
-                xv[u][c] = *reinterpret_cast<const float4*>(xr);
+              const XT* xr = X + (int64_t)jj[u] * P.Cin + c4;
+              if (c4 + 3 < P.Cin && vec_ok) {
+                xv[u][c] = ld4(xr);
               } else {  // ragged tail of a row whose length is not a multiple of 4
-                xv[u][c].x = xr[0];
-                if (c4 + 1 < P.Cin) xv[u][c].y = xr[1];
-                if (c4 + 2 < P.Cin) xv[u][c].z = xr[2];
+                xv[u][c].x = (float)xr[0];
+                if (c4 + 1 < P.Cin) xv[u][c].y = (float)xr[1];
+                if (c4 + 2 < P.Cin) xv[u][c].z = (float)xr[2];
+                if (c4 + 3 < P.Cin) xv[u][c].w = (float)xr[3];
               }
             }
           }
@@ -297,13 +316,14 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
 #pragma unroll
         for (int kk = 0; kk < KMAX - 1; ++kk) {
           if (kk < P.K) {
-            float* o = P.A + (n * P.K + kk) * P.Cin + c4;
-            if (c4 + 3 < P.Cin) {
-              *reinterpret_cast<float4*>(o) = acc[c][kk];
+            XT* o = Aout + (n * P.K + kk) * P.Cin + c4;
+            if (c4 + 3 < P.Cin && vec_ok) {
+              st4(o, acc[c][kk]);
             } else {
-              o[0] = acc[c][kk].x;
-              if (c4 + 1 < P.Cin) o[1] = acc[c][kk].y;
-              if (c4 + 2 < P.Cin) o[2] = acc[c][kk].z;
+              o[0] = (XT)acc[c][kk].x;
+              if (c4 + 1 < P.Cin) o[1] = (XT)acc[c][kk].y;
+              if (c4 + 2 < P.Cin) o[2] = (XT)acc[c][kk].z;
+              if (c4 + 3 < P.Cin) o[3] = (XT)acc[c][kk].w;
             }
           }
         }
@@ -493,7 +513,7 @@ __global__ void kpconv_min_d2_bwd(KPParams P) {
   atomicAdd(P.d_offsets + t * 3 + 2, -2.f * bz * g);
 }
 
-template <int NCH>
+template <int NCH, typename XT = float>
 int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
   const int c4 = (P.Cin + 3) / 4;
   const int LPP = c4 < 64 ? c4 : 64;  // lanes per point
@@ -501,7 +521,7 @@ int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
   const int HC = 64 / PPW;            // neighbours per chunk and point
   const bool fast = P.influence == MVK_INFL_LINEAR && P.aggregation == MVK_AGG_SUM;
   dim3 grid((unsigned)cdiv64(cdiv64(P.Nq, PPW), GWPB)), block(64 * GWPB);
-#define LV(I64, F) hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F>), grid, block, 0, st, P, LPP, PPW, HC)
+#define LV(I64, F) hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F, XT>), grid, block, 0, st, P, LPP, PPW, HC)
   if (idx64) {
     if (fast) LV(true, true); else LV(true, false);
   } else {
@@ -614,6 +634,32 @@ extern "C" int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s
   } else {
     launch_lane_channel<1, false>(P, idx64, st);
   }
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// fp16-feature mode of the rigid gather (BASELINE config 5): x [Ns,Cin] and A_out [Nq,K,Cin] are fp16 in
+// memory (half the gather and aggregate bytes), correlation weights and the aggregation sums stay f32.
+extern "C" int mvk_kpconv_gather_fwd_f16(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                                         const void* idx, int idx64, int H, const void* x_f16, int Cin,
+                                         const float* kp, int K, float extent, int influence,
+                                         int aggregation, void* A_out_f16, void* stream) {
+  if (int e = check_common(Nq, Ns, H, Cin, K, influence, aggregation)) return e;
+  MVK_REQUIRE(Cin <= 512, "kpconv (fp16 features): Cin=%d unsupported (<= 512)", Cin);
+  if (Nq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  KPParams P{};
+  P.q = q; P.s = s; P.idx = idx; P.x = (const float*)x_f16; P.kp = kp;
+  P.A = (float*)A_out_f16; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
+  P.influence = influence; P.aggregation = aggregation;
+  if (H == 0) {
+    MVK_CHECK_HIP(hipMemsetAsync(A_out_f16, 0, 2 * Nq * K * Cin, st));
+    return 0;
+  }
+  if (Cin <= 256)
+    launch_vec<1, _Float16>(P, idx64, st);
+  else
+    launch_vec<2, _Float16>(P, idx64, st);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

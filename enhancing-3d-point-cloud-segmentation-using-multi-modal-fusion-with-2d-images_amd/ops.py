@@ -117,6 +117,31 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
     return out
 
 
+def gemm_f16(A, B, transA=False, transB=False, split_k=None, out_f16=False):
+    """C = op(A) @ op(B) with both operands rounded to fp16 (stored as f32 or f16), fp16 MFMA, f32
+    accumulation (mvk_gemm_f16); C is f32, or fp16 with out_f16 (then without a split reduction)."""
+    _dev(A, B)
+    for t in (A, B):
+        if t.dtype not in (torch.float32, torch.float16):
+            raise RuntimeError("gemm_f16: operands must be float32 or float16")
+    A, B = A.contiguous(), B.contiguous()
+    M, Kd = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
+    N = B.shape[0] if transB else B.shape[1]
+    assert (B.shape[1] if transB else B.shape[0]) == Kd, "gemm_f16: inner dimensions differ"
+    odt = torch.float16 if out_f16 else torch.float32
+    if M == 0 or N == 0 or Kd == 0:
+        return torch.zeros((M, N), device=A.device, dtype=odt)
+    if split_k is None:
+        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        split_k = int(max(1, min((1000 + tiles - 1) // tiles, 32, Kd // 128)))
+    if out_f16:
+        split_k = 1
+    out = _zeros((M, N), A.device) if split_k > 1 else torch.empty((M, N), device=A.device, dtype=odt)
+    check(lib().mvk_gemm_f16(_p(A), int(A.dtype == torch.float16), _p(B), int(B.dtype == torch.float16), _p(out),
+                             int(out_f16), M, N, Kd, int(transA), int(transB), int(split_k), _stream()))
+    return out
+
+
 # ---- optional per-launch timing of the gather kernel (bench.py roofline): HIP events on the
 # current stream around the C-ABI call; nothing is recorded unless profile_reset(enabled=True).
 _PROF = {"on": False, "rec": [], "gemm": []}
@@ -173,8 +198,9 @@ def profile_collect(h_eff=None):
         name, Nq, Ns, H, Cin, K = key
         he = (h_eff or {}).get((Nq, Ns, H), H)
         # algorithmic bytes: feature row + xyz + int32 index per real neighbour,
-        # query xyz, and the [Nq,K,Cin] aggregate written by the gather kernel
-        r["bytes_per_launch"] = Nq * he * (Cin * 4 + 12 + 4) + Nq * 12 + Nq * K * Cin * 4
+        # query xyz, and the [Nq,K,Cin] aggregate written by the gather kernel (s_x = 2 in the fp16 mode)
+        sx = 2 if name.endswith("[f16]") else 4
+        r["bytes_per_launch"] = Nq * he * (Cin * sx + 12 + 4) + Nq * 12 + Nq * K * Cin * sx
         r["kernel"] = name
         r["shape"] = {"Nq": Nq, "Ns": Ns, "H": H, "H_eff": he, "Cin": Cin, "K": K}
     return out
@@ -285,13 +311,104 @@ class _KPConvFn(torch.autograd.Function):
         return None, None, None, dx, None, dW, d_off, d_mod, None, None, None
 
 
-def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", offsets=None, modulations=None):
-    """Returns (y [Nq,Cout], min_d2 [Nq,K] or None)."""
+def kpconv_gather_f16(q, s, idx, x16, kp, extent, influence="linear", aggregation="sum"):
+    """fp16-feature mode of kpconv_gather (rigid): x16 [Ns,Cin] fp16 -> A [Nq,K,Cin] fp16."""
+    _dev(q, s, idx, x16, kp)
+    if x16.dtype != torch.float16:
+        raise RuntimeError("kpconv_gather_f16: features must be float16")
+    q, s, kp, x16 = _f32c(q), _f32c(s), _f32c(kp), x16.contiguous()
+    idx, i64 = _idx(idx)
+    Nq, Ns, H, Cin, K = q.shape[0], s.shape[0], idx.shape[1] if idx.dim() == 2 else 0, x16.shape[1], kp.shape[0]
+    if x16.shape[0] != Ns:
+        raise RuntimeError("kpconv: features and support points differ in length")
+    A = torch.empty((Nq, K, Cin), device=q.device, dtype=torch.float16)
+    if _PROF["on"]:
+        e0, e1 = _timing_events()
+    check(lib().mvk_kpconv_gather_fwd_f16(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, _p(x16), Cin, _p(kp), K, float(extent),
+                                          INFLUENCE[influence], AGGREGATION[aggregation], _p(A), _stream()))
+    if _PROF["on"]:
+        e1.record()
+        _PROF["rec"].append(((_gather_kernel_name(Cin, False) + "[f16]", Nq, Ns, H, Cin, K), e0, e1))
+    return A
+
+
+class _KPConv16Fn(torch.autograd.Function):
+    """KPConv in the fp16-feature mode (BASELINE config 5): the features entering the layer, the aggregate A
+    and the weights are rounded to fp16, the K x Cin x Cout contraction runs on the fp16 MFMA with f32
+    accumulation; geometry, correlation weights, aggregation sums, the output and the whole backward
+    (f32 MFMA on the rounded operands, no gradient is ever rounded to fp16) stay f32. Rigid layers read
+    fp16 feature rows and write an fp16 aggregate (half the gather bytes); deformable layers keep the f32
+    kernels on the fp16-rounded values. Gradients are those of y = A16 . W16 (straight-through rounding)."""
+
+    @staticmethod
+    def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation):
+        K, Cin, Cout = W.shape
+        x16 = x.to(torch.float16)
+        W16 = W.reshape(K * Cin, Cout).to(torch.float16)
+        min_d2 = None
+        if offsets is None and Cin <= 512:
+            A = kpconv_gather_f16(q, s, idx, x16, kp, extent, influence, aggregation)
+        else:
+            A, min_d2 = kpconv_gather(q, s, idx, x16.float(), kp, extent, influence, aggregation, offsets,
+                                      want_min_d2=offsets is not None)
+        Am = A.float() * modulations.unsqueeze(2) if modulations is not None else A
+        if _PROF["on"]:
+            e0, e1 = _timing_events()
+        y = gemm_f16(Am.view(-1, K * Cin), W16)
+        if _PROF["on"]:
+            e1.record()
+            _PROF["gemm"].append(((q.shape[0], K * Cin, Cout), e0, e1))
+        ctx.save_for_backward(q, s, idx, x16, kp, W16, A, offsets, modulations)
+        ctx.cfg = (extent, influence, aggregation, (K, Cin, Cout))
+        return y, min_d2
+
+    @staticmethod
+    def backward(ctx, gy, g_min_d2):
+        q, s, idx, x16, kp, W16, A, offsets, modulations = ctx.saved_tensors
+        extent, influence, aggregation, (K, Cin, Cout) = ctx.cfg
+        Nq = q.shape[0]
+        gy = _f32c(gy)
+        A32 = A.float()
+        Am = A32 * modulations.unsqueeze(2) if modulations is not None else A32
+        dW = dx = d_off = d_mod = None
+        if ctx.needs_input_grad[5]:
+            tiles = ((K * Cin + 63) // 64) * ((Cout + 63) // 64)
+            dW = gemm(Am.view(Nq, K * Cin), gy, transA=True, split_k=_split_for(Nq, tiles)).view(K, Cin, Cout)
+        if ctx.needs_input_grad[3] or offsets is not None:
+            dAm = gemm(gy, W16.float(), transB=True).view(Nq, K, Cin)
+            if modulations is not None:
+                if ctx.needs_input_grad[7]:
+                    d_mod = (dAm * A32).sum(dim=2)
+                dA = dAm * modulations.unsqueeze(2)
+            else:
+                dA = dAm
+            dx, d_off = kpconv_scatter(q, s, idx, dA, kp, extent, influence, aggregation,
+                                       x=x16.float() if offsets is not None else None, offsets=offsets,
+                                       g_min_d2=g_min_d2 if offsets is not None else None)
+        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None
+
+
+_FEATURE_DTYPE = {"dtype": torch.float32}
+
+
+def set_feature_dtype(dtype):
+    """torch.float32 (default) or torch.float16: the feature / weight storage type of every KPConv layer
+    (the fp16-feature mode of BASELINE config 5, see _KPConv16Fn)."""
+    if dtype not in (torch.float32, torch.float16):
+        raise ValueError("feature dtype must be torch.float32 or torch.float16")
+    _FEATURE_DTYPE["dtype"] = dtype
+
+
+def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", offsets=None, modulations=None,
+           feature_dtype=None):
+    """Returns (y [Nq,Cout], min_d2 [Nq,K] or None). feature_dtype: None = the mode set by
+    set_feature_dtype()."""
     if influence not in INFLUENCE:
         raise ValueError("Unknown influence function type (config.KP_influence)")
     if aggregation not in AGGREGATION:
         raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
-    return _KPConvFn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation)
+    fn = _KPConv16Fn if (feature_dtype or _FEATURE_DTYPE["dtype"]) == torch.float16 else _KPConvFn
+    return fn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation)
 
 
 # --------------------------------------------------------------------------------------------

@@ -56,6 +56,12 @@ int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s, int64_t Ns
                           const float* kp, int K, float extent, int influence, int aggregation,
                           const float* offsets, float* min_d2, float* A_out, void* stream);
 
+/* fp16-feature mode of mvk_kpconv_gather_fwd (rigid KPConv, Cin <= 512): x [Ns,Cin] and A_out
+ * [Nq,K,Cin] are fp16 in memory; geometry, correlation weights and the sums are f32. */
+int mvk_kpconv_gather_fwd_f16(const float* q, int64_t Nq, const float* s, int64_t Ns, const void* idx,
+                              int idx64, int H, const void* x_f16, int Cin, const float* kp, int K,
+                              float extent, int influence, int aggregation, void* A_out_f16, void* stream);
+
 /* dx[idx[n,h], c] += sum_k w[n,h,k] * dA[n,k,c]   (shadow rows discarded).
  * dx [Ns,Cin] must be zero-initialised by the caller (accumulated with f32 atomics).
  * Deformable extras (all NULL for rigid):
@@ -79,6 +85,12 @@ int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s, int64_t N
  *   KPConv uses: y = A @ W (NN), dA = g @ W^T (NT), dW = A^T @ g (TN, split over points). */
 int mvk_gemm_f32(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd,
                  int transA, int transB, int accumulate, int split_k, void* stream);
+
+/* fp16-feature mode of the same contraction (BASELINE config 5): operands are rounded to fp16 (each may be
+ * stored as f32 or f16 in memory: a_f16 / b_f16), multiplied on v_mfma_f32_32x32x8_f16 and accumulated in
+ * f32; C is f32 [M,N] (split_k > 1: atomics onto a zero-initialised C) or, with c_f16, fp16 [M,N]. */
+int mvk_gemm_f16(const void* A, int a_f16, const void* B, int b_f16, void* C, int c_f16, int64_t M, int64_t N,
+                 int64_t Kd, int transA, int transB, int split_k, void* stream);
 
 /* ---------------- masked BatchNorm + LeakyReLU (capacity-padded levels) --- */
 

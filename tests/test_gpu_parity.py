@@ -317,6 +317,63 @@ def test_kpconv_deformable_golden(ops, name, modulated):
     assert rel_err(bo.grad.cpu().numpy(), g["offset_bias_grad"]) < 5e-4
 
 
+@pytest.mark.parametrize("cin,cout,H", [(66, 64, 40), (64, 128, 33), (7, 16, 20), (300, 32, 12), (600, 24, 9)])
+def test_kpconv_fp16_feature_mode_vs_numpy_oracle(ops, cin, cout, H):
+    """BASELINE config 5 ("fp16 features with MFMA on the KP contraction"): features, aggregate and weights
+    rounded to fp16, exact products, f32 accumulation. The float64 oracle gets the same rounded operands
+    (x16, W16, and A rounded to fp16 before the contraction), so what is left is accumulation order:
+    tolerance 1e-3 on the output (fp16 rounding of A is reproduced only to its last bit), and the
+    backward (f32 MFMA on the rounded operands) against the oracle's backward on those operands."""
+    from oracle import npref
+    rng = np.random.default_rng(cin * 17 + H)
+    Nq, Ns, K = 257, 301, 15
+    q = (rng.random((Nq, 3)) * 0.3).astype(np.float32)
+    s = (rng.random((Ns, 3)) * 0.3).astype(np.float32)
+    idx = rng.integers(0, Ns + 1, (Nq, H)).astype(np.int32)
+    idx[5] = Ns
+    x = rng.normal(size=(Ns, cin)).astype(np.float32)
+    kp = (rng.normal(size=(K, 3)) * 0.05).astype(np.float32)
+    W = (rng.normal(size=(K, cin, cout)) * 0.1).astype(np.float32)
+    g = rng.normal(size=(Nq, cout)).astype(np.float32)
+    xt, Wt = T(x).requires_grad_(True), T(W).requires_grad_(True)
+    y, _ = ops.kpconv(T(q), T(s), T(idx), xt, T(kp), Wt, 0.06, feature_dtype=torch.float16)
+    (y * T(g)).sum().backward()
+    x16 = x.astype(np.float16).astype(np.float64)
+    W16 = W.astype(np.float16).astype(np.float64)
+    a64 = [q.astype(np.float64), s.astype(np.float64), idx.astype(np.int64), x16, kp.astype(np.float64), W16, 0.06]
+    _, A, _ = npref.kpconv_forward(*a64, return_A=True)
+    A16 = A.astype(np.float16).astype(np.float64)
+    want = np.einsum("nkc,kco->no", A16, W16)
+    assert rel_err(y.detach().cpu().numpy(), want) < 1e-3
+    dW = np.einsum("nkc,no->kco", A16, g.astype(np.float64))
+    dx, _ = npref.kpconv_backward(*a64, g.astype(np.float64))
+    assert rel_err(Wt.grad.cpu().numpy(), dW) < 1e-3
+    assert rel_err(xt.grad.cpu().numpy(), dx) < FP_TOL
+    # and the mode really is within fp16 rounding of the f32 operator
+    y32, _ = ops.kpconv(T(q), T(s), T(idx), T(x), T(kp), T(W), 0.06)
+    assert rel_err(y.detach().cpu().numpy(), y32.cpu().numpy()) < 5e-3
+
+
+def test_kpconv_fp16_feature_mode_deformable_close_to_f32(ops):
+    """Deformable + modulated layer in the fp16-feature mode (f32 kernels on fp16-rounded values, fp16 MFMA
+    contraction) against the reference golden of the f32 layer: within fp16 rounding."""
+    g = load_golden("g4_kpconv_deform_mod")
+    K = 15
+    q, s, idx = T(g["q"]), T(g["s"]), T(g["idx"])
+    ext = float(g["extent"])
+    x = T(g["x"]).requires_grad_(True)
+    W = T(g["weights"]).requires_grad_(True)
+    feat, _ = ops.kpconv(q, s, idx, x, T(g["offset_kernel_points"]), T(g["offset_weights"]), ext)
+    feat = feat + T(g["offset_bias"])
+    off, mod = feat[:, :3 * K].reshape(-1, K, 3) * ext, 2 * torch.sigmoid(feat[:, 3 * K:])
+    y, min_d2 = ops.kpconv(q, s, idx, x, T(g["kernel_points"]), W, ext, offsets=off, modulations=mod,
+                           feature_dtype=torch.float16)
+    (y * T(g["g"])).sum().backward()
+    assert rel_err(y.detach().cpu().numpy(), g["y"]) < 5e-3
+    assert rel_err(min_d2.detach().cpu().numpy(), g["min_d2"]) < FP_TOL        # geometry is untouched by the mode
+    assert x.grad is not None and torch.isfinite(x.grad).all() and torch.isfinite(W.grad).all()
+
+
 def test_kpconv_linearity_full_size(ops):
     """BASELINE-size property: KPConv is linear in x and in W (20k points, Cin=Cout=64)."""
     rng = np.random.default_rng(1)
@@ -400,6 +457,26 @@ def test_masked_bn_lrelu_vs_torch(ops, R, D, n, slope):
     assert rel_err(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy()) < 1e-5
     assert rel_err(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 1e-5
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 2
+
+
+@pytest.mark.parametrize("M,N,K", [(19464, 64, 990), (65, 512, 7680), (990, 64, 19464), (130, 70, 37), (4096, 128, 960)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False)])
+def test_gemm_f16_mfma(ops, M, N, K, ta, tb):
+    """fp16-feature contraction: operands rounded to fp16 (stored as f16 or f32), exact products, f32
+    accumulation -> equals an f32/f64 matmul of the rounded operands up to summation order."""
+    torch.manual_seed(M + N + K)
+    A = torch.randn((K, M) if ta else (M, K), device="cuda")
+    B = torch.randn((N, K) if tb else (K, N), device="cuda")
+    Ar, Br = A.half().double(), B.half().double()
+    want = ((Ar.t() if ta else Ar) @ (Br.t() if tb else Br))
+    scale = want.abs().max().item()
+    for a_in, b_in in ((A.half(), B.half()), (A, B.half()), (A.half(), B), (A, B)):
+        got = ops.gemm_f16(a_in, b_in, transA=ta, transB=tb)
+        assert got.dtype == torch.float32 and (got.double() - want).abs().max().item() / scale < 2e-5
+    got16 = ops.gemm_f16(A.half(), B.half(), transA=ta, transB=tb, out_f16=True)
+    assert got16.dtype == torch.float16 and (got16.double() - want).abs().max().item() / scale < 2e-3
+    one = ops.gemm_f16(A.half(), B.half(), transA=ta, transB=tb, split_k=1)
+    assert (one.double() - want).abs().max().item() / scale < 2e-5
 
 
 # ------------------------------------------------------------------ group_points (reference test shapes)

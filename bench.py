@@ -65,7 +65,15 @@ def main():
         local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # rehearsal hook: MVK_BENCH_FORCE_DP=1 takes the N > 1 code path (RCCL process group, eager all-reduce
+    # between the two graphs) with a single rank, so that path can be exercised on a one-GPU box
+    force_dp = world == 1 and os.environ.get("MVK_BENCH_FORCE_DP") == "1"
+    if force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dp:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -92,7 +100,7 @@ def main():
     opt = torch.optim.SGD([{"params": other}, {"params": deform, "lr": cfg.learning_rate * cfg.deform_lr_factor}],
                           lr=cfg.learning_rate, momentum=cfg.momentum, weight_decay=cfg.weight_decay,
                           fused=os.environ.get("MVK_FUSED_SGD", "1") == "1")  # trainer.py:72-79; fused = one multi-tensor kernel per step
-    reducer = mvkpconv.sub("dp").FlatAllReduce(params, world) if world > 1 else None
+    reducer = mvkpconv.sub("dp").FlatAllReduce(params, world) if (world > 1 or force_dp) else None
 
     # ---- synthetic raw inputs, staged in HBM once (data-parallel: different spheres per rank)
     spheres = [syn.raw_sphere(seed=1000 * rank + i, radius=args.in_radius) for i in range(args.spheres)]
@@ -118,7 +126,7 @@ def main():
 
     def sync():
         torch.cuda.synchronize()
-        if world > 1:
+        if world > 1 or force_dp:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -171,7 +179,7 @@ def main():
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     pts = torch.tensor([float(sum(lens))], device=dev, dtype=torch.float64)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(pts, op=dist.ReduceOp.SUM)
     dt = t.item()
@@ -200,7 +208,7 @@ def main():
         if not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(cfg, net, staged, limits, spheres, args)
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
 

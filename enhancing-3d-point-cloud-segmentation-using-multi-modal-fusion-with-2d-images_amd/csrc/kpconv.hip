@@ -160,11 +160,11 @@ __device__ __forceinline__ void st4(_Float16* p, float4 v) {
   *reinterpret_cast<half4_t*>(p) = h;
 }
 
-template <int NCH, bool IDX64, bool FAST, typename XT = float>
+template <int NCH, bool IDX64, bool FAST, typename XT = float, bool VEC = true>
 __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPParams P, int LPP, int PPW, int HC) {
   const XT* __restrict__ X = reinterpret_cast<const XT*>(P.x);      // features [Ns,Cin]
   XT* __restrict__ Aout = reinterpret_cast<XT*>(P.A);                // aggregate [Nq,K,Cin]
-  const bool vec_ok = sizeof(XT) == 4 || (P.Cin & 1) == 0;           // f16 rows of odd length: scalar loads
+  constexpr bool vec_ok = VEC;   // false: f16 rows of odd length (2-byte aligned), scalar loads
   constexpr int UB = NCH == 1 ? 6 : 4;  // feature rows in flight per lane (8 spills two VGPRs to scratch)
   __shared__ float wl_all[GWPB][64 * 16 + 64 * 4];
   float* wl = wl_all[threadIdx.x >> 6];
@@ -513,7 +513,7 @@ __global__ void kpconv_min_d2_bwd(KPParams P) {
   atomicAdd(P.d_offsets + t * 3 + 2, -2.f * bz * g);
 }
 
-template <int NCH, typename XT = float>
+template <int NCH, typename XT = float, bool VEC = true>
 int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
   const int c4 = (P.Cin + 3) / 4;
   const int LPP = c4 < 64 ? c4 : 64;  // lanes per point
@@ -521,7 +521,7 @@ int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
   const int HC = 64 / PPW;            // neighbours per chunk and point
   const bool fast = P.influence == MVK_INFL_LINEAR && P.aggregation == MVK_AGG_SUM;
   dim3 grid((unsigned)cdiv64(cdiv64(P.Nq, PPW), GWPB)), block(64 * GWPB);
-#define LV(I64, F) hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F, XT>), grid, block, 0, st, P, LPP, PPW, HC)
+#define LV(I64, F) hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F, XT, VEC>), grid, block, 0, st, P, LPP, PPW, HC)
   if (idx64) {
     if (fast) LV(true, true); else LV(true, false);
   } else {
@@ -656,10 +656,11 @@ extern "C" int mvk_kpconv_gather_fwd_f16(const float* q, int64_t Nq, const float
     MVK_CHECK_HIP(hipMemsetAsync(A_out_f16, 0, 2 * Nq * K * Cin, st));
     return 0;
   }
-  if (Cin <= 256)
-    launch_vec<1, _Float16>(P, idx64, st);
-  else
-    launch_vec<2, _Float16>(P, idx64, st);
+  if (Cin & 1) {   // odd row length: rows are only 2-byte aligned
+    if (Cin <= 256) launch_vec<1, _Float16, false>(P, idx64, st); else launch_vec<2, _Float16, false>(P, idx64, st);
+  } else {
+    if (Cin <= 256) launch_vec<1, _Float16, true>(P, idx64, st); else launch_vec<2, _Float16, true>(P, idx64, st);
+  }
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -205,8 +205,8 @@ def main():
                                      GBps=r["bytes_per_launch"] / (r["total_ms"] / r["launches"] * 1e-3) / 1e9, **r["shape"])
                                 for r in sorted(prof.values(), key=lambda r: -r["total_ms"])],
         }
-        if not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, net, staged, limits, spheres, args)
+        if not args.no_cpu_baseline:           # timed on rank 0 at N = 1 only (the other ranks would sit in the barrier)
+            res["cpu_baseline"] = cpu_baseline(cfg, net, staged, limits, spheres, args) if world == 1 else None
         print(json.dumps(res))
     if world > 1 or force_dp:
         dist.barrier()

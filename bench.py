@@ -368,9 +368,13 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         chains[0].build(statics[0])             # batch 0; every later batch is built by the graph before it
         state["slot"] = 0
 
+        replayed = [None, None]                 # per static set: event after the last replay that built into it
+
         def step_chain():
             slot = state["slot"]
             check_status()
+            if replayed[slot ^ 1] is not None:  # bound the host's run-ahead to two steps: the pinned staging
+                replayed[slot ^ 1].synchronize()   # buffer of this chain must not be rewritten before its copy ran
             chains[slot ^ 1].draw_rotations()   # host draw + one small async copy: the orientations of batch k+1
             if enc is not None:
                 enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
@@ -382,6 +386,8 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                 ev = torch.cuda.Event()
                 ev.record()
                 pending.append((ev, host))
+            replayed[slot ^ 1] = torch.cuda.Event()
+            replayed[slot ^ 1].record()
             state.setdefault("host", []).append((time.perf_counter() - ta, 0.0))
             state["slot"] = slot ^ 1
             return lens0, replays[slot][1]

@@ -1,5 +1,6 @@
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (tools/ sits next to the package); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (tools/ sits next to the package)
+sys.path.insert(0, ROOT)
 import mvkpconv
 ops = mvkpconv.sub("ops")
 dev = torch.device("cuda:0")

@@ -1,7 +1,8 @@
 """Development-only: wall-clock split of one bench step (with syncs between stages)."""
 import os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (tools/ sits next to the package); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (tools/ sits next to the package)
+sys.path.insert(0, ROOT)
 import mvkpconv
 syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
 dev = torch.device("cuda:0")

@@ -8,9 +8,10 @@
 // the f32 MFMA forms are used.
 //
 // Shapes are tall-skinny (20 000 x 990 x 64) or short-and-deep (65 x 7680 x 512), never square:
-//   * 64 x 64 output tile per 256-thread workgroup, BK = 32; four waves in a 2 x 2 arrangement, each
-//     owning one 32 x 32 accumulator (16 VGPRs) -> 16 MFMAs (>= 1024 cycles) per wave and k-tile;
-//   * operands staged k-major in LDS ([BK][64 + 4]): the MFMA operand reads (lane l -> row/col l & 31,
+//   * 64 x 64 output tile per 256-thread workgroup (128 x 32 for outputs of at most 32 columns), BK = 32;
+//     four waves in a 2 x 2 (4 x 1) arrangement, each owning one 32 x 32 accumulator (16 VGPRs) -> 16 MFMAs
+//     (>= 1024 cycles) per wave and k-tile;
+//   * operands staged k-major in LDS ([BK][rows + 4]): the MFMA operand reads (lane l -> row/col l & 31,
 //     k = l >> 5) are bank-conflict free, m/n-contiguous sources are written with ds_write_b128;
 //   * two LDS buffers + register prefetch: the global loads of k-tile t+1 are issued before the MFMAs
 //     of tile t and written to the other buffer after them -> one barrier per k-tile, loads hidden;
@@ -21,20 +22,23 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 64, BN = 64, BK = 32, LDP = 68;
+constexpr int BK = 32;
 
-// One operand tile = 64 (i) x 32 (k) elements, 2 float4 per thread.
+// One operand tile = ROWS (i) x 32 (k) elements, ROWS / 32 float4 per thread (ROWS = 32, 64 or 128).
 //   CONTIG_K == true : source element (i,k) at src[i*ld + k]  (contiguous along k)
 //   CONTIG_K == false: source element (i,k) at src[k*ld + i]  (contiguous along i)
-template <bool CONTIG_K>
+template <bool CONTIG_K, int ROWS>
 struct TileLoader {
-  float4 v[2];
+  static constexpr int NV = ROWS / 32;          // float4 per thread
+  static constexpr int IPT = ROWS / 4;          // threads along i (i-contiguous sources)
+  static constexpr int KSTEP = 256 / IPT;       // k rows covered per pass
+  float4 v[NV];
 
   // vec: 4 = rows 16-byte aligned, 2 = 8-byte aligned (e.g. K*Cin = 990), 1 = scalar
   __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int64_t i0, int64_t imax,
                                        int64_t k0, int64_t kmax, int vec, int tid) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NV; ++u) {
       float t[4] = {0.f, 0.f, 0.f, 0.f};
       if (CONTIG_K) {
         const int i = (tid >> 3) + 32 * u, kq = (tid & 7) * 4;
@@ -54,7 +58,7 @@ struct TileLoader {
           }
         }
       } else {
-        const int k = (tid >> 4) + 16 * u, iq = (tid & 15) * 4;
+        const int k = tid / IPT + KSTEP * u, iq = (tid % IPT) * 4;
         const int64_t gk = k0 + k, gi = i0 + iq;
         if (gk < kmax) {
           const float* p = src + gk * ld + gi;
@@ -75,9 +79,9 @@ struct TileLoader {
     }
   }
 
-  __device__ __forceinline__ void store(float (*T)[LDP], int tid) const {
+  __device__ __forceinline__ void store(float (*T)[ROWS + 4], int tid) const {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < NV; ++u) {
       if (CONTIG_K) {
         const int i = (tid >> 3) + 32 * u, kq = (tid & 7) * 4;
         T[kq + 0][i] = v[u].x;
@@ -85,25 +89,28 @@ struct TileLoader {
         T[kq + 2][i] = v[u].z;
         T[kq + 3][i] = v[u].w;
       } else {
-        const int k = (tid >> 4) + 16 * u, iq = (tid & 15) * 4;
+        const int k = tid / IPT + KSTEP * u, iq = (tid % IPT) * 4;
         *reinterpret_cast<float4*>(&T[k][iq]) = v[u];
       }
     }
   }
 };
 
-template <bool TA, bool TB>
+// TM x TN output tile per 256-thread workgroup: 64 x 64 (waves 2 x 2) or, for outputs of at most 32
+// columns (Cout = 32 layers, logits), 128 x 32 (waves 4 x 1) so that no MFMA work is spent on padding.
+template <bool TA, bool TB, int TM, int TN>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A,
                                                      const float* __restrict__ B,
                                                      float* __restrict__ C, int64_t M, int64_t N,
                                                      int64_t Kd, int64_t lda, int64_t ldb,
                                                      int64_t k_per_split, int atomic_out,
                                                      int accumulate, int vecA, int vecB) {
-  __shared__ __attribute__((aligned(16))) float As[2][BK][LDP];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDP];
+  static_assert((TM / 32) * (TN / 32) == 4, "four 32 x 32 wave tiles per workgroup");
+  __shared__ __attribute__((aligned(16))) float As[2][BK][TM + 4];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][TN + 4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+  const int wm = wave / (TN / 32), wn = wave % (TN / 32);
+  const int64_t m0 = (int64_t)blockIdx.y * TM, n0 = (int64_t)blockIdx.x * TN;
   const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
   const int64_t kend = kbeg + k_per_split < Kd ? kbeg + k_per_split : Kd;
 
@@ -113,8 +120,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A
 
   // A tile: element (m,k); TA == false -> A[m*lda + k] (k-contiguous). B tile: element (n,k);
   // TB == false -> B[k*ldb + n] (n-contiguous).
-  TileLoader<!TA> la;
-  TileLoader<TB> lb;
+  TileLoader<!TA, TM> la;
+  TileLoader<TB, TN> lb;
   la.load(A, lda, m0, M, kbeg, kend, vecA, tid);
   lb.load(B, ldb, n0, N, kbeg, kend, vecB, tid);
   la.store(As[0], tid);
@@ -181,12 +188,20 @@ extern "C" int mvk_gemm_f32(const float* A, const float* B, float* C, int64_t M,
   const int64_t lda = transA ? M : Kd, ldb = transB ? Kd : N;
   const int vecA = ((lda % 4 == 0) && ((uintptr_t)A % 16 == 0)) ? 4 : ((lda % 2 == 0) && ((uintptr_t)A % 8 == 0)) ? 2 : 1;
   const int vecB = ((ldb % 4 == 0) && ((uintptr_t)B % 16 == 0)) ? 4 : ((ldb % 2 == 0) && ((uintptr_t)B % 8 == 0)) ? 2 : 1;
-  MVK_REQUIRE(cdiv64(M, BM) < 65536 && split_k < 65536, "gemm: grid too large");
-  dim3 grid((unsigned)cdiv64(N, BN), (unsigned)cdiv64(M, BM), (unsigned)split_k), block(256);
+  const bool narrow = N <= 32;   // 128 x 32 tiles: no MFMA work on padded columns
+  const int TMh = narrow ? 128 : 64, TNh = narrow ? 32 : 64;
+  MVK_REQUIRE(cdiv64(M, TMh) < 65536 && split_k < 65536, "gemm: grid too large");
+  dim3 grid((unsigned)cdiv64(N, TNh), (unsigned)cdiv64(M, TMh), (unsigned)split_k), block(256);
   const int atomic_out = split_k > 1;
-#define LAUNCH(TA, TB)                                                                         \
-  hipLaunchKernelGGL((gemm_f32_mfma<TA, TB>), grid, block, 0, st, A, B, C, M, N, Kd, lda, ldb, \
-                     k_per_split, atomic_out, accumulate, vecA, vecB)
+#define LAUNCH(TA, TB)                                                                                     \
+  do {                                                                                                     \
+    if (narrow)                                                                                            \
+      hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, 128, 32>), grid, block, 0, st, A, B, C, M, N, Kd, lda, ldb, \
+                         k_per_split, atomic_out, accumulate, vecA, vecB);                                 \
+    else                                                                                                   \
+      hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, 64, 64>), grid, block, 0, st, A, B, C, M, N, Kd, lda, ldb,  \
+                         k_per_split, atomic_out, accumulate, vecA, vecB);                                 \
+  } while (0)
   if (!transA && !transB) LAUNCH(false, false);
   else if (!transA && transB) LAUNCH(false, true);
   else if (transA && !transB) LAUNCH(true, false);

@@ -92,6 +92,11 @@ def _zeros(shape, device, dtype=torch.float32):
 # raw kernels
 # --------------------------------------------------------------------------------------------
 
+def _gemm_tiles(M, N):
+    """Workgroups of mvk_gemm_f32 per split: 64 x 64 output tiles, 128 x 32 when N <= 32."""
+    return ((M + 127) // 128) if N <= 32 else ((M + 63) // 64) * ((N + 63) // 64)
+
+
 def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=None, keep=False):
     """C = op(A) @ op(B) on v_mfma_f32_32x32x2_f32 (mvk_gemm_f32). split_k=None picks a split of
     the reduction so that small-M / deep-K products (the coarse KPConv layers: 85 x 7680 x 512)
@@ -107,7 +112,7 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
     if split_k is None:
         # measured on MI355X (tests/dev_gemm_bench.py): ~4 workgroups per CU hide the global-load
         # latency of the k-loop; keep >= 4 k-tiles (128 columns) per split
-        tiles = ((M + 63) // 64) * ((N + 63) // 64)
+        tiles = _gemm_tiles(M, N)
         split_k = int(max(1, min((1000 + tiles - 1) // tiles, 32, Kd // 128)))
     if out is None:
         out = ((torch.zeros((M, N), device=A.device, dtype=torch.float32) if keep else _zeros((M, N), A.device))
@@ -294,7 +299,7 @@ class _KPConvFn(torch.autograd.Function):
         Am = A * modulations.unsqueeze(2) if modulations is not None else A
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
-            tiles = ((K * Cin + 63) // 64) * ((Cout + 63) // 64)
+            tiles = _gemm_tiles(K * Cin, Cout)
             dW = gemm(Am.view(Nq, K * Cin), gy, transA=True, split_k=_split_for(Nq, tiles)).view(K, Cin, Cout)
         need_dA = ctx.needs_input_grad[3] or (offsets is not None)
         if need_dA:
@@ -372,7 +377,7 @@ class _KPConv16Fn(torch.autograd.Function):
         Am = A32 * modulations.unsqueeze(2) if modulations is not None else A32
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
-            tiles = ((K * Cin + 63) // 64) * ((Cout + 63) // 64)
+            tiles = _gemm_tiles(K * Cin, Cout)
             dW = gemm(Am.view(Nq, K * Cin), gy, transA=True, split_k=_split_for(Nq, tiles)).view(K, Cin, Cout)
         if ctx.needs_input_grad[3] or offsets is not None:
             dAm = gemm(gy, W16.float(), transB=True).view(Nq, K, Cin)

@@ -408,8 +408,10 @@ def test_pools_golden(ops):
 
 # ------------------------------------------------------------------ gemm
 
-@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (100, 45, 990), (4096, 64, 960), (33, 70, 7), (1, 1, 1)])
+@pytest.mark.parametrize("M,N,K", [(64, 64, 16), (100, 45, 990), (4096, 64, 960), (33, 70, 7), (1, 1, 1),
+                                   (19464, 32, 480), (300, 20, 129), (130, 7, 990), (990, 32, 4001)])
 def test_gemm_f32_mfma(ops, M, N, K):
+    """64 x 64 tiles and, for N <= 32, the 128 x 32 tiles; all three operand layouts, with and without split-K."""
     torch.manual_seed(0)
     A = torch.randn(M, K, device="cuda")
     B = torch.randn(K, N, device="cuda") + 0.1 * torch.arange(N, device="cuda")   # asymmetric
@@ -417,6 +419,7 @@ def test_gemm_f32_mfma(ops, M, N, K):
     assert rel_err(ops.gemm(A, B).cpu().numpy(), ref) < 1e-5
     assert rel_err(ops.gemm(A, B.t().contiguous(), transB=True).cpu().numpy(), ref) < 1e-5
     assert rel_err(ops.gemm(A.t().contiguous(), B, transA=True, split_k=3).cpu().numpy(), ref) < 1e-5
+    assert rel_err(ops.gemm(A.t().contiguous(), B.t().contiguous(), transA=True, transB=True, split_k=1).cpu().numpy(), ref) < 1e-5
 
 
 # ------------------------------------------------------------------ masked BatchNorm + LeakyReLU

@@ -438,7 +438,41 @@ def g8_metrics():
     save("g8_metrics", true=true, pred=pred, confusion=conf.astype(np.int64), iou=IoU_from_confusions(conf))
 
 
-GROUPS = {"g8": g8_metrics, "g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn,
+def g9_ply():
+    """PLY files written by the reference's utils/ply.py::write_ply (a cloud with mixed field types, a
+    triangular mesh) + what its read_ply returns for them; and one cloud of the preprocess cache
+    (mvpnet/data/preprocess/preprocess.py:177-186 schema) subsampled like load_subsampled_clouds
+    (ScanNet_sphere_color.py:935-948) by the compiled reference core."""
+    _ref_blocks()
+    from utils.ply import read_ply, write_ply
+    rng = np.random.default_rng(909)
+    pts = rng.normal(size=(57, 3)).astype(np.float32)
+    cols = rng.integers(0, 256, (57, 3)).astype(np.uint8)
+    labels = rng.integers(-1, 20, 57).astype(np.int32)
+    score = rng.random(57)                                            # float64 field
+    names = ['x', 'y', 'z', 'red', 'green', 'blue', 'class', 'score']
+    cloud = os.path.join(OUT, "g9_cloud.ply")
+    assert write_ply(cloud, [pts, cols, labels, score], names)
+    back = read_ply(cloud)
+    faces = rng.integers(0, 57, (31, 3)).astype(np.int32)
+    mesh = os.path.join(OUT, "g9_mesh.ply")
+    assert write_ply(mesh, [pts, cols], names[:6], triangular_faces=faces)
+    vdata, fdata = read_ply(mesh, triangular_mesh=True)
+    # scene-load subsampling with colours as features and labels (reference core, float32 features)
+    n = 6000
+    spts = (rng.random((n, 3)) * [3.0, 2.0, 0.4]).astype(np.float32)
+    scol = rng.integers(0, 256, (n, 3)).astype(np.uint8)
+    slab = rng.integers(0, 21, n).astype(np.int32)
+    sp, sl, sf, slb = cport.subsample_batch(spts, [n], features=scol.astype(np.float32), labels=slab.reshape(-1, 1), dl=0.04,
+                                            impl="ref")
+    save("g9_ply", points=pts, colors=cols, labels=labels, score=score, faces=faces,
+         read_x=back['x'], read_class=back['class'], read_score=back['score'], read_blue=back['blue'],
+         mesh_faces=fdata, mesh_red=vdata['red'],
+         scene_points=spts, scene_colors=scol, scene_labels=slab, sub_points=sp, sub_colors=(sf / 255).astype(np.float32),
+         sub_labels=np.squeeze(slb).astype(np.int32))
+
+
+GROUPS = {"g9": g9_ply, "g8": g8_metrics, "g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn,
           "g6": g6_fusion}
 
 if __name__ == "__main__":

@@ -213,3 +213,18 @@ def test_voting_metrics_and_frame_selection():
         ok = d2[np.arange(len(nn)), nn] <= 0.01
         want[nn[ok], f] = True
     assert np.array_equal(got, want)
+
+
+def test_scene_load_subsampling_vs_reference_core():
+    """datasets/scene_cache.subsample_scene (ScanNet_sphere_color.py:935-948: colours as features, labels,
+    dl = 0.04) against the compiled reference core (G9): points, order, colour barycentres / 255, majority labels."""
+    sc = importlib.import_module(PKG + ".dropin.datasets.scene_cache")
+    g = load_golden("g9_ply")
+    out = sc.subsample_scene({'points': g["scene_points"], 'colors': g["scene_colors"], 'seg_label': g["scene_labels"]}, 0.04)
+    assert bits_equal(out['sub_points'], g["sub_points"])
+    assert bits_equal(out['sub_colors'], g["sub_colors"]) and out['sub_colors'].dtype == np.float32
+    assert np.array_equal(out['sub_labels'], g["sub_labels"])
+    remap = np.arange(21)[::-1].copy()
+    out2 = sc.subsample_scene({'points': g["scene_points"], 'colors': g["scene_colors"], 'seg_label': g["scene_labels"]},
+                              0.04, label_map=remap)
+    assert np.array_equal(out2['sub_labels'], remap[g["sub_labels"]])

@@ -59,7 +59,9 @@ def subsample_scene(scan, dl, label_map=None, device=None):
     p, _, f, l = ops.grid_subsample_batch(torch.from_numpy(points).to(dev), [points.shape[0]],
                                           features=torch.from_numpy(colors.astype(np.float32)).to(dev),
                                           labels=torch.from_numpy(labels).to(dev), dl=dl)
-    return {'sub_points': p.cpu().numpy(), 'sub_colors': (f / 255).cpu().numpy(),
+    # the division runs in NumPy like the reference's (:944): the tensor library divides by a scalar through a
+    # reciprocal multiply, which is not the correctly rounded quotient
+    return {'sub_points': p.cpu().numpy(), 'sub_colors': f.cpu().numpy() / 255,
             'sub_labels': np.squeeze(l.cpu().numpy())}
 
 

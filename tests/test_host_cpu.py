@@ -263,3 +263,61 @@ def test_scene_cache_pickle_schemas_round_trip(tmp_path):
     sc.save_projection(tree, 'scene0000_00', np.arange(50)[::-1], scans[0]['seg_label'])
     proj, lab = sc.load_projection(tree, 'scene0000_00')
     assert proj.dtype == np.int32 and np.array_equal(proj, np.arange(50)[::-1]) and np.array_equal(lab, scans[0]['seg_label'])
+
+
+def test_sampler_calibration_controller_and_cache_files(tmp_path):
+    """datasets/calibration.py against a literal NumPy replay of ScanNet_sphere_color.py:1380-1464 on a
+    simulated sampler (spheres per batch ~ batch_limit / sphere size + noise), and the reference's cache
+    file keys."""
+    import pickle
+    import types
+    cal_mod = _dropin("datasets.calibration")
+    cfg = types.SimpleNamespace(batch_num=5, in_radius=1.2, first_subsampling_dl=0.04, num_layers=3, conv_radius=2.5,
+                                deform_radius=6.0, deform_layers=[False, False, True])
+    rng = np.random.default_rng(3)
+
+    def sampler(limit, r):
+        b = max(1, int(limit // 20000 + r.integers(-1, 2)))
+        mats = []
+        for layer in range(3):
+            n = 400 >> layer
+            counts = r.integers(5, 60 + 100 * (layer == 2), n)
+            m = np.full((n, int(counts.max())), n, dtype=np.int64)
+            for i, c in enumerate(counts):
+                m[i, :c] = r.integers(0, n, c)
+            mats.append(m)
+        return mats, b
+
+    cal = cal_mod.Calibrator(cfg, batch_limit=50000)
+    hist_n = int(np.ceil(4 / 3 * np.pi * (6.0 + 1) ** 3))
+    hists = np.zeros((3, hist_n), np.int64)
+    estim_b, T, finer, limit, errs, steps = 0.0, 10, False, 50000.0, [], 0
+    r1, r2 = np.random.default_rng(9), np.random.default_rng(9)
+    while not cal.converged and cal.steps < 5000:
+        mats, b = sampler(cal.batch_limit, r1)
+        cal.update([torch.from_numpy(m) for m in mats], b)
+        mats2, b2 = sampler(limit, r2)                                 # the literal replay, same random stream
+        assert b2 == b
+        hists += np.vstack([np.bincount(np.sum(m < m.shape[0], axis=1), minlength=hist_n)[:hist_n] for m in mats2])
+        estim_b += (b2 - estim_b) / T
+        errs = (errs + [5 - estim_b])[-10:]
+        limit += 100.0 * (5 - b2)
+        if not finer and abs(estim_b - 5) < 1:
+            T, finer = 100, True
+        steps += 1
+        assert limit == cal.batch_limit
+        if finer and np.max(np.abs(errs)) < 0.1:
+            break
+    assert cal.converged and cal.steps == steps and abs(cal.estim_b - 5) < 0.2
+    cs = np.cumsum(hists.T, axis=0)
+    want = np.sum(cs < 0.9 * cs[hist_n - 1, :], axis=0)
+    assert np.array_equal(cal.neighborhood_limits(0.9), want)
+    cal_mod.save_calibration(cfg, str(tmp_path), cal.batch_limit, [int(x) for x in want])
+    with open(tmp_path / "batch_limits.pkl", "rb") as f:
+        assert pickle.load(f) == {"potentials_1.200_0.040_5": float(cal.batch_limit)}
+    with open(tmp_path / "neighbors_limits.pkl", "rb") as f:
+        assert sorted(pickle.load(f)) == ["0.040_0.100", "0.080_0.200", "0.160_0.960"]
+    b, lim = cal_mod.load_calibration(cfg, str(tmp_path))
+    assert b == float(cal.batch_limit) and lim == [int(x) for x in want]
+    cfg.batch_num = 6
+    assert cal_mod.load_calibration(cfg, str(tmp_path))[0] is None

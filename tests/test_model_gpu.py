@@ -294,3 +294,29 @@ def test_graph_replay_trains_like_eager(device_chain):
         ops.zero_arena_disable()
         torch.cuda.synchronize()
         torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_bench_emits_one_valid_json_line():
+    """bench.py end to end (default workload, few steps): exactly one JSON line on stdout carrying the
+    contract's keys, the roofline and cpu_baseline objects, no capacity overflow."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "points/s" and d["vs_baseline"] is None
+    assert d["value"] > 5e4 and d["config"]["execution"].startswith("hipGraph") and d["config"]["capacity_overflow"] is False
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["kernel"].startswith("kpconv_gather_vec") and 0.2 < r["frac"] < 1.0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["unit"] == "points/s" and c["cores"] >= 1 and c["value"] > 0

@@ -408,9 +408,11 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             print("DIAG graph replay (network + encoder + input chain branches) %.2f ms | input chain alone, eager "
                   "%.2f ms" % ((t1 - t0) * 50, (t2 - t1) * 100), file=sys.stderr)
         state_ref.append(state)
-        return step_chain, ("hipGraph with three branches per step: network fwd+loss+bwd+clip+SGD on static set k%2 | "
-                            "sync-free input chain (pyramid, unprojection, 3-NN; device-side counts) of batch k+1 | "
-                            + ("frozen 2D encoder of batch k+1" if enc is not None else "no 2D encoder"))
+        return step_chain, ("hipGraph with %s branches per step: network fwd+loss+bwd+clip+SGD on static set k%%2 | "
+                            "sync-free input chain (pyramid, unprojection, 3-NN; device-side counts) of batch k+1"
+                            % ("three" if enc is not None else "two")
+                            + (" | frozen 2D encoder of batch k+1" if enc is not None else
+                               (" (2D encoder in line with the network)" if hasattr(net, "net_2d") else "")))
 
     def build_async(slot):
         """Enqueues batch k+1 on the build / encode streams and pads it into static set `slot`."""

@@ -187,6 +187,106 @@ __global__ void bn_bwd_apply(const float* __restrict__ x, const float* __restric
   dx[t] = v;
 }
 
+// ---- finish + apply in one launch: every workgroup of the apply grid first reduces the per-row-block
+// partials of its 64 channels itself (same fixed order everywhere -> every workgroup holds the same
+// mean / invstd bit for bit; nblk x 512 bytes from L2, at most 64 workgroups per channel group do it), then
+// normalises its share of the rows. 3 graph nodes -> 2 per BatchNorm pass; the first row-group publishes
+// mean / invstd (saved for the backward), the running statistics and the batch counter.
+//   grid (ceil(D/64), gy <= 64), block 1024 = 64 channels x 16 row lanes; rows are dealt round-robin.
+constexpr int BN_FUSED_GY = 64;
+
+__global__ __launch_bounds__(1024) void bn_finish_apply(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
+                                                        int D, const float* __restrict__ part, float eps, float momentum,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float slope, float* __restrict__ mean, float* __restrict__ invstd,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        long long* __restrict__ nbt, float* __restrict__ y) {
+  __shared__ float smu[64], sis[64];
+  const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int n = min(*n_valid, R);
+  float p1, p2;
+  const bool owner = bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, &p1, &p2);   // lanes pr == 0, c < D
+  if (owner) {
+    float mu = 0.f, is = 0.f, var = 0.f;
+    if (n > 0) {
+      const float k = x[c];
+      const float m1 = p1 / (float)n, m2 = p2 / (float)n;
+      mu = k + m1;
+      var = m2 - m1 * m1;  // biased
+      var = var > 0.f ? var : 0.f;
+      is = rsqrtf(var + eps);
+    }
+    smu[cl] = mu;
+    sis[cl] = is;
+    if (blockIdx.y == 0) {
+      mean[c] = mu;
+      invstd[c] = is;
+      if (running_mean && n > 0) {
+        const float unbiased = n > 1 ? var * ((float)n / (float)(n - 1)) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mu;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+      }
+    }
+  }
+  if (nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *nbt += 1;
+  __syncthreads();
+  if (c >= D) return;
+  const float mu = smu[cl], is = sis[cl], ga = gamma[c], be = beta[c];
+  for (int r = blockIdx.y * 16 + pr; r < R; r += gridDim.y * 16) {
+    float v = 0.f;
+    if (r < n) {
+      v = (x[(int64_t)r * D + c] - mu) * is * ga + be;
+      v = v > 0.f ? v : v * slope;
+    }
+    y[(int64_t)r * D + c] = v;
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_bwd_finish_apply(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const int* __restrict__ n_valid, int R, int D,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float slope, const float* __restrict__ part,
+                                                            float* __restrict__ dgb, float* __restrict__ dx) {
+  __shared__ float sa[64], sb[64];
+  const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int n = min(*n_valid, R);
+  float a, b;
+  if (bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, &a, &b)) {
+    sa[cl] = a;
+    sb[cl] = b;
+    if (blockIdx.y == 0) {
+      dgb[c] = a;
+      dgb[D + c] = b;
+    }
+  }
+  __syncthreads();
+  if (c >= D) return;
+  const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c], s1 = sa[cl], s2 = sb[cl];
+  const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
+  for (int r = blockIdx.y * 16 + pr; r < R; r += gridDim.y * 16) {
+    float v = 0.f;
+    if (r < n) {
+      const float xh = (x[(int64_t)r * D + c] - mu) * is;
+      float gv = g[(int64_t)r * D + c];
+      if (xh * ga + be <= 0.f) gv *= slope;
+      v = ga * is * (gv - s1 * inv_n - xh * s2 * inv_n);
+    }
+    dx[(int64_t)r * D + c] = v;
+  }
+}
+
+bool bn_fused_finish() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MVK_BN_FUSED_FINISH");
+    v = (e && e[0] == '0') ? 0 : 1;
+  }
+  return v == 1;
+}
+
 // ---- small tensors (coarse pyramid levels): one workgroup per 64 channels does statistics AND
 // normalisation in a single launch (the rows are re-read from L2), 3 kernel nodes -> 1.
 constexpr int BN_SMALL_ROWS_DEFAULT = 128;   // measured: above ~128 rows three parallel launches beat one workgroup per 64 channels
@@ -346,6 +446,13 @@ extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t 
   }
   dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
   hipLaunchKernelGGL(bn_stats_partial, g1, dim3(BN_T), 0, st, x, n_valid, (int)R, D, scratch2D);
+  if (bn_fused_finish()) {
+    const unsigned gy = g1.y < (unsigned)BN_FUSED_GY ? g1.y : (unsigned)BN_FUSED_GY;
+    hipLaunchKernelGGL(bn_finish_apply, dim3(g1.x, gy), dim3(1024), 0, st, x, n_valid, (int)R, D, scratch2D, eps, momentum,
+                       gamma, beta, slope, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked, y);
+    MVK_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(bn_stats_finish, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, x, n_valid, (int)R, D, scratch2D,
                      eps, momentum, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked);
   hipLaunchKernelGGL(bn_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, n_valid, (int)R, D, mean, invstd,
@@ -373,6 +480,13 @@ extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n
   dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
   hipLaunchKernelGGL(bn_bwd_reduce, g1, dim3(BN_T), 0, st, x, g, n_valid, (int)R, D, mean, invstd, gamma, beta, slope,
                      scratch);
+  if (bn_fused_finish()) {
+    const unsigned gy = g1.y < (unsigned)BN_FUSED_GY ? g1.y : (unsigned)BN_FUSED_GY;
+    hipLaunchKernelGGL(bn_bwd_finish_apply, dim3(g1.x, gy), dim3(1024), 0, st, x, g, n_valid, (int)R, D, mean, invstd, gamma,
+                       beta, slope, scratch, dgamma_dbeta, dx);
+    MVK_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(bn_bwd_finish, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, scratch, (int)R, D, dgamma_dbeta);
   hipLaunchKernelGGL(bn_bwd_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, g, n_valid, (int)R, D, mean,
                      invstd, gamma, beta, slope, dgamma_dbeta, dx);

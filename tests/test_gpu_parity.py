@@ -581,3 +581,16 @@ def test_capacity_errors_are_loud(ops):
     with pytest.raises(RuntimeError, match="kernel size"):
         ops.kpconv(p, p, torch.zeros(500, 2, dtype=torch.int32, device="cuda"), torch.rand(500, 4, device="cuda"),
                    torch.zeros(17, 3, device="cuda"), torch.zeros(17, 4, 4, device="cuda"), 0.1)
+
+
+def test_randomised_sweep_index_kernels_vs_oracle():
+    """tools/fuzz_parity.py as a regression test: ragged batches (empty clouds included), lattice points
+    (exact ties), features + labels, searches with and without a column limit, pruned vs brute-force 3-NN --
+    12 seeded cases, zero mismatches against the CPU oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "3", "12"], capture_output=True,
+                       text=True, timeout=600, cwd=root)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "fuzz done, mismatches: 0" in p.stdout, p.stdout[-2000:]

@@ -321,3 +321,24 @@ def test_sampler_calibration_controller_and_cache_files(tmp_path):
     assert b == float(cal.batch_limit) and lim == [int(x) for x in want]
     cfg.batch_num = 6
     assert cal_mod.load_calibration(cfg, str(tmp_path))[0] is None
+
+
+def test_metrics_module_under_reference_names():
+    """utils.metrics drop-in (fast_confusion, IoU_from_confusions) against the reference's outputs (G8) and
+    its argument checks; non-contiguous label values go through the lookup-table branch."""
+    from conftest import load_golden
+    m = _dropin("utils.metrics")
+    g = load_golden("g8_metrics")
+    conf = m.fast_confusion(g["true"], g["pred"], np.arange(20, dtype=np.int32))
+    assert isinstance(conf, np.ndarray) and np.array_equal(conf, g["confusion"])
+    assert np.allclose(m.IoU_from_confusions(conf), g["iou"], rtol=0, atol=1e-12)
+    remap = np.array([3, 7, 11, 40, 41] + list(range(50, 65)), dtype=np.int64)           # 20 arbitrary label values
+    conf2 = m.fast_confusion(remap[g["true"]], remap[g["pred"]], remap)
+    assert np.array_equal(conf2, g["confusion"])
+    assert m.fast_confusion(g["true"], g["pred"]).shape[0] == len(np.unique(np.hstack([g["true"], g["pred"]])))
+    with pytest.raises(ValueError):
+        m.fast_confusion(g["true"].astype(np.float32), g["pred"])
+    with pytest.raises(ValueError):
+        m.fast_confusion(g["true"], g["pred"], np.array([0, 0, 1]))
+    with pytest.raises(ValueError):
+        m.fast_confusion(np.zeros((3, 3), np.int32), np.zeros(9, np.int32))

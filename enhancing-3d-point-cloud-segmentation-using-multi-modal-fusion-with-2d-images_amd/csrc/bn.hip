@@ -110,7 +110,7 @@ __global__ __launch_bounds__(1024) void bn_stats_finish(const float* __restrict_
 __global__ void bn_apply(const float* __restrict__ x, const int* __restrict__ n_valid, int R, int D,
                          const float* __restrict__ mean, const float* __restrict__ invstd,
                          const float* __restrict__ gamma, const float* __restrict__ beta, float slope,
-                         float* __restrict__ y) {
+                         const float* __restrict__ addend, float* __restrict__ y) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)R * D) return;
   const int n = min(*n_valid, R);
@@ -119,6 +119,7 @@ __global__ void bn_apply(const float* __restrict__ x, const int* __restrict__ n_
   float v = 0.f;
   if (r < n) {
     v = (x[t] - mean[c]) * invstd[c] * gamma[c] + beta[c];
+    if (addend) v += addend[t];   // residual join (blocks.py:649) fused with its LeakyReLU
     v = v > 0.f ? v : v * slope;
   }
   y[t] = v;
@@ -129,7 +130,9 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce(const float* __restrict__ 
                                                       const int* __restrict__ n_valid, int R, int D,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                      float slope, float* __restrict__ part /* [nblk,2,D] */) {
+                                                      float slope, const float* __restrict__ yout,
+                                                      float* __restrict__ part /* [nblk,2,D] */) {
+  // yout != NULL: the forward added a residual before the LeakyReLU, so its sign comes from the saved output
   __shared__ float s1[4][64], s2[4][64];
   const int n = min(*n_valid, R);
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce(const float* __restrict__ 
     for (int r = r0 + rl; r < r1; r += 4) {
       const float xh = (x[(int64_t)r * D + c] - mu) * is;
       float gv = g[(int64_t)r * D + c];
-      if (xh * ga + be <= 0.f) gv *= slope;
+      if (yout ? yout[(int64_t)r * D + c] <= 0.f : xh * ga + be <= 0.f) gv *= slope;
       a += gv;
       b += gv * xh;
     }
@@ -170,21 +173,23 @@ __global__ void bn_bwd_apply(const float* __restrict__ x, const float* __restric
                              const int* __restrict__ n_valid, int R, int D, const float* __restrict__ mean,
                              const float* __restrict__ invstd, const float* __restrict__ gamma,
                              const float* __restrict__ beta, float slope, const float* __restrict__ part,
-                             float* __restrict__ dx) {
+                             const float* __restrict__ yout, float* __restrict__ d_addend, float* __restrict__ dx) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)R * D) return;
   const int n = min(*n_valid, R);
   const int c = (int)(t % D);
   const int64_t r = t / D;
-  float v = 0.f;
+  float v = 0.f, ga_out = 0.f;
   if (r < n) {
     const float xh = (x[t] - mean[c]) * invstd[c];
     float gv = g[t];
-    if (xh * gamma[c] + beta[c] <= 0.f) gv *= slope;
+    if (yout ? yout[t] <= 0.f : xh * gamma[c] + beta[c] <= 0.f) gv *= slope;
     const float inv_n = 1.f / (float)n;
     v = gamma[c] * invstd[c] * (gv - part[c] * inv_n - xh * part[D + c] * inv_n);
+    ga_out = gv;
   }
   dx[t] = v;
+  if (d_addend) d_addend[t] = ga_out;
 }
 
 // ---- finish + apply in one launch: every workgroup of the apply grid first reduces the per-row-block
@@ -200,7 +205,8 @@ __global__ __launch_bounds__(1024) void bn_finish_apply(const float* __restrict_
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float slope, float* __restrict__ mean, float* __restrict__ invstd,
                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                        long long* __restrict__ nbt, float* __restrict__ y) {
+                                                        long long* __restrict__ nbt, const float* __restrict__ addend,
+                                                        float* __restrict__ y) {
   __shared__ float smu[64], sis[64];
   const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -237,6 +243,7 @@ __global__ __launch_bounds__(1024) void bn_finish_apply(const float* __restrict_
     float v = 0.f;
     if (r < n) {
       v = (x[(int64_t)r * D + c] - mu) * is * ga + be;
+      if (addend) v += addend[(int64_t)r * D + c];
       v = v > 0.f ? v : v * slope;
     }
     y[(int64_t)r * D + c] = v;
@@ -248,6 +255,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finish_apply(const float* __restr
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
                                                             float slope, const float* __restrict__ part,
+                                                            const float* __restrict__ yout, float* __restrict__ d_addend,
                                                             float* __restrict__ dgb, float* __restrict__ dx) {
   __shared__ float sa[64], sb[64];
   const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
@@ -267,14 +275,16 @@ __global__ __launch_bounds__(1024) void bn_bwd_finish_apply(const float* __restr
   const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c], s1 = sa[cl], s2 = sb[cl];
   const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
   for (int r = blockIdx.y * 16 + pr; r < R; r += gridDim.y * 16) {
-    float v = 0.f;
+    float v = 0.f, ga_out = 0.f;
     if (r < n) {
       const float xh = (x[(int64_t)r * D + c] - mu) * is;
       float gv = g[(int64_t)r * D + c];
-      if (xh * ga + be <= 0.f) gv *= slope;
+      if (yout ? yout[(int64_t)r * D + c] <= 0.f : xh * ga + be <= 0.f) gv *= slope;
       v = ga * is * (gv - s1 * inv_n - xh * s2 * inv_n);
+      ga_out = gv;
     }
     dx[(int64_t)r * D + c] = v;
+    if (d_addend) d_addend[(int64_t)r * D + c] = ga_out;
   }
 }
 
@@ -314,7 +324,7 @@ __global__ __launch_bounds__(1024) void bn_small_fwd(const float* __restrict__ x
                                                      float slope, float* __restrict__ running_mean,
                                                      float* __restrict__ running_var, float* __restrict__ mean,
                                                      float* __restrict__ invstd, float* __restrict__ y,
-                                                     long long* __restrict__ nbt) {
+                                                     long long* __restrict__ nbt, const float* __restrict__ addend) {
   __shared__ float r1[16][64], r2[16][64];
   if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
   const int n = min(*n_valid, R);
@@ -356,6 +366,7 @@ __global__ __launch_bounds__(1024) void bn_small_fwd(const float* __restrict__ x
       float v = 0.f;
       if (r < n) {
         v = (x[(int64_t)r * D + c] - mu) * is * ga + be;
+        if (addend) v += addend[(int64_t)r * D + c];
         v = v > 0.f ? v : v * slope;
       }
       y[(int64_t)r * D + c] = v;
@@ -367,7 +378,9 @@ __global__ __launch_bounds__(1024) void bn_small_bwd(const float* __restrict__ x
                                                      const int* __restrict__ n_valid, int R, int D,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     float slope, float* __restrict__ dgb, float* __restrict__ dx) {
+                                                     float slope, const float* __restrict__ yout,
+                                                     float* __restrict__ d_addend, float* __restrict__ dgb,
+                                                     float* __restrict__ dx) {
   __shared__ float r1[16][64], r2[16][64];
   const int n = min(*n_valid, R);
   const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
@@ -379,7 +392,7 @@ __global__ __launch_bounds__(1024) void bn_small_bwd(const float* __restrict__ x
     for (int r = pr; r < n; r += 16) {
       const float xh = (x[(int64_t)r * D + c] - mu) * is;
       float gv = g[(int64_t)r * D + c];
-      if (xh * ga + be <= 0.f) gv *= slope;
+      if (yout ? yout[(int64_t)r * D + c] <= 0.f : xh * ga + be <= 0.f) gv *= slope;
       a += gv;
       b += gv * xh;
     }
@@ -391,14 +404,16 @@ __global__ __launch_bounds__(1024) void bn_small_bwd(const float* __restrict__ x
     }
     const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
     for (int r = pr; r < R; r += 16) {
-      float v = 0.f;
+      float v = 0.f, ga_out = 0.f;
       if (r < n) {
         const float xh = (x[(int64_t)r * D + c] - mu) * is;
         float gv = g[(int64_t)r * D + c];
-        if (xh * ga + be <= 0.f) gv *= slope;
+        if (yout ? yout[(int64_t)r * D + c] <= 0.f : xh * ga + be <= 0.f) gv *= slope;
         v = ga * is * (gv - a * inv_n - xh * b * inv_n);
+        ga_out = gv;
       }
       dx[(int64_t)r * D + c] = v;
+      if (d_addend) d_addend[(int64_t)r * D + c] = ga_out;
     }
   }
 }
@@ -434,13 +449,13 @@ int bn_small_rows() {
 extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t R, int D, const float* gamma,
                                 const float* beta, float eps, float momentum, float slope, float* running_mean,
                                 float* running_var, float* mean, float* invstd, float* scratch2D /* [ceil(R/64),2,D] */, float* y,
-                                int64_t* num_batches_tracked, void* stream) {
+                                int64_t* num_batches_tracked, const float* addend, void* stream) {
   MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
   if (R == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (R <= bn_small_rows()) {
     hipLaunchKernelGGL(bn_small_fwd, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, x, n_valid, (int)R, D, gamma, beta,
-                       eps, momentum, slope, running_mean, running_var, mean, invstd, y, (long long*)num_batches_tracked);
+                       eps, momentum, slope, running_mean, running_var, mean, invstd, y, (long long*)num_batches_tracked, addend);
     MVK_CHECK_HIP(hipGetLastError());
     return 0;
   }
@@ -449,14 +464,14 @@ extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t 
   if (bn_fused_finish()) {
     const unsigned gy = g1.y < (unsigned)BN_FUSED_GY ? g1.y : (unsigned)BN_FUSED_GY;
     hipLaunchKernelGGL(bn_finish_apply, dim3(g1.x, gy), dim3(1024), 0, st, x, n_valid, (int)R, D, scratch2D, eps, momentum,
-                       gamma, beta, slope, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked, y);
+                       gamma, beta, slope, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked, addend, y);
     MVK_CHECK_HIP(hipGetLastError());
     return 0;
   }
   hipLaunchKernelGGL(bn_stats_finish, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, x, n_valid, (int)R, D, scratch2D,
                      eps, momentum, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked);
   hipLaunchKernelGGL(bn_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, n_valid, (int)R, D, mean, invstd,
-                     gamma, beta, slope, y);
+                     gamma, beta, slope, addend, y);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -464,8 +479,10 @@ extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t 
 extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n_valid, int64_t R, int D,
                                 const float* gamma, const float* beta, const float* mean, const float* invstd,
                                 float slope, float* scratch /* [ceil(R/64),2,D] */,
-                                float* dgamma_dbeta /* [2,D]: dbeta then dgamma */, float* dx, void* stream) {
+                                float* dgamma_dbeta /* [2,D]: dbeta then dgamma */, float* dx, const float* y_out,
+                                float* d_addend, void* stream) {
   MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
+  MVK_REQUIRE((y_out == nullptr) == (d_addend == nullptr), "bn: y_out and d_addend go together (residual-join mode)");
   hipStream_t st = (hipStream_t)stream;
   if (R == 0) {
     MVK_CHECK_HIP(hipMemsetAsync(dgamma_dbeta, 0, sizeof(float) * 2 * D, st));
@@ -473,23 +490,23 @@ extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n
   }
   if (R <= bn_small_rows()) {
     hipLaunchKernelGGL(bn_small_bwd, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, x, g, n_valid, (int)R, D, mean,
-                       invstd, gamma, beta, slope, dgamma_dbeta, dx);
+                       invstd, gamma, beta, slope, y_out, d_addend, dgamma_dbeta, dx);
     MVK_CHECK_HIP(hipGetLastError());
     return 0;
   }
   dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
   hipLaunchKernelGGL(bn_bwd_reduce, g1, dim3(BN_T), 0, st, x, g, n_valid, (int)R, D, mean, invstd, gamma, beta, slope,
-                     scratch);
+                     y_out, scratch);
   if (bn_fused_finish()) {
     const unsigned gy = g1.y < (unsigned)BN_FUSED_GY ? g1.y : (unsigned)BN_FUSED_GY;
     hipLaunchKernelGGL(bn_bwd_finish_apply, dim3(g1.x, gy), dim3(1024), 0, st, x, g, n_valid, (int)R, D, mean, invstd, gamma,
-                       beta, slope, scratch, dgamma_dbeta, dx);
+                       beta, slope, scratch, y_out, d_addend, dgamma_dbeta, dx);
     MVK_CHECK_HIP(hipGetLastError());
     return 0;
   }
   hipLaunchKernelGGL(bn_bwd_finish, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, scratch, (int)R, D, dgamma_dbeta);
   hipLaunchKernelGGL(bn_bwd_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, g, n_valid, (int)R, D, mean,
-                     invstd, gamma, beta, slope, dgamma_dbeta, dx);
+                     invstd, gamma, beta, slope, dgamma_dbeta, y_out, d_addend, dx);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -181,19 +181,23 @@ class BatchNormBlock(nn.Module):
     def reset_parameters(self):
         nn.init.zeros_(self.bias)
 
-    def forward(self, x, slope=None):
+    def forward(self, x, slope=None, addend=None):
         """slope: when given, the LeakyReLU that follows every BatchNormBlock in the reference's blocks
-        is applied here (fused into the masked kernel in capacity-padded mode)."""
+        is applied here (fused into the masked kernel in capacity-padded mode). addend: the shortcut of a
+        residual block, added before that activation (blocks.py:649), in the same launch when masked."""
         if self.use_bn:
             n_valid = ops.row_count_for(x.shape[0]) if self.training else None
             if n_valid is not None:
                 # capacity-padded level (hipGraph replay): statistics over the valid rows only
-                return ops.bn_lrelu(x, n_valid, self.batch_norm, 1.0 if slope is None else slope)
+                return ops.bn_lrelu(x, n_valid, self.batch_norm, 1.0 if slope is None else slope, addend)
             # [N, C] is already BatchNorm1d's (batch, channel) layout: same statistics as the
             # reference's unsqueeze/transpose round trip (blocks.py:456-460) without the copies
             x = self.batch_norm(x)
         else:
             x = x + self.bias
+        if addend is not None:
+            return ops.add_lrelu(x, addend, 1.0 if slope is None else slope) if _FUSE_ADD else \
+                nn.functional.leaky_relu(x + addend, 1.0 if slope is None else slope)
         return x if slope is None else nn.functional.leaky_relu(x, slope)
 
     def __repr__(self):
@@ -215,10 +219,13 @@ class UnaryBlock(nn.Module):
         if not no_relu:
             self.leaky_relu = nn.LeakyReLU(0.1)
 
-    def forward(self, x, batch=None):
+    def forward(self, x, batch=None, join=None):
+        """join = (shortcut, slope): finish a residual block here -- LeakyReLU_slope(BN(x W^T) + shortcut)."""
         # nn.Linear(bias=False) = x @ W^T: on the f32 MFMA GEMM (faster than the library GEMM on these
         # tall-skinny shapes, tools/gemm_bench.py); parameters stay those of self.mlp (state-dict compatible)
         y = ops.linear(x, self.mlp.weight) if (_MFMA_LINEAR and x.is_cuda) else self.mlp(x)
+        if join is not None:
+            return self.batch_norm(y, join[1], addend=join[0])
         return self.batch_norm(y, None if self.no_relu else 0.1)
 
     def __repr__(self):
@@ -287,11 +294,11 @@ class ResnetBottleneckBlock(nn.Module):
         q_pts, s_pts, inds = _conv_inputs(self.block_name, self.layer_ind, batch)
         x = self.unary1(features)
         x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x), 0.1)
-        x = self.unary2(x)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
-        if _FUSE_ADD:
-            return ops.add_lrelu(x, self.unary_shortcut(shortcut), 0.1)
-        return self.leaky_relu(x + self.unary_shortcut(shortcut))
+        shortcut = self.unary_shortcut(shortcut)
+        if _FUSE_ADD:       # x = unary2(x); return leaky_relu(x + shortcut)  (blocks.py:644-649), join fused
+            return self.unary2(x, join=(shortcut, 0.1))
+        return self.leaky_relu(self.unary2(x) + shortcut)
 
 
 class GlobalAverageBlock(nn.Module):

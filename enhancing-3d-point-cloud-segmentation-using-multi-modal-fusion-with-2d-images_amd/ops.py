@@ -449,9 +449,14 @@ def full_count(rows, device):
 
 class _BNLReLUFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, n_valid, gamma, beta, running_mean, running_var, eps, momentum, slope, training, nbt=None):
-        _dev(x, n_valid, gamma, beta)
+    def forward(ctx, x, n_valid, gamma, beta, running_mean, running_var, eps, momentum, slope, training, nbt=None,
+                addend=None):
+        _dev(x, n_valid, gamma, beta, addend)
         x = _f32c(x)
+        if addend is not None:
+            addend = _f32c(addend)
+            if addend.shape != x.shape:
+                raise RuntimeError("bn_lrelu: the residual addend must have the shape of the input")
         R, D = x.shape
         y = torch.empty_like(x)
         mean = torch.empty(D, device=x.device, dtype=torch.float32)
@@ -461,31 +466,33 @@ class _BNLReLUFn(torch.autograd.Function):
             raise RuntimeError("masked BatchNorm is a training-mode op; use nn.BatchNorm1d in eval mode")
         check(lib().mvk_bn_lrelu_fwd(_p(x), _p(n_valid), R, D, _p(gamma), _p(beta), float(eps), float(momentum),
                                      float(slope), _p(running_mean), _p(running_var), _p(mean), _p(invstd),
-                                     _p(scratch), _p(y), _p(nbt), _stream()))
-        ctx.save_for_backward(x, n_valid, gamma, beta, mean, invstd)
+                                     _p(scratch), _p(y), _p(nbt), _p(addend), _stream()))
+        ctx.save_for_backward(x, n_valid, gamma, beta, mean, invstd, y if addend is not None else None)
         ctx.slope = float(slope)
         return y
 
     @staticmethod
     def backward(ctx, g):
-        x, n_valid, gamma, beta, mean, invstd = ctx.saved_tensors
+        x, n_valid, gamma, beta, mean, invstd, yout = ctx.saved_tensors
         g = _f32c(g)
         R, D = x.shape
         dgb = torch.empty(2 * D, device=x.device, dtype=torch.float32)
         scratch = torch.empty(((R + 63) // 64) * 2 * D, device=x.device, dtype=torch.float32)
         dx = torch.empty_like(x)
+        d_add = torch.empty_like(x) if yout is not None else None
         check(lib().mvk_bn_lrelu_bwd(_p(x), _p(g), _p(n_valid), R, D, _p(gamma), _p(beta), _p(mean), _p(invstd),
-                                     ctx.slope, _p(scratch), _p(dgb), _p(dx), _stream()))
-        return dx, None, dgb[D:], dgb[:D], None, None, None, None, None, None, None
+                                     ctx.slope, _p(scratch), _p(dgb), _p(dx), _p(yout), _p(d_add), _stream()))
+        return dx, None, dgb[D:], dgb[:D], None, None, None, None, None, None, None, d_add
 
 
-def bn_lrelu(x, n_valid, bn, slope=1.0):
-    """y = LeakyReLU_slope(BatchNorm1d(x[:n_valid])) with rows >= n_valid zeroed; `bn` is an
+def bn_lrelu(x, n_valid, bn, slope=1.0, addend=None):
+    """y = LeakyReLU_slope(BatchNorm1d(x[:n_valid]) [+ addend]) with rows >= n_valid zeroed; `bn` is an
     nn.BatchNorm1d whose parameters / running statistics are used and updated; n_valid is a DEVICE
-    int32 tensor of one element."""
+    int32 tensor of one element. addend [R,D]: the shortcut of a residual block, joined before the
+    activation (blocks.py:649) inside the same launch; it receives its own gradient."""
     nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # += 1 inside the kernel
     return _BNLReLUFn.apply(x, n_valid, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                            bn.momentum if bn.momentum is not None else 0.0, slope, bn.training, nbt)
+                            bn.momentum if bn.momentum is not None else 0.0, slope, bn.training, nbt, addend)
 
 
 class _AddLReLUFn(torch.autograd.Function):

@@ -104,11 +104,15 @@ int mvk_gemm_f16(const void* A, int a_f16, const void* B, int b_f16, void* C, in
 int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t R, int D, const float* gamma,
                      const float* beta, float eps, float momentum, float slope, float* running_mean,
                      float* running_var, float* mean, float* invstd, float* scratch, float* y,
-                     int64_t* num_batches_tracked /* DEVICE counter += 1, may be NULL */, void* stream);
+                     int64_t* num_batches_tracked /* DEVICE counter += 1, may be NULL */,
+                     const float* addend /* [R,D] or NULL: y = LeakyReLU(BN(x) + addend), the residual join of
+                                            ResnetBottleneckBlock (blocks.py:649) */, void* stream);
 /* dgamma_dbeta [2,D] receives dbeta (row 0) and dgamma (row 1); dx [R,D] (rows >= n_valid zero). */
 int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n_valid, int64_t R, int D,
                      const float* gamma, const float* beta, const float* mean, const float* invstd,
-                     float slope, float* scratch, float* dgamma_dbeta, float* dx, void* stream);
+                     float slope, float* scratch, float* dgamma_dbeta, float* dx,
+                     const float* y_out /* forward output, needed (with d_addend) when the forward had an addend */,
+                     float* d_addend /* [R,D] gradient of the addend, or NULL */, void* stream);
 
 /* y = LeakyReLU_slope(a + b) over n elements and its backward d = g * (y > 0 ? 1 : slope) (both
  * addends receive d): the residual join of ResnetBottleneckBlock (blocks.py:649), slope > 0. */

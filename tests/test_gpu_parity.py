@@ -482,6 +482,35 @@ def test_gemm_f16_mfma(ops, M, N, K, ta, tb):
     assert (one.double() - want).abs().max().item() / scale < 2e-5
 
 
+@pytest.mark.parametrize("R,D,n", [(100, 64, 90), (3000, 128, 2873), (19464, 64, 19464), (4096, 200, 4000)])
+def test_masked_bn_with_residual_join_vs_torch(ops, R, D, n):
+    """y = LeakyReLU(BN(x) + shortcut) in one launch (ResnetBottleneckBlock's join, blocks.py:644-649) against
+    the unfused torch expression: output, and the gradients of x, the shortcut and the BN parameters."""
+    torch.manual_seed(R * 3 + D)
+    x = (torch.randn(R, D, device="cuda") * 2 + 1).requires_grad_(True)
+    sc = torch.randn(R, D, device="cuda").requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(D, momentum=0.02).cuda()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    ref = torch.nn.BatchNorm1d(D, momentum=0.02).cuda()
+    ref.load_state_dict(bn.state_dict())
+    nv = torch.tensor([n], dtype=torch.int32, device="cuda")
+    go = torch.randn(R, D, device="cuda")
+    y = ops.bn_lrelu(x, nv, bn, slope=0.1, addend=sc)
+    gx, gs, gw, gb = torch.autograd.grad(y, [x, sc, bn.weight, bn.bias], go)
+    xr, sr = x.detach()[:n].clone().requires_grad_(True), sc.detach()[:n].clone().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(ref(xr) + sr, 0.1)
+    gxr, gsr, gwr, gbr = torch.autograd.grad(yr, [xr, sr, ref.weight, ref.bias], go[:n])
+    assert (y[n:] == 0).all() and (gx[n:] == 0).all() and (gs[n:] == 0).all()
+    assert rel_err(y[:n].detach().cpu().numpy(), yr.detach().cpu().numpy()) < 1e-5
+    away = (yr.detach().abs() > 1e-4).float()                      # elements on the LeakyReLU kink may flip slope
+    assert away.mean() > 0.99
+    assert rel_err((gs[:n] * away).cpu().numpy(), (gsr * away).cpu().numpy()) < 1e-6
+    assert rel_err((gx[:n] * away).cpu().numpy(), (gxr * away).cpu().numpy()) < 1e-2
+    assert rel_err(gw.cpu().numpy(), gwr.cpu().numpy()) < 1e-2 and rel_err(gb.cpu().numpy(), gbr.cpu().numpy()) < 1e-2
+
+
 # ------------------------------------------------------------------ group_points (reference test shapes)
 
 @pytest.mark.parametrize("b,c,n1,n2,k", [(2, 3, 512, 128, 32), (5, 64, 513, 129, 33)])

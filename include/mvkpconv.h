@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVK_ABI_VERSION 1
+#define MVK_ABI_VERSION 2   /* 2: masked BatchNorm takes the batch counter and a residual addend; enqueue-only / device-lens pyramid entry points; fp16-feature mode; capacity padding */
 
 /* influence / aggregation codes (blocks.py:329-354) */
 #define MVK_INFL_CONSTANT 0

@@ -47,17 +47,58 @@ def parse():
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="replay the network part (fwd+loss+bwd+clip+SGD) as one hipGraph over capacity-padded levels")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=1)
+    ap.add_argument("--cpu-baseline-steps", type=int, default=5)
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process
+    (python -m torch.distributed.run, one rank per GPU) before this process has touched the GPU, relay
+    rank 0's JSON line and return the child's exit code. A process that has initialised HIP is never
+    re-exec'ed."""
+    import socket
+    import subprocess
+    one_gpu = os.environ.get("MVK_BENCH_ONE_GPU") == "1" or os.environ.get("MVK_BENCH_DRY") == "1"
+    have = torch.cuda.device_count()            # counting devices does not initialise the GPU
+    if not one_gpu and have < args.gpus:
+        print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if proc.returncode != 0 or line is None:
+        print("bench.py: the %d-rank child run failed (exit %d)" % (args.gpus, proc.returncode), file=sys.stderr)
+        return proc.returncode or 1
+    res = json.loads(line)
+    if res.get("n_gpus") != args.gpus or res.get("config", {}).get("ranks") != args.gpus:
+        print("bench.py: asked for %d ranks, the run reports %s" % (args.gpus, res.get("n_gpus")), file=sys.stderr)
+        return 3
+    print(line)
+    return 0
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, or "
+                         "without a launcher: bench.py starts the ranks itself)" % (args.gpus, world, args.gpus))
+    if os.environ.get("MVK_BENCH_DRY") == "1":
+        return dry_run(args, world, rank)
     # rehearsal hook: MVK_BENCH_BACKEND=gloo + MVK_BENCH_ONE_GPU=1 runs N ranks on ONE card (development
     # only; the driver's multi-GPU runs use the defaults: RCCL, one rank per GPU)
     backend = os.environ.get("MVK_BENCH_BACKEND", "nccl")
@@ -179,9 +220,16 @@ def main():
 
     t = torch.tensor([dt], device=dev, dtype=torch.float64)
     pts = torch.tensor([float(sum(lens))], device=dev, dtype=torch.float64)
+    ranks_seen, per_rank_ms = 1, [dt / args.steps * 1e3]
     if world > 1 or force_dp:
+        ranks_seen = dist.get_world_size()      # what the process group (RCCL) actually spans
+        every = [torch.zeros_like(t) for _ in range(ranks_seen)]
+        dist.all_gather(every, t)
+        per_rank_ms = [float(v.item()) / args.steps * 1e3 for v in every]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(pts, op=dist.ReduceOp.SUM)
+    if ranks_seen != world:
+        raise SystemExit("process group spans %d ranks, WORLD_SIZE=%d" % (ranks_seen, world))
     dt = t.item()
     total_points = pts.item() * args.steps
 
@@ -197,6 +245,9 @@ def main():
                 args.spheres, "_deformable" if args.deformable else ""),
                 "points_per_step_per_gpu": int(sum(lens)), "views": args.views if fusion else 0,
                 "image_hw": [120, 160] if fusion else None, "parallelism": "dp%d" % world, "execution": graph_note,
+                "ranks": ranks_seen, "backend": ("rccl" if backend == "nccl" else backend) if (world > 1 or force_dp) else None,
+                "rccl_ranks": ranks_seen if (backend == "nccl" and (world > 1 or force_dp)) else None,
+                "ms_per_step_per_rank": per_rank_ms,
                 "final_loss": float(loss.item()),
                 "capacity_overflow": bool(state_ref and state_ref[-1].get("overflow", False))},
             "roofline": roofline(prof),
@@ -449,7 +500,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             opt.zero_grad(set_to_none=True)     # fresh .grad tensors: the captured ones are slices of the zero arena
             if enc is not None:                 # keep the encoder pipeline going: features for the next set
                 statics[slot ^ 1].feature_2d.copy_(encode(enc_in))
-            loss = net_step_eager(net, batch, cfg, params, opt, reducer)
+            loss = net_step_captured(net, batch, cfg, params, opt, reducer)   # plain eager step on the exact-size batch
             ops._ARENA["on"] = arena_was
             main.synchronize()                  # rare path: `batch` lives in the build stream's pool
             state["next"] = build_async(slot)
@@ -507,12 +558,6 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                   (" | frozen 2D encoder of the next batch as a parallel branch of the same graph" if enc is not None else ""))
 
 
-def net_step_eager(net, batch, cfg, params, opt, reducer):
-    """Fallback for a batch that does not fit the captured capacities: one plain eager step on the
-    exact-size batch (fresh .grad tensors; the graphs keep the addresses they captured)."""
-    return net_step_captured(net, batch, cfg, params, opt, reducer)
-
-
 def net_step_captured(net, static, cfg, params, opt, reducer):
     """Body of the captured graph: identical to an eager network step (no host sync inside)."""
     import mvkpconv
@@ -527,6 +572,26 @@ def net_step_captured(net, static, cfg, params, opt, reducer):
     return loss
 
 
+def dry_run(args, world, rank):
+    """Launch rehearsal without a GPU (CPU test of the --gpus N path): every rank joins a gloo group,
+    takes part in the same barrier / MAX / SUM reductions as the real run and rank 0 prints the JSON
+    skeleton. No hot-path work, value = 0."""
+    dist.init_process_group("gloo")
+    got = dist.get_world_size()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(got)]
+    dist.all_gather(per_rank, t)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launch rehearsal, no GPU work)", "value": 0.0, "unit": "points/s",
+                          "n_gpus": got, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t.item(),
+                          "config": {"ranks": got, "backend": "gloo", "parallelism": "dp%d" % got,
+                                     "ms_per_step_per_rank": [float(v.item()) for v in per_rank]}}))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if got == args.gpus else 3
+
+
 def roofline(prof):
     """Dominant KPConv gather launch class: achieved = algorithmic gathered bytes / average launch
     duration (HIP events), against the HBM peak. Bytes per launch:
@@ -534,11 +599,13 @@ def roofline(prof):
     if not prof:
         return None
     best = max(prof.values(), key=lambda r: r["total_ms"])
-    traffic = pmc_traffic(best)
+    traffic, traffic_note = pmc_traffic(best)
     avg_ms = best["total_ms"] / best["launches"]
     achieved = best["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": best["kernel"],
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
+            "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "kernel": best["kernel"],
             "launch": best["shape"], "avg_launch_us": avg_ms * 1e3, "launches": best["launches"],
             "measured_in": "HIP events on the launch stream around every gather launch of 8 instrumented eager steps run between warm-up and the timed region",
             "algorithmic_bytes_per_launch": best["bytes_per_launch"]}
@@ -566,20 +633,29 @@ def mfma_report(contraction, features="f32"):
 
 
 def pmc_traffic(best):
-    """HBM bytes per launch of the dominant gather launch from the committed PMC profile
-    (profiles/r01_pmc_gather.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command,
-    gfx950 correction 2*FETCH + WRITE). PMC counters cannot be read from inside the process, so the
-    value is only reported when the launch geometry of this run matches the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_gather.json")
-    if not os.path.exists(path):
-        return None
+    """HBM bytes per launch of the dominant gather launch from the newest committed PMC profile
+    (profiles/rNN_pmc_gather.json: rocprofv3 FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950
+    correction 2*FETCH + WRITE; PMC counters cannot be read from inside the process). Returns
+    (bytes or None, note): the value is reported only when the profile was taken with the csrc/kpconv.hip
+    of this tree (sha256 recorded in the file) and the launch geometry matches."""
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_gather.json")))
+    if not files:
+        return None, "no profiles/rNN_pmc_gather.json"
+    path = files[-1]
+    prof = json.load(open(path))
+    src = os.path.join(ROOT, "enhancing-3d-point-cloud-segmentation-using-multi-modal-fusion-with-2d-images_amd", "csrc", "kpconv.hip")
+    sha = hashlib.sha256(open(src, "rb").read()).hexdigest()
+    if prof.get("kpconv_hip_sha256") != sha:
+        return None, "%s was taken with another csrc/kpconv.hip (sha mismatch): re-run the --pmc passes" % os.path.basename(path)
     sh = best["shape"]
     lpp = min((sh["Cin"] + 3) // 4, 64)
     grid_threads = -(-sh["Nq"] // (64 // lpp)) * 64
-    for l in json.load(open(path))["launches"]:
+    for l in prof["launches"]:
         if l["kernel"].startswith("kpconv_gather_vec") and l["grid_threads"] == grid_threads:
-            return l["traffic_bytes"]
-    return None
+            return l["traffic_bytes"], "%s (%s)" % (os.path.basename(path), prof.get("command", ""))
+    return None, "%s holds no launch with this run's grid" % os.path.basename(path)
 
 
 def cpu_baseline(cfg, net, staged, limits, spheres, args):
@@ -630,22 +706,26 @@ def cpu_baseline(cfg, net, staged, limits, spheres, args):
         return t1 - t0, time.perf_counter() - t1
 
     a, b = cpu_step()  # warm-up (also the sample itself when one step already exceeds the time bound)
-    tp = tn = 0.0
-    n = 0
+    samples = []
     if a + b < 20.0:
-        for _ in range(args.cpu_baseline_steps):
-            a, b = cpu_step()
-            tp += a
-            tn += b
-            n += 1
+        t_end = time.perf_counter() + 25.0       # bounded sample: about 10-30 s of CPU work
+        for _ in range(max(args.cpu_baseline_steps, 1)):
+            samples.append(cpu_step())
+            if time.perf_counter() > t_end:
+                break
     else:
-        tp, tn, n = a, b, 1
-    return {"value": lens[0] * n / (tp + tn), "unit": "points/s", "cores": cores,
+        samples = [(a, b)]
+    n = len(samples)
+    tot = sorted(x + y for x, y in samples)
+    med = tot[n // 2] if n % 2 else 0.5 * (tot[n // 2 - 1] + tot[n // 2])
+    tp, tn = float(np.median([x for x, _ in samples])), float(np.median([y for _, y in samples]))
+    return {"value": lens[0] / med, "unit": "points/s", "cores": cores,
             "kind": "port",
-            "sample": "%d step(s) of ONE %d-point sphere of the same workload: pyramid by %s (1 thread, %.0f ms/step) "
-                      "+ unfused PyTorch-CPU network fwd+bwd on %d threads (%.0f ms/step); no optimizer step" % (
+            "sample": "median of %d step(s) after 1 warm-up over ONE %d-point sphere of the same workload: pyramid by %s "
+                      "(1 thread, median %.0f ms/step) + unfused PyTorch-CPU network fwd+bwd on %d threads (median %.0f "
+                      "ms/step); no optimizer step" % (
                           n, lens[0], "the compiled reference core (oracle/_ref)" if cport.ref() else "the C oracle",
-                          tp / n * 1e3, cores, tn / n * 1e3)}
+                          tp * 1e3, cores, tn * 1e3)}
 
 
 if __name__ == "__main__":

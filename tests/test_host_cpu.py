@@ -342,3 +342,23 @@ def test_metrics_module_under_reference_names():
         m.fast_confusion(g["true"], g["pred"], np.array([0, 0, 1]))
     with pytest.raises(ValueError):
         m.fast_confusion(np.zeros((3, 3), np.int32), np.zeros(9, np.int32))
+
+
+def test_bench_gpus_n_starts_n_ranks_itself():
+    """`python bench.py --gpus 2` without a launcher must start two ranks as a child process (never report
+    n_gpus 1): launch rehearsal with MVK_BENCH_DRY=1 (gloo, no GPU work)."""
+    import json
+    env = dict(os.environ, MVK_BENCH_DRY="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["config"]["ranks"] == 2 and len(res["config"]["ms_per_step_per_rank"]) == 2
+    # a world size that contradicts --gpus is refused loudly
+    env2 = dict(env, WORLD_SIZE="1", RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                        env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
+    assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)

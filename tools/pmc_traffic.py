@@ -1,7 +1,14 @@
-"""Development-only: builds profiles/r01_pmc_gather.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
+"""Development-only: builds profiles/rNN_pmc_gather.json from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json>"""
-import collections, csv, json, sys
+usage: pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <out.json> ["<bench command>"]
+
+The file records the sha256 of csrc/kpconv.hip it was taken with: bench.py reports roofline.traffic only
+while the kernel source still has that hash."""
+import collections, csv, hashlib, json, os, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KPCONV = os.path.join(ROOT, "enhancing-3d-point-cloud-segmentation-using-multi-modal-fusion-with-2d-images_amd", "csrc", "kpconv.hip")
+CMD = sys.argv[4] if len(sys.argv) > 4 else "python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 
 
 def per_launch(path, counter):
@@ -18,8 +25,8 @@ def per_launch(path, counter):
 
 
 fetch, write = per_launch(sys.argv[1], "FETCH_SIZE"), per_launch(sys.argv[2], "WRITE_SIZE")
-out = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --steps 3 "
-                 "--warmup 1 --no-cpu-baseline --no-graph; per-dispatch averages; counters are KiB; traffic_bytes = "
+out = {"kpconv_hip_sha256": hashlib.sha256(open(KPCONV, "rb").read()).hexdigest(), "command": CMD,
+       "method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- " + CMD + "; per-dispatch averages; counters are KiB; traffic_bytes = "
                  "(2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports half the bytes of "
                  "16-B-per-lane coalesced reads; WRITE_SIZE is exact for 16-B-per-lane stores)",
        "launches": []}

@@ -129,9 +129,10 @@ ARCH_RIGID = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb', 'res
               'resnetb', 'resnetb_strided', 'resnetb', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb',
               'nearest_upsample', 'unary', 'nearest_upsample', 'unary', 'nearest_upsample', 'unary',
               'nearest_upsample', 'unary']
-ARCH_DEFORM = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb', 'resnetb_strided', 'resnetb',
-               'resnetb', 'resnetb_strided', 'resnetb_deformable', 'resnetb_deformable',
-               'resnetb_deformable_strided', 'resnetb_deformable', 'resnetb_deformable',
+# the deformable architecture the reference trains (train_ScanNet_sphere_middle_fusion.py:87-105,
+# train_ScanNet_sphere_late_fusion.py:88-106): 10 encoder blocks, deformable from the third level on
+ARCH_DEFORM = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_strided', 'resnetb_deformable',
+               'resnetb_deformable_strided', 'resnetb_deformable', 'resnetb_deformable_strided', 'resnetb_deformable',
                'nearest_upsample', 'unary', 'nearest_upsample', 'unary', 'nearest_upsample', 'unary',
                'nearest_upsample', 'unary']
 

@@ -324,6 +324,100 @@ def g5_kpfcnn():
     save("g5_kpfcnn", **arrs)
 
 
+ARCH_DEFORM = ['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_strided', 'resnetb_deformable',
+               'resnetb_deformable_strided', 'resnetb_deformable', 'resnetb_deformable_strided', 'resnetb_deformable',
+               'nearest_upsample', 'unary', 'nearest_upsample', 'unary', 'nearest_upsample', 'unary',
+               'nearest_upsample', 'unary']      # train_ScanNet_sphere_middle_fusion.py:87-105
+
+
+class _CfgDeform(_Cfg):
+    architecture = ARCH_DEFORM
+
+
+def g5b_kpfcnn_deformable():
+    """The reference's KPFCNN (models/architectures.py) with the DEFORMABLE architecture of
+    train_ScanNet_sphere_middle_fusion.py:87-105, modulated False and True, non-zero offset_bias: logits,
+    output loss, p2p_fitting_regularizer (architectures.py:20-58), total loss and gradients of an
+    offset_conv.weights, an offset_bias and ordinary weights, with the state dict."""
+    import types
+    import torch
+    from oracle import pyramid
+    rb = _ref_blocks()
+    from models.architectures import KPFCNN
+    from utils.config import Config
+
+    rng = np.random.default_rng(515)
+    raw = room_cloud(rng, 90000, 1.15)
+    p0, l0 = cport.subsample_batch(raw, [raw.shape[0]], dl=0.04, impl="ref")
+    np.random.seed(56)
+    rots = [pyramid.draw_rotations(1) for _ in range(4)]
+    limits = [28, 30, 60, 48, 20]          # deformable levels 2.. use deform_radius: wider rows
+    pyr = pyramid.segmentation_inputs(_CfgDeform, p0, l0, limits, rots, impl="ref")
+    feats = np.concatenate([np.ones((p0.shape[0], 1), np.float32), p0[:, 2:3]], 1)
+    labels = rng.integers(0, 20, p0.shape[0]).astype(np.int64)
+    for modulated in (False, True):
+        class C(Config):
+            dataset = 'ScanNet'
+            dataset_task = 'cloud_segmentation'
+            num_classes = 20
+            architecture = ARCH_DEFORM
+            num_kernel_points = 15
+            first_subsampling_dl = 0.04
+            conv_radius = 2.5
+            deform_radius = 6.0
+            KP_extent = 1.2
+            KP_influence = 'linear'
+            aggregation_mode = 'sum'
+            first_features_dim = 16
+            in_features_dim = 2
+            in_points_dim = 3
+            use_batch_norm = True
+            batch_norm_momentum = 0.02
+            deform_fitting_mode = 'point2point'
+            deform_fitting_power = 1.0
+            deform_lr_factor = 0.1
+            repulse_extent = 1.2
+            class_w = []
+        C.modulated = modulated
+        cfg = C()
+        torch.manual_seed(7 + int(modulated))
+        np.random.seed(7 + int(modulated))
+        net = KPFCNN(cfg, list(range(20)), [])
+        with torch.no_grad():
+            for n, p in net.named_parameters():
+                if n.endswith("offset_bias"):
+                    p.normal_(0.0, 0.15)                  # non-zero: every kernel point moves
+        net.train()
+        batch = types.SimpleNamespace(
+            points=[torch.from_numpy(a) for a in pyr['points']], neighbors=[torch.from_numpy(a) for a in pyr['neighbors']],
+            pools=[torch.from_numpy(a) for a in pyr['pools']], upsamples=[torch.from_numpy(a) for a in pyr['upsamples']],
+            lengths=[torch.from_numpy(a) for a in pyr['lengths']], features=torch.from_numpy(feats),
+            labels=torch.from_numpy(labels))
+        sd0 = {k: v.detach().clone().numpy() for k, v in net.state_dict().items()}
+        out = net(batch, cfg)
+        loss = net.loss(out, batch.labels)
+        loss.backward()
+        arrs = dict(points0=p0, lens0=l0, limits=np.array(limits, np.int32), rotations=np.stack(rots, 0),
+                    features=feats, labels=labels, logits=out.detach().numpy(), loss=np.float32(loss.item()),
+                    output_loss=np.float32(net.output_loss.item()), reg_loss=np.float32(net.reg_loss.item()),
+                    modulated=np.int32(modulated))
+        for l in range(5):
+            arrs["neighbors%d" % l] = pyr['neighbors'][l].astype(np.int32)
+            arrs["pools%d" % l] = pyr['pools'][l].astype(np.int32)
+            arrs["upsamples%d" % l] = pyr['upsamples'][l].astype(np.int32)
+            arrs["points%d" % l] = pyr['points'][l]
+        for k, v in sd0.items():
+            arrs["sd/" + k] = v
+        named = dict(net.named_parameters())
+        for k in ("encoder_blocks.0.KPConv.weights", "encoder_blocks.5.KPConv.weights",
+                  "encoder_blocks.5.KPConv.offset_conv.weights", "encoder_blocks.5.KPConv.offset_bias",
+                  "encoder_blocks.6.KPConv.offset_conv.weights", "encoder_blocks.9.KPConv.offset_bias",
+                  "encoder_blocks.9.unary2.mlp.weight", "decoder_blocks.7.mlp.weight", "head_softmax.mlp.weight"):
+            assert named[k].grad is not None and float(named[k].grad.abs().max()) > 0, k
+            arrs["grad/" + k] = named[k].grad.numpy()
+        save("g5b_kpfcnn_deform_mod" if modulated else "g5b_kpfcnn_deform", **arrs)
+
+
 def g6_fusion():
     """2D -> 3D fusion: sklearn ball_tree 3-NN on float64 unprojected pixels (the reference's call,
     ScanNet_sphere_color.py:448-451), group_points as the reference test restates it, and the
@@ -472,7 +566,7 @@ def g9_ply():
          sub_labels=np.squeeze(slb).astype(np.int32))
 
 
-GROUPS = {"g9": g9_ply, "g8": g8_metrics, "g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn,
+GROUPS = {"g9": g9_ply, "g8": g8_metrics, "g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn, "g5b": g5b_kpfcnn_deformable,
           "g6": g6_fusion}
 
 if __name__ == "__main__":

@@ -61,11 +61,33 @@ _SIGNATURES = {
 
 EXPORTS = tuple(_SIGNATURES)
 _lib = None
+_owner_pid = None
+
+FORK_MESSAGE = ("the MV-KPConv HIP library was initialised in process %d and is being called from its forked child %d: "
+                "a HIP context does not survive fork(). Start DataLoader workers with multiprocessing_context='spawn', "
+                "or let the workers emit only stacked points / lengths and build the pyramid "
+                "(datasets.common.segmentation_inputs_sphere) in the main process -- see INTEGRATION.md")
+
+
+def _check_process():
+    """Loud failure instead of a hang when a forked worker (the reference builds the pyramid in
+    num_workers forked DataLoader processes, train_ScanNet_sphere.py:365-377) calls into the library."""
+    pid = os.getpid()
+    if _owner_pid is not None and pid != _owner_pid:
+        raise RuntimeError(FORK_MESSAGE % (_owner_pid, pid))
+    try:
+        import torch
+        if torch.cuda._is_in_bad_fork():
+            raise RuntimeError(FORK_MESSAGE % (os.getppid(), pid))
+    except (ImportError, AttributeError):
+        pass
 
 
 def lib():
-    """The loaded library. Raises (never falls back) when it is absent or has the wrong ABI."""
-    global _lib
+    """The loaded library. Raises (never falls back) when it is absent or has the wrong ABI, or when the
+    caller is a forked child of the process that initialised it."""
+    global _lib, _owner_pid
+    _check_process()
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(
@@ -79,6 +101,7 @@ def lib():
         if l.mvk_abi_version() != ABI_VERSION:
             raise RuntimeError("libmvkpconv.so ABI %d != expected %d; rebuild" % (l.mvk_abi_version(), ABI_VERSION))
         _lib = l
+        _owner_pid = os.getpid()
     return _lib
 
 

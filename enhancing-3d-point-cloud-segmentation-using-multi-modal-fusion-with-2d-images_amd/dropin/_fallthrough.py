@@ -1,0 +1,48 @@
+"""Fall-through for the mirrored packages: names the drop-in does not provide resolve to the
+reference's own modules.
+
+``dropin/`` mirrors only the hot-path modules of the reference's packages (``datasets``, ``utils``,
+``models``, ``kernels``, ``cpp_wrappers``, ``mvpnet``, ``common``). Once it precedes the reference on
+``sys.path`` those package names belong to the drop-in, so every mirrored ``__init__`` appends the
+same-named directories found LATER on ``sys.path`` (and in the current directory, which stands for
+``sys.path[0] == ''`` of a script run from the reference tree) to its ``__path__``: the drop-in's
+modules win, everything else (``datasets.ScanNet_sphere_color``, ``utils.trainer``,
+``utils.mayavi_visu``, ``mvpnet.utils.visualize``, ``common.utils.*`` ...) is imported from the
+reference unchanged. All of the reference's own ``__init__.py`` files of these packages are empty,
+so nothing is lost by not executing them.
+"""
+import os
+import sys
+
+_DROPIN = os.path.dirname(os.path.abspath(__file__))
+
+
+def extend(pkg_path, pkg_name, pkg_file):
+    """pkg_path: the package's ``__path__`` (extended in place); only when the package was imported as a
+    top-level mirror (``datasets``), not as ``<package>.dropin.datasets``."""
+    here = os.path.dirname(os.path.abspath(pkg_file))
+    rel = os.path.relpath(here, _DROPIN)
+    if pkg_name != rel.replace(os.sep, "."):
+        return pkg_path
+    seen = {os.path.realpath(p) for p in pkg_path}
+    for entry in list(sys.path):
+        base = os.path.abspath(entry or os.getcwd())
+        if os.path.realpath(base) == os.path.realpath(_DROPIN):
+            continue
+        cand = os.path.join(base, rel)
+        if os.path.isdir(cand) and os.path.realpath(cand) not in seen:
+            seen.add(os.path.realpath(cand))
+            pkg_path.append(cand)
+    return pkg_path
+
+
+def reference_module_file(rel_py):
+    """Path of the reference's own ``rel_py`` (e.g. 'utils/config.py') further along ``sys.path``, or None."""
+    for entry in list(sys.path):
+        base = os.path.abspath(entry or os.getcwd())
+        if os.path.realpath(base) == os.path.realpath(_DROPIN):
+            continue
+        cand = os.path.join(base, rel_py)
+        if os.path.isfile(cand):
+            return cand
+    return None

@@ -6,6 +6,12 @@ import warnings
 import torch
 from torch import nn
 
+try:    # submodules the fusion path does not use (common.nn.freezer, .functional, ...) fall through to the reference
+    from _fallthrough import extend as _extend
+    __path__ = _extend(list(__path__), __name__, __file__)
+except ImportError:
+    pass
+
 
 def _bn_native(bn, x):
     """BatchNorm with the MIOpen path switched off (PyTorch's native kernels instead): on this ROCm

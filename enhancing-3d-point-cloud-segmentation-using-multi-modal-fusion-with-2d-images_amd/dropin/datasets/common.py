@@ -10,12 +10,16 @@ staged once) and NumPy outputs can be requested with ``as_numpy=True`` for calib
 import numpy as np
 import torch
 
+from torch.utils.data import Dataset
+
 try:
     from .._native import ops
     from ..kernels.kernel_points import create_3D_rotations
+    from ..utils.config import Config
 except ImportError:
     from _native import ops
     from kernels.kernel_points import create_3D_rotations
+    from utils.config import Config
 
 
 def _dev():
@@ -220,3 +224,223 @@ class SphereBatch:
             if t is not None:
                 setattr(self, name, t.to(device))
         return self
+
+
+# ---------------------------------------------------------------- batch containers (a17)
+
+def _tensor(a):
+    """NumPy array (what the reference's collate hands over) or tensor (CPU or already in HBM) -> tensor."""
+    return a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))
+
+
+def _pin(t):
+    return t.pin_memory() if (not t.is_cuda and not t.is_pinned() and torch.cuda.is_available()) else t
+
+
+class _FlatListBatch:
+    """Shared part of the two reference containers: the flat ``input_list`` of one collated batch is
+    ``points[L] + neighbors[L] + pools[L] + upsamples[L] + lengths[L] + tail`` (common.py:897-898 /
+    :648-650 plus what potential_item appends, ScanNet_sphere_color.py:812), L = (len - TAIL) // 5."""
+    TAIL = ()             # attribute names of the tail, in list order
+    PLAIN = ()            # tail entries that stay Python objects (knn_list)
+
+    def __init__(self, input_list):
+        input_list = input_list[0]                                  # drop the DataLoader's batch dimension
+        L = (len(input_list) - len(self.TAIL)) // 5
+        if L < 1 or 5 * L + len(self.TAIL) != len(input_list):
+            raise ValueError("batch list of %d entries is not 5*L+%d" % (len(input_list), len(self.TAIL)))
+        for j, name in enumerate(('points', 'neighbors', 'pools', 'upsamples', 'lengths')):
+            setattr(self, name, [_tensor(a) for a in input_list[j * L:(j + 1) * L]])
+        for j, name in enumerate(self.TAIL):
+            a = input_list[5 * L + j]
+            setattr(self, name, a if name in self.PLAIN else _tensor(a))
+
+    def _map(self, fn):
+        for name in ('points', 'neighbors', 'pools', 'upsamples', 'lengths'):
+            setattr(self, name, [fn(t) for t in getattr(self, name)])
+        for name in self.TAIL:
+            if name not in self.PLAIN:
+                setattr(self, name, fn(getattr(self, name)))
+        return self
+
+    def pin_memory(self):
+        """Manual pinning (ScanNet_sphere_color.py:1574-1597); tensors that already live in HBM stay there."""
+        return self._map(_pin)
+
+    def to(self, device):
+        return self._map(lambda t: t.to(device, non_blocking=True))
+
+    # ScanNet_sphere_color.py:1623-1690
+    def unstack_points(self, layer=None):
+        return self.unstack_elements('points', layer)
+
+    def unstack_neighbors(self, layer=None):
+        return self.unstack_elements('neighbors', layer)
+
+    def unstack_pools(self, layer=None):
+        return self.unstack_elements('pools', layer)
+
+    def unstack_elements(self, element_name, layer=None, to_numpy=True):
+        """Per-cloud pieces of one stacked list; neighbour / pool indices are rebased to their own cloud and
+        shadow entries become -1 (on copies: the reference edits the batch's own tensors in place)."""
+        if element_name not in ('points', 'neighbors', 'pools'):
+            raise ValueError('Unknown element name: {:s}'.format(element_name))
+        elements = self.pools[:-1] if element_name == 'pools' else getattr(self, element_name)
+        all_p_list = []
+        for layer_i, layer_elems in enumerate(elements):
+            if layer is None or layer == layer_i:
+                i0, p_list = 0, []
+                lengths = self.lengths[layer_i + 1] if element_name == 'pools' else self.lengths[layer_i]
+                for b_i, length in enumerate(lengths):
+                    length = int(length)
+                    elem = layer_elems[i0:i0 + length]
+                    if element_name == 'neighbors':
+                        elem = elem.clone()
+                        elem[elem >= self.points[layer_i].shape[0]] = -1
+                        elem[elem >= 0] -= i0
+                    elif element_name == 'pools':
+                        elem = elem.clone()
+                        elem[elem >= self.points[layer_i].shape[0]] = -1
+                        elem[elem >= 0] -= int(torch.sum(self.lengths[layer_i][:b_i]))
+                    i0 += length
+                    p_list.append(elem.cpu().numpy() if to_numpy else elem)
+                if layer == layer_i:
+                    return p_list
+                all_p_list.append(p_list)
+        return all_p_list
+
+
+class ScanNetCustomBatch(_FlatListBatch):
+    """Fusion batch (datasets/ScanNet_sphere_color.py:1525-1619): ``ScanNetCustomBatch(input_list)`` with
+    L = (len - 11) // 5; accepts the reference's NumPy arrays as well as tensors already in HBM."""
+    TAIL = ('feat_aggre_points', 'image_xyz', 'images', 'labels', 'scales', 'rots', 'cloud_inds', 'center_inds',
+            'input_inds', 'knn_list', 'feature_3d')
+    PLAIN = ('knn_list',)
+    features = None
+
+
+class ScanNetBaselineCustomBatch(_FlatListBatch):
+    """Baseline batch (datasets/ScanNet_baseline_color.py:1198-1272): L = (len - 7) // 5."""
+    TAIL = ('features', 'labels', 'scales', 'rots', 'cloud_inds', 'center_inds', 'input_inds')
+    feature_3d = feat_aggre_points = image_xyz = images = knn_list = None
+
+
+def ScanNetCollate(batch_data):
+    """collate_fn of the loaders (ScanNet_sphere_color.py:1693-1694)."""
+    return ScanNetCustomBatch(batch_data)
+
+
+# ---------------------------------------------------------------- dataset parent class (common.py:205-900)
+
+class PointCloudDataset(Dataset):
+    """Parent class of the reference's datasets (datasets/common.py:205-900) with the pyramid builders on
+    the HIP kernels. The ``*_inputs`` methods return the reference's flat list; arrays are NumPy (as the
+    reference's) unless ``self.device_resident`` is set, in which case the per-layer tensors stay in HBM
+    (the batch containers above take either)."""
+
+    device_resident = False
+
+    def __init__(self, name):
+        self.name = name
+        self.path = ''
+        self.label_to_names = {}
+        self.num_classes = 0
+        self.label_values = np.zeros((0,), dtype=np.int32)
+        self.label_names = []
+        self.label_to_idx = {}
+        self.name_to_label = {}
+        self.config = Config()
+        self.neighborhood_limits = []
+
+    def __len__(self):
+        return 0
+
+    def __getitem__(self, idx):
+        return 0
+
+    def init_labels(self):
+        """common.py:239-250 (the ScanNet benchmark's 21 names are hard-wired there)."""
+        self.num_classes = len(self.label_to_names)
+        self.label_values = np.sort([k for k, v in self.label_to_names.items()])
+        self.label_names = ['unclassified', 'wall', 'floor', 'cabinet', 'bed', 'chair', 'sofa', 'table', 'door', 'window',
+                            'bookshelf', 'picture', 'counter', 'desk', 'curtain', 'refridgerator', 'showercurtain', 'toilet',
+                            'sink', 'bathtub', 'otherfurniture']
+        self.label_to_idx = {l: i for i, l in enumerate(self.label_values)}
+
+    def _draw_augmentation(self, n, dim):
+        """The draws of common.py:259-308 in the reference's order from the global NumPy RNG: rotation
+        (vertical: 1 draw, all: 3), scale (anisotropic: dim draws; isotropic: 1 -- the reference computes
+        ``rand*(max-min) - min`` there, kept), symmetries (dim draws), noise (n*dim normals)."""
+        c = self.config
+        R = np.eye(dim)
+        if dim == 3:
+            if c.augment_rotation == 'vertical':
+                theta = np.random.rand() * 2 * np.pi
+                cs, sn = np.cos(theta), np.sin(theta)
+                R = np.array([[cs, -sn, 0], [sn, cs, 0], [0, 0, 1]], dtype=np.float32)
+            elif c.augment_rotation == 'all':
+                theta = np.random.rand() * 2 * np.pi
+                phi = (np.random.rand() - 0.5) * np.pi
+                u = np.array([np.cos(theta) * np.cos(phi), np.sin(theta) * np.cos(phi), np.sin(phi)])
+                alpha = np.random.rand() * 2 * np.pi
+                R = create_3D_rotations(np.reshape(u, (1, -1)), np.reshape(alpha, (1, -1)))[0]
+        R = R.astype(np.float32)
+        lo, hi = c.augment_scale_min, c.augment_scale_max
+        if c.augment_scale_anisotropic:
+            scale = np.random.rand(dim) * (hi - lo) + lo
+        else:
+            scale = np.random.rand() * (hi - lo) - lo
+        sym = np.array(c.augment_symmetries).astype(np.int32)
+        sym *= np.random.randint(2, size=dim)
+        scale = (scale * (1 - sym * 2)).astype(np.float32)
+        noise = (np.random.randn(n, dim) * c.augment_noise).astype(np.float32)
+        return R, scale, noise
+
+    @staticmethod
+    def _augment_normals(normals, R, scale):
+        ns = scale[[1, 2, 0]] * scale[[2, 0, 1]]
+        an = np.dot(normals, R) * ns
+        return an * (1 / (np.linalg.norm(an, axis=1, keepdims=True) + 1e-6))
+
+    def augmentation_transform(self, points, normals=None, verbose=False):
+        """common.py:252-329."""
+        R, scale, noise = self._draw_augmentation(points.shape[0], points.shape[1])
+        aug = np.sum(np.expand_dims(points, 2) * R, axis=1) * scale + noise
+        if normals is None:
+            return aug, scale, R
+        return aug, self._augment_normals(normals, R, scale), scale, R
+
+    def augmentation_transform_new(self, points, image_xyz, normals=None):
+        """common.py:331-409: the same transform applied to the unprojected pixels (without the noise)."""
+        R, scale, noise = self._draw_augmentation(points.shape[0], points.shape[1])
+        aug = np.sum(np.expand_dims(points, 2) * R, axis=1) * scale + noise
+        shape = image_xyz.shape
+        aug_xyz = (np.sum(np.expand_dims(image_xyz.reshape([-1, 3]), 2) * R, axis=1) * scale).reshape(shape)
+        if normals is None:
+            return aug, scale, R, aug_xyz
+        return aug, self._augment_normals(normals, R, scale), scale, R, aug_xyz
+
+    def big_neighborhood_filter(self, neighbors, layer):
+        """common.py:411-421."""
+        if len(self.neighborhood_limits) > 0:
+            return neighbors[:, :self.neighborhood_limits[layer]]
+        return neighbors
+
+    def _pyramid_list(self, stacked_points, stack_lengths):
+        pyr = segmentation_inputs_sphere(self.config, stacked_points, stack_lengths,
+                                         self.neighborhood_limits if len(self.neighborhood_limits) > 0 else None,
+                                         torch.int64)
+        groups = [pyr['points'], pyr['neighbors'], pyr['pools'], pyr['upsamples'], pyr['lengths']]
+        if not self.device_resident:
+            groups = [[t.cpu().numpy() for t in g] for g in groups]
+        return [t for g in groups for t in g]
+
+    def segmentation_inputs(self, stacked_points, stacked_features, labels, stack_lengths):
+        """common.py:536-650: ``points + neighbors + pools + upsamples + lengths + [features, labels]``."""
+        return self._pyramid_list(stacked_points, stack_lengths) + [stacked_features, labels]
+
+    def segmentation_inputs_sphere(self, stacked_points, stacked_image_xyz, stacked_images, stacked_feature_points,
+                                   labels, stack_lengths):
+        """common.py:779-900: ``... + [feature points, image_xyz, images, labels]``."""
+        return self._pyramid_list(stacked_points, stack_lengths) + [stacked_feature_points, stacked_image_xyz,
+                                                                     stacked_images, labels]

@@ -18,12 +18,16 @@ except ImportError:
 
 def build_2d_branch(net, config):
     """FeatureAggregation(64) + frozen UNetResNet34 in eval mode (architectures_sphere.py:205-237).
-    The 2D checkpoint config.path_2D is loaded when it exists; without it (synthetic benchmarks:
-    no checkpoint can be downloaded) the encoder keeps its random initialisation."""
+    The 2D checkpoint config.path_2D is loaded like the reference does (:228-230) and a missing file fails
+    as loudly as its torch.load; only an EMPTY path (synthetic benchmarks: no checkpoint can be
+    downloaded) keeps the random initialisation."""
     net.feat_aggreg = FeatureAggregation(64)
     net.net_2d = UNetResNet34(20, p=0.5, pretrained=True)
     path = getattr(config, 'path_2D', '')
-    if path and os.path.exists(path):
+    if path:
+        if not os.path.exists(path):
+            raise FileNotFoundError("config.path_2D = %r does not exist (the frozen 2D encoder would silently stay "
+                                    "randomly initialised)" % path)
         checkpoint = torch.load(path, map_location=torch.device("cpu"))
         net.net_2d.load_state_dict(checkpoint['model'])
     for _, params in net.net_2d.named_parameters():

@@ -4,6 +4,12 @@ txt (de)serialiser, dataset paths and visualisation switches are out of scope.""
 import numpy as np
 
 
+class bcolors:
+    """ANSI escape codes the reference's console messages use (utils/config.py:24-32)."""
+    HEADER, OKBLUE, OKGREEN, WARNING, FAIL = '\033[95m', '\033[94m', '\033[92m', '\033[93m', '\033[91m'
+    ENDC, BOLD, UNDERLINE = '\033[0m', '\033[1m', '\033[4m'
+
+
 class Config:
     # input / task
     dataset = ''
@@ -88,3 +94,29 @@ class Config:
             layer_blocks = []
             if 'global' in block or 'upsample' in block:
                 break
+
+
+def _adopt_reference_config():
+    """When dropin/ shadows a reference tree (INTEGRATION.md route 1), ``utils.config`` must stay the
+    reference's own module -- dataset paths, save() / load() of parameters.txt, every field of its train
+    scripts -- because nothing in it is on the hot path. The class above is only the stand-alone bag the
+    synthetic harness uses when no reference is present."""
+    if __name__ != "utils.config":
+        return
+    try:
+        from _fallthrough import reference_module_file
+    except ImportError:
+        return
+    path = reference_module_file("utils/config.py")
+    if path is None:
+        return
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("utils._reference_config", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    for k, v in vars(mod).items():
+        if not k.startswith("__"):
+            globals()[k] = v
+
+
+_adopt_reference_config()

@@ -362,3 +362,157 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
                         env=env2, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=120)
     assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
+
+
+# ---------------------------------------------------------------- drop-in boundary (INTEGRATION.md route 1)
+
+_STUB_TREE = {
+    "datasets/__init__.py": "",
+    "datasets/ScanNet_sphere_color.py": (
+        "from datasets.common import PointCloudDataset, grid_subsampling\n"
+        "from utils.mayavi_visu import *\n"
+        "from utils.config import bcolors, Config\n"
+        "class StubDataset(PointCloudDataset):\n"
+        "    def __init__(self):\n"
+        "        PointCloudDataset.__init__(self, 'stub')\n"
+        "MARK = 'stub ScanNet_sphere_color'\n"),
+    "datasets/common.py": "raise ImportError('the reference datasets.common must be shadowed by the drop-in')\n",
+    "utils/__init__.py": "",
+    "utils/config.py": ("class bcolors:\n    OKBLUE = 'b'\n    ENDC = 'e'\n"
+                        "class Config:\n    architecture = []\n    stub_field = 17\n    def save(self):\n        return 'saved'\n"),
+    "utils/mayavi_visu.py": "def show_ModelNet_models(*a):\n    return 'visu'\n",
+    "utils/trainer.py": ("from utils.ply import read_ply, write_ply\nfrom utils.metrics import IoU_from_confusions, fast_confusion\n"
+                         "from utils.config import Config\nfrom mvpnet.utils.visualize import *\n"
+                         "class ModelTrainer:\n    pass\n"),
+    "models/__init__.py": "",
+    "models/blocks.py": "raise ImportError('the reference models.blocks must be shadowed by the drop-in')\n",
+    "kernels/__init__.py": "",
+    "cpp_wrappers/__init__.py": "",
+}
+_STUB_ROOT = {
+    "mvpnet/__init__.py": "",
+    "mvpnet/utils/__init__.py": "",
+    "mvpnet/utils/visualize.py": "def visualize_labels(*a):\n    return 'labels'\n",
+    "mvpnet/models/__init__.py": "",
+    "mvpnet/models/mvpnet_2d.py": "MARK = 'stub mvpnet_2d'\n",
+    "common/__init__.py": "",
+    "common/utils/__init__.py": "",
+    "common/utils/checkpoint.py": "MARK = 'stub checkpoint'\n",
+}
+
+
+def test_dropin_first_on_sys_path_still_reaches_the_reference_modules(tmp_path):
+    """INTEGRATION.md route 1 with a stub 'reference' tree (own text) behind dropin/ on sys.path: the
+    modules the drop-in mirrors win, every other submodule of the same packages -- datasets.ScanNet_sphere_color,
+    utils.trainer, utils.mayavi_visu, mvpnet.utils.visualize, common.utils.* -- still imports, and
+    utils.config stays the reference's own (its fields / save())."""
+    kp, root = tmp_path / "KPConv-PyTorch", tmp_path
+    for base, tree in ((kp, _STUB_TREE), (root, _STUB_ROOT)):
+        for rel, text in tree.items():
+            f = base / rel
+            f.parent.mkdir(parents=True, exist_ok=True)
+            f.write_text(text)
+    prog = (
+        "import sys\n"
+        "sys.path.insert(0, %r); sys.path.append(%r)\n"                 # what a user adds: dropin first, repo root for mvpnet/common
+        "import datasets.ScanNet_sphere_color as S, utils.trainer as T, utils.config as Cf\n"
+        "import datasets.common as DC, models.blocks as MB, mvpnet.utils.visualize as V, common.utils.checkpoint as CK\n"
+        "import mvpnet.models.mvpnet_2d as M2, mvpnet.models.mvpnet_3d as M3, mvpnet.ops.group_points as GP\n"
+        "from common.nn import SharedMLP\n"
+        "import cpp_wrappers.cpp_subsampling.grid_subsampling as G, cpp_wrappers.cpp_neighbors.radius_neighbors as R\n"
+        "assert S.MARK.startswith('stub') and CK.MARK.startswith('stub') and M2.MARK.startswith('stub')\n"
+        "assert 'dropin' in DC.__file__ and 'dropin' in MB.__file__ and 'dropin' in M3.__file__ and 'dropin' in G.__file__\n"
+        "assert hasattr(MB, 'KPConv') and hasattr(M3, 'FeatureAggregation') and hasattr(DC, 'ScanNetCustomBatch')\n"
+        "assert Cf.Config.stub_field == 17 and Cf.Config().save() == 'saved' and Cf.bcolors.OKBLUE == 'b'\n"
+        "d = S.StubDataset(); assert d.name == 'stub' and d.config.stub_field == 17\n"
+        "assert T.visualize_labels() == 'labels' and S.show_ModelNet_models() == 'visu'\n"
+        "print('FALLTHROUGH OK')\n") % (os.path.join(ROOT, PKG, "dropin"), str(root))
+    r = subprocess.run([sys.executable, "-c", prog], cwd=str(kp), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=300)
+    assert r.returncode == 0 and "FALLTHROUGH OK" in r.stdout, r.stderr[-3000:]
+
+
+def test_scannet_custom_batch_round_trips_the_flat_list():
+    """ScanNetCustomBatch(input_list): L = (len - 11) // 5 (ScanNet_sphere_color.py:1535), dtypes kept,
+    pin_memory() / to() return self; the baseline variant with L = (len - 7) // 5."""
+    common = importlib.import_module(PKG + ".dropin.datasets.common")
+    rng = np.random.default_rng(0)
+    L, n = 3, [50, 20, 8]
+    pts = [rng.random((m, 3)).astype(np.float32) for m in n]
+    nb = [np.concatenate([rng.integers(0, m - 5, (m - 5, 6)), rng.integers(m - 5, m + 1, (5, 6))]).astype(np.int64) for m in n]
+    pools = [rng.integers(0, n[i] + 1, (n[i + 1], 5)).astype(np.int64) for i in range(L - 1)] + [np.zeros((0, 1), np.int64)]
+    ups = [rng.integers(0, n[i + 1] + 1, (n[i], 4)).astype(np.int64) for i in range(L - 1)] + [np.zeros((0, 1), np.int64)]
+    lens = [np.array([m - 5, 5], np.int32) for m in n]
+    tail = [rng.random((1, 50, 3)).astype(np.float32), rng.random((2, 3, 4, 5, 3)).astype(np.float32),
+            rng.random((2, 3, 3, 4, 5)).astype(np.float32), rng.integers(0, 20, 50).astype(np.int64),
+            np.ones((2, 3), np.float32), np.tile(np.eye(3, dtype=np.float32), (2, 1, 1)), np.array([0, 1], np.int32),
+            np.array([3, 4], np.int32), np.arange(50, dtype=np.int32), [np.zeros((45, 3), np.int64), np.zeros((5, 3), np.int64)],
+            rng.random((50, 4)).astype(np.float32)]
+    flat = pts + nb + pools + ups + lens + tail
+    assert len(flat) == 5 * L + 11
+    b = common.ScanNetCustomBatch([flat])
+    assert len(b.points) == len(b.neighbors) == len(b.pools) == len(b.upsamples) == len(b.lengths) == L
+    assert b.points[1].dtype == torch.float32 and b.neighbors[0].dtype == torch.int64 and b.lengths[0].dtype == torch.int32
+    assert b.labels.dtype == torch.int64 and torch.equal(b.feature_3d, torch.from_numpy(tail[-1]))
+    assert b.knn_list is tail[9] and np.array_equal(b.images.numpy(), tail[2])
+    assert b.pin_memory() is b and b.to("cpu") is b
+    back = b.points + b.neighbors + b.pools + b.upsamples + b.lengths
+    assert all(np.array_equal(t.numpy(), a) for t, a in zip(back, flat[:5 * L]))
+    un = b.unstack_neighbors(0)
+    assert len(un) == 2 and un[0].shape == (45, 6) and un[1].max() < 5 and un[1].min() >= -1
+    with pytest.raises(ValueError):
+        common.ScanNetCustomBatch([flat[:-1]])
+    base = common.ScanNetBaselineCustomBatch([flat[:5 * L] + [tail[-1], tail[3], tail[4], tail[5], tail[6], tail[7], tail[8]]])
+    assert len(base.points) == L and base.features.shape == (50, 4) and base.input_inds.dtype == torch.int32
+
+
+def test_point_cloud_dataset_augmentation_matches_the_reference_draw_order():
+    """PointCloudDataset.augmentation_transform(_new): same RNG consumption and arithmetic as the cited
+    lines (common.py:252-409), checked against a literal replay with the same seed."""
+    common = importlib.import_module(PKG + ".dropin.datasets.common")
+    ds = common.PointCloudDataset("x")
+    ds.config.augment_rotation, ds.config.augment_scale_anisotropic = 'vertical', True
+    ds.config.augment_symmetries, ds.config.augment_noise = [True, False, False], 0.001
+    ds.config.augment_scale_min, ds.config.augment_scale_max = 0.8, 1.2
+    pts = np.random.default_rng(1).random((40, 3)).astype(np.float32)
+    xyz = np.random.default_rng(2).random((2, 3, 4, 3)).astype(np.float32)
+    np.random.seed(7)
+    a, scale, R, axyz = ds.augmentation_transform_new(pts, xyz)
+    np.random.seed(7)
+    theta = np.random.rand() * 2 * np.pi
+    c, s = np.cos(theta), np.sin(theta)
+    R0 = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]], dtype=np.float32)
+    sc = np.random.rand(3) * 0.4 + 0.8
+    sym = np.array([1, 0, 0], np.int32) * np.random.randint(2, size=3)
+    sc = (sc * (1 - sym * 2)).astype(np.float32)
+    noise = (np.random.randn(40, 3) * 0.001).astype(np.float32)
+    assert np.array_equal(R, R0) and np.array_equal(scale, sc)
+    assert np.array_equal(a, np.sum(np.expand_dims(pts, 2) * R0, axis=1) * sc + noise)
+    assert np.array_equal(axyz, (np.sum(np.expand_dims(xyz.reshape(-1, 3), 2) * R0, axis=1) * sc).reshape(xyz.shape))
+    assert ds.big_neighborhood_filter(np.zeros((4, 9)), 0).shape == (4, 9)
+    ds.neighborhood_limits = [5]
+    assert ds.big_neighborhood_filter(np.zeros((4, 9)), 0).shape == (4, 5)
+
+
+def _forked_child_calls_lib(q):
+    lib_mod = importlib.import_module(PKG + "._lib")
+    try:
+        lib_mod.lib()
+        q.put("no error")
+    except RuntimeError as e:
+        q.put(str(e))
+
+
+def test_forked_child_fails_loudly():
+    """A forked child of the process that loaded the HIP library must get a RuntimeError with the
+    INTEGRATION note (spawn / main-process pyramid), never a hang inside HIP."""
+    import multiprocessing as mp
+    lib_mod = importlib.import_module(PKG + "._lib")
+    lib_mod.lib()
+    ctx = mp.get_context("fork")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forked_child_calls_lib, args=(q,))
+    p.start()
+    msg = q.get(timeout=60)
+    p.join(60)
+    assert "forked child" in msg and "spawn" in msg and "INTEGRATION.md" in msg

@@ -26,6 +26,7 @@ except ImportError:  # dropin/ put on sys.path directly
 
 
 _FUSE_ADD = os.environ.get("MVK_FUSE_ADD", "1") == "1"      # development switches for A/B timing
+_HIP_BN = os.environ.get("MVK_HIP_BN", "0") == "1"
 _MFMA_LINEAR = os.environ.get("MVK_MFMA_LINEAR", "1") == "1"
 
 
@@ -187,6 +188,8 @@ class BatchNormBlock(nn.Module):
         residual block, added before that activation (blocks.py:649), in the same launch when masked."""
         if self.use_bn:
             n_valid = ops.row_count_for(x.shape[0]) if self.training else None
+            if n_valid is None and _HIP_BN and self.training and x.is_cuda:
+                n_valid = ops.full_count(x.shape[0], x.device)
             if n_valid is not None:
                 # capacity-padded level (hipGraph replay): statistics over the valid rows only
                 return ops.bn_lrelu(x, n_valid, self.batch_norm, 1.0 if slope is None else slope, addend)

@@ -347,11 +347,11 @@ def g5b_kpfcnn_deformable():
     from utils.config import Config
 
     rng = np.random.default_rng(515)
-    raw = room_cloud(rng, 90000, 1.15)
+    raw = room_cloud(rng, 40000, 0.8)
     p0, l0 = cport.subsample_batch(raw, [raw.shape[0]], dl=0.04, impl="ref")
     np.random.seed(56)
     rots = [pyramid.draw_rotations(1) for _ in range(4)]
-    limits = [28, 30, 60, 48, 20]          # deformable levels 2.. use deform_radius: wider rows
+    limits = [28, 30, 60, 40, 12]          # deformable levels 2.. use deform_radius: wider rows
     pyr = pyramid.segmentation_inputs(_CfgDeform, p0, l0, limits, rots, impl="ref")
     feats = np.concatenate([np.ones((p0.shape[0], 1), np.float32), p0[:, 2:3]], 1)
     labels = rng.integers(0, 20, p0.shape[0]).astype(np.int64)
@@ -380,19 +380,39 @@ def g5b_kpfcnn_deformable():
             class_w = []
         C.modulated = modulated
         cfg = C()
-        torch.manual_seed(7 + int(modulated))
-        np.random.seed(7 + int(modulated))
-        net = KPFCNN(cfg, list(range(20)), [])
-        with torch.no_grad():
-            for n, p in net.named_parameters():
-                if n.endswith("offset_bias"):
-                    p.normal_(0.0, 0.15)                  # non-zero: every kernel point moves
-        net.train()
         batch = types.SimpleNamespace(
             points=[torch.from_numpy(a) for a in pyr['points']], neighbors=[torch.from_numpy(a) for a in pyr['neighbors']],
             pools=[torch.from_numpy(a) for a in pyr['pools']], upsamples=[torch.from_numpy(a) for a in pyr['upsamples']],
             lengths=[torch.from_numpy(a) for a in pyr['lengths']], features=torch.from_numpy(feats),
             labels=torch.from_numpy(labels))
+        # A LeakyReLU input within float32 rounding of zero makes the GRADIENT discontinuous: an implementation
+        # whose rounding differs in the last bits lands on the other side of the kink and the end-to-end
+        # gradients move by percents (train-mode BatchNorm spreads one flipped element over a whole level).
+        # Like the tie-free neighbour fixtures, the weights are drawn so that every activation input keeps a
+        # margin of 5e-6 of its tensor's scale -- the comparison is then of a locally smooth function.
+        for seed in range(7 + 100 * int(modulated), 7 + 100 * int(modulated) + 300):
+            torch.manual_seed(seed)
+            np.random.seed(seed)
+            net = KPFCNN(cfg, list(range(20)), [])
+            with torch.no_grad():
+                for n, p in net.named_parameters():
+                    if n.endswith("offset_bias"):
+                        p.normal_(0.0, 0.15)                  # non-zero: every kernel point moves
+            net.train()
+            margins = []
+            hooks = [m.register_forward_hook(lambda m, i, o: margins.append(float(i[0].abs().min() / i[0].abs().max())))
+                     for m in net.modules() if isinstance(m, torch.nn.LeakyReLU)]
+            sd0 = {k: v.detach().clone().numpy() for k, v in net.state_dict().items()}
+            with torch.no_grad():
+                net(batch, cfg)
+            for h in hooks:
+                h.remove()
+            print("seed", seed, "LeakyReLU calls", len(margins), "min margin %.2e" % min(margins))
+            if min(margins) > 5e-6:
+                break
+        else:
+            raise RuntimeError("no kink-free seed found")
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd0.items()})
         sd0 = {k: v.detach().clone().numpy() for k, v in net.state_dict().items()}
         out = net(batch, cfg)
         loss = net.loss(out, batch.labels)
@@ -400,7 +420,7 @@ def g5b_kpfcnn_deformable():
         arrs = dict(points0=p0, lens0=l0, limits=np.array(limits, np.int32), rotations=np.stack(rots, 0),
                     features=feats, labels=labels, logits=out.detach().numpy(), loss=np.float32(loss.item()),
                     output_loss=np.float32(net.output_loss.item()), reg_loss=np.float32(net.reg_loss.item()),
-                    modulated=np.int32(modulated))
+                    modulated=np.int32(modulated), seed=np.int32(seed), min_kink_margin=np.float32(min(margins)))
         for l in range(5):
             arrs["neighbors%d" % l] = pyr['neighbors'][l].astype(np.int32)
             arrs["pools%d" % l] = pyr['pools'][l].astype(np.int32)

@@ -138,9 +138,14 @@ def main():
     params = [p for p in net.parameters() if p.requires_grad]
     deform = [p for n, p in net.named_parameters() if p.requires_grad and "offset" in n]
     other = [p for n, p in net.named_parameters() if p.requires_grad and "offset" not in n]
-    opt = torch.optim.SGD([{"params": other}, {"params": deform, "lr": cfg.learning_rate * cfg.deform_lr_factor}],
-                          lr=cfg.learning_rate, momentum=cfg.momentum, weight_decay=cfg.weight_decay,
-                          fused=os.environ.get("MVK_FUSED_SGD", "1") == "1")  # trainer.py:72-79; fused = one multi-tensor kernel per step
+    groups = [{"params": other}, {"params": deform, "lr": cfg.learning_rate * cfg.deform_lr_factor}]   # trainer.py:72-79
+    if os.environ.get("MVK_HIP_SGD", "1") == "1":
+        # clip_grad_value_ + SGD (momentum, weight decay) of trainer.py:190-195 as ONE launch over all tensors
+        opt = mvkpconv.sub("optim").FusedClipSGD(groups, lr=cfg.learning_rate, momentum=cfg.momentum,
+                                                 weight_decay=cfg.weight_decay, clip_value=cfg.grad_clip_norm)
+    else:
+        opt = torch.optim.SGD(groups, lr=cfg.learning_rate, momentum=cfg.momentum, weight_decay=cfg.weight_decay,
+                              fused=os.environ.get("MVK_FUSED_SGD", "1") == "1")
     reducer = mvkpconv.sub("dp").FlatAllReduce(params, world) if (world > 1 or force_dp) else None
 
     # ---- synthetic raw inputs, staged in HBM once (data-parallel: different spheres per rank)
@@ -157,8 +162,7 @@ def main():
         loss.backward()
         if reducer is not None:
             reducer()
-        torch.nn.utils.clip_grad_value_(params, cfg.grad_clip_norm)     # trainer.py:193
-        opt.step()
+        clip_and_step(params, opt, cfg)
         return loss
 
     def eager_step():
@@ -386,8 +390,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             join_encoder()
         graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph_b, capture_error_mode="thread_local"):
-            torch.nn.utils.clip_grad_value_(params, cfg.grad_clip_norm)
-            opt.step()
+            clip_and_step(params, opt, cfg)
 
         grads = [p.grad for p in reducer.params if p.grad is not None]
 
@@ -567,9 +570,17 @@ def net_step_captured(net, static, cfg, params, opt, reducer):
     loss.backward()
     if reducer is not None:
         reducer()
-    torch.nn.utils.clip_grad_value_(params, cfg.grad_clip_norm)
-    opt.step()
+    clip_and_step(params, opt, cfg)
     return loss
+
+
+def clip_and_step(params, opt, cfg):
+    """utils/trainer.py:190-195: clip_grad_value_(grad_clip_norm) then optimizer.step()."""
+    if hasattr(opt, "clip"):            # FusedClipSGD clips inside its single launch
+        opt.step()
+    else:
+        torch.nn.utils.clip_grad_value_(params, cfg.grad_clip_norm)
+        opt.step()
 
 
 def dry_run(args, world, rank):

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvkpconv.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -22,9 +22,13 @@ _SIGNATURES = {
     "mvk_kpconv_scatter_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i, _f, _i, _i,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvk_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
+    "mvk_gemm_f32_plan": (C.c_int, [_i64, _i64, _i64, _i, _i, _vp, _vp]),
+    "mvk_gemm_f32_ex": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mvk_gemm_f16": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i64, _i64, _i64, _i, _i, _i, _vp]),
+    "mvk_sgd_chunk_elems": (C.c_int, []),
+    "mvk_sgd_clip_step": (C.c_int, [_vp, _vp, _i64, _f, _f, _i, _vp]),
     "mvk_bn_lrelu_fwd": (C.c_int, [_vp, _vp, _i64, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                  _vp]),
+                                  _vp, _i, _vp]),
     "mvk_bn_lrelu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvk_add_lrelu_fwd": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp]),
     "mvk_add_lrelu_bwd": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp]),

@@ -21,6 +21,7 @@ SOURCES = [
     ("gemm16.hip", []),
     ("pool.hip", []),
     ("bn.hip", []),
+    ("optim.hip", []),
     ("batchpad.hip", []),
     ("subsample.hip", ["-ffp-contract=off"]),
     ("neighbors.hip", ["-ffp-contract=off"]),

@@ -77,6 +77,47 @@ __device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ part, 
   return true;
 }
 
+// The same for partials written by the GEMM epilogue (csrc/gemm.hip): per row block of `blk` rows the plain
+// column sum and the sum of squares about the block's own mean. Two fixed-order passes: total -> mean, then
+// M2 = sum_b [ M2_b + n_b (mean_b - mean)^2 ]. Returns (mean, M2) to the lanes with part == 0.
+__device__ __forceinline__ bool bn_sum_partials_m2(const float* __restrict__ part, int R, int blk, int n, int D, float* mean,
+                                                   float* m2) {
+  __shared__ float q1[16][64], qm[64];
+  const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int nblk = (R + blk - 1) / blk;
+  float x = 0.f;
+  if (c < D)
+    for (int i = pr; i < nblk && i * blk < n; i += 16) x += part[((int64_t)i * 2) * D + c];
+  q1[pr][cl] = x;
+  __syncthreads();
+  if (pr == 0) {
+    x = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x += q1[i][cl];
+    qm[cl] = n > 0 ? x / (float)n : 0.f;
+  }
+  __syncthreads();
+  const float mu = qm[cl];
+  float y = 0.f;
+  if (c < D)
+    for (int i = pr; i < nblk && i * blk < n; i += 16) {
+      const int ni = min(blk, n - i * blk);
+      const float d = part[((int64_t)i * 2) * D + c] / (float)ni - mu;
+      y += part[((int64_t)i * 2 + 1) * D + c] + (float)ni * d * d;
+    }
+  __syncthreads();
+  q1[pr][cl] = y;
+  __syncthreads();
+  if (pr != 0 || c >= D) return false;
+  y = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) y += q1[i][cl];
+  *mean = mu;
+  *m2 = y;
+  return true;
+}
+
 // grid ceil(D/64), block 1024
 __global__ __launch_bounds__(1024) void bn_stats_finish(const float* __restrict__ x, const int* __restrict__ n_valid,
                                                         int R, int D, const float* __restrict__ part, float eps,
@@ -206,16 +247,23 @@ __global__ __launch_bounds__(1024) void bn_finish_apply(const float* __restrict_
                                                         float slope, float* __restrict__ mean, float* __restrict__ invstd,
                                                         float* __restrict__ running_mean, float* __restrict__ running_var,
                                                         long long* __restrict__ nbt, const float* __restrict__ addend,
-                                                        float* __restrict__ y) {
+                                                        float* __restrict__ y, int ext_rows) {
+  // ext_rows == 0: `part` holds the shifted sums of bn_stats_partial; > 0: the (sum, centred M2) partials of the
+  // GEMM epilogue, one slot per ext_rows rows
   __shared__ float smu[64], sis[64];
   const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   const int n = min(*n_valid, R);
   float p1, p2;
-  const bool owner = bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, &p1, &p2);   // lanes pr == 0, c < D
+  const bool owner = ext_rows > 0 ? bn_sum_partials_m2(part, R, ext_rows, n, D, &p1, &p2)
+                                  : bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, &p1, &p2);   // lanes pr == 0, c < D
   if (owner) {
     float mu = 0.f, is = 0.f, var = 0.f;
-    if (n > 0) {
+    if (n > 0 && ext_rows > 0) {
+      mu = p1;
+      var = p2 / (float)n;  // biased
+      is = rsqrtf(var + eps);
+    } else if (n > 0) {
       const float k = x[c];
       const float m1 = p1 / (float)n, m2 = p2 / (float)n;
       mu = k + m1;
@@ -449,8 +497,10 @@ int bn_small_rows() {
 extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t R, int D, const float* gamma,
                                 const float* beta, float eps, float momentum, float slope, float* running_mean,
                                 float* running_var, float* mean, float* invstd, float* scratch2D /* [ceil(R/64),2,D] */, float* y,
-                                int64_t* num_batches_tracked, const float* addend, void* stream) {
+                                int64_t* num_batches_tracked, const float* addend, const float* ext_part, int ext_rows,
+                                void* stream) {
   MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
+  MVK_REQUIRE((ext_part == nullptr) == (ext_rows == 0) && ext_rows >= 0, "bn: ext_part and ext_rows go together");
   if (R == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (R <= bn_small_rows()) {
@@ -460,11 +510,19 @@ extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t 
     return 0;
   }
   dim3 g1((unsigned)cdiv64(D, 64), (unsigned)cdiv64(R, BN_ROWS));
+  if (ext_part && bn_fused_finish()) {       // statistics already produced by the GEMM epilogue: one launch
+    const unsigned gy = g1.y < (unsigned)BN_FUSED_GY ? g1.y : (unsigned)BN_FUSED_GY;
+    hipLaunchKernelGGL(bn_finish_apply, dim3(g1.x, gy), dim3(1024), 0, st, x, n_valid, (int)R, D, ext_part, eps, momentum,
+                       gamma, beta, slope, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked, addend, y,
+                       ext_rows);
+    MVK_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(bn_stats_partial, g1, dim3(BN_T), 0, st, x, n_valid, (int)R, D, scratch2D);
   if (bn_fused_finish()) {
     const unsigned gy = g1.y < (unsigned)BN_FUSED_GY ? g1.y : (unsigned)BN_FUSED_GY;
     hipLaunchKernelGGL(bn_finish_apply, dim3(g1.x, gy), dim3(1024), 0, st, x, n_valid, (int)R, D, scratch2D, eps, momentum,
-                       gamma, beta, slope, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked, addend, y);
+                       gamma, beta, slope, mean, invstd, running_mean, running_var, (long long*)num_batches_tracked, addend, y, 0);
     MVK_CHECK_HIP(hipGetLastError());
     return 0;
   }

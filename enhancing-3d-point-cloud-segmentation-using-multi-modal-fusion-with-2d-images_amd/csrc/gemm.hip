@@ -1,37 +1,53 @@
 // fp32-in / fp32-accumulate GEMM on the gfx950 matrix cores
-// (v_mfma_f32_32x32x2_f32: exact f32, k-ordered fmaf chain, 64 FLOP/clk/SIMD).
+// (v_mfma_f32_16x16x4_f32: exact f32, k-ordered fmaf chain, 64 FLOP/clk/SIMD = the f32 MFMA peak).
 //
 // This is the dense K x Cin x Cout contraction of KPConv (reference
 // KPConv-PyTorch/models/blocks.py:370-374: permute + matmul + sum over K ==
-// one [N, K*Cin] x [K*Cin, Cout] GEMM) and its two backward
-// products. bf16/fp16 MFMA would miss the 1e-4 parity bar, so
-// the f32 MFMA forms are used.
+// one [N, K*Cin] x [K*Cin, Cout] GEMM), its two backward
+// products and the unary (nn.Linear) layers of the blocks (blocks.py:470-504).
+// bf16/fp16 MFMA would miss the 1e-4 parity bar, so the f32 MFMA forms are used.
 //
-// Shapes are tall-skinny (20 000 x 990 x 64) or short-and-deep (65 x 7680 x 512), never square:
-//   * 64 x 64 output tile per 256-thread workgroup (128 x 32 for outputs of at most 32 columns), BK = 32;
-//     four waves in a 2 x 2 (4 x 1) arrangement, each owning one 32 x 32 accumulator (16 VGPRs) -> 16 MFMAs
-//     (>= 1024 cycles) per wave and k-tile;
-//   * operands staged k-major in LDS ([BK][rows + 4]): the MFMA operand reads (lane l -> row/col l & 31,
-//     k = l >> 5) are bank-conflict free, m/n-contiguous sources are written with ds_write_b128;
-//   * two LDS buffers + register prefetch: the global loads of k-tile t+1 are issued before the MFMAs
-//     of tile t and written to the other buffer after them -> one barrier per k-tile, loads hidden;
-//   * split-K (grid.z) with f32 atomics fills the chip when M*N is small (coarse layers, dW).
+// Shapes are tall-skinny (19 464 x 990 x 64) or short-and-deep (85 x 7680 x 512), never square, and the
+// chip has 1024 SIMDs to balance, so the ROW granularity of a workgroup tile is a launch choice:
+//   * 256-thread workgroup = 4 waves; the 16 x 16 x 4 MFMA gives a row granularity of 16: the tile is
+//     (16*PM*WM) x (16*QN*WN), every wave owns PM x QN accumulator blocks (4 VGPRs each). For outputs of >= 48
+//     columns the waves split the columns (WM, WN = 1, 4; TN = 64 or 128) and every wave sweeps all 16*PM rows;
+//     for <= 32 columns they split the rows (4, 1). Measured (plan_gemm below): the products are latency bound,
+//     small row tiles with 3-5 workgroups per CU win everywhere, so the plan uses PM = 2 (32 rows) / 1 and only
+//     chooses the split of the reduction; the larger instantiations stay selectable (MVK_GEMM_FORCE);
+//   * operands staged through LDS in the layout their SOURCE is contiguous in: a k-contiguous source
+//     ([rows][k], A of NN / NT, B of NT) is stored [row][40] and read with one ds_read_b128 per lane and four
+//     k-steps (the k order inside a 16-deep chunk is permuted: step s of lane group g uses k = 4g + s -- both
+//     operands agree, and a sum does not care); a row-contiguous source ([k][rows]) is stored [k][rows + 4]
+//     and read with ds_read_b32. Both reads and both ds_write_b128 patterns are bank-conflict free;
+//   * two LDS buffers + TWO register sets: the global loads of k-tile t+2 are issued before the MFMAs of
+//     tile t and written to LDS after those of tile t+1 -> one barrier per k-tile, two tiles in flight;
+//   * split-K (grid.z) with f32 atomics only where the output is small (coarse layers, dW);
+//   * optional epilogue for the BatchNorm that follows (blocks.py:456-460): per (wave row block, column) the
+//     sum and the centred sum of squares over the rows below a DEVICE-side row count, straight from the
+//     accumulators -- the separate statistics pass over the GEMM output disappears.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
 
-// One operand tile = ROWS (i) x 32 (k) elements, ROWS / 32 float4 per thread (ROWS = 32, 64 or 128).
-//   CONTIG_K == true : source element (i,k) at src[i*ld + k]  (contiguous along k)
-//   CONTIG_K == false: source element (i,k) at src[k*ld + i]  (contiguous along i)
+// One operand tile = ROWS (i) x 32 (k) elements staged by 256 threads.
+//   CONTIG_K == true : source element (i,k) at src[i*ld + k]; LDS image [i][40]
+//   CONTIG_K == false: source element (i,k) at src[k*ld + i]; LDS image [k][ROWS + 4]
 template <bool CONTIG_K, int ROWS>
-struct TileLoader {
-  static constexpr int NV = ROWS / 32;          // float4 per thread
-  static constexpr int IPT = ROWS / 4;          // threads along i (i-contiguous sources)
-  static constexpr int KSTEP = 256 / IPT;       // k rows covered per pass
+struct Tile {
+  static constexpr int LD = CONTIG_K ? 40 : ROWS + 4;
+  static constexpr int FLOATS = CONTIG_K ? ROWS * 40 : BK * (ROWS + 4);
+  static constexpr int NF4 = ROWS * BK / 4;        // float4 of one tile
+  static constexpr int NV = (NF4 + 255) / 256;     // float4 per thread
+  static constexpr int IPT = ROWS / 4;             // threads along i (row-contiguous sources)
   float4 v[NV];
 
   // vec: 4 = rows 16-byte aligned, 2 = 8-byte aligned (e.g. K*Cin = 990), 1 = scalar
@@ -40,38 +56,41 @@ struct TileLoader {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
       float t[4] = {0.f, 0.f, 0.f, 0.f};
-      if (CONTIG_K) {
-        const int i = (tid >> 3) + 32 * u, kq = (tid & 7) * 4;
-        const int64_t gi = i0 + i, gk = k0 + kq;
-        if (gi < imax) {
-          const float* p = src + gi * ld + gk;
-          if (vec == 4 && gk + 3 < kmax) {
-            const float4 q = *reinterpret_cast<const float4*>(p);
-            t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
-          } else if (vec == 2 && gk + 3 < kmax) {
-            const float2 q0 = *reinterpret_cast<const float2*>(p), q1 = *reinterpret_cast<const float2*>(p + 2);
-            t[0] = q0.x; t[1] = q0.y; t[2] = q1.x; t[3] = q1.y;
-          } else {
+      const int f = tid + 256 * u;
+      if (NF4 % 256 == 0 || f < NF4) {
+        if (CONTIG_K) {
+          const int i = f >> 3, kq = (f & 7) * 4;
+          const int64_t gi = i0 + i, gk = k0 + kq;
+          if (gi < imax) {
+            const float* p = src + gi * ld + gk;
+            if (vec == 4 && gk + 3 < kmax) {
+              const float4 q = *reinterpret_cast<const float4*>(p);
+              t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+            } else if (vec == 2 && gk + 3 < kmax) {
+              const float2 q0 = *reinterpret_cast<const float2*>(p), q1 = *reinterpret_cast<const float2*>(p + 2);
+              t[0] = q0.x; t[1] = q0.y; t[2] = q1.x; t[3] = q1.y;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (gk + e < kmax) t[e] = p[e];
+              for (int e = 0; e < 4; ++e)
+                if (gk + e < kmax) t[e] = p[e];
+            }
           }
-        }
-      } else {
-        const int k = tid / IPT + KSTEP * u, iq = (tid % IPT) * 4;
-        const int64_t gk = k0 + k, gi = i0 + iq;
-        if (gk < kmax) {
-          const float* p = src + gk * ld + gi;
-          if (vec == 4 && gi + 3 < imax) {
-            const float4 q = *reinterpret_cast<const float4*>(p);
-            t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
-          } else if (vec == 2 && gi + 3 < imax) {
-            const float2 q0 = *reinterpret_cast<const float2*>(p), q1 = *reinterpret_cast<const float2*>(p + 2);
-            t[0] = q0.x; t[1] = q0.y; t[2] = q1.x; t[3] = q1.y;
-          } else {
+        } else {
+          const int k = f / IPT, iq = (f % IPT) * 4;
+          const int64_t gk = k0 + k, gi = i0 + iq;
+          if (gk < kmax) {
+            const float* p = src + gk * ld + gi;
+            if (vec == 4 && gi + 3 < imax) {
+              const float4 q = *reinterpret_cast<const float4*>(p);
+              t[0] = q.x; t[1] = q.y; t[2] = q.z; t[3] = q.w;
+            } else if (vec == 2 && gi + 3 < imax) {
+              const float2 q0 = *reinterpret_cast<const float2*>(p), q1 = *reinterpret_cast<const float2*>(p + 2);
+              t[0] = q0.x; t[1] = q0.y; t[2] = q1.x; t[3] = q1.y;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (gi + e < imax) t[e] = p[e];
+              for (int e = 0; e < 4; ++e)
+                if (gi + e < imax) t[e] = p[e];
+            }
           }
         }
       }
@@ -79,134 +98,402 @@ struct TileLoader {
     }
   }
 
-  __device__ __forceinline__ void store(float (*T)[ROWS + 4], int tid) const {
+  // Branch-free load of a k-tile that lies fully inside [k0, kmax): out-of-range rows are CLAMPED to the last valid
+  // row / float4 (they only feed output rows / columns that are never stored) and threads beyond the tile
+  // re-load its last float4 (their store is predicated), so no load result is merged under a predicate and the
+  // loads stay asynchronous until the LDS write. Requires fast_ok().
+  template <int VEC>
+  __device__ __forceinline__ void load_fast(const float* __restrict__ src, int64_t ld, int64_t i0, int64_t imax,
+                                            int64_t k0, int tid) {
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
+      int f = tid + 256 * u;
+      if (NF4 % 256 != 0) f = f < NF4 ? f : NF4 - 1;
+      const float* p;
       if (CONTIG_K) {
-        const int i = (tid >> 3) + 32 * u, kq = (tid & 7) * 4;
-        T[kq + 0][i] = v[u].x;
-        T[kq + 1][i] = v[u].y;
-        T[kq + 2][i] = v[u].z;
-        T[kq + 3][i] = v[u].w;
+        const int i = f >> 3, kq = (f & 7) * 4;
+        int64_t gi = i0 + i;
+        gi = gi < imax ? gi : imax - 1;
+        p = src + gi * ld + (k0 + kq);
       } else {
-        const int k = tid / IPT + KSTEP * u, iq = (tid % IPT) * 4;
-        *reinterpret_cast<float4*>(&T[k][iq]) = v[u];
+        const int k = f / IPT, iq = (f % IPT) * 4;
+        int64_t gi = i0 + iq;
+        gi = gi + 3 < imax ? gi : imax - 4;
+        p = src + (k0 + k) * ld + gi;
       }
+      if (VEC == 4) {
+        v[u] = *reinterpret_cast<const float4*>(p);
+      } else {
+        const float2 q0 = *reinterpret_cast<const float2*>(p), q1 = *reinterpret_cast<const float2*>(p + 2);
+        v[u] = make_float4(q0.x, q0.y, q1.x, q1.y);
+      }
+    }
+  }
+
+  // whether load_fast may be used for full k-tiles of this operand (wave-uniform)
+  static __device__ __forceinline__ bool fast_ok(int64_t imax, int vec) {
+    return CONTIG_K ? (vec >= 2 && imax >= 1) : (vec == 4 && imax >= 4 && (imax & 3) == 0);
+  }
+
+  // VEC = 4 / 2: load_fast (full k-tiles only); VEC = 0: the general predicated load
+  template <int VEC>
+  __device__ __forceinline__ void fetch(const float* __restrict__ src, int64_t ld, int64_t i0, int64_t imax, int64_t k0,
+                                        int64_t kmax, int vec, int tid) {
+    if (VEC == 0)
+      load(src, ld, i0, imax, k0, kmax, vec, tid);
+    else
+      load_fast<VEC>(src, ld, i0, imax, k0, tid);
+  }
+
+  __device__ __forceinline__ void store(float* __restrict__ T, int tid) const {
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int f = tid + 256 * u;
+      if (NF4 % 256 == 0 || f < NF4) {
+        if (CONTIG_K) {
+          const int i = f >> 3, kq = (f & 7) * 4;
+          *reinterpret_cast<float4*>(&T[i * LD + kq]) = v[u];
+        } else {
+          const int k = f / IPT, iq = (f % IPT) * 4;
+          *reinterpret_cast<float4*>(&T[k * LD + iq]) = v[u];
+        }
+      }
+    }
+  }
+
+  // operand fragment of the 16-row block at r0 for the 16-deep k chunk j: element s feeds k-step s
+  // (lane group g = lane >> 4 holds k = 16 j + 4 g + s)
+  static __device__ __forceinline__ f32x4 frag(const float* __restrict__ T, int r0, int j, int lane) {
+    const int i = lane & 15, g = lane >> 4;
+    if (CONTIG_K) {
+      return *reinterpret_cast<const f32x4*>(&T[(r0 + i) * LD + 16 * j + 4 * g]);
+    } else {
+      f32x4 r;
+      const float* p = &T[(16 * j + 4 * g) * LD + r0 + i];
+      r[0] = p[0];
+      r[1] = p[LD];
+      r[2] = p[2 * LD];
+      r[3] = p[3 * LD];
+      return r;
     }
   }
 };
 
-// TM x TN output tile per 256-thread workgroup: 64 x 64 (waves 2 x 2) or, for outputs of at most 32
-// columns (Cout = 32 layers, logits), 128 x 32 (waves 4 x 1) so that no MFMA work is spent on padding.
-template <bool TA, bool TB, int TM, int TN>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(const float* __restrict__ A,
-                                                     const float* __restrict__ B,
-                                                     float* __restrict__ C, int64_t M, int64_t N,
-                                                     int64_t Kd, int64_t lda, int64_t ldb,
-                                                     int64_t k_per_split, int atomic_out,
-                                                     int accumulate, int vecA, int vecB) {
-  static_assert((TM / 32) * (TN / 32) == 4, "four 32 x 32 wave tiles per workgroup");
-  __shared__ __attribute__((aligned(16))) float As[2][BK][TM + 4];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][TN + 4];
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int64_t M, N, Kd, lda, ldb, k_per_split;
+  int atomic_out, accumulate, vecA, vecB;
+  float* bn_part;          // [ceil(M / (16 PM)), 2, N]: column sum and centred sum of squares per wave row block
+  const int32_t* n_valid;  // device row count for the statistics (null: M)
+};
+
+template <bool TA, bool TB, int PM, int QN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs a) {
+  static_assert(WM * WN == 4, "four waves per workgroup");
+  constexpr int TM = 16 * PM * WM, TN = 16 * QN * WN;
+  typedef Tile<!TA, TM> TileA;   // A tile element (m,k): TA == false -> A[m*lda + k] (k-contiguous)
+  typedef Tile<TB, TN> TileB;    // B tile element (n,k): TB == false -> B[k*ldb + n] (n-contiguous)
+  __shared__ __attribute__((aligned(16))) float lds[2 * (TileA::FLOATS + TileB::FLOATS)];
+  float* const As = lds;                          // two buffers of each operand
+  float* const Bs = lds + 2 * TileA::FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / (TN / 32), wn = wave % (TN / 32);
+  const int wm = wave / WN, wn = wave % WN;
   const int64_t m0 = (int64_t)blockIdx.y * TM, n0 = (int64_t)blockIdx.x * TN;
-  const int64_t kbeg = (int64_t)blockIdx.z * k_per_split;
-  const int64_t kend = kbeg + k_per_split < Kd ? kbeg + k_per_split : Kd;
+  int64_t kbeg = (int64_t)blockIdx.z * a.k_per_split;
+  const int64_t kend = kbeg + a.k_per_split < a.Kd ? kbeg + a.k_per_split : a.Kd;
 
-  f32x16 acc;
+  f32x4 acc[PM][QN];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
-  // A tile: element (m,k); TA == false -> A[m*lda + k] (k-contiguous). B tile: element (n,k);
-  // TB == false -> B[k*ldb + n] (n-contiguous).
-  TileLoader<!TA, TM> la;
-  TileLoader<TB, TN> lb;
-  la.load(A, lda, m0, M, kbeg, kend, vecA, tid);
-  lb.load(B, ldb, n0, N, kbeg, kend, vecB, tid);
-  la.store(As[0], tid);
-  lb.store(Bs[0], tid);
-  __syncthreads();
-
-  const int i = wm * 32 + (lane & 31), j = wn * 32 + (lane & 31), kh = lane >> 5;
-  int buf = 0;
-  for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-    const bool more = k0 + BK < kend;
-    if (more) {  // prefetch the next k-tile into registers while this one is multiplied
-      la.load(A, lda, m0, M, k0 + BK, kend, vecA, tid);
-      lb.load(B, ldb, n0, N, k0 + BK, kend, vecB, tid);
-    }
+  for (int p = 0; p < PM; ++p)
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a = As[buf][kk + kh][i];
-      const float b = Bs[buf][kk + kh][j];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    for (int q = 0; q < QN; ++q) acc[p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // Two register sets: the loads of k-tile t+2 are issued before the MFMAs of tile t and written to LDS after
+  // the MFMAs of tile t+1 -- two k-tiles of global-memory latency budget, two tiles of bytes in flight per
+  // workgroup (the A operand streams from HBM: 77 MB for the first layer). The loop is unrolled by two so
+  // that the sets are compile-time registers.
+  TileA la0, la1;
+  TileB lb0, lb1;
+  const int ra = wm * 16 * PM, rb = wn * 16 * QN;
+  auto compute = [&](const float* __restrict__ Ta, const float* __restrict__ Tb) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      f32x4 fa[PM], fb[QN];
+#pragma unroll
+      for (int p = 0; p < PM; ++p) fa[p] = TileA::frag(Ta, ra + 16 * p, j, lane);
+#pragma unroll
+      for (int q = 0; q < QN; ++q) fb[q] = TileB::frag(Tb, rb + 16 * q, j, lane);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int p = 0; p < PM; ++p)
+#pragma unroll
+          for (int q = 0; q < QN; ++q)
+            acc[p][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[p][s], fb[q][s], acc[p][q], 0, 0, 0);
     }
-    if (more) {
-      la.store(As[buf ^ 1], tid);
-      lb.store(Bs[buf ^ 1], tid);
+  };
+  float* const A0 = As;
+  float* const A1 = As + TileA::FLOATS;
+  float* const B0 = Bs;
+  float* const B1 = Bs + TileB::FLOATS;
+  // The pipeline over [kbeg, klim) with loaders fixed at compile time (VA, VB = 4 / 2: branch-free loads of full
+  // k-tiles; 0: the general loader, which also masks a ragged k-tail). Selected ONCE per workgroup below: a loader
+  // chosen inside the loop would merge the loaded registers of its alternatives at every join, and each such
+  // copy is a wait for the load it copies -- the loads would be synchronous again.
+  auto pipeline = [&](auto va, auto vb, const int64_t klim) {
+    constexpr int VA = decltype(va)::value, VB = decltype(vb)::value;
+    if (kbeg >= klim) return;
+    la0.template fetch<VA>(a.A, a.lda, m0, a.M, kbeg, klim, a.vecA, tid);
+    lb0.template fetch<VB>(a.B, a.ldb, n0, a.N, kbeg, klim, a.vecB, tid);
+    if (kbeg + BK < klim) {
+      la1.template fetch<VA>(a.A, a.lda, m0, a.M, kbeg + BK, klim, a.vecA, tid);
+      lb1.template fetch<VB>(a.B, a.ldb, n0, a.N, kbeg + BK, klim, a.vecB, tid);
     }
+    la0.store(A0, tid);
+    lb0.store(B0, tid);
     __syncthreads();
-    buf ^= 1;
+    for (int64_t k0 = kbeg; k0 < klim; k0 += 2 * BK) {
+      // even k-tile (buffer 0): fetch tile +2 into set 0, multiply, publish tile +1 (set 1) in buffer 1
+      if (k0 + 2 * BK < klim) {
+        la0.template fetch<VA>(a.A, a.lda, m0, a.M, k0 + 2 * BK, klim, a.vecA, tid);
+        lb0.template fetch<VB>(a.B, a.ldb, n0, a.N, k0 + 2 * BK, klim, a.vecB, tid);
+      }
+      compute(A0, B0);
+      if (k0 + BK >= klim) break;
+      la1.store(A1, tid);
+      lb1.store(B1, tid);
+      __syncthreads();
+      // odd k-tile (buffer 1): fetch tile +3 into set 1, multiply, publish tile +2 (set 0) in buffer 0
+      if (k0 + 3 * BK < klim) {
+        la1.template fetch<VA>(a.A, a.lda, m0, a.M, k0 + 3 * BK, klim, a.vecA, tid);
+        lb1.template fetch<VB>(a.B, a.ldb, n0, a.N, k0 + 3 * BK, klim, a.vecB, tid);
+      }
+      compute(A1, B1);
+      if (k0 + 2 * BK >= klim) break;
+      la0.store(A0, tid);
+      lb0.store(B0, tid);
+      __syncthreads();
+    }
+  };
+  const bool fastA = TileA::fast_ok(a.M, a.vecA), fastB = TileB::fast_ok(a.N, a.vecB);
+  const int64_t kfull = kbeg + (kend - kbeg) / BK * BK;     // end of the full k-tiles of this split
+  typedef std::integral_constant<int, 4> I4;
+  typedef std::integral_constant<int, 2> I2;
+  typedef std::integral_constant<int, 0> I0;
+  if (fastA && fastB && a.vecA == 4 && a.vecB == 4) {
+    pipeline(I4(), I4(), kfull);
+  } else if (fastA && fastB && a.vecA == 2 && a.vecB == 4) {      // K*Cin = 990: rows of A are only 8-byte aligned
+    pipeline(I2(), I4(), kfull);
+  } else {
+    pipeline(I0(), I0(), kend);
+    kbeg = kend;
+  }
+  if (kfull < kend && kbeg < kend) {     // ragged k-tail of a fast pipeline: one predicated tile, unpipelined
+    __syncthreads();
+    la0.load(a.A, a.lda, m0, a.M, kfull, kend, a.vecA, tid);
+    lb0.load(a.B, a.ldb, n0, a.N, kfull, kend, a.vecB, tid);
+    la0.store(A0, tid);
+    lb0.store(B0, tid);
+    __syncthreads();
+    compute(A0, B0);
   }
 
-  const int64_t col = n0 + wn * 32 + (lane & 31);
-  if (col < N) {
+  // C/D map of the 16 x 16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
+  const int ci = lane & 15, g4 = (lane >> 4) * 4;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int64_t row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-      if (row < M) {
-        float* c = C + row * N + col;
-        if (atomic_out)
-          atomicAdd(c, acc[r]);
-        else if (accumulate)
-          *c += acc[r];
-        else
-          *c = acc[r];
+  for (int q = 0; q < QN; ++q) {
+    const int64_t col = n0 + rb + 16 * q + ci;
+    if (col < a.N) {
+#pragma unroll
+      for (int p = 0; p < PM; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = m0 + ra + 16 * p + g4 + r;
+          if (row < a.M) {
+            float* c = a.C + row * a.N + col;
+            if (a.atomic_out)
+              atomicAdd(c, acc[p][q][r]);
+            else if (a.accumulate)
+              *c += acc[p][q][r];
+            else
+              *c = acc[p][q][r];
+          }
+        }
+    }
+  }
+
+  if (a.bn_part) {
+    // statistics of this wave's 16*PM rows for the BatchNorm that consumes C (host guarantees one split and
+    // no accumulate): rows below n_valid only; sum, then the sum of squares about the block's own mean
+    // (combined across blocks with the parallel-variance formula -- no E[x^2] - E[x]^2 cancellation).
+    int64_t nv = a.n_valid ? (int64_t)*a.n_valid : a.M;
+    nv = nv < a.M ? nv : a.M;
+    const int64_t rbase = m0 + ra;
+    const int64_t cnt = nv - rbase < 0 ? 0 : (nv - rbase > 16 * PM ? 16 * PM : nv - rbase);
+    const int64_t blk = rbase / (16 * PM);
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      float s = 0.f;
+#pragma unroll
+      for (int p = 0; p < PM; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * p + g4 + r < cnt) s += acc[p][q][r];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      const float mu = cnt > 0 ? s / (float)cnt : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int p = 0; p < PM; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (16 * p + g4 + r < cnt) {
+            const float d = acc[p][q][r] - mu;
+            m2 += d * d;
+          }
+      m2 += __shfl_xor(m2, 16);
+      m2 += __shfl_xor(m2, 32);
+      const int64_t col = n0 + rb + 16 * q + ci;
+      if (lane < 16 && col < a.N && rbase < a.M) {
+        a.bn_part[(blk * 2) * a.N + col] = s;
+        a.bn_part[(blk * 2 + 1) * a.N + col] = m2;
       }
     }
   }
 }
 
+// ---------------------------------------------------------------------------------------------- host side
+
+struct Plan {
+  int pm, qn, narrow, split;
+};
+
+// Measured on MI355X (tools/gemm_bench.py --sweep, device time of graph-captured launches): for every product
+// shape of the networks the fastest tiles are the SMALL ones -- 32 rows per workgroup for wide outputs (PM = 2),
+// 64 for narrow ones (PM = 1) -- with the reduction split until ~800-1200 workgroups are in flight (3-5 per CU):
+// the products are bound by the latency of their operand streams, which only concurrency hides; larger row tiles
+// (PM = 4, 5, 8) won nowhere by more than 2 %. The plan therefore fixes the tile and models only the split.
+Plan plan_gemm(int64_t M, int64_t N, int64_t Kd, int split_req, bool want_stats) {
+  const int narrow = N <= 32 ? 1 : 0;
+  const int pm = narrow ? 1 : 2, qn = narrow ? (N <= 16 ? 1 : 2) : 1;
+  const int64_t tm = narrow ? 64 * pm : 16 * pm, tn = narrow ? 16 * qn : 64 * qn;
+  const int64_t tiles = cdiv64(M, tm) * cdiv64(N, tn), ksteps = cdiv64(Kd, BK);
+  Plan best{pm, qn, narrow, 1};
+  double best_t = 1e300, t1 = 1e300;
+  for (int split = 1; split <= 64; ++split) {
+    if (split_req > 0 && split != split_req) continue;
+    if (split > 1 && ksteps / split < 4) break;               // keep >= 4 k-tiles per workgroup
+    const int64_t kt = cdiv64(ksteps, split), wgs = tiles * split;
+    // shader cycles: latency chain of one workgroup (k-tiles x ~700 with ~4 workgroups per CU overlapping) per
+    // round of 1024 resident workgroups + MFMA work spread over the 256 CUs + the atomic epilogue of a split
+    double t = (double)cdiv64(wgs, 1024) * (kt * 700.0 + 3000.0) + (double)wgs * kt * 256.0 * pm * qn / 256.0;
+    if (split > 1) t += (double)M * N * split * 4.0 / 1080.0;
+    if (split == 1) t1 = t;
+    if (t < best_t) {
+      best_t = t;
+      best.split = split;
+    }
+  }
+  // statistics in the epilogue need the whole reduction in one workgroup: worth it unless a split saves more
+  // than the separate statistics launch costs (~6 us)
+  if (want_stats && t1 <= best_t + 14000.0) best.split = 1;
+  const char* e = getenv("MVK_GEMM_FORCE");       // development override: "pm,qn,split"
+  if (e) {
+    int pm = 0, qn = 0, sp = 0;
+    if (sscanf(e, "%d,%d,%d", &pm, &qn, &sp) == 3) {
+      if (pm > 0) best.pm = pm;
+      if (qn > 0 && !best.narrow) best.qn = qn;
+      if (sp > 0 && split_req <= 0) best.split = sp;
+    }
+  }
+  return best;
+}
+
+template <bool TA, bool TB, int PM, int QN, int WM, int WN>
+void launch_one(dim3 grid, hipStream_t st, const GemmArgs& a) {
+  hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, PM, QN, WM, WN>), grid, dim3(256), 0, st, a);
+}
+
+template <bool TA, bool TB>
+bool launch_cfg(const Plan& p, dim3 grid, hipStream_t st, const GemmArgs& a) {
+  if (p.narrow) {
+#define NARROW(PMv, QNv) \
+  if (p.pm == PMv && p.qn == QNv) return launch_one<TA, TB, PMv, QNv, 4, 1>(grid, st, a), true
+    NARROW(1, 1); NARROW(2, 1); NARROW(1, 2); NARROW(2, 2);
+#undef NARROW
+    return false;
+  }
+#define WIDE(PMv, QNv) \
+  if (p.pm == PMv && p.qn == QNv) return launch_one<TA, TB, PMv, QNv, 1, 4>(grid, st, a), true
+  WIDE(1, 1); WIDE(2, 1); WIDE(4, 1); WIDE(5, 1);
+  WIDE(1, 2); WIDE(2, 2); WIDE(4, 2);
+#undef WIDE
+  return false;
+}
+
 }  // namespace
 
-extern "C" int mvk_gemm_f32(const float* A, const float* B, float* C, int64_t M, int64_t N,
-                            int64_t Kd, int transA, int transB, int accumulate, int split_k,
-                            void* stream) {
+// Plan of mvk_gemm_f32_ex for a shape: the split of the reduction it will use (the caller zeroes C when > 1)
+// and the row-block size of the BatchNorm partials (0: no statistics are produced for this shape).
+extern "C" int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, int want_stats, int* out_split,
+                                 int* out_stat_rows) {
+  MVK_REQUIRE(M >= 0 && N >= 0 && Kd >= 0 && out_split && out_stat_rows, "gemm plan: bad arguments");
+  if (M == 0 || N == 0 || Kd == 0) {
+    *out_split = 1;
+    *out_stat_rows = 0;
+    return 0;
+  }
+  const Plan p = plan_gemm(M, N, Kd, split_k > 0 ? split_k : 0, want_stats != 0);
+  *out_split = p.split;
+  *out_stat_rows = (want_stats && p.split == 1) ? 16 * p.pm : 0;
+  return 0;
+}
+
+extern "C" int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd,
+                               int transA, int transB, int accumulate, int split_k, float* bn_part,
+                               const int32_t* n_valid, void* stream) {
   MVK_REQUIRE(M >= 0 && N >= 0 && Kd >= 0, "gemm: negative size");
   if (M == 0 || N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  MVK_REQUIRE(!(bn_part && (accumulate || Kd == 0)), "gemm: BatchNorm statistics need a plain store of a non-empty product");
   if (Kd == 0) {
     if (!accumulate && split_k <= 1) MVK_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * M * N, st));
     return 0;
   }
-  if (split_k < 1) split_k = 1;
-  int64_t ksteps = cdiv64(Kd, BK);
-  if (split_k > ksteps) split_k = (int)ksteps;
-  int64_t k_per_split = cdiv64(ksteps, split_k) * BK;
-  split_k = (int)cdiv64(Kd, k_per_split);
-  const int64_t lda = transA ? M : Kd, ldb = transB ? Kd : N;
-  const int vecA = ((lda % 4 == 0) && ((uintptr_t)A % 16 == 0)) ? 4 : ((lda % 2 == 0) && ((uintptr_t)A % 8 == 0)) ? 2 : 1;
-  const int vecB = ((ldb % 4 == 0) && ((uintptr_t)B % 16 == 0)) ? 4 : ((ldb % 2 == 0) && ((uintptr_t)B % 8 == 0)) ? 2 : 1;
-  const bool narrow = N <= 32;   // 128 x 32 tiles: no MFMA work on padded columns
-  const int TMh = narrow ? 128 : 64, TNh = narrow ? 32 : 64;
-  MVK_REQUIRE(cdiv64(M, TMh) < 65536 && split_k < 65536, "gemm: grid too large");
-  dim3 grid((unsigned)cdiv64(N, TNh), (unsigned)cdiv64(M, TMh), (unsigned)split_k), block(256);
-  const int atomic_out = split_k > 1;
-#define LAUNCH(TA, TB)                                                                                     \
-  do {                                                                                                     \
-    if (narrow)                                                                                            \
-      hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, 128, 32>), grid, block, 0, st, A, B, C, M, N, Kd, lda, ldb, \
-                         k_per_split, atomic_out, accumulate, vecA, vecB);                                 \
-    else                                                                                                   \
-      hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, 64, 64>), grid, block, 0, st, A, B, C, M, N, Kd, lda, ldb,  \
-                         k_per_split, atomic_out, accumulate, vecA, vecB);                                 \
-  } while (0)
-  if (!transA && !transB) LAUNCH(false, false);
-  else if (!transA && transB) LAUNCH(false, true);
-  else if (transA && !transB) LAUNCH(true, false);
-  else LAUNCH(true, true);
-#undef LAUNCH
+  MVK_REQUIRE(!(bn_part && split_k > 1), "gemm: BatchNorm statistics need an unsplit reduction");
+  Plan p = plan_gemm(M, N, Kd, bn_part ? 1 : (split_k > 0 ? split_k : 0), bn_part != nullptr);
+  int split = p.split;
+  const int64_t ksteps = cdiv64(Kd, BK);
+  if (split > ksteps) split = (int)ksteps;
+  const int64_t k_per_split = cdiv64(ksteps, split) * BK;
+  split = (int)cdiv64(Kd, k_per_split);
+  GemmArgs a;
+  a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.Kd = Kd;
+  a.lda = transA ? M : Kd;
+  a.ldb = transB ? Kd : N;
+  a.k_per_split = k_per_split;
+  a.atomic_out = split > 1;
+  a.accumulate = accumulate;
+  a.vecA = ((a.lda % 4 == 0) && ((uintptr_t)A % 16 == 0)) ? 4 : ((a.lda % 2 == 0) && ((uintptr_t)A % 8 == 0)) ? 2 : 1;
+  a.vecB = ((a.ldb % 4 == 0) && ((uintptr_t)B % 16 == 0)) ? 4 : ((a.ldb % 2 == 0) && ((uintptr_t)B % 8 == 0)) ? 2 : 1;
+  a.bn_part = bn_part;
+  a.n_valid = n_valid;
+  const int64_t tm = p.narrow ? 64 * p.pm : 16 * p.pm, tn = p.narrow ? 16 * p.qn : 64 * p.qn;
+  MVK_REQUIRE(cdiv64(M, tm) < 65536 && split < 65536, "gemm: grid too large");
+  dim3 grid((unsigned)cdiv64(N, tn), (unsigned)cdiv64(M, tm), (unsigned)split);
+  bool ok;
+  if (!transA && !transB) ok = launch_cfg<false, false>(p, grid, st, a);
+  else if (!transA && transB) ok = launch_cfg<false, true>(p, grid, st, a);
+  else if (transA && !transB) ok = launch_cfg<true, false>(p, grid, st, a);
+  else ok = launch_cfg<true, true>(p, grid, st, a);
+  MVK_REQUIRE(ok, "gemm: no kernel for plan pm=%d qn=%d narrow=%d", p.pm, p.qn, p.narrow);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int mvk_gemm_f32(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA,
+                            int transB, int accumulate, int split_k, void* stream) {
+  return mvk_gemm_f32_ex(A, B, C, M, N, Kd, transA, transB, accumulate, split_k, nullptr, nullptr, stream);
 }

@@ -26,7 +26,20 @@ except ImportError:  # dropin/ put on sys.path directly
 
 
 _FUSE_ADD = os.environ.get("MVK_FUSE_ADD", "1") == "1"      # development switches for A/B timing
-_HIP_BN = os.environ.get("MVK_HIP_BN", "0") == "1"
+_HIP_BN = os.environ.get("MVK_HIP_BN", "1") == "1"          # training-mode BatchNorm on the masked HIP kernel (0: nn.BatchNorm1d)
+_GEMM_STATS = os.environ.get("MVK_GEMM_STATS", "1") == "1"  # BatchNorm statistics from the producing GEMM's epilogue
+
+
+def _bn_rows(x, module, use_bn=True):
+    """DEVICE row count the BatchNorm after a layer will normalise over (capacity-padded level: its valid rows;
+    otherwise all rows), or None when that BatchNorm does not run on the HIP kernel."""
+    if not (use_bn and module.training and x.is_cuda):
+        return None
+    n_valid = ops.row_count_for(x.shape[0])
+    if n_valid is None and _HIP_BN:
+        n_valid = ops.full_count(x.shape[0], x.device)
+    return n_valid
+
 _MFMA_LINEAR = os.environ.get("MVK_MFMA_LINEAR", "1") == "1"
 
 
@@ -114,7 +127,9 @@ class KPConv(nn.Module):
         kp = load_kernels(self.radius, self.K, dimension=self.p_dim, fixed=self.fixed_kernel_points)
         return Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)
 
-    def forward(self, q_pts, s_pts, neighb_inds, x):
+    def forward(self, q_pts, s_pts, neighb_inds, x, stats_n_valid=None):
+        """stats_n_valid: DEVICE row count of the BatchNorm that follows this convolution (the contraction
+        then delivers its statistics, ops.bn_stats_of); not part of the reference signature."""
         if self.KP_influence not in ops.INFLUENCE:
             raise ValueError('Unknown influence function type (config.KP_influence)')
         if self.aggregation_mode not in ops.AGGREGATION:
@@ -132,7 +147,8 @@ class KPConv(nn.Module):
             offsets = unscaled * self.KP_extent
             self.deformed_KP = offsets + self.kernel_points          # blocks.py:287
         y, min_d2 = ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent,
-                               self.KP_influence, self.aggregation_mode, offsets, modulations)
+                               self.KP_influence, self.aggregation_mode, offsets, modulations,
+                               stats_n_valid=stats_n_valid)
         if self.deformable:
             self.min_d2 = min_d2                                      # blocks.py:303
         return y
@@ -187,9 +203,7 @@ class BatchNormBlock(nn.Module):
         is applied here (fused into the masked kernel in capacity-padded mode). addend: the shortcut of a
         residual block, added before that activation (blocks.py:649), in the same launch when masked."""
         if self.use_bn:
-            n_valid = ops.row_count_for(x.shape[0]) if self.training else None
-            if n_valid is None and _HIP_BN and self.training and x.is_cuda:
-                n_valid = ops.full_count(x.shape[0], x.device)
+            n_valid = _bn_rows(x, self)
             if n_valid is not None:
                 # capacity-padded level (hipGraph replay): statistics over the valid rows only
                 return ops.bn_lrelu(x, n_valid, self.batch_norm, 1.0 if slope is None else slope, addend)
@@ -226,7 +240,11 @@ class UnaryBlock(nn.Module):
         """join = (shortcut, slope): finish a residual block here -- LeakyReLU_slope(BN(x W^T) + shortcut)."""
         # nn.Linear(bias=False) = x @ W^T: on the f32 MFMA GEMM (faster than the library GEMM on these
         # tall-skinny shapes, tools/gemm_bench.py); parameters stay those of self.mlp (state-dict compatible)
-        y = ops.linear(x, self.mlp.weight) if (_MFMA_LINEAR and x.is_cuda) else self.mlp(x)
+        if _MFMA_LINEAR and x.is_cuda:
+            nv = _bn_rows(x, self, self.use_bn) if _GEMM_STATS else None
+            y = ops.linear(x, self.mlp.weight, stats_n_valid=nv)
+        else:
+            y = self.mlp(x)
         if join is not None:
             return self.batch_norm(y, join[1], addend=join[0])
         return self.batch_norm(y, None if self.no_relu else 0.1)
@@ -263,7 +281,8 @@ class SimpleBlock(nn.Module):
 
     def forward(self, x, batch):
         q_pts, s_pts, inds = _conv_inputs(self.block_name, self.layer_ind, batch)
-        return self.batch_norm(self.KPConv(q_pts, s_pts, inds, x), 0.1)
+        nv = _bn_rows(q_pts, self, self.use_bn) if _GEMM_STATS else None
+        return self.batch_norm(self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv), 0.1)
 
 
 class ResnetBottleneckBlock(nn.Module):
@@ -296,7 +315,8 @@ class ResnetBottleneckBlock(nn.Module):
     def forward(self, features, batch):
         q_pts, s_pts, inds = _conv_inputs(self.block_name, self.layer_ind, batch)
         x = self.unary1(features)
-        x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x), 0.1)
+        nv = _bn_rows(q_pts, self, self.use_bn) if _GEMM_STATS else None
+        x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv), 0.1)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
         shortcut = self.unary_shortcut(shortcut)
         if _FUSE_ADD:       # x = unary2(x); return leaky_relu(x + shortcut)  (blocks.py:644-649), join fused

@@ -92,33 +92,44 @@ def _zeros(shape, device, dtype=torch.float32):
 # raw kernels
 # --------------------------------------------------------------------------------------------
 
-def _gemm_tiles(M, N):
-    """Workgroups of mvk_gemm_f32 per split: 64 x 64 output tiles, 128 x 32 when N <= 32."""
-    return ((M + 127) // 128) if N <= 32 else ((M + 63) // 64) * ((N + 63) // 64)
+def gemm_plan(M, N, Kd, split_k=None, want_stats=False):
+    """(split, stat_rows) mvk_gemm_f32_ex will use for this shape: the split of the reduction (the output must
+    be zero-initialised when > 1) and the row-block size of the BatchNorm partials (0 = none produced)."""
+    sp, rows = C.c_int(0), C.c_int(0)
+    check(lib().mvk_gemm_f32_plan(int(M), int(N), int(Kd), int(split_k or 0), int(bool(want_stats)), C.byref(sp),
+                                  C.byref(rows)))
+    return sp.value, rows.value
 
 
-def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=None, keep=False):
-    """C = op(A) @ op(B) on v_mfma_f32_32x32x2_f32 (mvk_gemm_f32). split_k=None picks a split of
-    the reduction so that small-M / deep-K products (the coarse KPConv layers: 85 x 7680 x 512)
-    still fill the 256 CUs. keep=True: the result outlives the step (a weight gradient that becomes
-    .grad), so it must not be a slice of the per-step zero arena."""
+BN_SMALL_ROWS = 128      # csrc/bn.hip: up to this many rows one launch does statistics and normalisation
+
+
+def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=None, keep=False, stats_n_valid=None):
+    """C = op(A) @ op(B) on v_mfma_f32_16x16x4_f32 (mvk_gemm_f32_ex). split_k=None lets the library pick the
+    row tile and the split of the reduction so that small-M / deep-K products (the coarse KPConv layers:
+    85 x 7680 x 512) still fill the 256 CUs. keep=True: the result outlives the step (a weight gradient that
+    becomes .grad), so it must not be a slice of the per-step zero arena.
+    stats_n_valid (DEVICE int32 [1]): also produce the column statistics of C over its first n_valid rows for
+    the BatchNorm that follows; returns (C, (partials, rows per block)) -- or (C, None) when the chosen plan
+    splits the reduction."""
     _dev(A, B)
     A, B = _f32c(A), _f32c(B)
     M, Kd = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
     N = B.shape[0] if transB else B.shape[1]
     assert (B.shape[1] if transB else B.shape[0]) == Kd, "gemm: inner dimensions differ"
+    want = stats_n_valid is not None
     if M == 0 or N == 0 or Kd == 0:
-        return out.zero_() if out is not None else torch.zeros((M, N), device=A.device, dtype=torch.float32)
-    if split_k is None:
-        # measured on MI355X (tests/dev_gemm_bench.py): ~4 workgroups per CU hide the global-load
-        # latency of the k-loop; keep >= 4 k-tiles (128 columns) per split
-        tiles = _gemm_tiles(M, N)
-        split_k = int(max(1, min((1000 + tiles - 1) // tiles, 32, Kd // 128)))
+        res = out.zero_() if out is not None else torch.zeros((M, N), device=A.device, dtype=torch.float32)
+        return (res, None) if want else res
+    split, rows = gemm_plan(M, N, Kd, split_k, want and out is None and not accumulate and M > BN_SMALL_ROWS)
     if out is None:
         out = ((torch.zeros((M, N), device=A.device, dtype=torch.float32) if keep else _zeros((M, N), A.device))
-               if split_k > 1 else torch.empty((M, N), device=A.device, dtype=torch.float32))
-    check(lib().mvk_gemm_f32(_p(A), _p(B), _p(out), M, N, Kd, int(transA), int(transB), int(accumulate),
-                             int(split_k), _stream()))
+               if split > 1 else torch.empty((M, N), device=A.device, dtype=torch.float32))
+    part = torch.empty(((M + rows - 1) // rows, 2, N), device=A.device, dtype=torch.float32) if rows > 0 else None
+    check(lib().mvk_gemm_f32_ex(_p(A), _p(B), _p(out), M, N, Kd, int(transA), int(transB), int(accumulate),
+                                int(split), _p(part), _p(stats_n_valid) if part is not None else None, _stream()))
+    if want:
+        return out, ((part, rows) if part is not None else None)
     return out
 
 
@@ -257,12 +268,6 @@ def kpconv_scatter(q, s, idx, dA, kp, extent, influence="linear", aggregation="s
     return dx, d_off
 
 
-def _split_for(n_red, tiles):
-    """split-K factor for reductions over the point axis: fill ~2 waves of workgroups per CU."""
-    want = max(1, (1024 + tiles - 1) // max(tiles, 1))
-    return int(max(1, min(want, 64, n_red // 256)))
-
-
 # --------------------------------------------------------------------------------------------
 # KPConv (rigid and deformable) as one autograd node
 # --------------------------------------------------------------------------------------------
@@ -274,23 +279,31 @@ class _KPConvFn(torch.autograd.Function):
     (KPConv-PyTorch/models/blocks.py:277-374) and its autograd backward."""
 
     @staticmethod
-    def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation):
+    def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation, stats_n_valid=None):
         K, Cin, Cout = W.shape
         deform = offsets is not None
         A, min_d2 = kpconv_gather(q, s, idx, x, kp, extent, influence, aggregation, offsets, want_min_d2=deform)
         Am = A * modulations.unsqueeze(2) if modulations is not None else A     # blocks.py:366-367
         if _PROF["on"]:
             e0, e1 = _timing_events()
-        y = gemm(Am.view(-1, K * Cin), W.reshape(K * Cin, Cout))                # blocks.py:370-374
+        st = None
+        if stats_n_valid is not None:                                           # blocks.py:370-374
+            y, st = gemm(Am.view(-1, K * Cin), W.reshape(K * Cin, Cout), stats_n_valid=stats_n_valid)
+        else:
+            y = gemm(Am.view(-1, K * Cin), W.reshape(K * Cin, Cout))
         if _PROF["on"]:
             e1.record()
             _PROF["gemm"].append(((q.shape[0], K * Cin, Cout), e0, e1))
         ctx.save_for_backward(q, s, idx, x, kp, W, A, offsets, modulations)
         ctx.cfg = (extent, influence, aggregation)
-        return y, min_d2
+        ctx.stat_rows = st[1] if st is not None else 0
+        part = st[0] if st is not None else None
+        if part is not None:
+            ctx.mark_non_differentiable(part)
+        return y, min_d2, part
 
     @staticmethod
-    def backward(ctx, gy, g_min_d2):
+    def backward(ctx, gy, g_min_d2, g_part=None):
         q, s, idx, x, kp, W, A, offsets, modulations = ctx.saved_tensors
         extent, influence, aggregation = ctx.cfg
         K, Cin, Cout = W.shape
@@ -299,8 +312,7 @@ class _KPConvFn(torch.autograd.Function):
         Am = A * modulations.unsqueeze(2) if modulations is not None else A
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
-            tiles = _gemm_tiles(K * Cin, Cout)
-            dW = gemm(Am.view(Nq, K * Cin), gy, transA=True, split_k=_split_for(Nq, tiles)).view(K, Cin, Cout)
+            dW = gemm(Am.view(Nq, K * Cin), gy, transA=True).view(K, Cin, Cout)
         need_dA = ctx.needs_input_grad[3] or (offsets is not None)
         if need_dA:
             dAm = gemm(gy, W.reshape(K * Cin, Cout), transB=True).view(Nq, K, Cin)
@@ -313,7 +325,7 @@ class _KPConvFn(torch.autograd.Function):
             dx, d_off = kpconv_scatter(q, s, idx, dA, kp, extent, influence, aggregation, x=x,
                                        offsets=offsets,
                                        g_min_d2=g_min_d2 if offsets is not None else None)
-        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None
+        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None
 
 
 def kpconv_gather_f16(q, s, idx, x16, kp, extent, influence="linear", aggregation="sum"):
@@ -346,7 +358,7 @@ class _KPConv16Fn(torch.autograd.Function):
     kernels on the fp16-rounded values. Gradients are those of y = A16 . W16 (straight-through rounding)."""
 
     @staticmethod
-    def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation):
+    def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation, stats_n_valid=None):
         K, Cin, Cout = W.shape
         x16 = x.to(torch.float16)
         W16 = W.reshape(K * Cin, Cout).to(torch.float16)
@@ -365,10 +377,10 @@ class _KPConv16Fn(torch.autograd.Function):
             _PROF["gemm"].append(((q.shape[0], K * Cin, Cout), e0, e1))
         ctx.save_for_backward(q, s, idx, x16, kp, W16, A, offsets, modulations)
         ctx.cfg = (extent, influence, aggregation, (K, Cin, Cout))
-        return y, min_d2
+        return y, min_d2, None          # (no BatchNorm-statistics epilogue in the fp16 contraction)
 
     @staticmethod
-    def backward(ctx, gy, g_min_d2):
+    def backward(ctx, gy, g_min_d2, g_part=None):
         q, s, idx, x16, kp, W16, A, offsets, modulations = ctx.saved_tensors
         extent, influence, aggregation, (K, Cin, Cout) = ctx.cfg
         Nq = q.shape[0]
@@ -377,8 +389,7 @@ class _KPConv16Fn(torch.autograd.Function):
         Am = A32 * modulations.unsqueeze(2) if modulations is not None else A32
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
-            tiles = _gemm_tiles(K * Cin, Cout)
-            dW = gemm(Am.view(Nq, K * Cin), gy, transA=True, split_k=_split_for(Nq, tiles)).view(K, Cin, Cout)
+            dW = gemm(Am.view(Nq, K * Cin), gy, transA=True).view(K, Cin, Cout)
         if ctx.needs_input_grad[3] or offsets is not None:
             dAm = gemm(gy, W16.float(), transB=True).view(Nq, K, Cin)
             if modulations is not None:
@@ -390,7 +401,7 @@ class _KPConv16Fn(torch.autograd.Function):
             dx, d_off = kpconv_scatter(q, s, idx, dA, kp, extent, influence, aggregation,
                                        x=x16.float() if offsets is not None else None, offsets=offsets,
                                        g_min_d2=g_min_d2 if offsets is not None else None)
-        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None
+        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None
 
 
 _FEATURE_DTYPE = {"dtype": torch.float32}
@@ -404,16 +415,26 @@ def set_feature_dtype(dtype):
     _FEATURE_DTYPE["dtype"] = dtype
 
 
+def bn_stats_of(t):
+    """(partials, rows per block) a producing GEMM attached to its output for the BatchNorm that follows, or None."""
+    return getattr(t, "_mvk_bn_stats", None)
+
+
 def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", offsets=None, modulations=None,
-           feature_dtype=None):
+           feature_dtype=None, stats_n_valid=None):
     """Returns (y [Nq,Cout], min_d2 [Nq,K] or None). feature_dtype: None = the mode set by
-    set_feature_dtype()."""
+    set_feature_dtype(). stats_n_valid (DEVICE int32 [1]): the contraction also produces the column statistics
+    of y over its first n_valid rows for the BatchNorm that follows (picked up by bn_lrelu via bn_stats_of)."""
     if influence not in INFLUENCE:
         raise ValueError("Unknown influence function type (config.KP_influence)")
     if aggregation not in AGGREGATION:
         raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
     fn = _KPConv16Fn if (feature_dtype or _FEATURE_DTYPE["dtype"]) == torch.float16 else _KPConvFn
-    return fn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation)
+    y, min_d2, part = fn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation,
+                               stats_n_valid)
+    if part is not None:        # the plan is a pure function of the shape: the same rows the contraction just used
+        y._mvk_bn_stats = (part, gemm_plan(y.shape[0], y.shape[1], W.shape[0] * W.shape[1], None, True)[1])
+    return y, min_d2
 
 
 # --------------------------------------------------------------------------------------------
@@ -450,7 +471,7 @@ def full_count(rows, device):
 class _BNLReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n_valid, gamma, beta, running_mean, running_var, eps, momentum, slope, training, nbt=None,
-                addend=None):
+                addend=None, ext=None):
         _dev(x, n_valid, gamma, beta, addend)
         x = _f32c(x)
         if addend is not None:
@@ -461,12 +482,16 @@ class _BNLReLUFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mean = torch.empty(D, device=x.device, dtype=torch.float32)
         invstd = torch.empty(D, device=x.device, dtype=torch.float32)
-        scratch = torch.empty(((R + 63) // 64) * 2 * D, device=x.device, dtype=torch.float32)
         if not training:
             raise RuntimeError("masked BatchNorm is a training-mode op; use nn.BatchNorm1d in eval mode")
+        ext_part, ext_rows = ext if ext is not None else (None, 0)
+        if ext_part is not None and (ext_part.shape[2] != D or ext_part.shape[0] != (R + ext_rows - 1) // ext_rows):
+            raise RuntimeError("bn_lrelu: the statistics partials do not belong to this tensor")
+        scratch = None if ext_part is not None else torch.empty(((R + 63) // 64) * 2 * D, device=x.device,
+                                                                dtype=torch.float32)
         check(lib().mvk_bn_lrelu_fwd(_p(x), _p(n_valid), R, D, _p(gamma), _p(beta), float(eps), float(momentum),
                                      float(slope), _p(running_mean), _p(running_var), _p(mean), _p(invstd),
-                                     _p(scratch), _p(y), _p(nbt), _p(addend), _stream()))
+                                     _p(scratch), _p(y), _p(nbt), _p(addend), _p(ext_part), int(ext_rows), _stream()))
         ctx.save_for_backward(x, n_valid, gamma, beta, mean, invstd, y if addend is not None else None)
         ctx.slope = float(slope)
         return y
@@ -482,7 +507,7 @@ class _BNLReLUFn(torch.autograd.Function):
         d_add = torch.empty_like(x) if yout is not None else None
         check(lib().mvk_bn_lrelu_bwd(_p(x), _p(g), _p(n_valid), R, D, _p(gamma), _p(beta), _p(mean), _p(invstd),
                                      ctx.slope, _p(scratch), _p(dgb), _p(dx), _p(yout), _p(d_add), _stream()))
-        return dx, None, dgb[D:], dgb[:D], None, None, None, None, None, None, None, d_add
+        return dx, None, dgb[D:], dgb[:D], None, None, None, None, None, None, None, d_add, None
 
 
 def bn_lrelu(x, n_valid, bn, slope=1.0, addend=None):
@@ -492,7 +517,8 @@ def bn_lrelu(x, n_valid, bn, slope=1.0, addend=None):
     activation (blocks.py:649) inside the same launch; it receives its own gradient."""
     nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # += 1 inside the kernel
     return _BNLReLUFn.apply(x, n_valid, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
-                            bn.momentum if bn.momentum is not None else 0.0, slope, bn.training, nbt, addend)
+                            bn.momentum if bn.momentum is not None else 0.0, slope, bn.training, nbt, addend,
+                            bn_stats_of(x))
 
 
 class _AddLReLUFn(torch.autograd.Function):
@@ -856,13 +882,19 @@ class _LinearFn(torch.autograd.Function):
     """y = x @ W^T on the f32 MFMA GEMM. x is [M,Kd] row-major, or [Kd,M] when x_is_transposed."""
 
     @staticmethod
-    def forward(ctx, x, W, x_is_transposed):
+    def forward(ctx, x, W, x_is_transposed, stats_n_valid=None):
         ctx.save_for_backward(x, W)
         ctx.xt = bool(x_is_transposed)
-        return gemm(x, W, transA=ctx.xt, transB=True)
+        if stats_n_valid is None:
+            return gemm(x, W, transA=ctx.xt, transB=True), None
+        y, st = gemm(x, W, transA=ctx.xt, transB=True, stats_n_valid=stats_n_valid)
+        part = st[0] if st is not None else None
+        if part is not None:
+            ctx.mark_non_differentiable(part)
+        return y, part
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_part=None):
         x, W = ctx.saved_tensors
         g = _f32c(g)
         dx = dW = None
@@ -870,13 +902,16 @@ class _LinearFn(torch.autograd.Function):
             dx = gemm(W, g, transA=True, transB=True) if ctx.xt else gemm(g, W)      # [Kd,M] or [M,Kd]
         if ctx.needs_input_grad[1]:
             # dW [N,Kd] = g^T [N,M] @ x [M,Kd]
-            dW = gemm(g, x, transA=True, transB=ctx.xt, split_k=_split_for(g.shape[0], 4))
-        return dx, dW, None
+            dW = gemm(g, x, transA=True, transB=ctx.xt)
+        return dx, dW, None, None
 
 
-def linear(x, W, x_is_transposed=False):
-    """nn.Linear without bias / a 1x1 convolution over rows, on gemm_f32_mfma."""
-    return _LinearFn.apply(x, W, x_is_transposed)
+def linear(x, W, x_is_transposed=False, stats_n_valid=None):
+    """nn.Linear without bias / a 1x1 convolution over rows, on gemm_f32_mfma. stats_n_valid: see kpconv()."""
+    y, part = _LinearFn.apply(x, W, x_is_transposed, stats_n_valid)
+    if part is not None:        # the plan is a pure function of the shape: the same rows the product just used
+        y._mvk_bn_stats = (part, gemm_plan(y.shape[0], y.shape[1], W.shape[1], None, True)[1])
+    return y
 
 
 # --------------------------------------------------------------------------------------------

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVK_ABI_VERSION 2   /* 2: masked BatchNorm takes the batch counter and a residual addend; enqueue-only / device-lens pyramid entry points; fp16-feature mode; capacity padding */
+#define MVK_ABI_VERSION 3   /* 3: gemm plan / BatchNorm-statistics epilogue, BatchNorm takes epilogue partials, fused clip + SGD; 2: masked BatchNorm takes the batch counter and a residual addend; enqueue-only / device-lens pyramid entry points; fp16-feature mode; capacity padding */
 
 /* influence / aggregation codes (blocks.py:329-354) */
 #define MVK_INFL_CONSTANT 0
@@ -86,11 +86,36 @@ int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s, int64_t N
 int mvk_gemm_f32(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd,
                  int transA, int transB, int accumulate, int split_k, void* stream);
 
+/* The same product with split_k <= 0 = "choose" and an optional epilogue for the BatchNorm that consumes C
+ * (BatchNormBlock after every KPConv / unary layer, blocks.py:456-460): bn_part [ceil(M/rows), 2, N] receives,
+ * per block of `rows` rows and column, the sum and the sum of squares about the block's own mean over the rows
+ * below *n_valid (DEVICE int32; NULL = M); `rows` and the split the call will use come from mvk_gemm_f32_plan
+ * for the same (M, N, Kd, split_k, want_stats = bn_part != NULL). The caller zeroes C when the plan's split
+ * is > 1; statistics are only produced by unsplit plans (plan: *out_stat_rows > 0). */
+int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, int want_stats, int* out_split,
+                      int* out_stat_rows);
+int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA,
+                    int transB, int accumulate, int split_k, float* bn_part, const int32_t* n_valid, void* stream);
+
 /* fp16-feature mode of the same contraction (BASELINE config 5): operands are rounded to fp16 (each may be
  * stored as f32 or f16 in memory: a_f16 / b_f16), multiplied on v_mfma_f32_32x32x8_f16 and accumulated in
  * f32; C is f32 [M,N] (split_k > 1: atomics onto a zero-initialised C) or, with c_f16, fp16 [M,N]. */
 int mvk_gemm_f16(const void* A, int a_f16, const void* B, int b_f16, void* C, int c_f16, int64_t M, int64_t N,
                  int64_t Kd, int transA, int transB, int split_k, void* stream);
+
+/* ---------------- optimiser tail of a training step ------------------------ */
+
+/* Gradient value clipping + SGD (momentum, weight decay; torch.optim.SGD semantics, dampening 0, no Nesterov) over
+ * ALL parameter tensors in one launch (utils/trainer.py:190-195: clip_grad_value_ + optimizer.step; groups with
+ * their own learning rate as built at trainer.py:72-79):
+ *     g' = clamp(g, -clip, clip); m = momentum * m + (g' + wd * p); p -= lr * m.
+ *   table : DEVICE array of records {float* p; const float* g; float* m; int64 n; float lr; float wd;} (40 bytes)
+ *   chunks: DEVICE int32 [n_chunks][2] = (record index, chunk index within the tensor); a chunk is
+ *           mvk_sgd_chunk_elems() consecutive elements; every tensor is covered by ceil(n / chunk) chunks.
+ *   clip_in_place != 0 also stores the clamped gradient (what clip_grad_value_ leaves in .grad). */
+int mvk_sgd_chunk_elems(void);
+int mvk_sgd_clip_step(const void* table, const int32_t* chunks, int64_t n_chunks, float clip, float momentum,
+                      int clip_in_place, void* stream);
 
 /* ---------------- masked BatchNorm + LeakyReLU (capacity-padded levels) --- */
 
@@ -106,7 +131,9 @@ int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t R, int D, c
                      float* running_var, float* mean, float* invstd, float* scratch, float* y,
                      int64_t* num_batches_tracked /* DEVICE counter += 1, may be NULL */,
                      const float* addend /* [R,D] or NULL: y = LeakyReLU(BN(x) + addend), the residual join of
-                                            ResnetBottleneckBlock (blocks.py:649) */, void* stream);
+                                            ResnetBottleneckBlock (blocks.py:649) */,
+                     const float* ext_part /* NULL, or the bn_part of the mvk_gemm_f32_ex call that produced x */,
+                     int ext_rows /* its row-block size (0 with NULL) */, void* stream);
 /* dgamma_dbeta [2,D] receives dbeta (row 0) and dgamma (row 1); dx [R,D] (rows >= n_valid zero). */
 int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n_valid, int64_t R, int D,
                      const float* gamma, const float* beta, const float* mean, const float* invstd,

@@ -422,6 +422,74 @@ def test_gemm_f32_mfma(ops, M, N, K):
     assert rel_err(ops.gemm(A.t().contiguous(), B.t().contiguous(), transA=True, transB=True, split_k=1).cpu().numpy(), ref) < 1e-5
 
 
+@pytest.mark.parametrize("pm,qn", [(1, 1), (2, 1), (4, 1), (5, 1), (1, 2), (2, 2), (4, 2)])
+def test_gemm_f32_every_tile_configuration(ops, pm, qn, monkeypatch):
+    """Every (rows per wave, column blocks per wave) instantiation of gemm_f32_mfma, all four operand layouts,
+    ragged sizes (M, N, K not multiples of the tile), with and without a split: MVK_GEMM_FORCE pins the plan."""
+    torch.manual_seed(pm * 10 + qn)
+    M, N, K = 16 * pm * 3 + 7, (150 if qn == 2 else 70), 203
+    A = torch.randn(M, K, device="cuda")
+    B = torch.randn(K, N, device="cuda") + 0.1 * torch.arange(N, device="cuda")
+    ref = (A.double() @ B.double()).cpu().numpy()
+    for split in (1, 3):
+        monkeypatch.setenv("MVK_GEMM_FORCE", "%d,%d,%d" % (pm, qn, split))
+        assert rel_err(ops.gemm(A, B).cpu().numpy(), ref) < 1e-5
+        assert rel_err(ops.gemm(A, B.t().contiguous(), transB=True).cpu().numpy(), ref) < 1e-5
+        assert rel_err(ops.gemm(A.t().contiguous(), B, transA=True).cpu().numpy(), ref) < 1e-5
+        assert rel_err(ops.gemm(A.t().contiguous(), B.t().contiguous(), transA=True, transB=True).cpu().numpy(), ref) < 1e-5
+    # narrow outputs (N <= 32: the waves split the rows)
+    for n_cols in (20, 32, 9):
+        monkeypatch.setenv("MVK_GEMM_FORCE", "%d,0,1" % min(pm, 2))
+        Bn = torch.randn(K, n_cols, device="cuda")
+        refn = (A.double() @ Bn.double()).cpu().numpy()
+        assert rel_err(ops.gemm(A, Bn).cpu().numpy(), refn) < 1e-5
+        assert rel_err(ops.gemm(A.t().contiguous(), Bn.t().contiguous(), transA=True, transB=True).cpu().numpy(), refn) < 1e-5
+
+
+@pytest.mark.parametrize("M,N,K,n", [(19464, 64, 990, 19464), (19464, 32, 480, 19000), (3986, 64, 960, 3986), (1300, 128, 96, 1207),
+                                     (4096, 200, 64, 4000), (300, 256, 64, 300), (19464, 128, 32, 19464), (5000, 20, 64, 4321)])
+def test_gemm_batchnorm_statistics_epilogue(ops, M, N, K, n):
+    """The statistics the GEMM epilogue hands to the BatchNorm that follows (per wave row block: column sum and
+    centred sum of squares over the rows below n_valid) give the same normalised output, running statistics and
+    saved mean / invstd as the separate statistics pass -- and as torch's batch_norm over the valid rows. The mean
+    is far from zero (|mean| ~ 50 sigma): a plain E[x^2] - E[x]^2 would lose the variance."""
+    torch.manual_seed(M + N)
+    A = torch.randn(M, K, device="cuda")
+    A[:, 0] = 40.0                                          # large common component -> large column means
+    B = torch.randn(K, N, device="cuda")
+    nv = torch.tensor([n], dtype=torch.int32, device="cuda")
+    y, st = ops.gemm(A, B, stats_n_valid=nv)
+    assert rel_err(y.cpu().numpy(), (A.double() @ B.double()).cpu().numpy()) < 1e-5
+    split, rows = ops.gemm_plan(M, N, K, None, True)
+    if st is None:
+        assert split > 1
+        pytest.skip("the plan splits the reduction of this shape: statistics stay a separate launch")
+    part, prow = st
+    assert prow == rows and part.shape == ((M + rows - 1) // rows, 2, N)
+    yv = y[:n].double()
+    # partials against float64: block sums and centred sums of squares
+    nb = (n + rows - 1) // rows
+    pad = torch.zeros(nb * rows - n, N, device="cuda", dtype=torch.float64)
+    blocks = torch.cat([yv, pad]).view(nb, rows, N)
+    cnt = torch.full((nb, 1), float(rows), device="cuda", dtype=torch.float64)
+    cnt[-1] = n - (nb - 1) * rows
+    sums = blocks.sum(1)
+    mask = (torch.arange(rows, device="cuda")[None, :, None] < cnt[:, :, None]).double()
+    m2 = (((blocks - (sums / cnt)[:, None, :]) * mask) ** 2).sum(1)
+    assert rel_err(part[:nb, 0].cpu().numpy(), sums.cpu().numpy()) < 1e-5
+    assert rel_err(part[:nb, 1].cpu().numpy(), m2.cpu().numpy()) < 1e-4
+    # the BatchNorm that consumes them
+    bn = torch.nn.BatchNorm1d(N, momentum=0.02).cuda()
+    ref = torch.nn.BatchNorm1d(N, momentum=0.02).cuda()
+    y._mvk_bn_stats = st
+    out = ops.bn_lrelu(y, nv, bn, slope=0.1)
+    want = torch.nn.functional.leaky_relu(ref(y[:n]), 0.1)
+    assert (out[n:] == 0).all()
+    assert rel_err(out[:n].detach().cpu().numpy(), want.detach().cpu().numpy()) < 2e-5
+    assert rel_err(bn.running_mean.cpu().numpy(), ref.running_mean.cpu().numpy()) < 1e-5
+    assert rel_err(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 1e-4
+
+
 # ------------------------------------------------------------------ masked BatchNorm + LeakyReLU
 
 @pytest.mark.parametrize("slope", [1.0, 0.1])
@@ -509,6 +577,56 @@ def test_masked_bn_with_residual_join_vs_torch(ops, R, D, n):
     assert rel_err((gs[:n] * away).cpu().numpy(), (gsr * away).cpu().numpy()) < 1e-6
     assert rel_err((gx[:n] * away).cpu().numpy(), (gxr * away).cpu().numpy()) < 1e-2
     assert rel_err(gw.cpu().numpy(), gwr.cpu().numpy()) < 1e-2 and rel_err(gb.cpu().numpy(), gbr.cpu().numpy()) < 1e-2
+
+
+# ------------------------------------------------------------------ fused clip + SGD
+
+def test_fused_clip_sgd_matches_torch_clip_and_sgd():
+    """mvk_sgd_clip_step against torch.nn.utils.clip_grad_value_ + torch.optim.SGD (momentum, weight decay, two
+    parameter groups with their own learning rate, utils/trainer.py:72-79, 190-195) over several steps, tensors
+    of awkward sizes (1 element, not a multiple of 4, larger than one chunk), one parameter without a gradient."""
+    import mvkpconv
+    optim = mvkpconv.sub("optim")
+    torch.manual_seed(0)
+    shapes = [(1,), (7,), (64,), (15, 66, 64), (4097,), (3, 5), (20000, 3), (33,)]
+    ours = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    mine = optim.FusedClipSGD([{"params": ours[:5]}, {"params": ours[5:], "lr": 1e-3}], lr=1e-2, momentum=0.98,
+                              weight_decay=1e-3, clip_value=0.5)
+    theirs = torch.optim.SGD([{"params": ref[:5]}, {"params": ref[5:], "lr": 1e-3}], lr=1e-2, momentum=0.98,
+                             weight_decay=1e-3)
+    for step in range(4):
+        for a, b in zip(ours, ref):
+            g = torch.randn_like(a) * (1.0 if step % 2 else 0.3)
+            a.grad, b.grad = g.clone(), g.clone()
+        ours[6].grad = None if step == 2 else ours[6].grad          # a parameter that got no gradient this step
+        ref[6].grad = None if step == 2 else ref[6].grad
+        torch.nn.utils.clip_grad_value_(ref, 0.5)
+        theirs.step()
+        mine.step()
+        for a, b in zip(ours, ref):
+            assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-6
+    for a, b in zip(ours, ref):
+        if b in theirs.state and "momentum_buffer" in theirs.state[b]:
+            assert rel_err(mine.state[a]["momentum_buffer"].cpu().numpy(), theirs.state[b]["momentum_buffer"].cpu().numpy()) < 1e-6
+    # under hipGraph capture (fixed gradient addresses, the table copy becomes a memcpy node)
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for a in ours:
+            a.grad = torch.zeros_like(a)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            mine.step()
+        for rep in range(2):                 # nothing ran during the capture: two replays = two more steps
+            for a, b in zip(ours, ref):
+                a.grad.copy_(torch.full_like(a, 0.7 - rep))
+                b.grad = torch.full_like(b, 0.7 - rep)
+            g.replay()
+            torch.nn.utils.clip_grad_value_(ref, 0.5)
+            theirs.step()
+        torch.cuda.synchronize()
+    for a, b in zip(ours, ref):
+        assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-6
 
 
 # ------------------------------------------------------------------ group_points (reference test shapes)

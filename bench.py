@@ -159,7 +159,7 @@ def main():
         opt.zero_grad(set_to_none=True)
         out = net(batch, cfg)
         loss = net.loss(out, batch.labels)
-        loss.backward()
+        backward(ops, loss)
         if reducer is not None:
             reducer()
         clip_and_step(params, opt, cfg)
@@ -289,6 +289,17 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     The host draws the random grid orientations, copies them to the device and launches the graph."""
     has_2d = hasattr(net, "net_2d") and os.environ.get("MVK_ENCODER_AHEAD", "1") == "1"
     dev = staged['points'][0].device
+    # Stream rule of the capture (cause of the abort recorded in round 1, gpurun_out/bench7.log: segfault in
+    # capture_end): autograd binds every parameter's AccumulateGrad node to the stream of the backward that created
+    # it, and the node lives as long as any autograd graph that references it (e.g. a loss tensor of a warm-up step
+    # that is still held). torch.cuda.graph() captures on its OWN side stream unless told otherwise, so a backward
+    # under capture met nodes of another stream: a cross-stream wait inside the capture -- on the legacy default
+    # stream that is not capturable and the runtime aborted. Hence: (1) refuse the default stream, (2) capture on
+    # the CURRENT stream, the one every eager warm-up step ran on, so no node ever changes stream.
+    main_stream = torch.cuda.current_stream()
+    if main_stream == torch.cuda.default_stream():
+        raise RuntimeError("make_graph_step must run under a non-default stream (torch.cuda.set_stream(torch.cuda.Stream())): "
+                           "autograd nodes created on the legacy default stream cannot take part in a graph capture")
     # all three streams at the same priority: on this driver a priority difference between queues that
     # are busy at the same time costs far more (2-3x the step) than any ordering it buys
     build_stream = torch.cuda.Stream(priority=int(os.environ.get("MVK_BUILD_PRIO", "0")))
@@ -375,21 +386,21 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                 torch.cuda.current_stream().wait_stream(build_stream)
 
         if reducer is None:
-            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+            with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
                 fork_encoder()
                 loss = net_step_captured(net, static, cfg, params, opt, None)
                 join_encoder()
             return graph.replay, loss
         # N > 1: the RCCL all-reduce stays an eager call between two graphs (forward+backward | clip+SGD).
         # thread_local capture mode: the process group's watchdog thread may query events meanwhile.
-        with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+        with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
             fork_encoder()
             ops.step_begin()
             loss = net.loss(net(static, cfg), static.labels)
-            loss.backward()
+            backward(ops, loss)
             join_encoder()
         graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph_b, capture_error_mode="thread_local"):
+        with torch.cuda.graph(graph_b, stream=main_stream, capture_error_mode="thread_local"):
             clip_and_step(params, opt, cfg)
 
         grads = [p.grad for p in reducer.params if p.grad is not None]
@@ -567,11 +578,21 @@ def net_step_captured(net, static, cfg, params, opt, reducer):
     mvkpconv.sub("ops").step_begin()
     out = net(static, cfg)
     loss = net.loss(out, static.labels)
-    loss.backward()
+    backward(mvkpconv.sub("ops"), loss)
     if reducer is not None:
         reducer()
     clip_and_step(params, opt, cfg)
     return loss
+
+
+def backward(ops, loss):
+    """loss.backward() with the weight-gradient products on a side branch (ops.overlap_weight_grads): nothing reads
+    a gradient before the optimiser (or the all-reduce), which run after the scope has joined."""
+    if os.environ.get("MVK_OVERLAP_DW", "1") == "1":
+        with ops.overlap_weight_grads():
+            loss.backward()
+    else:
+        loss.backward()
 
 
 def clip_and_step(params, opt, cfg):

@@ -185,7 +185,7 @@ struct GemmArgs {
   float* C;
   int64_t M, N, Kd, lda, ldb, k_per_split;
   int atomic_out, accumulate, vecA, vecB;
-  float* bn_part;          // [ceil(M / (16 PM)), 2, N]: column sum and centred sum of squares per wave row block
+  float* bn_part;          // [ceil(M / TM), 2, N]: column sum and centred sum of squares per workgroup row block
   const int32_t* n_valid;  // device row count for the statistics (null: M)
 };
 
@@ -325,40 +325,77 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs a) {
   }
 
   if (a.bn_part) {
-    // statistics of this wave's 16*PM rows for the BatchNorm that consumes C (host guarantees one split and
-    // no accumulate): rows below n_valid only; sum, then the sum of squares about the block's own mean
-    // (combined across blocks with the parallel-variance formula -- no E[x^2] - E[x]^2 cancellation).
+    // statistics of this workgroup's TM rows for the BatchNorm that consumes C (host guarantees one split and no
+    // accumulate): rows below n_valid only; the sum, then the sum of squares about the block's OWN mean (combined
+    // across blocks with the parallel-variance formula -- no E[x^2] - E[x]^2 cancellation). Waves that share
+    // columns (narrow tiles: WM = 4) combine through LDS in a fixed order.
     int64_t nv = a.n_valid ? (int64_t)*a.n_valid : a.M;
     nv = nv < a.M ? nv : a.M;
-    const int64_t rbase = m0 + ra;
-    const int64_t cnt = nv - rbase < 0 ? 0 : (nv - rbase > 16 * PM ? 16 * PM : nv - rbase);
-    const int64_t blk = rbase / (16 * PM);
+    const int64_t wcnt = nv - (m0 + ra) < 0 ? 0 : (nv - (m0 + ra) > 16 * PM ? 16 * PM : nv - (m0 + ra));   // this wave's rows
+    const int64_t bcnt = nv - m0 < 0 ? 0 : (nv - m0 > TM ? TM : nv - m0);                                  // the block's
+    const int64_t blk = m0 / TM;
+    float* red = lds;                      // [WM][TN] sums, then [WM][TN] centred squares (operand tiles are dead)
+    if (WM > 1) __syncthreads();
+    float s[QN], mu[QN];
 #pragma unroll
     for (int q = 0; q < QN; ++q) {
-      float s = 0.f;
+      s[q] = 0.f;
 #pragma unroll
       for (int p = 0; p < PM; ++p)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (16 * p + g4 + r < cnt) s += acc[p][q][r];
-      s += __shfl_xor(s, 16);
-      s += __shfl_xor(s, 32);
-      const float mu = cnt > 0 ? s / (float)cnt : 0.f;
+          if (16 * p + g4 + r < wcnt) s[q] += acc[p][q][r];
+      s[q] += __shfl_xor(s[q], 16);
+      s[q] += __shfl_xor(s[q], 32);
+      if (WM > 1 && lane < 16) red[wm * TN + rb + 16 * q + ci] = s[q];
+    }
+    if (WM > 1) {
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        s[q] = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) s[q] += red[w * TN + rb + 16 * q + ci];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      mu[q] = bcnt > 0 ? s[q] / (float)bcnt : 0.f;
       float m2 = 0.f;
 #pragma unroll
       for (int p = 0; p < PM; ++p)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (16 * p + g4 + r < cnt) {
-            const float d = acc[p][q][r] - mu;
+          if (16 * p + g4 + r < wcnt) {
+            const float d = acc[p][q][r] - mu[q];
             m2 += d * d;
           }
       m2 += __shfl_xor(m2, 16);
       m2 += __shfl_xor(m2, 32);
-      const int64_t col = n0 + rb + 16 * q + ci;
-      if (lane < 16 && col < a.N && rbase < a.M) {
-        a.bn_part[(blk * 2) * a.N + col] = s;
-        a.bn_part[(blk * 2 + 1) * a.N + col] = m2;
+      if (WM > 1) {
+        if (lane < 16) red[(WM + wm) * TN + rb + 16 * q + ci] = m2;
+      } else {
+        const int64_t col = n0 + rb + 16 * q + ci;
+        if (lane < 16 && col < a.N && m0 < a.M) {
+          a.bn_part[(blk * 2) * a.N + col] = s[q];
+          a.bn_part[(blk * 2 + 1) * a.N + col] = m2;
+        }
+      }
+    }
+    if (WM > 1) {
+      __syncthreads();
+      if (wm == 0 && lane < 16) {
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          float m2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < WM; ++w) m2 += red[(WM + w) * TN + rb + 16 * q + ci];
+          const int64_t col = n0 + rb + 16 * q + ci;
+          if (col < a.N && m0 < a.M) {
+            a.bn_part[(blk * 2) * a.N + col] = s[q];
+            a.bn_part[(blk * 2 + 1) * a.N + col] = m2;
+          }
+        }
       }
     }
   }
@@ -377,7 +414,8 @@ struct Plan {
 // (PM = 4, 5, 8) won nowhere by more than 2 %. The plan therefore fixes the tile and models only the split.
 Plan plan_gemm(int64_t M, int64_t N, int64_t Kd, int split_req, bool want_stats) {
   const int narrow = N <= 32 ? 1 : 0;
-  const int pm = narrow ? 1 : 2, qn = narrow ? (N <= 16 ? 1 : 2) : 1;
+  // with statistics: 64-row tiles (one partial per 64 rows keeps the BatchNorm's reduction of the partials short)
+  const int pm = narrow ? 1 : (want_stats ? 4 : 2), qn = narrow ? (N <= 16 ? 1 : 2) : 1;
   const int64_t tm = narrow ? 64 * pm : 16 * pm, tn = narrow ? 16 * qn : 64 * qn;
   const int64_t tiles = cdiv64(M, tm) * cdiv64(N, tn), ksteps = cdiv64(Kd, BK);
   Plan best{pm, qn, narrow, 1};
@@ -447,7 +485,7 @@ extern "C" int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, 
   }
   const Plan p = plan_gemm(M, N, Kd, split_k > 0 ? split_k : 0, want_stats != 0);
   *out_split = p.split;
-  *out_stat_rows = (want_stats && p.split == 1) ? 16 * p.pm : 0;
+  *out_stat_rows = (want_stats && p.split == 1) ? (p.narrow ? 64 * p.pm : 16 * p.pm) : 0;
   return 0;
 }
 

@@ -111,3 +111,43 @@ extern "C" int mvk_gather_rows_bwd(const float* g, const void* idx, int idx64, i
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }
+
+// ---- pointwise epilogue of the frozen 2D encoder's convolutions (mvpnet/models/unet_resnet34.py: conv -> BatchNorm
+// (eval) -> [+ identity] -> ReLU): with the BatchNorm folded into the convolution weights what is left is
+// y = act(x + bias[c] (+ res (+ bias2[c]))) over a channels-last tensor -- one launch instead of three or four.
+namespace {
+__global__ void bias_act_nhwc_k(const float4* __restrict__ x, const float4* __restrict__ bias, const float4* __restrict__ res,
+                                const float4* __restrict__ bias2, float4* __restrict__ y, int64_t n4, int c4, int relu) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n4) return;
+  const int c = (int)(t % c4);
+  float4 v = x[t];
+  const float4 b = bias[c];
+  v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  if (res) {
+    const float4 r = res[t];
+    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    if (bias2) {
+      const float4 b2 = bias2[c];
+      v.x += b2.x; v.y += b2.y; v.z += b2.z; v.w += b2.w;
+    }
+  }
+  if (relu) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+  }
+  y[t] = v;
+}
+}  // namespace
+
+extern "C" int mvk_bias_act_nhwc(const float* x, const float* bias, const float* res, const float* bias2, float* y,
+                                 int64_t n_elems, int channels, int relu, void* stream) {
+  MVK_REQUIRE(n_elems >= 0 && channels > 0 && channels % 4 == 0 && n_elems % channels == 0,
+              "bias_act: the channel count must be a multiple of 4 and divide the element count");
+  MVK_REQUIRE(!(bias2 && !res), "bias_act: a second bias belongs to a residual");
+  if (n_elems == 0) return 0;
+  const int64_t n4 = n_elems / 4;
+  hipLaunchKernelGGL(bias_act_nhwc_k, dim3((unsigned)cdiv64(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4*)x,
+                     (const float4*)bias, (const float4*)res, (const float4*)bias2, (float4*)y, n4, channels / 4, relu);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}

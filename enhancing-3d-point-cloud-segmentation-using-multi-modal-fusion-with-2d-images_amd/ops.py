@@ -269,6 +269,54 @@ def kpconv_scatter(q, s, idx, dA, kp, extent, influence="linear", aggregation="s
 
 
 # --------------------------------------------------------------------------------------------
+# weight-gradient products off the critical chain
+# --------------------------------------------------------------------------------------------
+# The backward of a layer launches two independent products, dW = A^T g and dA = g W^T; only dA feeds the rest
+# of the backward chain, dW is not read before the optimiser. Every product here is a small, latency-bound
+# launch (~10 us whatever its size), so inside `with overlap_weight_grads():` the dW products are enqueued on a
+# side stream forked from the current one (a parallel branch of the captured hipGraph) and joined when the scope
+# ends -- about a hundred launches leave the serial chain of a step. Opt-in: gradients must not be read (or
+# accumulated into an existing .grad) before the scope has been left.
+_OVERLAP = {"on": False, "streams": None, "i": 0, "used": []}
+
+
+class overlap_weight_grads:
+    def __init__(self, n_streams=2):
+        self.n = int(n_streams)
+
+    def __enter__(self):
+        if _OVERLAP["streams"] is None or len(_OVERLAP["streams"]) != self.n:
+            _OVERLAP["streams"] = [torch.cuda.Stream() for _ in range(self.n)]
+        _OVERLAP.update(on=True, i=0, used=[])
+        return self
+
+    def __exit__(self, *exc):
+        cur = torch.cuda.current_stream()
+        for st in _OVERLAP["used"]:
+            cur.wait_stream(st)
+        _OVERLAP.update(on=False, used=[])
+        return False
+
+
+def _gemm_off_chain(A, B, **kw):
+    """gemm() whose result nothing on the current stream reads before the overlap scope is left (a weight gradient)."""
+    if not _OVERLAP["on"]:
+        return gemm(A, B, **kw)
+    cur = torch.cuda.current_stream()
+    side = _OVERLAP["streams"][_OVERLAP["i"] % len(_OVERLAP["streams"])]
+    _OVERLAP["i"] += 1
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        out = gemm(A, B, **kw)
+    for t in (A, B):
+        t.record_stream(side)          # their memory must not be recycled by the current stream while the side product runs
+    out.record_stream(cur)
+    if side not in _OVERLAP["used"]:
+        _OVERLAP["used"].append(side)
+    return out
+
+
+# --------------------------------------------------------------------------------------------
 # KPConv (rigid and deformable) as one autograd node
 # --------------------------------------------------------------------------------------------
 
@@ -312,7 +360,7 @@ class _KPConvFn(torch.autograd.Function):
         Am = A * modulations.unsqueeze(2) if modulations is not None else A
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
-            dW = gemm(Am.view(Nq, K * Cin), gy, transA=True).view(K, Cin, Cout)
+            dW = _gemm_off_chain(Am.view(Nq, K * Cin), gy, transA=True).view(K, Cin, Cout)
         need_dA = ctx.needs_input_grad[3] or (offsets is not None)
         if need_dA:
             dAm = gemm(gy, W.reshape(K * Cin, Cout), transB=True).view(Nq, K, Cin)
@@ -389,7 +437,7 @@ class _KPConv16Fn(torch.autograd.Function):
         Am = A32 * modulations.unsqueeze(2) if modulations is not None else A32
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
-            dW = gemm(Am.view(Nq, K * Cin), gy, transA=True).view(K, Cin, Cout)
+            dW = _gemm_off_chain(Am.view(Nq, K * Cin), gy, transA=True).view(K, Cin, Cout)
         if ctx.needs_input_grad[3] or offsets is not None:
             dAm = gemm(gy, W16.float(), transB=True).view(Nq, K, Cin)
             if modulations is not None:
@@ -902,7 +950,7 @@ class _LinearFn(torch.autograd.Function):
             dx = gemm(W, g, transA=True, transB=True) if ctx.xt else gemm(g, W)      # [Kd,M] or [M,Kd]
         if ctx.needs_input_grad[1]:
             # dW [N,Kd] = g^T [N,M] @ x [M,Kd]
-            dW = gemm(g, x, transA=True, transB=ctx.xt)
+            dW = _gemm_off_chain(g, x, transA=True, transB=ctx.xt)
         return dx, dW, None, None
 
 
@@ -911,6 +959,20 @@ def linear(x, W, x_is_transposed=False, stats_n_valid=None):
     y, part = _LinearFn.apply(x, W, x_is_transposed, stats_n_valid)
     if part is not None:        # the plan is a pure function of the shape: the same rows the product just used
         y._mvk_bn_stats = (part, gemm_plan(y.shape[0], y.shape[1], W.shape[1], None, True)[1])
+    return y
+
+
+def bias_act_nhwc(x, bias, res=None, bias2=None, relu=True, out=None):
+    """act(x + bias[c] (+ res (+ bias2[c]))) on a channels-last 4-D tensor (in place unless `out`): the pointwise
+    tail of a convolution of the frozen 2D encoder after its BatchNorm was folded into the weights."""
+    _dev(x, bias, res, bias2)
+    if x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last) or x.dtype != torch.float32:
+        raise RuntimeError("bias_act_nhwc: x must be a float32 channels-last (N,C,H,W) tensor")
+    if res is not None and (res.shape != x.shape or not res.is_contiguous(memory_format=torch.channels_last)):
+        raise RuntimeError("bias_act_nhwc: the residual must have the shape and layout of x")
+    y = x if out is None else out
+    check(lib().mvk_bias_act_nhwc(_p(x), _p(bias), _p(res), _p(bias2), _p(y), x.numel(), x.shape[1], int(bool(relu)),
+                                  _stream()))
     return y
 
 

@@ -103,6 +103,15 @@ int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t
 int mvk_gemm_f16(const void* A, int a_f16, const void* B, int b_f16, void* C, int c_f16, int64_t M, int64_t N,
                  int64_t Kd, int transA, int transB, int split_k, void* stream);
 
+/* ---------------- frozen 2D encoder: pointwise epilogue of a convolution --- */
+
+/* y = act(x + bias[c] (+ res (+ bias2[c]))) over a channels-last (N,H,W,C) f32 tensor, C % 4 == 0: what is left of
+ * conv -> BatchNorm(eval) -> [+ identity] -> ReLU of the frozen UNet-ResNet34 (mvpnet/models/unet_resnet34.py:9-125,
+ * frozen in architectures_sphere.py:232-237) once the BatchNorm is folded into the convolution weights.
+ * res / bias2 may be NULL; y may alias x. */
+int mvk_bias_act_nhwc(const float* x, const float* bias, const float* res, const float* bias2, float* y,
+                      int64_t n_elems, int channels, int relu, void* stream);
+
 /* ---------------- optimiser tail of a training step ------------------------ */
 
 /* Gradient value clipping + SGD (momentum, weight decay; torch.optim.SGD semantics, dampening 0, no Nesterov) over

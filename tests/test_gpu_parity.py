@@ -629,6 +629,38 @@ def test_fused_clip_sgd_matches_torch_clip_and_sgd():
         assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-6
 
 
+# ------------------------------------------------------------------ frozen 2D encoder fast path
+
+@pytest.mark.parametrize("hw", [(120, 160), (60, 80)])
+def test_frozen_encoder_fast_path_equals_the_module_forward(hw):
+    """UNetResNet34 in eval mode with frozen weights: BatchNorm folded into the convolutions + the fused pointwise
+    epilogue (ops.bias_act_nhwc, channels-last) against the module-by-module forward (non-trivial running
+    statistics, ragged padding to a multiple of 16)."""
+    import mvkpconv
+    unet = importlib.import_module(mvkpconv.PKG_NAME + ".dropin.mvpnet.models.unet_resnet34")
+    torch.manual_seed(3)
+    net = unet.UNetResNet34(20, p=0.5).cuda()
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2)
+                m.running_var.uniform_(0.5, 1.5)
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+    for p in net.parameters():
+        p.requires_grad = False
+    net.eval()
+    x = torch.randn(3, 3, hw[0], hw[1], device="cuda")
+    assert net._frozen_ok(x)
+    with torch.no_grad():
+        want = net._forward_modules(x)["feature"]
+        got = net({"image": x})["feature"]
+    assert got.shape == want.shape == (3, 64, hw[0], hw[1])
+    assert rel_err(got.cpu().numpy(), want.cpu().numpy()) < 2e-4        # MIOpen picks its algorithm per layout / shape
+    net.train()
+    assert not net._frozen_ok(x)
+
+
 # ------------------------------------------------------------------ group_points (reference test shapes)
 
 @pytest.mark.parametrize("b,c,n1,n2,k", [(2, 3, 512, 128, 32), (5, 64, 513, 129, 33)])

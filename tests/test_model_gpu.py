@@ -282,18 +282,39 @@ def test_graph_replay_trains_like_eager(device_chain):
             losses_e.append(bench.net_step_captured(net, batch, cfg, params, opt, None).item())
         w_e = torch.cat([p.detach().reshape(-1) for p in params]).clone()
         net, params, opt = make()
-        step, note = bench.make_graph_step(shim, ops, cfg, net, staged, limits, params, opt, None)   # 2 eager steps inside
-        assert note.startswith("hipGraph")
-        losses_g = [step()[1].item() for _ in range(3)]
-        torch.cuda.synchronize()
+        import warnings
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            held = bench.net_step_captured(net, shim.build_batch(cfg, staged, limits, torch.int32)[0], cfg, params, opt, None)
+            # `held` keeps an eager autograd graph (and its AccumulateGrad nodes) alive across the capture, like the
+            # loss of bench.py's warm-up: the capture must run on the same stream as that backward did
+            step, note = bench.make_graph_step(shim, ops, cfg, net, staged, limits, params, opt, None)   # 2 eager steps inside
+            assert note.startswith("hipGraph")
+            losses_g = [step()[1].item() for _ in range(2)]
+            torch.cuda.synchronize()
+        assert not [w for w in caught if "AccumulateGrad" in str(w.message)], "stream mismatch between eager and captured backward"
+        del held
         w_g = torch.cat([p.detach().reshape(-1) for p in params])
-        assert np.allclose(losses_g, losses_e[2:], rtol=2e-3), (losses_g, losses_e)
+        assert np.allclose(losses_g, losses_e[3:], rtol=2e-3), (losses_g, losses_e)
         assert ((w_g - w_e).norm() / w_e.norm()).item() < 1e-3
     finally:
         ops.set_row_counts(None)
         ops.zero_arena_disable()
         torch.cuda.synchronize()
         torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_graph_capture_refuses_the_default_stream():
+    """Guard of the round-1 abort (segfault in capture_end): make_graph_step under the legacy default stream must
+    raise instead of starting a capture that cannot succeed."""
+    import importlib
+    import mvkpconv
+    bench = importlib.import_module("bench")
+    torch.cuda.set_stream(torch.cuda.default_stream())
+    staged = {"points": [torch.zeros(4, 3, device="cuda")]}
+    with pytest.raises(RuntimeError, match="non-default stream"):
+        bench.make_graph_step(mvkpconv.sub("synthetic"), mvkpconv.sub("ops"), None, torch.nn.Linear(2, 2).cuda(), staged, None,
+                              [], None, None)
 
 
 def test_bench_emits_one_valid_json_line():

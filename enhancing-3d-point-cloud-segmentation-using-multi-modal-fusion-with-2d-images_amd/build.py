@@ -22,6 +22,7 @@ SOURCES = [
     ("pool.hip", []),
     ("bn.hip", []),
     ("optim.hip", []),
+    ("deform.hip", []),
     ("batchpad.hip", []),
     ("subsample.hip", ["-ffp-contract=off"]),
     ("neighbors.hip", ["-ffp-contract=off"]),

@@ -1,0 +1,320 @@
+// Deformable KPConv: gradient of the kernel-point offsets, and the offset regulariser.
+//
+// (1) d_offsets. With A[n,k,c] = sum_h w[n,h,k] x[j_h,c] and w a function of (s[j_h] - q[n]) - (kp[k] + off[n,k])
+//     (reference KPConv-PyTorch/models/blocks.py:283-344, deformable branch :286-327), autograd gives
+//         d_off[n,k,:] = sum_h (dw[n,h,k] / d off[n,k,:]) * B[n,h,k],   B[n,h,k] = sum_c x[j_h,c] dA[n,k,c]
+//     plus, through min_d2 (blocks.py:303, read by the regulariser), -2 (rel[h*] - kpdef[k]) g_min[n,k] at the arg-min
+//     neighbour h*. Round 1 accumulated sum_h x[j_h,c] dw/doff per CHANNEL lane (45 registers per 64 channels, one
+//     launch per 64 channels, atomics): the slow lane of the deformable networks (4.3 of 24 ms per step).
+//     Here: one wave per query point, lane = NEIGHBOUR. Pass 1 walks all H entries (in-range filter blocks.py:306-325,
+//     arg-min bookkeeping) and compacts the kept neighbours into an LDS list; pass 2 takes 64 kept neighbours at a
+//     time: every lane streams ITS neighbour's feature row (64 rows in flight per wave) against the point's dA block
+//     staged in LDS (broadcast reads) -> B[15] per lane, then 45 offset-gradient accumulators; one wave reduction per
+//     point at the end, plain stores (the wave owns d_off[n]). 3x fewer flops than the per-channel form, no atomics,
+//     one launch whatever Cin is.
+//
+// (2) p2p_fitting_regularizer (models/architectures.py:20-58): per deformable layer
+//         power * ( 2 * mean_{n,k} min_d2 / ext^2  +  sum_i mean_n sum_{j != i} clamp_max(|loc_i - sg(loc_j)| - R, 0)^2 / K )
+//     with loc = deformed_KP / ext. One lane per point evaluates the 15 x 14 pairs, the launch also writes both
+//     gradients (they do not depend on anything upstream), so the ~50 tensor ops per layer become one launch.
+#include "common.h"
+
+#define DKMAX 16
+
+namespace {
+
+constexpr int DOFF_LIST = 2048;   // most neighbour columns one point can keep (rows of the neighbour matrix are narrower)
+
+struct DoffParams {
+  const float* q;
+  const float* s;
+  const void* idx;
+  const float* x;
+  const float* kp;
+  const float* offsets;   // [Nq,K,3]
+  const float* dA;        // [Nq,K,Cin]
+  const float* g_min_d2;  // [Nq,K] or null
+  float* d_offsets;       // [Nq,K,3] out
+  int64_t Nq, Ns;
+  int H, Cin, K;
+  float extent;
+  int influence;
+};
+
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <bool IDX64>
+__global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];   // [K][Cin4] dA block of this point, then the int list
+  const int lane = threadIdx.x;
+  const int64_t n = blockIdx.x;
+  const int Cin4 = (P.Cin + 3) & ~3;
+  float* dA_l = dsm;
+  float* bestv = dsm + (size_t)DKMAX * Cin4;                    // [K][3]: (rel - kpdef) of the arg-min entry
+  int* list = reinterpret_cast<int*>(bestv + DKMAX * 3);
+
+  // stage dA[n] (zero padded to a multiple of 4 channels)
+  for (int e = lane; e < P.K * Cin4; e += 64) {
+    const int kk = e / Cin4, c = e - kk * Cin4;
+    dA_l[e] = c < P.Cin ? P.dA[(n * P.K + kk) * P.Cin + c] : 0.f;
+  }
+  const float qx = P.q[n * 3], qy = P.q[n * 3 + 1], qz = P.q[n * 3 + 2];
+  float kx[DKMAX - 1], ky[DKMAX - 1], kz[DKMAX - 1];   // deformed kernel points (wave uniform), blocks.py:287
+#pragma unroll
+  for (int kk = 0; kk < DKMAX - 1; ++kk) {
+    kx[kk] = ky[kk] = kz[kk] = 0.f;
+    if (kk < P.K) {
+      const float* o = P.offsets + (n * P.K + kk) * 3;
+      kx[kk] = P.kp[kk * 3] + o[0];
+      ky[kk] = P.kp[kk * 3 + 1] + o[1];
+      kz[kk] = P.kp[kk * 3 + 2] + o[2];
+    }
+  }
+  const float ext2 = P.extent * P.extent;
+  float dOff[(DKMAX - 1) * 3];
+#pragma unroll
+  for (int e = 0; e < (DKMAX - 1) * 3; ++e) dOff[e] = 0.f;
+
+  // ---- pass 1: all H entries. Keep list (real neighbours within the extent of some deformed kernel point) and the
+  //      min_d2 path: per kernel point the FIRST entry attaining min_h d2 (shadow entries included, like torch.min over
+  //      dim 1), found here by a wave arg-min per chunk -- not by comparing with the forward's stored minimum, whose
+  //      last bit may differ between two separately compiled kernels.
+  float best[DKMAX - 1];
+#pragma unroll
+  for (int kk = 0; kk < DKMAX - 1; ++kk) best[kk] = INFINITY;
+  int nkept = 0;
+  for (int h0 = 0; h0 < P.H; h0 += 64) {
+    const int h = h0 + lane;
+    int j = -2;
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (h < P.H) {
+      j = load_idx<IDX64>(P.idx, n * P.H + h, P.Ns);
+      if (j >= 0) {
+        const float* sp = P.s + (int64_t)j * 3;
+        rx = sp[0] - qx; ry = sp[1] - qy; rz = sp[2] - qz;
+      } else {
+        rx = 1e6f - qx; ry = 1e6f - qy; rz = 1e6f - qz;
+      }
+    }
+    bool keep = false;
+#pragma unroll
+    for (int kk = 0; kk < DKMAX - 1; ++kk) {
+      if (kk < P.K) {
+        const float dx = rx - kx[kk], dy = ry - ky[kk], dz = rz - kz[kk];
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        if (j >= 0 && d2 < ext2) keep = true;
+        if (P.g_min_d2 != nullptr) {
+          float bd = j >= -1 ? d2 : INFINITY;
+          int bl = lane;
+#pragma unroll
+          for (int m = 1; m < 64; m <<= 1) {
+            const float od = __shfl_xor(bd, m);
+            const int ol = __shfl_xor(bl, m);
+            if (od < bd || (od == bd && ol < bl)) {
+              bd = od;
+              bl = ol;
+            }
+          }
+          if (bd < best[kk]) {            // wave uniform; strict: an earlier chunk keeps a tie
+            best[kk] = bd;
+            if (lane == bl) {
+              bestv[kk * 3 + 0] = dx;
+              bestv[kk * 3 + 1] = dy;
+              bestv[kk * 3 + 2] = dz;
+            }
+          }
+        }
+      }
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (keep) {
+      const int pos = nkept + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+      if (pos < DOFF_LIST) list[pos] = j;
+    }
+    nkept += __builtin_popcountll(bal);
+  }
+  nkept = nkept < DOFF_LIST ? nkept : DOFF_LIST;
+  wave_lds_sync();
+  if (P.g_min_d2 != nullptr && lane < P.K && best[0] < INFINITY) {      // d min_d2 / d off = -2 (rel[h*] - kpdef)
+    const float g = -2.f * P.g_min_d2[n * P.K + lane];
+    // lane k carries kernel point k's term in its own accumulators (summed over the wave at the end)
+#pragma unroll
+    for (int kk = 0; kk < DKMAX - 1; ++kk) {
+      if (kk == lane) {
+        dOff[kk * 3 + 0] += g * bestv[kk * 3 + 0];
+        dOff[kk * 3 + 1] += g * bestv[kk * 3 + 1];
+        dOff[kk * 3 + 2] += g * bestv[kk * 3 + 2];
+      }
+    }
+  }
+
+  // ---- pass 2: 64 kept neighbours at a time, lane = neighbour
+  for (int t0 = 0; t0 < nkept; t0 += 64) {
+    const bool on = t0 + lane < nkept;
+    const int j = on ? list[t0 + lane] : 0;
+    float B[DKMAX - 1];
+#pragma unroll
+    for (int kk = 0; kk < DKMAX - 1; ++kk) B[kk] = 0.f;
+    const float* xr = P.x + (int64_t)j * P.Cin;
+    if ((P.Cin & 3) == 0) {
+      for (int c = 0; c < P.Cin; c += 4) {
+        const float4 xv = on ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kk = 0; kk < DKMAX - 1; ++kk) {
+          if (kk < P.K) {
+            const float4 d = *reinterpret_cast<const float4*>(dA_l + kk * Cin4 + c);   // broadcast read
+            B[kk] += xv.x * d.x + xv.y * d.y + xv.z * d.z + xv.w * d.w;
+          }
+        }
+      }
+    } else {
+      for (int c = 0; c < P.Cin; ++c) {
+        const float xv = on ? xr[c] : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < DKMAX - 1; ++kk)
+          if (kk < P.K) B[kk] += xv * dA_l[kk * Cin4 + c];
+      }
+    }
+    if (on) {
+      const float* sp = P.s + (int64_t)j * 3;
+      const float rx = sp[0] - qx, ry = sp[1] - qy, rz = sp[2] - qz;
+#pragma unroll
+      for (int kk = 0; kk < DKMAX - 1; ++kk) {
+        if (kk < P.K) {
+          const float dx = rx - kx[kk], dy = ry - ky[kk], dz = rz - kz[kk];
+          const float d2 = dx * dx + dy * dy + dz * dz;
+          // d w / d off[k,:] = sc * (rel - kpdef):  linear  w = 1 - sqrt(d2)/ext (w > 0): sc = 1 / (ext sqrt(d2));
+          //                                         gaussian w = exp(-d2/den):            sc = 2 w / den;  constant: 0
+          float sc = 0.f;
+          if (P.influence == MVK_INFL_LINEAR) {
+            const float dist = sqrtf(d2);
+            if (1.0f - dist / P.extent > 0.f && d2 > 0.f) sc = 1.0f / (P.extent * dist);
+          } else if (P.influence == MVK_INFL_GAUSSIAN) {
+            const float sig = P.extent * 0.3f, den = 2.0f * sig * sig + 1e-9f;
+            sc = 2.0f * expf(-d2 / den) / den;
+          }
+          const float f = sc * B[kk];
+          dOff[kk * 3 + 0] += f * dx;
+          dOff[kk * 3 + 1] += f * dy;
+          dOff[kk * 3 + 2] += f * dz;
+        }
+      }
+    }
+  }
+
+  // ---- one reduction over the 64 lanes per component, plain stores
+#pragma unroll
+  for (int e = 0; e < (DKMAX - 1) * 3; ++e) {
+    float v = dOff[e];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    if (lane == 0 && e < P.K * 3) P.d_offsets[n * P.K * 3 + e] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// regulariser: one lane per point
+__global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __restrict__ min_d2, const float* __restrict__ dkp,
+                                                                const int32_t* __restrict__ n_valid, int64_t N, int K,
+                                                                float extent, float repulse, float power,
+                                                                float* __restrict__ loss /* [1], += */,
+                                                                float* __restrict__ d_min_d2 /* [N,K] */,
+                                                                float* __restrict__ d_dkp /* [N,K,3] */) {
+  __shared__ float red[4];
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t nv = n_valid ? (int64_t)*n_valid : N;
+  nv = nv < N ? nv : N;
+  float part = 0.f;
+  if (n < N) {
+    const bool valid = n < nv;
+    const float inv_e = 1.0f / extent;
+    const float cf = valid ? power * 2.0f / (extent * extent * (float)nv * (float)K) : 0.f;   // d loss / d min_d2
+    const float cr = valid ? power / ((float)nv * (float)K) : 0.f;                                // weight of one point's pair sum
+    float lx[DKMAX - 1], ly[DKMAX - 1], lz[DKMAX - 1];
+#pragma unroll
+    for (int i = 0; i < DKMAX - 1; ++i) {
+      lx[i] = ly[i] = lz[i] = 0.f;
+      if (i < K) {
+        const float* p = dkp + (n * K + i) * 3;
+        lx[i] = p[0] * inv_e; ly[i] = p[1] * inv_e; lz[i] = p[2] * inv_e;     // KP_locs (architectures.py:44)
+        const float m = min_d2[n * K + i];
+        d_min_d2[n * K + i] = m > 0.f ? cf : (m < 0.f ? -cf : 0.f);            // L1 to zero: sign(m)
+        part += cf * fabsf(m);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DKMAX - 1; ++i) {
+      if (i < K) {
+        float gx = 0.f, gy = 0.f, gz = 0.f, acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < DKMAX - 1; ++j) {
+          if (j < K && j != i) {
+            const float dx = lx[i] - lx[j], dy = ly[i] - ly[j], dz = lz[i] - lz[j];
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            const float c = fminf(d - repulse, 0.f);           // clamp_max(dist - repulse_extent, 0)  (:52)
+            acc += c * c;
+            const float s = 2.f * c / d;                        // d c^2 / d loc_i  (the other point is detached, :49)
+            gx += s * dx; gy += s * dy; gz += s * dz;
+          }
+        }
+        part += cr * acc;
+        float* o = d_dkp + (n * K + i) * 3;
+        o[0] = cr * gx * inv_e; o[1] = cr * gy * inv_e; o[2] = cr * gz * inv_e;
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1]) + (red[2] + red[3]));
+}
+
+}  // namespace
+
+extern "C" int mvk_kpconv_deform_doff(const float* q, int64_t Nq, const float* s, int64_t Ns, const void* idx,
+                                      int idx64, int H, const float* x, int Cin, const float* kp, int K, float extent,
+                                      int influence, const float* offsets, const float* dA,
+                                      const float* g_min_d2, float* d_offsets, void* stream) {
+  MVK_REQUIRE(Nq >= 0 && Ns >= 0 && H >= 0 && Cin > 0 && K >= 1 && K < DKMAX, "deform d_offsets: bad sizes");
+  MVK_REQUIRE(influence >= 0 && influence <= 2, "Unknown influence function type (config.KP_influence)");
+  MVK_REQUIRE(offsets && dA && d_offsets && x, "deform d_offsets: null operand");
+  MVK_REQUIRE(H <= DOFF_LIST, "deform d_offsets: neighbour rows wider than %d columns", DOFF_LIST);
+  MVK_REQUIRE(Nq < (1ll << 31), "deform d_offsets: Nq too large for one launch");
+  if (Nq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  DoffParams P{};
+  P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets; P.dA = dA;
+  P.g_min_d2 = g_min_d2; P.d_offsets = d_offsets; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K;
+  P.extent = extent; P.influence = influence;
+  const int Cin4 = (Cin + 3) & ~3;
+  const size_t lds = sizeof(float) * ((size_t)DKMAX * Cin4 + DKMAX * 3) + sizeof(int) * (size_t)(H < 64 ? 64 : H);
+  MVK_REQUIRE(lds <= 160 * 1024, "deform d_offsets: Cin=%d does not fit the LDS staging", Cin);
+  if (idx64) {
+    if (lds > 64 * 1024)
+      MVK_CHECK_HIP(hipFuncSetAttribute((const void*)kpconv_deform_doff<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((kpconv_deform_doff<true>), dim3((unsigned)Nq), dim3(64), lds, st, P);
+  } else {
+    if (lds > 64 * 1024)
+      MVK_CHECK_HIP(hipFuncSetAttribute((const void*)kpconv_deform_doff<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((kpconv_deform_doff<false>), dim3((unsigned)Nq), dim3(64), lds, st, P);
+  }
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_deform_regularizer(const float* min_d2, const float* deformed_kp, const int32_t* n_valid, int64_t N,
+                                      int K, float extent, float repulse_extent, float power, float* loss_accum,
+                                      float* d_min_d2, float* d_deformed_kp, void* stream) {
+  MVK_REQUIRE(N >= 0 && K >= 1 && K < DKMAX && extent > 0.f, "regulariser: bad sizes");
+  MVK_REQUIRE(min_d2 && deformed_kp && loss_accum && d_min_d2 && d_deformed_kp, "regulariser: null operand");
+  if (N == 0) return 0;
+  hipLaunchKernelGGL(deform_regularizer_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, (hipStream_t)stream, min_d2,
+                     deformed_kp, n_valid, N, K, extent, repulse_extent, power, loss_accum, d_min_d2, d_deformed_kp);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -11,8 +11,9 @@
 // backward recomputes it instead of storing [N,H,K].
 //
 // Work decomposition (one 64-lane wavefront per workgroup): see the comment on
-// kpconv_gather_vec (forward, rigid) and kpconv_lane_channel (backward scatter, deformable
-// forward/backward: lane = channel, one point per wave, wave-uniform neighbour loop).
+// kpconv_gather_vec (forward, rigid) and kpconv_lane_channel (backward scatter dx, deformable forward:
+// lane = channel, one point per wave, wave-uniform neighbour loop). The offset gradient of the deformable
+// layers is csrc/deform.hip (lane = neighbour).
 #include "common.h"
 
 #define KMAX 16
@@ -342,7 +343,6 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
   constexpr int HC = 64, WPAD = 0;
   __shared__ float4 rel[64];
   __shared__ float wl[64 * 16];
-  __shared__ float cf[DEFORM && MODE == 1 ? 64 * 16 * 3 : 1];  // dw/d(offset) per (h,k,dim)
   const int lane = threadIdx.x;
   const int64_t n = blockIdx.x;
   const float* qp = P.q + n * 3;
@@ -363,7 +363,6 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
   float run_min = INFINITY;
 
   float acc[NSLOT][KMAX - 1];  // MODE 0: A accumulators; MODE 1: dA values
-  float S[(DEFORM && MODE == 1) ? NSLOT : 1][(DEFORM && MODE == 1) ? (KMAX - 1) * 3 : 1];
 #pragma unroll
   for (int sidx = 0; sidx < NSLOT; ++sidx) {
     const int c = c0 + lane + 64 * sidx;
@@ -374,41 +373,11 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
       else
         acc[sidx][kk] = (c < P.Cin && kk < P.K) ? P.A[(n * P.K + kk) * P.Cin + c] : 0.f;
     }
-    if (DEFORM && MODE == 1) {
-#pragma unroll
-      for (int e = 0; e < (KMAX - 1) * 3; ++e) S[sidx][e] = 0.f;
-    }
   }
 
   for (int h0 = 0; h0 < P.H; h0 += HC) {
     int j = phase_a<1, HC, WPAD, IDX64, DEFORM>(P, n, h0, lane, rel, wl, qx, qy, qz, true, kx, ky,
                                                  kz, &run_min);
-    if (DEFORM && MODE == 1) {
-      // d w[h,k] / d offset[k,:] for the linear influence:  w = 1 - sqrt(d2)/ext  (w > 0)
-      //   dw/dd2 = -1/(2 ext sqrt(d2));  dd2/doff = -2 (rel - kpdef)   =>  (rel - kpdef) / (ext sqrt(d2))
-      // gaussian: w = exp(-d2/den): dw/doff = w * 2 (rel - kpdef) / den.  constant: 0.
-#pragma unroll
-      for (int t = 0; t < 16; ++t) {
-        const int ph = t * 4 + (lane >> 4);
-        const float4 r = rel[ph];
-        const float w = wl[ph * 16 + k];
-        float ddx = r.x - kx, ddy = r.y - ky, ddz = r.z - kz;
-        float d2 = ddx * ddx + ddy * ddy + ddz * ddz;
-        float sc = 0.f;
-        if (w > 0.f && k < P.K) {
-          if (P.influence == MVK_INFL_LINEAR)
-            sc = d2 > 0.f ? 1.0f / (P.extent * sqrtf(d2)) : 0.f;
-          else if (P.influence == MVK_INFL_GAUSSIAN) {
-            float sig = P.extent * 0.3f;
-            sc = 2.0f * w / (2.0f * sig * sig + 1e-9f);
-          }
-        }
-        cf[(ph * 16 + k) * 3 + 0] = sc * ddx;
-        cf[(ph * 16 + k) * 3 + 1] = sc * ddy;
-        cf[(ph * 16 + k) * 3 + 2] = sc * ddz;
-      }
-      __syncthreads();
-    }
     if (__ballot(j >= 0) != 0ull) {
       const int hend = min(HC, P.H - h0);
       for (int hh = 0; hh < hend; ++hh) {
@@ -431,12 +400,6 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
 #pragma unroll
               for (int kk = 0; kk < KMAX - 1; ++kk) contrib += wv[kk] * acc[sidx][kk];
               atomicAdd(P.dx + (int64_t)jj * P.Cin + c, contrib);
-              if (DEFORM) {
-                const float xv = P.x[(int64_t)jj * P.Cin + c];
-                const float* cfr = cf + hh * 16 * 3;
-#pragma unroll
-                for (int e = 0; e < (KMAX - 1) * 3; ++e) S[sidx][e] += xv * cfr[e];
-              }
             }
           }
         }
@@ -461,56 +424,7 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
       m = fminf(m, __shfl_xor(m, 32));
       if (lane < 16 && lane < P.K) P.min_d2[n * P.K + lane] = m;
     }
-  } else if (DEFORM) {
-    // d_offsets[n,k,d] (+)= sum_c S_c[k][d] * dA[n,k,c]   (see header comment / DESIGN.md)
-#pragma unroll
-    for (int kk = 0; kk < KMAX - 1; ++kk) {
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        float v = 0.f;
-#pragma unroll
-        for (int sidx = 0; sidx < NSLOT; ++sidx) v += S[sidx][kk * 3 + d] * acc[sidx][kk];
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-        if (lane == 0 && kk < P.K) atomicAdd(P.d_offsets + (n * P.K + kk) * 3 + d, v);
-      }
-    }
   }
-}
-
-// min_d2 backward for the deformable path: d min_d2[n,k] / d offset[n,k,:] = -2 (rel[h*] - kpdef)
-// with h* = argmin_h d2 (first minimum). One lane per (n,k).
-template <bool IDX64>
-__global__ void kpconv_min_d2_bwd(KPParams P) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= P.Nq * P.K) return;
-  const int64_t n = t / P.K;
-  const int k = (int)(t % P.K);
-  const float g = P.g_min_d2[t];
-  const float* o = P.offsets + t * 3;
-  const float kx = P.kp[k * 3] + o[0], ky = P.kp[k * 3 + 1] + o[1], kz = P.kp[k * 3 + 2] + o[2];
-  const float qx = P.q[n * 3], qy = P.q[n * 3 + 1], qz = P.q[n * 3 + 2];
-  float best = INFINITY, bx = 0.f, by = 0.f, bz = 0.f;
-  for (int h = 0; h < P.H; ++h) {
-    int j = load_idx<IDX64>(P.idx, n * P.H + h, P.Ns);
-    float sx = 1e6f, sy = 1e6f, sz = 1e6f;
-    if (j >= 0) {
-      sx = P.s[(int64_t)j * 3];
-      sy = P.s[(int64_t)j * 3 + 1];
-      sz = P.s[(int64_t)j * 3 + 2];
-    }
-    float dx = (sx - qx) - kx, dy = (sy - qy) - ky, dz = (sz - qz) - kz;
-    float d2 = dx * dx + dy * dy + dz * dz;
-    if (d2 < best) {
-      best = d2;
-      bx = dx;
-      by = dy;
-      bz = dz;
-    }
-  }
-  atomicAdd(P.d_offsets + t * 3 + 0, -2.f * bx * g);
-  atomicAdd(P.d_offsets + t * 3 + 1, -2.f * by * g);
-  atomicAdd(P.d_offsets + t * 3 + 2, -2.f * bz * g);
 }
 
 template <int NCH, typename XT = float, bool VEC = true>
@@ -542,16 +456,7 @@ int launch_lane_channel(const KPParams& P, int idx64, hipStream_t st) {
     hipLaunchKernelGGL((kpconv_lane_channel<NS, true, MODE, DEFORM>), grid, block, 0, st, P, c0);    \
   else                                                                                               \
     hipLaunchKernelGGL((kpconv_lane_channel<NS, false, MODE, DEFORM>), grid, block, 0, st, P, c0);
-    if (DEFORM && MODE == 1) {
-      // register budget: S[NSLOT][45] -> keep slots small, more launches
-      for (int cc = c0; cc < c0 + cw; cc += 64) {
-        KPParams Q = P;
-        if (idx64)
-          hipLaunchKernelGGL((kpconv_lane_channel<1, true, MODE, DEFORM>), grid, block, 0, st, Q, cc);
-        else
-          hipLaunchKernelGGL((kpconv_lane_channel<1, false, MODE, DEFORM>), grid, block, 0, st, Q, cc);
-      }
-    } else if (ns <= 1) {
+    if (ns <= 1) {
       LC(1)
     } else if (ns <= 2) {
       LC(2)
@@ -623,14 +528,11 @@ extern "C" int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s
   if (offsets != nullptr) {
     MVK_REQUIRE(x != nullptr && d_offsets != nullptr, "kpconv bwd: deformable needs x and d_offsets");
     MVK_REQUIRE(aggregation == MVK_AGG_SUM, "kpconv bwd: deformable + 'closest' aggregation has no offset gradient path");
-    launch_lane_channel<1, true>(P, idx64, st);
-    if (g_min_d2 != nullptr) {
-      int64_t tot = Nq * K;
-      if (idx64)
-        hipLaunchKernelGGL((kpconv_min_d2_bwd<true>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, P);
-      else
-        hipLaunchKernelGGL((kpconv_min_d2_bwd<false>), dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, st, P);
-    }
+    launch_lane_channel<1, true>(P, idx64, st);      // dx: same scatter as the rigid layers, deformed weights + in-range filter
+    MVK_CHECK_HIP(hipGetLastError());
+    // d_offsets (A path and min_d2 path): one wave per point, lane = neighbour (csrc/deform.hip)
+    return mvk_kpconv_deform_doff(q, Nq, s, Ns, idx, idx64, H, x, Cin, kp, K, extent, influence, offsets, dA, g_min_d2,
+                                  d_offsets, stream);
   } else {
     launch_lane_channel<1, false>(P, idx64, st);
   }

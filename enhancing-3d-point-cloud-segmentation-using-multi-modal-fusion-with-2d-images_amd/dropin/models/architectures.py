@@ -1,6 +1,8 @@
 """KPFCNN segmentation network, baseline variant (reference KPConv-PyTorch/models/architectures.py:
 p2p_fitting_regularizer :25-58, KPFCNN :189-394). Module / parameter names match the reference
 (encoder_blocks.N.*, decoder_blocks.N.*, head_mlp.*, head_softmax.*) for state-dict compatibility."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -13,17 +15,25 @@ except ImportError:
     from _native import ops as _ops
 
 
+_FUSED_REG = os.environ.get("MVK_FUSED_REGULARIZER", "1") == "1"   # development switch: 0 = the tensor-op form below
+
+
 def p2p_fitting_regularizer(net):
     """Deformable-kernel regulariser (architectures.py:25-58): fitting loss = mean |min_d2| / extent^2
     (kernel point -> closest input point) and repulsive loss between the deformed kernel points of a
     point (the "other" points detached, :52). Same arithmetic as the reference's per-kernel-point
     Python loop, evaluated for all K points at once (one [N,K,K] distance tensor instead of 15 x 8 small
-    kernels per deformable layer); in capacity-padded mode the means run over the valid rows only."""
-    fitting_loss = 0
-    repulsive_loss = 0
+    kernels per deformable layer); in capacity-padded mode the means run over the valid rows only.
+    On the GPU each layer's term and both its gradients come from ONE launch (ops.deform_regularizer)."""
+    total = 0
     for m in net.modules():
         if isinstance(m, KPConv) and m.deformable:
             rows = m.min_d2.shape[0]
+            if m.min_d2.is_cuda and _FUSED_REG:
+                # one launch per layer (csrc/deform.hip): loss term and both gradients
+                total = total + _ops.deform_regularizer(m.min_d2, m.deformed_KP, m.KP_extent, net.repulse_extent,
+                                                        net.deform_fitting_power, _ops.row_count_for(rows))
+                continue
             n_valid = _ops.row_count_for(rows)
             if n_valid is None:
                 mask, denom = None, float(rows)
@@ -38,7 +48,7 @@ def p2p_fitting_regularizer(net):
                 return v.sum() / (denom * v.shape[1])
 
             # fitting: squared distance to the closest input point, normalised by the extent (:35-38)
-            fitting_loss = fitting_loss + mean_rows(m.min_d2 / (m.KP_extent ** 2))
+            fitting_loss = mean_rows(m.min_d2 / (m.KP_extent ** 2))
             # repulsion (:44-56): d[n,i,j] = |KP_i - sg(KP_j)|, j != i
             KP_locs = m.deformed_KP / m.KP_extent
             K = KP_locs.shape[1]
@@ -48,8 +58,9 @@ def p2p_fitting_regularizer(net):
             dist = torch.sqrt(d2)
             rep = torch.clamp_max(dist - net.repulse_extent, max=0.0) ** 2 * (1 - eye)
             rep_loss = rep.sum(dim=2)                                                  # [N,K]: sum over the other points
-            repulsive_loss = repulsive_loss + mean_rows(rep_loss) * rep_loss.shape[1] / net.K
-    return net.deform_fitting_power * (2 * fitting_loss + repulsive_loss)
+            repulsive_loss = mean_rows(rep_loss) * rep_loss.shape[1] / net.K
+            total = total + net.deform_fitting_power * (2 * fitting_loss + repulsive_loss)
+    return total
 
 
 def build_encoder(config, in_dim):

@@ -259,7 +259,7 @@ def kpconv_scatter(q, s, idx, dA, kp, extent, influence="linear", aggregation="s
     d_off = None
     if offsets is not None:
         offsets, x = _f32c(offsets), _f32c(x)
-        d_off = _zeros((Nq, K, 3), q.device)
+        d_off = torch.empty((Nq, K, 3), device=q.device, dtype=torch.float32)    # written whole by mvk_kpconv_deform_doff
         if g_min_d2 is not None:
             g_min_d2 = _f32c(g_min_d2)
     check(lib().mvk_kpconv_scatter_bwd(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, Cin, _p(kp), K, float(extent),
@@ -483,6 +483,39 @@ def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", o
     if part is not None:        # the plan is a pure function of the shape: the same rows the contraction just used
         y._mvk_bn_stats = (part, gemm_plan(y.shape[0], y.shape[1], W.shape[0] * W.shape[1], None, True)[1])
     return y, min_d2
+
+
+# --------------------------------------------------------------------------------------------
+# offset regulariser of the deformable layers
+# --------------------------------------------------------------------------------------------
+
+class _DeformRegFn(torch.autograd.Function):
+    """p2p_fitting_regularizer of one deformable KPConv (models/architectures.py:20-58) as one launch that also
+    produces both gradients (mvk_deform_regularizer); the backward only scales them by the upstream gradient."""
+
+    @staticmethod
+    def forward(ctx, min_d2, deformed_kp, n_valid, extent, repulse_extent, power):
+        _dev(min_d2, deformed_kp, n_valid)
+        min_d2, dkp = _f32c(min_d2), _f32c(deformed_kp)
+        N, K = min_d2.shape
+        loss = _zeros((1,), min_d2.device)
+        d_min = torch.empty_like(min_d2)
+        d_dkp = torch.empty_like(dkp)
+        check(lib().mvk_deform_regularizer(_p(min_d2), _p(dkp), _p(n_valid), N, K, float(extent), float(repulse_extent),
+                                           float(power), _p(loss), _p(d_min), _p(d_dkp), _stream()))
+        ctx.save_for_backward(d_min, d_dkp)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        d_min, d_dkp = ctx.saved_tensors
+        return d_min * g, d_dkp * g, None, None, None, None
+
+
+def deform_regularizer(min_d2, deformed_kp, extent, repulse_extent, power=1.0, n_valid=None):
+    """power * (2 * fitting + repulsive) of one deformable layer; min_d2 [N,K], deformed_kp [N,K,3]; n_valid: DEVICE
+    int32 [1] row count of a capacity-padded level (means over the valid rows only) or None."""
+    return _DeformRegFn.apply(min_d2, deformed_kp, n_valid, extent, repulse_extent, power)
 
 
 # --------------------------------------------------------------------------------------------

@@ -103,6 +103,25 @@ int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t
 int mvk_gemm_f16(const void* A, int a_f16, const void* B, int b_f16, void* C, int c_f16, int64_t M, int64_t N,
                  int64_t Kd, int transA, int transB, int split_k, void* stream);
 
+/* ---------------- deformable KPConv: offset gradient, offset regulariser ---- */
+
+/* d_offsets [Nq,K,3] of a deformable KPConv (blocks.py:286-327, 366-374 through autograd):
+ *   sum_h dw[n,h,k]/d off[n,k,:] * (sum_c x[j_h,c] dA[n,k,c])  -  2 (rel[h*] - kpdef[k]) g_min_d2[n,k]
+ * over the neighbours kept by the in-range filter (h* = first arg-min of d2 over ALL entries, shadow included).
+ * dA is the gradient of the aggregate (already multiplied by the modulations when modulated); g_min_d2 may be NULL.
+ * Plain stores (no zero-initialisation needed). Called by mvk_kpconv_scatter_bwd for deformable layers. */
+int mvk_kpconv_deform_doff(const float* q, int64_t Nq, const float* s, int64_t Ns, const void* idx, int idx64, int H,
+                           const float* x, int Cin, const float* kp, int K, float extent, int influence,
+                           const float* offsets, const float* dA, const float* g_min_d2, float* d_offsets, void* stream);
+
+/* p2p_fitting_regularizer of ONE deformable layer (models/architectures.py:20-58) and both its gradients:
+ *   *loss_accum += power * ( 2 * mean_{n<nv,k} |min_d2| / ext^2 + sum_i mean_{n<nv} sum_{j!=i} clamp_max(|loc_i - loc_j| - R, 0)^2 / K ),
+ *   loc = deformed_kp / ext, the other point of a pair detached; d_min_d2 [N,K] and d_deformed_kp [N,K,3] receive
+ *   d loss / d input (for an upstream gradient of 1). n_valid: DEVICE int32 row count or NULL (= N). */
+int mvk_deform_regularizer(const float* min_d2, const float* deformed_kp, const int32_t* n_valid, int64_t N, int K,
+                           float extent, float repulse_extent, float power, float* loss_accum, float* d_min_d2,
+                           float* d_deformed_kp, void* stream);
+
 /* ---------------- frozen 2D encoder: pointwise epilogue of a convolution --- */
 
 /* y = act(x + bias[c] (+ res (+ bias2[c]))) over a channels-last (N,H,W,C) f32 tensor, C % 4 == 0: what is left of

@@ -629,6 +629,38 @@ def test_fused_clip_sgd_matches_torch_clip_and_sgd():
         assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-6
 
 
+# ------------------------------------------------------------------ deformable: regulariser kernel
+
+@pytest.mark.parametrize("N,n", [(300, 300), (2000, 1873), (1, 1)])
+def test_deform_regularizer_kernel_vs_reference_formula(ops, N, n):
+    """mvk_deform_regularizer against the cited lines of p2p_fitting_regularizer (models/architectures.py:20-58)
+    written with tensor ops in float64: the layer's loss term and the gradients wrt min_d2 and deformed_KP, with a
+    row count below the capacity (padded rows must not contribute and must get zero gradient)."""
+    torch.manual_seed(N)
+    K, ext, rep, power = 15, 0.6, 1.2, 1.0
+    min_d2 = (torch.rand(N, K, device="cuda") * 0.3).requires_grad_(True)
+    dkp = (torch.randn(N, K, 3, device="cuda") * 0.4).requires_grad_(True)
+    nv = torch.tensor([n], dtype=torch.int32, device="cuda")
+    loss = ops.deform_regularizer(min_d2, dkp, ext, rep, power, nv)
+    g1, g2 = torch.autograd.grad(loss, [min_d2, dkp])
+    m64 = min_d2.detach().double()[:n].requires_grad_(True)
+    k64 = dkp.detach().double()[:n].requires_grad_(True)
+    l1 = torch.nn.L1Loss()
+    fit = l1(m64 / ext ** 2, torch.zeros_like(m64))
+    locs = k64 / ext
+    rl = 0
+    for i in range(K):
+        other = torch.cat([locs[:, :i, :], locs[:, i + 1:, :]], dim=1).detach()
+        d = torch.sqrt(torch.sum((other - locs[:, i:i + 1, :]) ** 2, dim=2))
+        r = torch.sum(torch.clamp_max(d - rep, max=0.0) ** 2, dim=1)
+        rl = rl + l1(r, torch.zeros_like(r)) / K
+    want = power * (2 * fit + rl)
+    w1, w2 = torch.autograd.grad(want, [m64, k64])
+    assert abs(loss.item() - want.item()) < 1e-5 * abs(want.item())
+    assert rel_err(g1[:n].cpu().numpy(), w1.cpu().numpy()) < 1e-5 and rel_err(g2[:n].cpu().numpy(), w2.cpu().numpy()) < 1e-5
+    assert (g1[n:] == 0).all() and (g2[n:] == 0).all()
+
+
 # ------------------------------------------------------------------ frozen 2D encoder fast path
 
 @pytest.mark.parametrize("hw", [(120, 160), (60, 80)])

@@ -16,17 +16,17 @@ _SIGNATURES = {
     "mvk_abi_version": (C.c_int, []),
     "mvk_last_error": (C.c_char_p, []),
     "mvk_kpconv_gather_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
-                                        _vp, _vp, _vp, _vp]),
+                                        _vp, _vp, _vp, _vp, _vp]),
     "mvk_kpconv_gather_fwd_f16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
                                             _vp, _vp]),
     "mvk_kpconv_scatter_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i, _f, _i, _i,
-                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvk_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
     "mvk_gemm_f32_plan": (C.c_int, [_i64, _i64, _i64, _i, _i, _vp, _vp]),
     "mvk_gemm_f32_ex": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mvk_gemm_f16": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i64, _i64, _i64, _i, _i, _i, _vp]),
     "mvk_kpconv_deform_doff": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp,
-                                        _vp]),
+                                        _vp, _vp]),
     "mvk_deform_regularizer": (C.c_int, [_vp, _vp, _vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "mvk_bias_act_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "mvk_sgd_chunk_elems": (C.c_int, []),

@@ -6,8 +6,8 @@
 //     plus, through min_d2 (blocks.py:303, read by the regulariser), -2 (rel[h*] - kpdef[k]) g_min[n,k] at the arg-min
 //     neighbour h*. Round 1 accumulated sum_h x[j_h,c] dw/doff per CHANNEL lane (45 registers per 64 channels, one
 //     launch per 64 channels, atomics): the slow lane of the deformable networks (4.3 of 24 ms per step).
-//     Here: one wave per query point, lane = NEIGHBOUR. Pass 1 walks all H entries (in-range filter blocks.py:306-325,
-//     arg-min bookkeeping) and compacts the kept neighbours into an LDS list; pass 2 takes 64 kept neighbours at a
+//     Here: one wave per query point, lane = NEIGHBOUR. Pass 1 walks all H entries (in-range filter blocks.py:306-325)
+//     and compacts the kept neighbours into an LDS list (the arg-min column of the min_d2 path comes from the forward); pass 2 takes 64 kept neighbours at a
 //     time: every lane streams ITS neighbour's feature row (64 rows in flight per wave) against the point's dA block
 //     staged in LDS (broadcast reads) -> B[15] per lane, then 45 offset-gradient accumulators; one wave reduction per
 //     point at the end, plain stores (the wave owns d_off[n]). 3x fewer flops than the per-channel form, no atomics,
@@ -34,6 +34,7 @@ struct DoffParams {
   const float* offsets;   // [Nq,K,3]
   const float* dA;        // [Nq,K,Cin]
   const float* g_min_d2;  // [Nq,K] or null
+  const int32_t* min_arg; // [Nq,K] column of the arg-min entry (forward), with g_min_d2
   float* d_offsets;       // [Nq,K,3] out
   int64_t Nq, Ns;
   int H, Cin, K;
@@ -54,19 +55,28 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
   const int64_t n = blockIdx.x;
   const int Cin4 = (P.Cin + 3) & ~3;
   float* dA_l = dsm;
-  float* bestv = dsm + (size_t)DKMAX * Cin4;                    // [K][3]: (rel - kpdef) of the arg-min entry
-  int* list = reinterpret_cast<int*>(bestv + DKMAX * 3);
+  int* list = reinterpret_cast<int*>(dsm + (size_t)DKMAX * Cin4);
 
   // stage dA[n] (zero padded to a multiple of 4 channels)
-  for (int e = lane; e < P.K * Cin4; e += 64) {
-    const int kk = e / Cin4, c = e - kk * Cin4;
-    dA_l[e] = c < P.Cin ? P.dA[(n * P.K + kk) * P.Cin + c] : 0.f;
+  if ((P.Cin & 3) == 0) {
+    const float4* src = reinterpret_cast<const float4*>(P.dA + n * P.K * P.Cin);     // K*Cin contiguous floats, 16-byte aligned
+    float4* dst = reinterpret_cast<float4*>(dA_l);
+    const int n4 = P.K * P.Cin / 4;
+#pragma unroll 4
+    for (int e = lane; e < n4; e += 64) dst[e] = src[e];
+    for (int e = n4 + lane; e < (DKMAX - 1) * Cin4 / 4; e += 64) dst[e] = make_float4(0.f, 0.f, 0.f, 0.f);   // rows k >= K
+  } else {
+    for (int e = P.K * Cin4 + lane; e < (DKMAX - 1) * Cin4; e += 64) dA_l[e] = 0.f;
+    for (int e = lane; e < P.K * Cin4; e += 64) {
+      const int kk = e / Cin4, c = e - kk * Cin4;
+      dA_l[e] = c < P.Cin ? P.dA[(n * P.K + kk) * P.Cin + c] : 0.f;
+    }
   }
   const float qx = P.q[n * 3], qy = P.q[n * 3 + 1], qz = P.q[n * 3 + 2];
   float kx[DKMAX - 1], ky[DKMAX - 1], kz[DKMAX - 1];   // deformed kernel points (wave uniform), blocks.py:287
 #pragma unroll
   for (int kk = 0; kk < DKMAX - 1; ++kk) {
-    kx[kk] = ky[kk] = kz[kk] = 0.f;
+    kx[kk] = ky[kk] = kz[kk] = 1e9f;      // kernel points beyond K: out of every range, zero weight, zero dA row
     if (kk < P.K) {
       const float* o = P.offsets + (n * P.K + kk) * 3;
       kx[kk] = P.kp[kk * 3] + o[0];
@@ -79,55 +89,21 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
 #pragma unroll
   for (int e = 0; e < (DKMAX - 1) * 3; ++e) dOff[e] = 0.f;
 
-  // ---- pass 1: all H entries. Keep list (real neighbours within the extent of some deformed kernel point) and the
-  //      min_d2 path: per kernel point the FIRST entry attaining min_h d2 (shadow entries included, like torch.min over
-  //      dim 1), found here by a wave arg-min per chunk -- not by comparing with the forward's stored minimum, whose
-  //      last bit may differ between two separately compiled kernels.
-  float best[DKMAX - 1];
-#pragma unroll
-  for (int kk = 0; kk < DKMAX - 1; ++kk) best[kk] = INFINITY;
+  // ---- pass 1: all H entries -> list of the kept neighbours (real neighbours within the extent of some deformed
+  //      kernel point, blocks.py:306-325). The index of the next chunk is loaded one chunk ahead.
   int nkept = 0;
+  int jn = lane < P.H ? load_idx<IDX64>(P.idx, n * P.H + lane, P.Ns) : -2;
   for (int h0 = 0; h0 < P.H; h0 += 64) {
-    const int h = h0 + lane;
-    int j = -2;
-    float rx = 0.f, ry = 0.f, rz = 0.f;
-    if (h < P.H) {
-      j = load_idx<IDX64>(P.idx, n * P.H + h, P.Ns);
-      if (j >= 0) {
-        const float* sp = P.s + (int64_t)j * 3;
-        rx = sp[0] - qx; ry = sp[1] - qy; rz = sp[2] - qz;
-      } else {
-        rx = 1e6f - qx; ry = 1e6f - qy; rz = 1e6f - qz;
-      }
-    }
+    const int j = jn;
+    jn = h0 + 64 + lane < P.H ? load_idx<IDX64>(P.idx, n * P.H + h0 + 64 + lane, P.Ns) : -2;
     bool keep = false;
+    if (j >= 0) {
+      const float* sp = P.s + (int64_t)j * 3;
+      const float rx = sp[0] - qx, ry = sp[1] - qy, rz = sp[2] - qz;
 #pragma unroll
-    for (int kk = 0; kk < DKMAX - 1; ++kk) {
-      if (kk < P.K) {
+      for (int kk = 0; kk < DKMAX - 1; ++kk) {
         const float dx = rx - kx[kk], dy = ry - ky[kk], dz = rz - kz[kk];
-        const float d2 = dx * dx + dy * dy + dz * dz;
-        if (j >= 0 && d2 < ext2) keep = true;
-        if (P.g_min_d2 != nullptr) {
-          float bd = j >= -1 ? d2 : INFINITY;
-          int bl = lane;
-#pragma unroll
-          for (int m = 1; m < 64; m <<= 1) {
-            const float od = __shfl_xor(bd, m);
-            const int ol = __shfl_xor(bl, m);
-            if (od < bd || (od == bd && ol < bl)) {
-              bd = od;
-              bl = ol;
-            }
-          }
-          if (bd < best[kk]) {            // wave uniform; strict: an earlier chunk keeps a tie
-            best[kk] = bd;
-            if (lane == bl) {
-              bestv[kk * 3 + 0] = dx;
-              bestv[kk * 3 + 1] = dy;
-              bestv[kk * 3 + 2] = dz;
-            }
-          }
-        }
+        keep = keep || (dx * dx + dy * dy + dz * dz < ext2);
       }
     }
     const unsigned long long bal = __ballot(keep);
@@ -138,19 +114,27 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
     nkept += __builtin_popcountll(bal);
   }
   nkept = nkept < DOFF_LIST ? nkept : DOFF_LIST;
-  wave_lds_sync();
-  if (P.g_min_d2 != nullptr && lane < P.K && best[0] < INFINITY) {      // d min_d2 / d off = -2 (rel[h*] - kpdef)
+  // ---- min_d2 path: d min_d2[n,k] / d off[n,k,:] = -2 (rel[h*] - kpdef[k]) at the forward's arg-min column h*
+  //      (shadow entries included, like torch.min over dim 1); lane k carries kernel point k's term
+  if (P.g_min_d2 != nullptr && lane < P.K && P.H > 0) {
+    const int hs = P.min_arg[n * P.K + lane];
+    const int j = load_idx<IDX64>(P.idx, n * P.H + hs, P.Ns);
+    float rx = 1e6f - qx, ry = 1e6f - qy, rz = 1e6f - qz;
+    if (j >= 0) {
+      const float* sp = P.s + (int64_t)j * 3;
+      rx = sp[0] - qx; ry = sp[1] - qy; rz = sp[2] - qz;
+    }
     const float g = -2.f * P.g_min_d2[n * P.K + lane];
-    // lane k carries kernel point k's term in its own accumulators (summed over the wave at the end)
 #pragma unroll
     for (int kk = 0; kk < DKMAX - 1; ++kk) {
       if (kk == lane) {
-        dOff[kk * 3 + 0] += g * bestv[kk * 3 + 0];
-        dOff[kk * 3 + 1] += g * bestv[kk * 3 + 1];
-        dOff[kk * 3 + 2] += g * bestv[kk * 3 + 2];
+        dOff[kk * 3 + 0] += g * (rx - kx[kk]);
+        dOff[kk * 3 + 1] += g * (ry - ky[kk]);
+        dOff[kk * 3 + 2] += g * (rz - kz[kk]);
       }
     }
   }
+  wave_lds_sync();
 
   // ---- pass 2: 64 kept neighbours at a time, lane = neighbour
   for (int t0 = 0; t0 < nkept; t0 += 64) {
@@ -161,13 +145,23 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
     for (int kk = 0; kk < DKMAX - 1; ++kk) B[kk] = 0.f;
     const float* xr = P.x + (int64_t)j * P.Cin;
     if ((P.Cin & 3) == 0) {
-      for (int c = 0; c < P.Cin; c += 4) {
-        const float4 xv = on ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      // 8 float4 of the lane's feature row in flight (the row loads are the long-latency part: 64 different rows
+      // per wave instruction), then their 15 x 4 FMAs against the broadcast dA block
+      constexpr int UB = 8;
+      for (int c0 = 0; c0 < P.Cin; c0 += 4 * UB) {
+        float4 xv[UB];
 #pragma unroll
-        for (int kk = 0; kk < DKMAX - 1; ++kk) {
-          if (kk < P.K) {
-            const float4 d = *reinterpret_cast<const float4*>(dA_l + kk * Cin4 + c);   // broadcast read
-            B[kk] += xv.x * d.x + xv.y * d.y + xv.z * d.z + xv.w * d.w;
+        for (int u = 0; u < UB; ++u)
+          xv[u] = (on && c0 + 4 * u < P.Cin) ? *reinterpret_cast<const float4*>(xr + c0 + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int c = c0 + 4 * u;
+          if (c < P.Cin) {          // wave uniform
+#pragma unroll
+            for (int kk = 0; kk < DKMAX - 1; ++kk) {
+              const float4 d = *reinterpret_cast<const float4*>(dA_l + kk * Cin4 + c);   // broadcast read
+              B[kk] = fmaf(xv[u].x, d.x, fmaf(xv[u].y, d.y, fmaf(xv[u].z, d.z, fmaf(xv[u].w, d.w, B[kk]))));
+            }
           }
         }
       }
@@ -175,8 +169,7 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
       for (int c = 0; c < P.Cin; ++c) {
         const float xv = on ? xr[c] : 0.f;
 #pragma unroll
-        for (int kk = 0; kk < DKMAX - 1; ++kk)
-          if (kk < P.K) B[kk] += xv * dA_l[kk * Cin4 + c];
+        for (int kk = 0; kk < DKMAX - 1; ++kk) B[kk] = fmaf(xv, dA_l[kk * Cin4 + c], B[kk]);
       }
     }
     if (on) {
@@ -184,24 +177,22 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
       const float rx = sp[0] - qx, ry = sp[1] - qy, rz = sp[2] - qz;
 #pragma unroll
       for (int kk = 0; kk < DKMAX - 1; ++kk) {
-        if (kk < P.K) {
-          const float dx = rx - kx[kk], dy = ry - ky[kk], dz = rz - kz[kk];
-          const float d2 = dx * dx + dy * dy + dz * dz;
-          // d w / d off[k,:] = sc * (rel - kpdef):  linear  w = 1 - sqrt(d2)/ext (w > 0): sc = 1 / (ext sqrt(d2));
-          //                                         gaussian w = exp(-d2/den):            sc = 2 w / den;  constant: 0
-          float sc = 0.f;
-          if (P.influence == MVK_INFL_LINEAR) {
-            const float dist = sqrtf(d2);
-            if (1.0f - dist / P.extent > 0.f && d2 > 0.f) sc = 1.0f / (P.extent * dist);
-          } else if (P.influence == MVK_INFL_GAUSSIAN) {
-            const float sig = P.extent * 0.3f, den = 2.0f * sig * sig + 1e-9f;
-            sc = 2.0f * expf(-d2 / den) / den;
-          }
-          const float f = sc * B[kk];
-          dOff[kk * 3 + 0] += f * dx;
-          dOff[kk * 3 + 1] += f * dy;
-          dOff[kk * 3 + 2] += f * dz;
+        const float dx = rx - kx[kk], dy = ry - ky[kk], dz = rz - kz[kk];
+        const float d2 = dx * dx + dy * dy + dz * dz;
+        // d w / d off[k,:] = sc * (rel - kpdef):  linear  w = 1 - sqrt(d2)/ext (w > 0): sc = 1 / (ext sqrt(d2));
+        //                                         gaussian w = exp(-d2/den):            sc = 2 w / den;  constant: 0
+        float sc = 0.f;
+        if (P.influence == MVK_INFL_LINEAR) {
+          const float dist = sqrtf(d2);
+          sc = (1.0f - dist / P.extent > 0.f && d2 > 0.f) ? 1.0f / (P.extent * dist) : 0.f;
+        } else if (P.influence == MVK_INFL_GAUSSIAN) {
+          const float sig = P.extent * 0.3f, den = 2.0f * sig * sig + 1e-9f;
+          sc = 2.0f * expf(-d2 / den) / den;
         }
+        const float f = sc * B[kk];
+        dOff[kk * 3 + 0] = fmaf(f, dx, dOff[kk * 3 + 0]);
+        dOff[kk * 3 + 1] = fmaf(f, dy, dOff[kk * 3 + 1]);
+        dOff[kk * 3 + 2] = fmaf(f, dz, dOff[kk * 3 + 2]);
       }
     }
   }
@@ -217,7 +208,8 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// regulariser: one lane per point
+// regulariser: one lane per (point, kernel point): 16-lane groups hold one point's deformed kernel points and
+// exchange them by shuffles
 __global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __restrict__ min_d2, const float* __restrict__ dkp,
                                                                 const int32_t* __restrict__ n_valid, int64_t N, int K,
                                                                 float extent, float repulse, float power,
@@ -225,47 +217,41 @@ __global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __
                                                                 float* __restrict__ d_min_d2 /* [N,K] */,
                                                                 float* __restrict__ d_dkp /* [N,K,3] */) {
   __shared__ float red[4];
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t n = t >> 4;
+  const int i = (int)(t & 15);
   int64_t nv = n_valid ? (int64_t)*n_valid : N;
   nv = nv < N ? nv : N;
-  float part = 0.f;
-  if (n < N) {
-    const bool valid = n < nv;
-    const float inv_e = 1.0f / extent;
-    const float cf = valid ? power * 2.0f / (extent * extent * (float)nv * (float)K) : 0.f;   // d loss / d min_d2
-    const float cr = valid ? power / ((float)nv * (float)K) : 0.f;                                // weight of one point's pair sum
-    float lx[DKMAX - 1], ly[DKMAX - 1], lz[DKMAX - 1];
+  const bool on = n < N && i < K;
+  const bool valid = on && n < nv;
+  const float inv_e = 1.0f / extent;
+  const float cf = valid ? power * 2.0f / (extent * extent * (float)nv * (float)K) : 0.f;   // d loss / d min_d2
+  const float cr = valid ? power / ((float)nv * (float)K) : 0.f;                                // weight of one (point, i) pair sum
+  float lx = 0.f, ly = 0.f, lz = 0.f, part = 0.f;
+  if (on) {
+    const float* p = dkp + (n * K + i) * 3;
+    lx = p[0] * inv_e; ly = p[1] * inv_e; lz = p[2] * inv_e;             // KP_locs (architectures.py:44)
+    const float m = min_d2[n * K + i];
+    d_min_d2[n * K + i] = m > 0.f ? cf : (m < 0.f ? -cf : 0.f);            // L1 to zero: sign(m)
+    part = cf * fabsf(m);
+  }
+  float gx = 0.f, gy = 0.f, gz = 0.f, acc = 0.f;
 #pragma unroll
-    for (int i = 0; i < DKMAX - 1; ++i) {
-      lx[i] = ly[i] = lz[i] = 0.f;
-      if (i < K) {
-        const float* p = dkp + (n * K + i) * 3;
-        lx[i] = p[0] * inv_e; ly[i] = p[1] * inv_e; lz[i] = p[2] * inv_e;     // KP_locs (architectures.py:44)
-        const float m = min_d2[n * K + i];
-        d_min_d2[n * K + i] = m > 0.f ? cf : (m < 0.f ? -cf : 0.f);            // L1 to zero: sign(m)
-        part += cf * fabsf(m);
-      }
+  for (int j = 0; j < DKMAX - 1; ++j) {
+    const float ox = __shfl(lx, j, 16), oy = __shfl(ly, j, 16), oz = __shfl(lz, j, 16);
+    if (j < K && j != i) {
+      const float dx = lx - ox, dy = ly - oy, dz = lz - oz;
+      const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float c = fminf(d - repulse, 0.f);           // clamp_max(dist - repulse_extent, 0)  (:52)
+      acc += c * c;
+      const float s = 2.f * c / d;                        // d c^2 / d loc_i  (the other point is detached, :49)
+      gx += s * dx; gy += s * dy; gz += s * dz;
     }
-#pragma unroll
-    for (int i = 0; i < DKMAX - 1; ++i) {
-      if (i < K) {
-        float gx = 0.f, gy = 0.f, gz = 0.f, acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < DKMAX - 1; ++j) {
-          if (j < K && j != i) {
-            const float dx = lx[i] - lx[j], dy = ly[i] - ly[j], dz = lz[i] - lz[j];
-            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-            const float c = fminf(d - repulse, 0.f);           // clamp_max(dist - repulse_extent, 0)  (:52)
-            acc += c * c;
-            const float s = 2.f * c / d;                        // d c^2 / d loc_i  (the other point is detached, :49)
-            gx += s * dx; gy += s * dy; gz += s * dz;
-          }
-        }
-        part += cr * acc;
-        float* o = d_dkp + (n * K + i) * 3;
-        o[0] = cr * gx * inv_e; o[1] = cr * gy * inv_e; o[2] = cr * gz * inv_e;
-      }
-    }
+  }
+  if (on) {
+    part += cr * acc;
+    float* o = d_dkp + (n * K + i) * 3;
+    o[0] = cr * gx * inv_e; o[1] = cr * gy * inv_e; o[2] = cr * gz * inv_e;
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m);
@@ -279,20 +265,21 @@ __global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __
 extern "C" int mvk_kpconv_deform_doff(const float* q, int64_t Nq, const float* s, int64_t Ns, const void* idx,
                                       int idx64, int H, const float* x, int Cin, const float* kp, int K, float extent,
                                       int influence, const float* offsets, const float* dA,
-                                      const float* g_min_d2, float* d_offsets, void* stream) {
+                                      const float* g_min_d2, const int32_t* min_arg, float* d_offsets, void* stream) {
   MVK_REQUIRE(Nq >= 0 && Ns >= 0 && H >= 0 && Cin > 0 && K >= 1 && K < DKMAX, "deform d_offsets: bad sizes");
   MVK_REQUIRE(influence >= 0 && influence <= 2, "Unknown influence function type (config.KP_influence)");
   MVK_REQUIRE(offsets && dA && d_offsets && x, "deform d_offsets: null operand");
+  MVK_REQUIRE(!g_min_d2 || min_arg, "deform d_offsets: the min_d2 gradient needs the forward's arg-min columns");
   MVK_REQUIRE(H <= DOFF_LIST, "deform d_offsets: neighbour rows wider than %d columns", DOFF_LIST);
   MVK_REQUIRE(Nq < (1ll << 31), "deform d_offsets: Nq too large for one launch");
   if (Nq == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   DoffParams P{};
   P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets; P.dA = dA;
-  P.g_min_d2 = g_min_d2; P.d_offsets = d_offsets; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K;
+  P.g_min_d2 = g_min_d2; P.min_arg = min_arg; P.d_offsets = d_offsets; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K;
   P.extent = extent; P.influence = influence;
   const int Cin4 = (Cin + 3) & ~3;
-  const size_t lds = sizeof(float) * ((size_t)DKMAX * Cin4 + DKMAX * 3) + sizeof(int) * (size_t)(H < 64 ? 64 : H);
+  const size_t lds = sizeof(float) * (size_t)DKMAX * Cin4 + sizeof(int) * (size_t)(H < 64 ? 64 : H);
   MVK_REQUIRE(lds <= 160 * 1024, "deform d_offsets: Cin=%d does not fit the LDS staging", Cin);
   if (idx64) {
     if (lds > 64 * 1024)
@@ -313,7 +300,7 @@ extern "C" int mvk_deform_regularizer(const float* min_d2, const float* deformed
   MVK_REQUIRE(N >= 0 && K >= 1 && K < DKMAX && extent > 0.f, "regulariser: bad sizes");
   MVK_REQUIRE(min_d2 && deformed_kp && loss_accum && d_min_d2 && d_deformed_kp, "regulariser: null operand");
   if (N == 0) return 0;
-  hipLaunchKernelGGL(deform_regularizer_kernel, dim3((unsigned)cdiv64(N, 256)), dim3(256), 0, (hipStream_t)stream, min_d2,
+  hipLaunchKernelGGL(deform_regularizer_kernel, dim3((unsigned)cdiv64(N * 16, 256)), dim3(256), 0, (hipStream_t)stream, min_d2,
                      deformed_kp, n_valid, N, K, extent, repulse_extent, power, loss_accum, d_min_d2, d_deformed_kp);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;

@@ -28,6 +28,7 @@ struct KPParams {
   const float* kp;
   const float* offsets;  // [Nq,K,3] or null
   float* min_d2;         // [Nq,K] or null
+  int32_t* min_arg;      // [Nq,K] or null: column h of the first entry attaining min_d2 (for the backward)
   float* A;              // fwd: out [Nq,K,Cin]; bwd: in dA
   float* dx;             // bwd out [Ns,Cin]
   const float* g_min_d2; // bwd deformable
@@ -58,7 +59,7 @@ template <int PPW, int HC, int WPAD, bool IDX64, bool DEFORM>
 __device__ __forceinline__ int phase_a(const KPParams& P, int64_t n0, int h0, int lane,
                                        float4* rel, float* wl, float qx, float qy, float qz,
                                        bool nvalid, float kx, float ky, float kz,
-                                       float* run_min /* DEFORM only, PPW==1 */) {
+                                       float* run_min /* DEFORM only, PPW==1 */, int* run_arg = nullptr) {
   const int p = lane / HC, h = lane % HC;
   const int64_t n = n0 + p;
   int j = -2;  // -2: no entry, -1: shadow entry
@@ -114,7 +115,10 @@ __device__ __forceinline__ int phase_a(const KPParams& P, int64_t n0, int h0, in
         if (k == 0 && jj >= 0) rel[ph].w = __int_as_float(-1);
       }
       // running min_h d2 over real + shadow entries (blocks.py:303)
-      if (jj >= -1 && k < P.K) *run_min = fminf(*run_min, d2);
+      if (jj >= -1 && k < P.K && d2 < *run_min) {     // strict: this lane visits its entries in ascending h
+        *run_min = d2;
+        if (run_arg) *run_arg = h0 + ph;
+      }
     }
     wl[(ph / HC) * (HC * 16 + WPAD) + (ph % HC) * 16 + k] = w;
   }
@@ -361,6 +365,7 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
     }
   }
   float run_min = INFINITY;
+  int run_arg = 0;
 
   float acc[NSLOT][KMAX - 1];  // MODE 0: A accumulators; MODE 1: dA values
 #pragma unroll
@@ -377,7 +382,7 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
 
   for (int h0 = 0; h0 < P.H; h0 += HC) {
     int j = phase_a<1, HC, WPAD, IDX64, DEFORM>(P, n, h0, lane, rel, wl, qx, qy, qz, true, kx, ky,
-                                                 kz, &run_min);
+                                                 kz, &run_min, &run_arg);
     if (__ballot(j >= 0) != 0ull) {
       const int hend = min(HC, P.H - h0);
       for (int hh = 0; hh < hend; ++hh) {
@@ -419,10 +424,21 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
       }
     }
     if (DEFORM && P.min_d2 != nullptr && c0 == 0) {
-      float m = run_min;
-      m = fminf(m, __shfl_xor(m, 16));
-      m = fminf(m, __shfl_xor(m, 32));
-      if (lane < 16 && lane < P.K) P.min_d2[n * P.K + lane] = m;
+      float m = run_min;      // lanes l, l^16, l^32, l^48 hold kernel point k = l & 15: (value, column) minimum, first column on ties
+      int a = run_arg;
+#pragma unroll
+      for (int sh = 16; sh <= 32; sh <<= 1) {
+        const float om = __shfl_xor(m, sh);
+        const int oa = __shfl_xor(a, sh);
+        if (om < m || (om == m && oa < a)) {
+          m = om;
+          a = oa;
+        }
+      }
+      if (lane < 16 && lane < P.K) {
+        P.min_d2[n * P.K + lane] = m;
+        if (P.min_arg) P.min_arg[n * P.K + lane] = a;
+      }
     }
   }
 }
@@ -486,12 +502,12 @@ extern "C" int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s,
                                      const void* idx, int idx64, int H, const float* x, int Cin,
                                      const float* kp, int K, float extent, int influence,
                                      int aggregation, const float* offsets, float* min_d2,
-                                     float* A_out, void* stream) {
+                                     int32_t* min_arg, float* A_out, void* stream) {
   if (int e = check_common(Nq, Ns, H, Cin, K, influence, aggregation)) return e;
   if (Nq == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   KPParams P{};
-  P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets; P.min_d2 = min_d2;
+  P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets; P.min_d2 = min_d2; P.min_arg = min_arg;
   P.A = A_out; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
   P.influence = influence; P.aggregation = aggregation;
   if (H == 0) {
@@ -515,7 +531,7 @@ extern "C" int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s
                                       const void* idx, int idx64, int H, int Cin, const float* kp,
                                       int K, float extent, int influence, int aggregation,
                                       const float* dA, float* dx, const float* x,
-                                      const float* offsets, const float* g_min_d2,
+                                      const float* offsets, const float* g_min_d2, const int32_t* min_arg,
                                       float* d_offsets, void* stream) {
   if (int e = check_common(Nq, Ns, H, Cin, K, influence, aggregation)) return e;
   if (Nq == 0 || H == 0) return 0;
@@ -532,7 +548,7 @@ extern "C" int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s
     MVK_CHECK_HIP(hipGetLastError());
     // d_offsets (A path and min_d2 path): one wave per point, lane = neighbour (csrc/deform.hip)
     return mvk_kpconv_deform_doff(q, Nq, s, Ns, idx, idx64, H, x, Cin, kp, K, extent, influence, offsets, dA, g_min_d2,
-                                  d_offsets, stream);
+                                  min_arg, d_offsets, stream);
   } else {
     launch_lane_channel<1, false>(P, idx64, st);
   }

@@ -232,24 +232,27 @@ def kpconv_gather(q, s, idx, x, kp, extent, influence="linear", aggregation="sum
     if x.shape[0] != Ns:
         raise RuntimeError("kpconv: features and support points differ in length")
     A = torch.empty((Nq, K, Cin), device=q.device, dtype=torch.float32)
-    min_d2 = None
+    min_d2 = min_arg = None
     if offsets is not None:
         offsets = _f32c(offsets)
         if want_min_d2:
             min_d2 = torch.empty((Nq, K), device=q.device, dtype=torch.float32)
+            min_arg = torch.empty((Nq, K), device=q.device, dtype=torch.int32)
     if _PROF["on"]:
         e0, e1 = _timing_events()
     check(lib().mvk_kpconv_gather_fwd(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, _p(x), Cin, _p(kp), K,
                                       float(extent), INFLUENCE[influence], AGGREGATION[aggregation],
-                                      _p(offsets), _p(min_d2), _p(A), _stream()))
+                                      _p(offsets), _p(min_d2), _p(min_arg), _p(A), _stream()))
     if _PROF["on"]:
         e1.record()
         _PROF["rec"].append(((_gather_kernel_name(Cin, offsets is not None), Nq, Ns, H, Cin, K), e0, e1))
+    if min_d2 is not None:
+        min_d2._mvk_min_arg = min_arg          # neighbour column of each minimum: the backward's min_d2 path starts there
     return A, min_d2
 
 
 def kpconv_scatter(q, s, idx, dA, kp, extent, influence="linear", aggregation="sum", x=None,
-                   offsets=None, g_min_d2=None):
+                   offsets=None, g_min_d2=None, min_arg=None):
     """dx[idx[n,h],c] += sum_k w[n,h,k] dA[n,k,c]; returns (dx, d_offsets or None)."""
     _dev(q, s, idx, dA, kp)
     q, s, dA, kp = _f32c(q), _f32c(s), _f32c(dA), _f32c(kp)
@@ -262,9 +265,11 @@ def kpconv_scatter(q, s, idx, dA, kp, extent, influence="linear", aggregation="s
         d_off = torch.empty((Nq, K, 3), device=q.device, dtype=torch.float32)    # written whole by mvk_kpconv_deform_doff
         if g_min_d2 is not None:
             g_min_d2 = _f32c(g_min_d2)
+            if min_arg is None:
+                raise RuntimeError("kpconv_scatter: the min_d2 gradient needs the forward's arg-min columns")
     check(lib().mvk_kpconv_scatter_bwd(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, Cin, _p(kp), K, float(extent),
                                        INFLUENCE[influence], AGGREGATION[aggregation], _p(dA), _p(dx),
-                                       _p(x), _p(offsets), _p(g_min_d2), _p(d_off), _stream()))
+                                       _p(x), _p(offsets), _p(g_min_d2), _p(min_arg), _p(d_off), _stream()))
     return dx, d_off
 
 
@@ -343,6 +348,7 @@ class _KPConvFn(torch.autograd.Function):
             e1.record()
             _PROF["gemm"].append(((q.shape[0], K * Cin, Cout), e0, e1))
         ctx.save_for_backward(q, s, idx, x, kp, W, A, offsets, modulations)
+        ctx.min_arg = getattr(min_d2, "_mvk_min_arg", None)
         ctx.cfg = (extent, influence, aggregation)
         ctx.stat_rows = st[1] if st is not None else 0
         part = st[0] if st is not None else None
@@ -372,7 +378,7 @@ class _KPConvFn(torch.autograd.Function):
                 dA = dAm
             dx, d_off = kpconv_scatter(q, s, idx, dA, kp, extent, influence, aggregation, x=x,
                                        offsets=offsets,
-                                       g_min_d2=g_min_d2 if offsets is not None else None)
+                                       g_min_d2=g_min_d2 if offsets is not None else None, min_arg=ctx.min_arg)
         return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None
 
 
@@ -424,6 +430,7 @@ class _KPConv16Fn(torch.autograd.Function):
             e1.record()
             _PROF["gemm"].append(((q.shape[0], K * Cin, Cout), e0, e1))
         ctx.save_for_backward(q, s, idx, x16, kp, W16, A, offsets, modulations)
+        ctx.min_arg = getattr(min_d2, "_mvk_min_arg", None)
         ctx.cfg = (extent, influence, aggregation, (K, Cin, Cout))
         return y, min_d2, None          # (no BatchNorm-statistics epilogue in the fp16 contraction)
 
@@ -448,7 +455,7 @@ class _KPConv16Fn(torch.autograd.Function):
                 dA = dAm
             dx, d_off = kpconv_scatter(q, s, idx, dA, kp, extent, influence, aggregation,
                                        x=x16.float() if offsets is not None else None, offsets=offsets,
-                                       g_min_d2=g_min_d2 if offsets is not None else None)
+                                       g_min_d2=g_min_d2 if offsets is not None else None, min_arg=ctx.min_arg)
         return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None
 
 

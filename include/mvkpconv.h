@@ -54,7 +54,9 @@ const char* mvk_last_error(void);
 int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s, int64_t Ns,
                           const void* idx, int idx64, int H, const float* x, int Cin,
                           const float* kp, int K, float extent, int influence, int aggregation,
-                          const float* offsets, float* min_d2, float* A_out, void* stream);
+                          const float* offsets, float* min_d2,
+                          int32_t* min_arg /* [Nq,K] or NULL: neighbour column of the first entry attaining min_d2 */,
+                          float* A_out, void* stream);
 
 /* fp16-feature mode of mvk_kpconv_gather_fwd (rigid KPConv, Cin <= 512): x [Ns,Cin] and A_out
  * [Nq,K,Cin] are fp16 in memory; geometry, correlation weights and the sums are f32. */
@@ -72,6 +74,7 @@ int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s, int64_t N
                            const float* kp, int K, float extent, int influence, int aggregation,
                            const float* dA, float* dx,
                            const float* x, const float* offsets, const float* g_min_d2,
+                           const int32_t* min_arg /* from the forward; needed with g_min_d2 */,
                            float* d_offsets, void* stream);
 
 /* ---------------- fp32 MFMA GEMM (the K x Cin x Cout contraction) -------- */
@@ -107,12 +110,14 @@ int mvk_gemm_f16(const void* A, int a_f16, const void* B, int b_f16, void* C, in
 
 /* d_offsets [Nq,K,3] of a deformable KPConv (blocks.py:286-327, 366-374 through autograd):
  *   sum_h dw[n,h,k]/d off[n,k,:] * (sum_c x[j_h,c] dA[n,k,c])  -  2 (rel[h*] - kpdef[k]) g_min_d2[n,k]
- * over the neighbours kept by the in-range filter (h* = first arg-min of d2 over ALL entries, shadow included).
+ * over the neighbours kept by the in-range filter (h* = min_arg[n,k], the first arg-min of d2 over ALL entries,
+ * shadow included, recorded by mvk_kpconv_gather_fwd).
  * dA is the gradient of the aggregate (already multiplied by the modulations when modulated); g_min_d2 may be NULL.
  * Plain stores (no zero-initialisation needed). Called by mvk_kpconv_scatter_bwd for deformable layers. */
 int mvk_kpconv_deform_doff(const float* q, int64_t Nq, const float* s, int64_t Ns, const void* idx, int idx64, int H,
                            const float* x, int Cin, const float* kp, int K, float extent, int influence,
-                           const float* offsets, const float* dA, const float* g_min_d2, float* d_offsets, void* stream);
+                           const float* offsets, const float* dA, const float* g_min_d2,
+                           const int32_t* min_arg, float* d_offsets, void* stream);
 
 /* p2p_fitting_regularizer of ONE deformable layer (models/architectures.py:20-58) and both its gradients:
  *   *loss_accum += power * ( 2 * mean_{n<nv,k} |min_d2| / ext^2 + sum_i mean_{n<nv} sum_{j!=i} clamp_max(|loc_i - loc_j| - R, 0)^2 / K ),

@@ -4,10 +4,12 @@
   ``{'scan_id', 'points' f32 (n,3), 'colors' u8 (n,3), 'seg_label'}`` dicts, one per scan;
 * the per-scene files of KPConv-PyTorch/datasets/ScanNet_sphere_color.py:904-991 under
   ``input_<dl>/``: ``<scan>.pkl`` = ``{'sub_points', 'sub_labels', 'sub_colors', 'rgbd_dict'}`` and
-  ``<scan>_proj.pkl`` = ``(proj_inds, labels)`` (:1074-1092). The reference also pickles a scikit-learn
-  KDTree per scene (``<scan>_KDTree.pkl``); here sphere picking runs on the GPU ball query
-  (sphere_picking.PotentialSphereSampler), so that file is neither written nor needed -- a directory
-  prepared by the reference loads as is.
+  ``<scan>_proj.pkl`` = ``(proj_inds, labels)`` (:1074-1092), proj_inds = the nearest subsampled point of every
+  original point (``reprojection_indices``: the exact float64 1-NN kernel instead of ``KDTree.query``, :1087-1089).
+  The reference also pickles a scikit-learn KDTree per scene (``<scan>_KDTree.pkl``, :947, :985): sphere picking
+  runs on the GPU ball query here (sphere_picking.PotentialSphereSampler) and does not need it, but
+  ``save_search_tree`` writes the same pickle (host side, scikit-learn) so that a directory prepared here also
+  serves the reference's loader, and a directory prepared by the reference loads as is.
 
 subsample_scene is the compute step between the two (scene-load subsampling with colours as features and
 labels, :935-948) on the HIP subsampling kernel."""
@@ -103,3 +105,28 @@ def load_projection(tree_path, cloud_name):
     with open(scene_paths(tree_path, cloud_name)['proj'], 'rb') as f:
         proj_inds, labels = pickle.load(f)
     return proj_inds, labels
+
+
+def reprojection_indices(sub_points, points, device=None):
+    """proj_inds of a scene (ScanNet_sphere_color.py:1087-1089: ``KDTree(sub_points).query(points)``): for every
+    ORIGINAL point the index of its nearest subsampled point, int32 [n]. Exact float64 distances of the float32
+    coordinates like scikit-learn's tree (ties: lowest index), on the k-NN kernel of csrc/fusion.hip."""
+    dev = torch.device(device if device is not None else 'cuda')
+    keys = torch.as_tensor(np.ascontiguousarray(sub_points, dtype=np.float32)).to(dev)
+    qs = torch.as_tensor(np.ascontiguousarray(points, dtype=np.float32)).to(dev)
+    if keys.shape[0] == 0:
+        raise ValueError('reprojection_indices: no subsampled points')
+    mask = torch.ones((1, keys.shape[0], 1), dtype=torch.bool, device=dev)
+    nn = ops.knn_pixels(qs, keys.double().reshape(1, -1, 1, 3), mask, k=1)[:, 0]
+    return nn.to(torch.int32).cpu().numpy()
+
+
+def save_search_tree(tree_path, cloud_name, sub_points, leaf_size=10):
+    """<scan>_KDTree.pkl = pickle of sklearn.neighbors.KDTree(sub_points, leaf_size=10) (:947, :985-986). Host-side
+    file format only (needs scikit-learn, like the reference)."""
+    from sklearn.neighbors import KDTree
+    os.makedirs(tree_path, exist_ok=True)
+    tree = KDTree(np.asarray(sub_points, dtype=np.float32), leaf_size=leaf_size)
+    with open(scene_paths(tree_path, cloud_name)['kdtree'], 'wb') as f:
+        pickle.dump(tree, f)
+    return tree

@@ -586,7 +586,27 @@ def g9_ply():
          sub_labels=np.squeeze(slb).astype(np.int32))
 
 
-GROUPS = {"g9": g9_ply, "g8": g8_metrics, "g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn, "g5b": g5b_kpfcnn_deformable,
+
+def g10_reprojection():
+    """proj_inds of a scene (ScanNet_sphere_color.py:1087-1089): scikit-learn KDTree(sub_points, leaf_size=10)
+    .query(points, return_distance=False) -- the reference's own call -- on a synthetic room: the full-resolution
+    cloud against its 4 cm subsampling (through the compiled reference core)."""
+    from sklearn.neighbors import KDTree
+    rng = np.random.default_rng(1010)
+    points = room_cloud(rng, 60000, 1.0)
+    sub, _ = cport.subsample_batch(points, [points.shape[0]], dl=0.04, impl="ref")
+    tree = KDTree(sub, leaf_size=10)
+    dist, idxs = tree.query(points, k=2, return_distance=True)
+    # an exact tie between the two nearest subsampled points would make the reference's answer depend on the tree
+    # traversal order: the fixture is tie free
+    assert np.all(dist[:, 1] > dist[:, 0])
+    proj = idxs[:, 0].astype(np.int32)
+    assert np.array_equal(proj, np.squeeze(tree.query(points, return_distance=False)).astype(np.int32))
+    dist = dist[:, 0]
+    save("g10_reprojection", points=points, sub_points=sub, proj_inds=proj, dist=np.squeeze(dist))
+
+
+GROUPS = {"g9": g9_ply, "g8": g8_metrics, "g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn, "g5b": g5b_kpfcnn_deformable, "g10": g10_reprojection,
           "g6": g6_fusion}
 
 if __name__ == "__main__":

@@ -263,3 +263,23 @@ def test_scene_load_subsampling_vs_reference_core():
     out2 = sc.subsample_scene({'points': g["scene_points"], 'colors': g["scene_colors"], 'seg_label': g["scene_labels"]},
                               0.04, label_map=remap)
     assert np.array_equal(out2['sub_labels'], remap[g["sub_labels"]])
+
+
+def test_reprojection_indices_vs_sklearn_kdtree_golden(tmp_path):
+    """proj_inds of a scene on the exact 1-NN kernel against scikit-learn's KDTree.query (G10, the
+    reference's call at ScanNet_sphere_color.py:1087-1089), then the <scan>_proj.pkl / <scan>_KDTree.pkl files in
+    the reference's schemas (a pickled sklearn KDTree answers the same query)."""
+    import pickle
+    sc = importlib.import_module(PKG + ".dropin.datasets.scene_cache")
+    g = load_golden("g10_reprojection")
+    proj = sc.reprojection_indices(g["sub_points"], g["points"])
+    assert proj.dtype == np.int32 and np.array_equal(proj, g["proj_inds"])
+    labels = np.arange(g["points"].shape[0]) % 21
+    sc.save_projection(str(tmp_path), "scene0000_00", proj, labels)
+    p2, l2 = sc.load_projection(str(tmp_path), "scene0000_00")
+    assert np.array_equal(p2, proj) and np.array_equal(l2, labels)
+    sc.save_search_tree(str(tmp_path), "scene0000_00", g["sub_points"])
+    with open(sc.scene_paths(str(tmp_path), "scene0000_00")["kdtree"], "rb") as f:
+        tree = pickle.load(f)
+    assert np.array_equal(np.squeeze(tree.query(g["points"][:500], return_distance=False)), proj[:500])
+    assert np.array_equal(np.asarray(tree.data, dtype=np.float32), g["sub_points"])

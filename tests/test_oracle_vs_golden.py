@@ -225,3 +225,11 @@ def test_sphere_picking_oracle_vs_sklearn_golden():
         assert np.array_equal(c, g["it%d_center" % it])
         assert np.array_equal(inp, g["it%d_input_inds" % it]) and np.array_equal(msk, g["it%d_mask_inds" % it])
         assert np.array_equal(pots[ci], g["it%d_pot" % it])          # float64 Tukey update, bit for bit
+
+
+def test_reprojection_oracle_vs_sklearn_kdtree_golden():
+    """proj_inds (ScanNet_sphere_color.py:1087-1089): the C oracle's exact float64 1-NN against the fixture from
+    scikit-learn's KDTree.query, the reference's call."""
+    g = load_golden("g10_reprojection")
+    nn = cport.knn_f64(g["points"].astype(np.float64), g["sub_points"].astype(np.float64), k=1)[0][:, 0]
+    assert np.array_equal(nn.astype(np.int32), g["proj_inds"])

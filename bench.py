@@ -146,7 +146,7 @@ def main():
     else:
         opt = torch.optim.SGD(groups, lr=cfg.learning_rate, momentum=cfg.momentum, weight_decay=cfg.weight_decay,
                               fused=os.environ.get("MVK_FUSED_SGD", "1") == "1")
-    reducer = mvkpconv.sub("dp").FlatAllReduce(params, world) if (world > 1 or force_dp) else None
+    reducer = make_reducer(mvkpconv.sub("dp"), net, cfg, params, world) if (world > 1 or force_dp) else None
 
     # ---- synthetic raw inputs, staged in HBM once (data-parallel: different spheres per rank)
     spheres = [syn.raw_sphere(seed=1000 * rank + i, radius=args.in_radius) for i in range(args.spheres)]
@@ -157,13 +157,7 @@ def main():
 
     def net_step(batch):
         opt.zero_grad(set_to_none=True)
-        out = net(batch, cfg)
-        loss = net.loss(out, batch.labels)
-        backward(ops, loss)
-        if reducer is not None:
-            reducer()
-        clip_and_step(params, opt, cfg)
-        return loss
+        return net_step_captured(net, batch, cfg, params, opt, reducer, begin=False)
 
     def eager_step():
         batch, lens = syn.build_batch(cfg, staged, limits, torch.int32)
@@ -391,24 +385,58 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                 loss = net_step_captured(net, static, cfg, params, opt, None)
                 join_encoder()
             return graph.replay, loss
-        # N > 1: the RCCL all-reduce stays an eager call between two graphs (forward+backward | clip+SGD).
+        # N > 1: the RCCL all-reduces stay eager calls between graphs (capturing them was tried with a one-rank process
+        # group: the group's watchdog thread queries an event recorded in the capturing stream and aborts with
+        # hipErrorCapturedEvent). With the staged exchange (dp.two_stage_backward) the step is three graphs:
+        #   G1 forward + loss + backward above the cut + pack bucket 0   | eager: start all-reduce 0 (asynchronous)
+        #   G2 backward below the cut + pack bucket 1                   | eager: start all-reduce 1, wait for both
+        #   G3 unpack + clip + SGD
+        # so the ring of bucket 0 (~95 % of the bytes) runs on RCCL's stream while G2 computes.
         # thread_local capture mode: the process group's watchdog thread may query events meanwhile.
+        staged_exchange = hasattr(reducer, "cut_block")
+        net.backward_cut = reducer.cut_block if staged_exchange else None
+        scope = backward_scope(ops)
         with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
             fork_encoder()
             ops.step_begin()
             loss = net.loss(net(static, cfg), static.labels)
-            backward(ops, loss)
+            if staged_exchange:
+                orig, leaves = net.cut_tensors
+                with scope():
+                    loss.backward()
+                reducer.pack(0)
+            else:
+                backward(ops, loss)
             join_encoder()
-        graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph_b, stream=main_stream, capture_error_mode="thread_local"):
-            clip_and_step(params, opt, cfg)
+        if not staged_exchange:
+            graph_b = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph_b, stream=main_stream, pool=graph.pool(), capture_error_mode="thread_local"):
+                clip_and_step(params, opt, cfg)
+            grads = [p.grad for p in reducer.params if p.grad is not None]
 
-        grads = [p.grad for p in reducer.params if p.grad is not None]
+            def replay():
+                graph.replay()
+                reducer(grads)
+                graph_b.replay()
+            return replay, loss
+        graph_2, graph_3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph_2, stream=main_stream, pool=graph.pool(), capture_error_mode="thread_local"):
+            pairs = [(t, l.grad) for t, l in zip(orig, leaves) if t.requires_grad and l.grad is not None]
+            with scope():
+                torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+            reducer.pack(1)
+        with torch.cuda.graph(graph_3, stream=main_stream, pool=graph.pool(), capture_error_mode="thread_local"):
+            reducer.unpack(0)
+            reducer.unpack(1)
+            clip_and_step(params, opt, cfg)
 
         def replay():
             graph.replay()
-            reducer(grads)
-            graph_b.replay()
+            reducer.launch(0)
+            graph_2.replay()
+            reducer.launch(1)
+            reducer.wait()
+            graph_3.replay()
         return replay, loss
 
     replays = [capture(s) for s in statics]
@@ -572,17 +600,53 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                   (" | frozen 2D encoder of the next batch as a parallel branch of the same graph" if enc is not None else ""))
 
 
-def net_step_captured(net, static, cfg, params, opt, reducer):
-    """Body of the captured graph: identical to an eager network step (no host sync inside)."""
+def make_reducer(dp, net, cfg, params, world):
+    """Gradient exchange of the N > 1 path: two buckets around a cut of the backward at the entry of encoder level 2
+    (dp.py: bucket 0 = head + decoder + levels >= 2 = ~95 % of the bytes, reduced while the backward of levels 0-1
+    still runs). MVK_DP_OVERLAP=0: one flat bucket after the whole backward."""
+    cut = dp.cut_block_of_layer(cfg.architecture, 2) if os.environ.get("MVK_DP_OVERLAP", "1") == "1" else None
+    if cut is None or not hasattr(net, "encoder_blocks"):
+        return dp.FlatAllReduce(params, world)
+    late, early = dp.split_parameters_at(net, cut)
+    red = dp.BucketedAllReduce([late, early], world)
+    red.cut_block = cut
+    red.dp = dp
+    return red
+
+
+def net_step_captured(net, static, cfg, params, opt, reducer, begin=True):
+    """One network step (no host sync inside): forward, loss, backward, gradient exchange (N > 1), clip, SGD --
+    the body of the captured graph for N = 1, and the eager step of every configuration."""
     import mvkpconv
-    mvkpconv.sub("ops").step_begin()
+    ops = mvkpconv.sub("ops")
+    if begin:
+        ops.step_begin()
+    staged_exchange = reducer is not None and hasattr(reducer, "cut_block")
+    net.backward_cut = reducer.cut_block if staged_exchange else None
     out = net(static, cfg)
     loss = net.loss(out, static.labels)
-    backward(mvkpconv.sub("ops"), loss)
-    if reducer is not None:
-        reducer()
+    if staged_exchange:
+        def between():
+            reducer.pack(0)
+            reducer.launch(0)
+        reducer.dp.two_stage_backward(loss, net.cut_tensors, between=between, backward_scope=backward_scope(ops))
+        reducer.pack(1)
+        reducer.launch(1)
+        reducer.wait()
+        reducer.unpack(0)
+        reducer.unpack(1)
+    else:
+        backward(ops, loss)
+        if reducer is not None:
+            reducer()
     clip_and_step(params, opt, cfg)
     return loss
+
+
+def backward_scope(ops):
+    """Context manager factory for a backward pass: the weight-gradient products on a side branch."""
+    import contextlib
+    return ops.overlap_weight_grads if os.environ.get("MVK_OVERLAP_DW", "1") == "1" else contextlib.nullcontext
 
 
 def backward(ops, loss):

@@ -2,10 +2,20 @@
 
 Spheres are independent in every kernel of the path (subsampling, neighbours, k-NN, group_points,
 KPConv never cross batch elements), so each rank processes its own spheres with no data-path
-collective; the only exchange is the gradient: one flat fp32 bucket, all-reduced (sum) by RCCL over
+collective; the only exchange is the gradient: flat fp32 buckets, all-reduced (sum) by RCCL over
 xGMI and divided by the world size. The reference has no counterpart (single GPU).
 BatchNorm statistics stay per rank (documented deviation from a single-GPU run over the same
-spheres; parity is defined on one GPU)."""
+spheres; parity is defined on one GPU).
+
+Overlap. xGMI is point to point (7 links x ~153 GB/s per GPU): a ring all-reduce of the 97.5 MB of KPFCNN
+gradients costs ~1.1 ms, 15-20 % of a step, if it only starts after the backward. The backward runs from the
+head through the decoder and then down the encoder from the coarsest level: the levels that hold almost all of
+the PARAMETERS (levels 2-4: 15 x 512 x 512 kernels) are finished long before the levels that hold almost all of
+the POINTS (levels 0-1), which take about half of the backward time and own a few percent of the bytes.
+`two_stage_backward` therefore cuts the backward at the entry of encoder level `cut_layer`: stage 1 produces the
+gradients of everything above the cut (bucket 0, ~95 % of the bytes), whose all-reduce is started asynchronously
+and runs on RCCL's stream while stage 2 (levels below the cut) is still computing; bucket 1 follows.
+"""
 import torch
 import torch.distributed as dist
 
@@ -33,6 +43,104 @@ class FlatAllReduce:
         dist.all_reduce(self.flat)
         self.flat.div_(self.world)
         torch._foreach_copy_([g.view(-1) for g in grads], list(self.flat.split(sizes)))
+
+
+class BucketedAllReduce:
+    """Gradient exchange in buckets that can be started one by one while the backward is still running.
+
+    pack(k) / unpack(k) are plain device copies (capturable in a hipGraph); launch(k) issues the asynchronous
+    all-reduce of bucket k (an eager RCCL call: it runs on the process group's own stream, ordered after the work
+    already enqueued on the current stream); wait() blocks the current stream until every launched bucket is done."""
+
+    def __init__(self, buckets, world=None):
+        self.buckets = [[p for p in b if p.requires_grad] for b in buckets]
+        self.world = world if world is not None else dist.get_world_size()
+        self.flat = [None] * len(self.buckets)
+        self.grads = [None] * len(self.buckets)
+        self.work = []
+
+    def pack(self, k, grads=None):
+        if grads is None:
+            grads = [p.grad for p in self.buckets[k] if p.grad is not None]
+        self.grads[k] = grads
+        if not grads:
+            return
+        n = sum(g.numel() for g in grads)
+        if self.flat[k] is None or self.flat[k].numel() != n or self.flat[k].device != grads[0].device:
+            self.flat[k] = torch.empty(n, device=grads[0].device, dtype=torch.float32)
+        torch._foreach_copy_(list(self.flat[k].split([g.numel() for g in grads])), [g.reshape(-1) for g in grads])
+
+    def launch(self, k):
+        if not self.grads[k]:
+            return
+        if dist.get_backend() == "nccl":        # RCCL: asynchronous on the group's stream, overlaps the rest of the backward
+            self.work.append(dist.all_reduce(self.flat[k], async_op=True))
+        else:                                   # gloo (CPU rehearsal): its asynchronous path on device tensors is far slower
+            dist.all_reduce(self.flat[k])
+
+    def wait(self):
+        for w in self.work:
+            w.wait()
+        self.work = []
+
+    def unpack(self, k):
+        grads = self.grads[k]
+        if not grads:
+            return
+        self.flat[k].div_(self.world)
+        torch._foreach_copy_([g.view(-1) for g in grads], list(self.flat[k].split([g.numel() for g in grads])))
+
+    def __call__(self):
+        """Everything at once (no overlap): the FlatAllReduce behaviour with several buckets."""
+        for k in range(len(self.buckets)):
+            self.pack(k)
+            self.launch(k)
+        self.wait()
+        for k in range(len(self.buckets)):
+            self.unpack(k)
+
+
+def split_parameters_at(net, cut_block):
+    """(late, early) parameter lists of a KPFCNN-style network for a cut at encoder block `cut_block`:
+    early = parameters of net.encoder_blocks[:cut_block]; late = every other trainable parameter."""
+    early = [p for blk in list(net.encoder_blocks)[:cut_block] for p in blk.parameters() if p.requires_grad]
+    ids = {id(p) for p in early}
+    late = [p for p in net.parameters() if p.requires_grad and id(p) not in ids]
+    return late, early
+
+
+def cut_block_of_layer(architecture, layer):
+    """Index of the first encoder block that runs at pyramid layer `layer` (blocks after the layer-th strided /
+    pooling block); None when the architecture is shallower."""
+    seen = 0
+    for i, name in enumerate(architecture):
+        if 'upsample' in name or 'global' in name:
+            return None
+        if seen == layer:
+            return i
+        if 'strided' in name or 'pool' in name:
+            seen += 1
+    return None
+
+
+def two_stage_backward(loss, cut_tensors, between=None, backward_scope=None):
+    """loss.backward() in two pieces around a severed graph: `cut_tensors` = (originals, leaves) as recorded by
+    run_encoder_decoder when net.backward_cut is set (everything downstream of the cut was computed from the
+    detached leaves). Stage 1 = loss.backward(): gradients of the parameters above the cut and of the leaves;
+    `between()` (e.g. start the all-reduce of the late bucket); stage 2 = backward of the originals with the leaves'
+    gradients: the parameters below the cut. The sum of both stages is exactly what an unsevered loss.backward()
+    computes. backward_scope: context manager factory wrapped around each stage (ops.overlap_weight_grads)."""
+    import contextlib
+    scope = backward_scope if backward_scope is not None else contextlib.nullcontext
+    orig, leaves = cut_tensors
+    with scope():
+        loss.backward()
+    if between is not None:
+        between()
+    pairs = [(t, l.grad) for t, l in zip(orig, leaves) if t.requires_grad and l.grad is not None]
+    if pairs:
+        with scope():
+            torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
 
 
 def shard_spheres(n_total, rank, world):

@@ -159,8 +159,21 @@ class _SegmentationLossMixin:
 
 
 def run_encoder_decoder(net, x, batch, encoder=None):
+    """Encoder / decoder walk of KPFCNN.forward (architectures.py:322-343). When ``net.backward_cut`` holds an
+    encoder block index (set ONLY by a harness that then calls dp.two_stage_backward instead of loss.backward()),
+    the autograd graph is severed there: the activations that cross the cut -- the input of that block and the skip
+    tensors recorded before it -- are replaced by detached leaves for everything downstream, and
+    ``net.cut_tensors = (originals, leaves)`` lets the second stage continue from the leaves' gradients."""
     skip_x = []
+    cut = getattr(net, "backward_cut", None) if encoder is None else None
+    if cut is not None:
+        net.cut_tensors = ([], [])
     for block_i, block_op in enumerate(encoder if encoder is not None else net.encoder_blocks):
+        if cut is not None and block_i == cut and torch.is_grad_enabled():
+            orig = [x] + list(skip_x)
+            leaves = [t.detach().requires_grad_() for t in orig]
+            net.cut_tensors = (orig, leaves)
+            x, skip_x = leaves[0], leaves[1:]
         if block_i in net.encoder_skips:
             skip_x.append(x)
         x = block_op(x, batch)

@@ -516,3 +516,76 @@ def test_forked_child_fails_loudly():
     msg = q.get(timeout=60)
     p.join(60)
     assert "forked child" in msg and "spawn" in msg and "INTEGRATION.md" in msg
+
+
+def _two_stage_worker(rank, world, port, q):
+    """A small torch-only network with the cut protocol of run_encoder_decoder: two-stage backward + bucketed
+    asynchronous all-reduce must give the gradients of plain backward + one all-reduce."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module(PKG + ".dp")
+    torch.manual_seed(0)
+    early = torch.nn.Sequential(torch.nn.Linear(6, 8), torch.nn.Tanh())
+    late = torch.nn.Sequential(torch.nn.Linear(8 + 6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 2))
+    x0 = torch.randn(7, 6, generator=torch.Generator().manual_seed(10 + rank))
+
+    def forward(sever):
+        skip = x0 * 1.0                                   # a tensor used on both sides of the cut
+        skip.requires_grad_(False)
+        s = skip + early[0].bias[:6].sum() * 0           # depends on an early parameter (gradient zero) -> requires grad
+        h = early(s)
+        if sever:
+            orig = [h, s]
+            leaves = [t.detach().requires_grad_() for t in orig]
+            h, s_use = leaves
+        else:
+            orig = leaves = None
+            s_use = s
+        return late(torch.cat([h, s_use], 1)).pow(2).sum(), (orig, leaves)
+
+    # reference: plain backward + all-reduce of everything
+    loss, _ = forward(False)
+    loss.backward()
+    params = list(early.parameters()) + list(late.parameters())
+    red = dp.FlatAllReduce(params, world)
+    red()
+    want = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    # two stages, two buckets, the late bucket in flight during stage 2
+    loss, cut = forward(True)
+    br = dp.BucketedAllReduce([list(late.parameters()), list(early.parameters())], world)
+
+    def between():
+        assert all(p.grad is not None for p in late.parameters()) and all(p.grad is None for p in early.parameters())
+        br.pack(0)
+        br.launch(0)
+    dp.two_stage_backward(loss, cut, between=between)
+    br.pack(1)
+    br.launch(1)
+    br.wait()
+    br.unpack(0)
+    br.unpack(1)
+    ok = all(torch.allclose(p.grad, w, rtol=1e-6, atol=1e-7) for p, w in zip(params, want))
+    q.put((rank, ok, dp.cut_block_of_layer(['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_strided', 'resnetb',
+                                            'nearest_upsample', 'unary'], 2)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_stage_backward_with_bucketed_allreduce_two_gloo_ranks():
+    import socket
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = [ctx.Process(target=_two_stage_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    assert all(ok for _, ok, _ in res) and res[0][2] == 5

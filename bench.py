@@ -297,7 +297,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     # all three streams at the same priority: on this driver a priority difference between queues that
     # are busy at the same time costs far more (2-3x the step) than any ordering it buys
     build_stream = torch.cuda.Stream(priority=int(os.environ.get("MVK_BUILD_PRIO", "0")))
-    enc_stream = torch.cuda.Stream()
+    enc_stream = build_stream if os.environ.get("MVK_ONE_SIDE_BRANCH") == "1" else torch.cuda.Stream()
     status = [torch.zeros(2, dtype=torch.int32, device=dev) for _ in range(2)]   # neighbour-search status words
 
     enc = None
@@ -644,18 +644,18 @@ def net_step_captured(net, static, cfg, params, opt, reducer, begin=True):
 
 
 def backward_scope(ops):
-    """Context manager factory for a backward pass: the weight-gradient products on a side branch."""
+    """Context manager factory for a backward pass: all weight-gradient products of the pass as one grouped launch at
+    its end (ops.defer_weight_grads, default), on a side branch (MVK_OVERLAP_DW=1), or in line (MVK_DEFER_DW=0)."""
     import contextlib
-    return ops.overlap_weight_grads if os.environ.get("MVK_OVERLAP_DW", "1") == "1" else contextlib.nullcontext
+    if os.environ.get("MVK_OVERLAP_DW", "0") == "1":
+        return ops.overlap_weight_grads
+    return ops.defer_weight_grads if os.environ.get("MVK_DEFER_DW", "1") == "1" else contextlib.nullcontext
 
 
 def backward(ops, loss):
     """loss.backward() with the weight-gradient products on a side branch (ops.overlap_weight_grads): nothing reads
     a gradient before the optimiser (or the all-reduce), which run after the scope has joined."""
-    if os.environ.get("MVK_OVERLAP_DW", "1") == "1":
-        with ops.overlap_weight_grads():
-            loss.backward()
-    else:
+    with backward_scope(ops)():
         loss.backward()
 
 

@@ -190,7 +190,7 @@ struct GemmArgs {
 };
 
 template <bool TA, bool TB, int PM, int QN, int WM, int WN>
-__global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs a) {
+__device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const int by, const int bz) {
   static_assert(WM * WN == 4, "four waves per workgroup");
   constexpr int TM = 16 * PM * WM, TN = 16 * QN * WN;
   typedef Tile<!TA, TM> TileA;   // A tile element (m,k): TA == false -> A[m*lda + k] (k-contiguous)
@@ -200,8 +200,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs a) {
   float* const Bs = lds + 2 * TileA::FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int64_t m0 = (int64_t)blockIdx.y * TM, n0 = (int64_t)blockIdx.x * TN;
-  int64_t kbeg = (int64_t)blockIdx.z * a.k_per_split;
+  const int64_t m0 = (int64_t)by * TM, n0 = (int64_t)bx * TN;
+  int64_t kbeg = (int64_t)bz * a.k_per_split;
   const int64_t kend = kbeg + a.k_per_split < a.Kd ? kbeg + a.k_per_split : a.Kd;
 
   f32x4 acc[PM][QN];
@@ -401,6 +401,38 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs a) {
   }
 }
 
+template <bool TA, bool TB, int PM, int QN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs a) {
+  gemm_body<TA, TB, PM, QN, WM, WN>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Grouped launch: ONE grid walks a table of independent products of the same operand layout and tile shape (the
+// weight gradients of a whole backward pass: ~100 TN products dW = A^T g, each a latency-bound launch of ~10 us on
+// its own). Workgroup b finds its problem by a search over the prefix sums of the problems' workgroup counts.
+struct GroupEntry {
+  GemmArgs args;
+  int gx, gy, gz;       // grid of this problem
+  int wg_begin;         // first workgroup of this problem in the grouped grid
+};
+
+template <bool TA, bool TB, int PM, int QN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_grouped(const GroupEntry* __restrict__ tab, int n_prob) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = n_prob - 1;          // last problem with wg_begin <= b (wave uniform: scalar loads)
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (tab[mid].wg_begin <= b)
+      lo = mid;
+    else
+      hi = mid - 1;
+  }
+  const GroupEntry& e = tab[lo];
+  const int local = b - e.wg_begin;
+  const int bx = local % e.gx, by = (local / e.gx) % e.gy, bz = local / (e.gx * e.gy);
+  const GemmArgs a = e.args;
+  gemm_body<TA, TB, PM, QN, WM, WN>(a, bx, by, bz);
+}
+
 // ---------------------------------------------------------------------------------------------- host side
 
 struct Plan {
@@ -527,6 +559,88 @@ extern "C" int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t
   else if (transA && !transB) ok = launch_cfg<true, false>(p, grid, st, a);
   else ok = launch_cfg<true, true>(p, grid, st, a);
   MVK_REQUIRE(ok, "gemm: no kernel for plan pm=%d qn=%d narrow=%d", p.pm, p.qn, p.narrow);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// One record of mvk_gemm_f32_tn_grouped (host side, 48 bytes): C [M,N] (+)= A^T B with A [Kd,M], B [Kd,N] row-major.
+struct MvkGemmProblem {
+  const float* A;
+  const float* B;
+  float* C;
+  int64_t M, N, Kd;
+};
+
+extern "C" int64_t mvk_gemm_group_entry_bytes(void) { return (int64_t)sizeof(GroupEntry); }
+
+// Fills `table_host` (n * mvk_gemm_group_entry_bytes() bytes, narrow problems first) for the device-side grouped launch
+// and reports how many of the problems are narrow (N <= 32) and the workgroup counts of the two launches.
+extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* table_host, int* n_narrow,
+                                            int64_t* wgs_narrow, int64_t* wgs_wide, int32_t* splits /* [n] out */) {
+  MVK_REQUIRE(n >= 0 && problems && table_host && n_narrow && wgs_narrow && wgs_wide && splits, "grouped gemm: bad arguments");
+  const MvkGemmProblem* pr = (const MvkGemmProblem*)problems;
+  GroupEntry* tab = (GroupEntry*)table_host;
+  int nn = 0;
+  for (int i = 0; i < n; ++i) nn += pr[i].N <= 32 ? 1 : 0;
+  int64_t wn = 0, ww = 0;
+  int in = 0, iw = nn;
+  for (int i = 0; i < n; ++i) {
+    const MvkGemmProblem& q = pr[i];
+    MVK_REQUIRE(q.M > 0 && q.N > 0 && q.Kd > 0 && q.A && q.B && q.C, "grouped gemm: empty problem %d", i);
+    const bool narrow = q.N <= 32;
+    MVK_REQUIRE(!narrow || q.N > 16, "grouped gemm: outputs of <= 16 columns are not grouped");
+    const Plan p = plan_gemm(q.M, q.N, q.Kd, 0, false);
+    int split = p.split;
+    const int64_t ksteps = cdiv64(q.Kd, BK);
+    if (split > ksteps) split = (int)ksteps;
+    const int64_t k_per_split = cdiv64(ksteps, split) * BK;
+    split = (int)cdiv64(q.Kd, k_per_split);
+    GroupEntry e;
+    e.args.A = q.A; e.args.B = q.B; e.args.C = q.C; e.args.M = q.M; e.args.N = q.N; e.args.Kd = q.Kd;
+    e.args.lda = q.M; e.args.ldb = q.N;      // TN: A [Kd,M], B [Kd,N]
+    e.args.k_per_split = k_per_split;
+    e.args.atomic_out = split > 1;
+    e.args.accumulate = 0;
+    e.args.vecA = ((q.M % 4 == 0) && ((uintptr_t)q.A % 16 == 0)) ? 4 : ((q.M % 2 == 0) && ((uintptr_t)q.A % 8 == 0)) ? 2 : 1;
+    e.args.vecB = ((q.N % 4 == 0) && ((uintptr_t)q.B % 16 == 0)) ? 4 : ((q.N % 2 == 0) && ((uintptr_t)q.B % 8 == 0)) ? 2 : 1;
+    e.args.bn_part = nullptr;
+    e.args.n_valid = nullptr;
+    const int64_t tm = narrow ? 64 : 32, tn = narrow ? 32 : 64;      // plan tiles: narrow (pm 1, qn 2), wide (pm 2, qn 1)
+    e.gx = (int)cdiv64(q.N, tn);
+    e.gy = (int)cdiv64(q.M, tm);
+    e.gz = split;
+    const int64_t wgs = (int64_t)e.gx * e.gy * e.gz;
+    if (narrow) {
+      e.wg_begin = (int)wn;
+      wn += wgs;
+      tab[in++] = e;
+    } else {
+      e.wg_begin = (int)ww;
+      ww += wgs;
+      tab[iw++] = e;
+    }
+    splits[i] = split;
+  }
+  MVK_REQUIRE(wn < (1ll << 31) && ww < (1ll << 31), "grouped gemm: grid too large");
+  *n_narrow = nn;
+  *wgs_narrow = wn;
+  *wgs_wide = ww;
+  return 0;
+}
+
+// Launches the table prepared by mvk_gemm_f32_tn_grouped_plan (now in DEVICE memory): at most two launches.
+// Every C with a split > 1 (plan: splits[i]) must be zero-initialised by the caller.
+extern "C" int mvk_gemm_f32_tn_grouped(const void* table_dev, int n, int n_narrow, int64_t wgs_narrow, int64_t wgs_wide,
+                                       void* stream) {
+  MVK_REQUIRE(n >= 0 && n_narrow >= 0 && n_narrow <= n, "grouped gemm: bad counts");
+  hipStream_t st = (hipStream_t)stream;
+  const GroupEntry* tab = (const GroupEntry*)table_dev;
+  if (n_narrow > 0 && wgs_narrow > 0)
+    hipLaunchKernelGGL((gemm_f32_mfma_grouped<true, false, 1, 2, 4, 1>), dim3((unsigned)wgs_narrow), dim3(256), 0, st, tab,
+                       n_narrow);
+  if (n - n_narrow > 0 && wgs_wide > 0)
+    hipLaunchKernelGGL((gemm_f32_mfma_grouped<true, false, 2, 1, 1, 4>), dim3((unsigned)wgs_wide), dim3(256), 0, st,
+                       tab + n_narrow, n - n_narrow);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

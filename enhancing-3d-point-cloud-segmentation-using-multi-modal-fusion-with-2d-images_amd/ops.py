@@ -321,6 +321,87 @@ def _gemm_off_chain(A, B, **kw):
     return out
 
 
+# ---- all weight gradients of a backward pass in (at most) two launches ------------------------------------
+# `with defer_weight_grads(): loss.backward()`: every dW product of the pass is only RECORDED (its zero-initialised
+# result tensor is handed to autograd at once) and the whole list runs as one grouped launch per tile shape when the
+# scope ends (mvk_gemm_f32_tn_grouped): ~100 latency-bound ~10 us launches leave the serial chain of a step. Same
+# contract as overlap_weight_grads: nothing may read a weight gradient before the scope has been left.
+_DEFER = {"on": False, "items": [], "slots": None, "eager": 0}
+_DW_MAX = 512
+
+
+def _defer_slots(device):
+    """Pinned host + device table buffers, allocated outside any capture (pinning is not capturable): two rotate for
+    eager passes, every captured pass takes one of its own (its memcpy node re-reads the pinned bytes at each replay)."""
+    if _DEFER["slots"] is None:
+        nb = _DW_MAX * int(lib().mvk_gemm_group_entry_bytes())
+        _DEFER["slots"] = [{"host": torch.empty(nb, dtype=torch.uint8).pin_memory(),
+                            "dev": torch.empty(nb, dtype=torch.uint8, device=device), "event": None} for _ in range(10)]
+    return _DEFER["slots"]
+
+
+class defer_weight_grads:
+    def __enter__(self):
+        _DEFER.update(on=True, items=[])
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            if exc[0] is None:
+                _flush_deferred()
+        finally:
+            _DEFER.update(on=False, items=[])
+        return False
+
+
+def _flush_deferred():
+    items = _DEFER["items"]
+    if not items:
+        return
+    import numpy as np
+    dev = items[0][0].device
+    n = len(items)
+    prob = np.zeros(n, dtype=np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i8"), ("N", "<i8"), ("Kd", "<i8")]))
+    for i, (A, B, out_ptr) in enumerate(items):
+        prob[i] = (A.data_ptr(), B.data_ptr(), out_ptr, A.shape[1], B.shape[1], A.shape[0])
+    slots = _defer_slots(dev)
+    if torch.cuda.is_current_stream_capturing():
+        if len(slots) <= 2:
+            raise RuntimeError("defer_weight_grads: out of pre-pinned table slots for graph captures")
+        slot = slots.pop()              # owned by this capture from now on
+        _DEFER.setdefault("captured", []).append(slot)
+    else:
+        slot = slots[_DEFER["eager"] % 2]
+        _DEFER["eager"] += 1
+        if slot["event"] is not None:
+            slot["event"].synchronize()
+    nn, wn, ww = C.c_int(0), C.c_int64(0), C.c_int64(0)
+    splits = np.zeros(n, np.int32)
+    check(lib().mvk_gemm_f32_tn_grouped_plan(prob.ctypes.data_as(C.c_void_p), n, C.c_void_p(slot["host"].data_ptr()),
+                                             C.byref(nn), C.byref(wn), C.byref(ww), splits.ctypes.data_as(C.c_void_p)))
+    nb = n * int(lib().mvk_gemm_group_entry_bytes())
+    slot["dev"][:nb].copy_(slot["host"][:nb], non_blocking=True)
+    check(lib().mvk_gemm_f32_tn_grouped(C.c_void_p(slot["dev"].data_ptr()), n, nn.value, wn.value, ww.value, _stream()))
+    if not torch.cuda.is_current_stream_capturing():
+        ev = torch.cuda.Event()
+        ev.record()
+        slot["event"] = ev
+
+
+def _dw_gemm(A, B, transB=False):
+    """A^T @ B for a weight gradient: deferred into the grouped launch inside defer_weight_grads(), on a side stream
+    inside overlap_weight_grads(), a plain product otherwise."""
+    if _DEFER["on"] and not transB and A.is_cuda and B.shape[1] > 16 and len(_DEFER["items"]) < _DW_MAX \
+            and A.shape[0] > 0 and A.shape[1] > 0:
+        A, B = _f32c(A), _f32c(B)
+        out = _zeros((A.shape[1], B.shape[1]), A.device)       # zero-initialised: a split reduction accumulates into it
+        # only the ADDRESS is recorded: a second reference to the tensor would make autograd's AccumulateGrad clone the
+        # gradient instead of adopting it (one copy launch per parameter); the tensor itself lives on as the .grad
+        _DEFER["items"].append((A, B, out.data_ptr()))
+        return out
+    return _gemm_off_chain(A, B, transA=True, transB=transB)
+
+
 # --------------------------------------------------------------------------------------------
 # KPConv (rigid and deformable) as one autograd node
 # --------------------------------------------------------------------------------------------
@@ -366,7 +447,7 @@ class _KPConvFn(torch.autograd.Function):
         Am = A * modulations.unsqueeze(2) if modulations is not None else A
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
-            dW = _gemm_off_chain(Am.view(Nq, K * Cin), gy, transA=True).view(K, Cin, Cout)
+            dW = _dw_gemm(Am.view(Nq, K * Cin), gy).view(K, Cin, Cout)
         need_dA = ctx.needs_input_grad[3] or (offsets is not None)
         if need_dA:
             dAm = gemm(gy, W.reshape(K * Cin, Cout), transB=True).view(Nq, K, Cin)
@@ -444,7 +525,7 @@ class _KPConv16Fn(torch.autograd.Function):
         Am = A32 * modulations.unsqueeze(2) if modulations is not None else A32
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
-            dW = _gemm_off_chain(Am.view(Nq, K * Cin), gy, transA=True).view(K, Cin, Cout)
+            dW = _dw_gemm(Am.view(Nq, K * Cin), gy).view(K, Cin, Cout)
         if ctx.needs_input_grad[3] or offsets is not None:
             dAm = gemm(gy, W16.float(), transB=True).view(Nq, K, Cin)
             if modulations is not None:
@@ -990,7 +1071,7 @@ class _LinearFn(torch.autograd.Function):
             dx = gemm(W, g, transA=True, transB=True) if ctx.xt else gemm(g, W)      # [Kd,M] or [M,Kd]
         if ctx.needs_input_grad[1]:
             # dW [N,Kd] = g^T [N,M] @ x [M,Kd]
-            dW = _gemm_off_chain(g, x, transA=True, transB=ctx.xt)
+            dW = _dw_gemm(g, x, transB=ctx.xt)
         return dx, dW, None, None
 
 

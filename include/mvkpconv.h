@@ -100,6 +100,18 @@ int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, int want_st
 int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA,
                     int transB, int accumulate, int split_k, float* bn_part, const int32_t* n_valid, void* stream);
 
+/* Grouped weight-gradient products: n independent TN products C_i [M_i,N_i] = A_i^T B_i (A_i [Kd_i,M_i], B_i [Kd_i,N_i],
+ * row-major: dW = A^T g of a KPConv layer, dW^T = g^T x of a unary layer, blocks.py / SURVEY.md A.6) in at most two
+ * launches. `problems` = HOST array of records {const float* A; const float* B; float* C; int64 M, N, Kd;} (48 bytes,
+ * N > 16). _plan fills `table_host` (n * mvk_gemm_group_entry_bytes() bytes) and reports per problem the split of its
+ * reduction (C_i must be zero-initialised when splits[i] > 1); the caller copies the table to the device and passes
+ * that copy to mvk_gemm_f32_tn_grouped together with the three counts the plan returned. */
+int64_t mvk_gemm_group_entry_bytes(void);
+int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* table_host, int* n_narrow, int64_t* wgs_narrow,
+                                 int64_t* wgs_wide, int32_t* splits);
+int mvk_gemm_f32_tn_grouped(const void* table_dev, int n, int n_narrow, int64_t wgs_narrow, int64_t wgs_wide,
+                            void* stream);
+
 /* fp16-feature mode of the same contraction (BASELINE config 5): operands are rounded to fp16 (each may be
  * stored as f32 or f16 in memory: a_f16 / b_f16), multiplied on v_mfma_f32_32x32x8_f16 and accumulated in
  * f32; C is f32 [M,N] (split_k > 1: atomics onto a zero-initialised C) or, with c_f16, fp16 [M,N]. */

@@ -490,6 +490,37 @@ def test_gemm_batchnorm_statistics_epilogue(ops, M, N, K, n):
     assert rel_err(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 1e-4
 
 
+def test_deferred_weight_gradients_run_as_one_grouped_launch(ops):
+    """ops.defer_weight_grads(): the dW products recorded during a backward pass (TN, wide and narrow outputs, ragged
+    sizes, split and unsplit reductions) come out of the grouped launch equal to the individual products; under
+    hipGraph capture too (table copy = a memcpy node)."""
+    torch.manual_seed(5)
+    shapes = [(19464, 990, 64), (3986, 960, 64), (65, 7680, 512), (19464, 64, 32), (19464, 128, 20), (300, 70, 45), (1, 33, 17),
+              (5000, 30, 64), (19464, 32, 128)]
+    As = [torch.randn(k, m, device="cuda") for (k, m, n) in shapes]
+    Bs = [torch.randn(k, n, device="cuda") for (k, m, n) in shapes]
+    want = [(a.double().t() @ b.double()).cpu().numpy() for a, b in zip(As, Bs)]
+    with ops.defer_weight_grads():
+        outs = [ops._dw_gemm(a, b) for a, b in zip(As, Bs)]
+        small = ops._dw_gemm(As[0][:, :8], Bs[0][:, :9])            # N <= 16: not grouped, computed at once
+    for o, w in zip(outs, want):
+        assert rel_err(o.cpu().numpy(), w) < 1e-5
+    assert rel_err(small.cpu().numpy(), (As[0][:, :8].double().t() @ Bs[0][:, :9].double()).cpu().numpy()) < 1e-5
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=st):
+            with ops.defer_weight_grads():
+                cap = [ops._dw_gemm(a, b) for a, b in zip(As[1:4], Bs[1:4])]
+        for o in cap:
+            o.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+    for o, w in zip(cap, want[1:4]):
+        assert rel_err(o.cpu().numpy(), w) < 1e-5
+
+
 # ------------------------------------------------------------------ masked BatchNorm + LeakyReLU
 
 @pytest.mark.parametrize("slope", [1.0, 0.1])

@@ -456,10 +456,11 @@ Plan plan_gemm(int64_t M, int64_t N, int64_t Kd, int split_req, bool want_stats)
     if (split_req > 0 && split != split_req) continue;
     if (split > 1 && ksteps / split < 4) break;               // keep >= 4 k-tiles per workgroup
     const int64_t kt = cdiv64(ksteps, split), wgs = tiles * split;
-    // shader cycles: latency chain of one workgroup (k-tiles x ~700 with ~4 workgroups per CU overlapping) per
-    // round of 1024 resident workgroups + MFMA work spread over the 256 CUs + the atomic epilogue of a split
-    double t = (double)cdiv64(wgs, 1024) * (kt * 700.0 + 3000.0) + (double)wgs * kt * 256.0 * pm * qn / 256.0;
-    if (split > 1) t += (double)M * N * split * 4.0 / 1080.0;
+    // shader cycles (fitted to tools/gemm_bench.py --sweep, device times): latency chain of one workgroup (k-tiles x
+    // ~1500 at ~5 resident workgroups per CU) per round of 1280 resident workgroups + MFMA work spread over the 256
+    // CUs + the atomic epilogue of a split (bytes, plus a per-split term: small outputs contend on few addresses)
+    double t = (double)cdiv64(wgs, 1280) * (kt * 1500.0 + 3000.0) + (double)wgs * kt * 256.0 * pm * qn / 256.0;
+    if (split > 1) t += (double)M * N * split * 4.0 / 2160.0 + 500.0 * split;
     if (split == 1) t1 = t;
     if (t < best_t) {
       best_t = t;

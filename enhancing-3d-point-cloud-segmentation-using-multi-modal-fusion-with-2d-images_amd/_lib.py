@@ -68,6 +68,8 @@ _SIGNATURES = {
     "mvk_fa_gather_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
     "mvk_group_points_fwd": (C.c_int, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
     "mvk_group_points_bwd": (C.c_int, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
+    "mvk_group_points_fwd_f64": (C.c_int, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
+    "mvk_group_points_bwd_f64": (C.c_int, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

@@ -479,19 +479,21 @@ __global__ __launch_bounds__(64 * PW) void knn_pruned_kernel(const float* __rest
 // index reads and output writes are coalesced; the gather itself is element granular by nature
 // (channel-major feature maps), served by L2 / Infinity Cache.
 // ---------------------------------------------------------------------------------------------
-__global__ void group_points_fwd_kernel(const float* __restrict__ in, const int64_t* __restrict__ idx, int B,
-                                        int C, int64_t N1, int64_t NK, float* __restrict__ out) {
+template <typename T>
+__global__ void group_points_fwd_kernel(const T* __restrict__ in, const int64_t* __restrict__ idx, int B,
+                                        int C, int64_t N1, int64_t NK, T* __restrict__ out) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)B * C * NK) return;
   const int64_t e = t % NK;
   const int64_t bc = t / NK;
   const int64_t b = bc / C;
   const int64_t j = idx[b * NK + e];
-  out[t] = (j >= 0 && j < N1) ? in[bc * N1 + j] : 0.f;
+  out[t] = (j >= 0 && j < N1) ? in[bc * N1 + j] : (T)0;
 }
 
-__global__ void group_points_bwd_kernel(const float* __restrict__ go, const int64_t* __restrict__ idx, int B,
-                                        int C, int64_t N1, int64_t NK, float* __restrict__ gi) {
+template <typename T>
+__global__ void group_points_bwd_kernel(const T* __restrict__ go, const int64_t* __restrict__ idx, int B,
+                                        int C, int64_t N1, int64_t NK, T* __restrict__ gi) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)B * C * NK) return;
   const int64_t e = t % NK;
@@ -818,8 +820,30 @@ extern "C" int mvk_group_points_fwd(const float* points, const int64_t* index, i
   MVK_REQUIRE(B >= 0 && C >= 0 && N1 >= 0 && N2 >= 0 && K >= 0, "group_points: bad sizes");
   const int64_t tot = (int64_t)B * C * N2 * K;
   if (tot == 0) return 0;
-  hipLaunchKernelGGL(group_points_fwd_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(group_points_fwd_kernel<float>, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
                      points, index, B, C, N1, N2 * K, out);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// float64 twins (the reference's extension dispatches float and double, group_points_kernel.cu:60,130)
+extern "C" int mvk_group_points_fwd_f64(const double* points, const int64_t* index, int B, int C, int64_t N1,
+                                        int64_t N2, int K, double* out, void* stream) {
+  MVK_REQUIRE(B >= 0 && C >= 0 && N1 >= 0 && N2 >= 0 && K >= 0, "group_points: bad sizes");
+  const int64_t tot = (int64_t)B * C * N2 * K;
+  if (tot == 0) return 0;
+  hipLaunchKernelGGL(group_points_fwd_kernel<double>, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
+                     points, index, B, C, N1, N2 * K, out);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_group_points_bwd_f64(const double* grad_out, const int64_t* index, int B, int C, int64_t N1,
+                                        int64_t N2, int K, double* grad_in, void* stream) {
+  const int64_t tot = (int64_t)B * C * N2 * K;
+  if (tot == 0) return 0;
+  hipLaunchKernelGGL(group_points_bwd_kernel<double>, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
+                     grad_out, index, B, C, N1, N2 * K, grad_in);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -828,7 +852,7 @@ extern "C" int mvk_group_points_bwd(const float* grad_out, const int64_t* index,
                                     int64_t N2, int K, float* grad_in, void* stream) {
   const int64_t tot = (int64_t)B * C * N2 * K;
   if (tot == 0) return 0;
-  hipLaunchKernelGGL(group_points_bwd_kernel, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(group_points_bwd_kernel<float>, dim3((unsigned)cdiv64(tot, 256)), dim3(256), 0, (hipStream_t)stream,
                      grad_out, index, B, C, N1, N2 * K, grad_in);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;

@@ -994,7 +994,7 @@ def knn_pixels(sphere_points, image_xyz, image_mask, k=3):
 
 
 class _GroupPointsFn(torch.autograd.Function):
-    """mvpnet/ops/group_points.py:5-17."""
+    """mvpnet/ops/group_points.py:5-17; float32 and float64 like the reference's extension."""
 
     @staticmethod
     def forward(ctx, points, index):
@@ -1003,22 +1003,25 @@ class _GroupPointsFn(torch.autograd.Function):
             raise RuntimeError("group_points: index must be int64")
         if points.dim() != 3 or index.dim() != 3 or points.shape[0] != index.shape[0]:
             raise RuntimeError("group_points: expected points (B,C,N1) and index (B,N2,K)")
-        points, index = _f32c(points), index.contiguous()
+        f64 = points.dtype == torch.float64
+        points, index = (points.contiguous() if f64 else _f32c(points)), index.contiguous()
         B, Cc, N1 = points.shape
         _, N2, K = index.shape
-        out = torch.empty((B, Cc, N2, K), device=points.device, dtype=torch.float32)
-        check(lib().mvk_group_points_fwd(_p(points), _p(index), B, Cc, N1, N2, K, _p(out), _stream()))
+        out = torch.empty((B, Cc, N2, K), device=points.device, dtype=points.dtype)
+        fn = lib().mvk_group_points_fwd_f64 if f64 else lib().mvk_group_points_fwd
+        check(fn(_p(points), _p(index), B, Cc, N1, N2, K, _p(out), _stream()))
         ctx.save_for_backward(index)
-        ctx.n1 = N1
+        ctx.n1, ctx.f64 = N1, f64
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         (index,) = ctx.saved_tensors
-        g = _f32c(grad_out)
+        g = grad_out.double().contiguous() if ctx.f64 else _f32c(grad_out)
         B, Cc, N2, K = g.shape
-        gi = torch.zeros((B, Cc, ctx.n1), device=g.device, dtype=torch.float32)
-        check(lib().mvk_group_points_bwd(_p(g), _p(index), B, Cc, ctx.n1, N2, K, _p(gi), _stream()))
+        gi = torch.zeros((B, Cc, ctx.n1), device=g.device, dtype=g.dtype)
+        fn = lib().mvk_group_points_bwd_f64 if ctx.f64 else lib().mvk_group_points_bwd
+        check(fn(_p(g), _p(index), B, Cc, ctx.n1, N2, K, _p(gi), _stream()))
         return gi, None
 
 

@@ -338,6 +338,11 @@ int mvk_group_points_fwd(const float* points, const int64_t* index, int B, int C
 /* backward: grad_in [B,C,N1] (zero-initialised by the caller) += scatter of grad_out. */
 int mvk_group_points_bwd(const float* grad_out, const int64_t* index, int B, int C, int64_t N1,
                          int64_t N2, int K, float* grad_in, void* stream);
+/* float64 twins of the two entry points above (group_points_kernel.cu:60,130 dispatch float and double). */
+int mvk_group_points_fwd_f64(const double* points, const int64_t* index, int B, int C, int64_t N1, int64_t N2, int K,
+                             double* out, void* stream);
+int mvk_group_points_bwd_f64(const double* grad_out, const int64_t* index, int B, int C, int64_t N1, int64_t N2, int K,
+                             double* grad_in, void* stream);
 
 #ifdef __cplusplus
 }

@@ -726,6 +726,20 @@ def test_frozen_encoder_fast_path_equals_the_module_forward(hw):
 
 # ------------------------------------------------------------------ group_points (reference test shapes)
 
+def test_group_points_float64_like_the_reference_extension(ops):
+    """group_points_kernel.cu:60,130 dispatch float and double: the double path, forward and backward."""
+    torch.manual_seed(1)
+    pts = torch.randn(2, 5, 300, dtype=torch.float64).cuda().requires_grad_(True)
+    index = torch.randint(0, 300, [2, 77, 9]).long().cuda()
+    want = pts.unsqueeze(2).expand(2, 5, 77, 300).gather(3, index.unsqueeze(1).expand(2, 5, 77, 9))
+    got = ops.group_points(pts, index)
+    assert got.dtype == torch.float64 and torch.equal(got, want)
+    go = torch.randn_like(want)
+    gw, = torch.autograd.grad(want, pts, go, retain_graph=True)
+    gg, = torch.autograd.grad(got, pts, go)
+    assert torch.allclose(gg, gw, rtol=1e-12, atol=1e-12)
+
+
 @pytest.mark.parametrize("b,c,n1,n2,k", [(2, 3, 512, 128, 32), (5, 64, 513, 129, 33)])
 def test_group_points_reference_test_shapes(ops, b, c, n1, n2, k):
     """Same shapes / seed / restatement as mvpnet/ops/tests/test_group_points.py:6-44."""

@@ -56,11 +56,28 @@ __device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ part, 
   const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   float x = 0.f, y = 0.f;
-  if (c < D)
-    for (int i = pr; i < nblk; i += 16) {
+  if (c < D) {
+    // four blocks per trip, all eight loads issued before the first add: the partials come from L2 and a chain of
+    // dependent loads was most of this kernel's time (same summation order as one block per trip)
+    int i = pr;
+    for (; i + 48 < nblk; i += 64) {
+      float u[4], v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        u[t] = part[((int64_t)(i + 16 * t) * 2) * D + c];
+        v[t] = part[((int64_t)(i + 16 * t) * 2 + 1) * D + c];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        x += u[t];
+        y += v[t];
+      }
+    }
+    for (; i < nblk; i += 16) {
       x += part[((int64_t)i * 2) * D + c];
       y += part[((int64_t)i * 2 + 1) * D + c];
     }
+  }
   r1[pr][cl] = x;
   r2[pr][cl] = y;
   __syncthreads();
@@ -78,43 +95,60 @@ __device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ part, 
 }
 
 // The same for partials written by the GEMM epilogue (csrc/gemm.hip): per row block of `blk` rows the plain
-// column sum and the sum of squares about the block's own mean. Two fixed-order passes: total -> mean, then
-// M2 = sum_b [ M2_b + n_b (mean_b - mean)^2 ]. Returns (mean, M2) to the lanes with part == 0.
+// column sum and the sum of squares about the block's own mean. ONE fixed-order pass with batched loads: about the
+// mean c of block 0 (every block's mean is close to it, so nothing cancels),
+//   S = sum_b sum_b,   Q = sum_b [ M2_b + n_b (mean_b - c)^2 ],   mean = S / n,   M2 = Q - n (mean - c)^2.
+// Returns (mean, M2) to the lanes with part == 0.
 __device__ __forceinline__ bool bn_sum_partials_m2(const float* __restrict__ part, int R, int blk, int n, int D, float* mean,
                                                    float* m2) {
-  __shared__ float q1[16][64], qm[64];
+  __shared__ float q1[16][64], q2[16][64];
   const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  const int nblk = (R + blk - 1) / blk;
-  float x = 0.f;
-  if (c < D)
-    for (int i = pr; i < nblk && i * blk < n; i += 16) x += part[((int64_t)i * 2) * D + c];
-  q1[pr][cl] = x;
-  __syncthreads();
-  if (pr == 0) {
-    x = 0.f;
+  const int nb = n > 0 ? (n + blk - 1) / blk : 0;          // blocks that hold valid rows
+  float x = 0.f, y = 0.f, ref = 0.f;
+  if (c < D && nb > 0) {
+    const int n0 = min(blk, n);
+    ref = part[c] / (float)n0;
+    int i = pr;
+    for (; i + 48 < nb; i += 64) {
+      float u[4], v[4];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) x += q1[i][cl];
-    qm[cl] = n > 0 ? x / (float)n : 0.f;
-  }
-  __syncthreads();
-  const float mu = qm[cl];
-  float y = 0.f;
-  if (c < D)
-    for (int i = pr; i < nblk && i * blk < n; i += 16) {
-      const int ni = min(blk, n - i * blk);
-      const float d = part[((int64_t)i * 2) * D + c] / (float)ni - mu;
-      y += part[((int64_t)i * 2 + 1) * D + c] + (float)ni * d * d;
+      for (int t = 0; t < 4; ++t) {
+        u[t] = part[((int64_t)(i + 16 * t) * 2) * D + c];
+        v[t] = part[((int64_t)(i + 16 * t) * 2 + 1) * D + c];
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int ni = min(blk, n - (i + 16 * t) * blk);
+        const float d = u[t] / (float)ni - ref;
+        x += u[t];
+        y += v[t] + (float)ni * d * d;
+      }
     }
-  __syncthreads();
-  q1[pr][cl] = y;
+    for (; i < nb; i += 16) {
+      const int ni = min(blk, n - i * blk);
+      const float u = part[((int64_t)i * 2) * D + c], v = part[((int64_t)i * 2 + 1) * D + c];
+      const float d = u / (float)ni - ref;
+      x += u;
+      y += v + (float)ni * d * d;
+    }
+  }
+  q1[pr][cl] = x;
+  q2[pr][cl] = y;
   __syncthreads();
   if (pr != 0 || c >= D) return false;
+  x = 0.f;
   y = 0.f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) y += q1[i][cl];
+  for (int i = 0; i < 16; ++i) {
+    x += q1[i][cl];
+    y += q2[i][cl];
+  }
+  const float mu = n > 0 ? x / (float)n : 0.f;
+  const float dm = mu - ref;
+  float M2 = y - (float)n * dm * dm;
   *mean = mu;
-  *m2 = y;
+  *m2 = M2 > 0.f ? M2 : 0.f;
   return true;
 }
 

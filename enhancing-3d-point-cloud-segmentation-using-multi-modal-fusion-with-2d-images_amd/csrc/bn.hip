@@ -32,7 +32,19 @@ __global__ __launch_bounds__(BN_T) void bn_stats_partial(const float* __restrict
   if (c < D && r0 < n) {
     const float k = x[c];  // shift: row 0 (n >= 1 here)
     const int r1 = min(r0 + BN_ROWS, n);
-    for (int r = r0 + rl; r < r1; r += 4) {
+    int r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {
+      float xv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) xv[t] = x[(int64_t)(r + 4 * t) * D + c];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float v = xv[t] - k;
+        a += v;
+        b += v * v;
+      }
+    }
+    for (; r < r1; r += 4) {
       const float v = x[(int64_t)r * D + c] - k;
       a += v;
       b += v * v;
@@ -216,7 +228,25 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce(const float* __restrict__ 
   if (c < D && r0 < n) {
     const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c];
     const int r1 = min(r0 + BN_ROWS, n);
-    for (int r = r0 + rl; r < r1; r += 4) {
+    int r = r0 + rl;
+    for (; r + 12 < r1; r += 16) {        // four rows per trip, loads first (same summation order)
+      float xv[4], gv4[4], yv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        xv[t] = x[(int64_t)(r + 4 * t) * D + c];
+        gv4[t] = g[(int64_t)(r + 4 * t) * D + c];
+        yv[t] = yout ? yout[(int64_t)(r + 4 * t) * D + c] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float xh = (xv[t] - mu) * is;
+        float gv = gv4[t];
+        if (yout ? yv[t] <= 0.f : xh * ga + be <= 0.f) gv *= slope;
+        a += gv;
+        b += gv * xh;
+      }
+    }
+    for (; r < r1; r += 4) {
       const float xh = (x[(int64_t)r * D + c] - mu) * is;
       float gv = g[(int64_t)r * D + c];
       if (yout ? yout[(int64_t)r * D + c] <= 0.f : xh * ga + be <= 0.f) gv *= slope;

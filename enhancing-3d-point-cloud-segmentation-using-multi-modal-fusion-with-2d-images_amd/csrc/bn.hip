@@ -360,7 +360,28 @@ __global__ __launch_bounds__(1024) void bn_finish_apply(const float* __restrict_
   __syncthreads();
   if (c >= D) return;
   const float mu = smu[cl], is = sis[cl], ga = gamma[c], be = beta[c];
-  for (int r = blockIdx.y * 16 + pr; r < R; r += gridDim.y * 16) {
+  const int step = gridDim.y * 16;
+  int r = blockIdx.y * 16 + pr;
+  for (; r + 3 * step < R; r += 4 * step) {      // four rows per trip, loads first
+    float xv[4], av[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rr = r + t * step;
+      xv[t] = rr < n ? x[(int64_t)rr * D + c] : 0.f;
+      av[t] = (addend && rr < n) ? addend[(int64_t)rr * D + c] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rr = r + t * step;
+      float v = 0.f;
+      if (rr < n) {
+        v = (xv[t] - mu) * is * ga + be + av[t];
+        v = v > 0.f ? v : v * slope;
+      }
+      y[(int64_t)rr * D + c] = v;
+    }
+  }
+  for (; r < R; r += step) {
     float v = 0.f;
     if (r < n) {
       v = (x[(int64_t)r * D + c] - mu) * is * ga + be;
@@ -395,7 +416,33 @@ __global__ __launch_bounds__(1024) void bn_bwd_finish_apply(const float* __restr
   if (c >= D) return;
   const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c], s1 = sa[cl], s2 = sb[cl];
   const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
-  for (int r = blockIdx.y * 16 + pr; r < R; r += gridDim.y * 16) {
+  const int step = gridDim.y * 16;
+  int r = blockIdx.y * 16 + pr;
+  for (; r + 3 * step < R; r += 4 * step) {      // four rows per trip, loads first
+    float xv[4], gv4[4], yv[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rr = r + t * step;
+      xv[t] = rr < n ? x[(int64_t)rr * D + c] : 0.f;
+      gv4[t] = rr < n ? g[(int64_t)rr * D + c] : 0.f;
+      yv[t] = (yout && rr < n) ? yout[(int64_t)rr * D + c] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int rr = r + t * step;
+      float v = 0.f, ga_out = 0.f;
+      if (rr < n) {
+        const float xh = (xv[t] - mu) * is;
+        float gv = gv4[t];
+        if (yout ? yv[t] <= 0.f : xh * ga + be <= 0.f) gv *= slope;
+        v = ga * is * (gv - s1 * inv_n - xh * s2 * inv_n);
+        ga_out = gv;
+      }
+      dx[(int64_t)rr * D + c] = v;
+      if (d_addend) d_addend[(int64_t)rr * D + c] = ga_out;
+    }
+  }
+  for (; r < R; r += step) {
     float v = 0.f, ga_out = 0.f;
     if (r < n) {
       const float xh = (x[(int64_t)r * D + c] - mu) * is;

@@ -15,9 +15,25 @@ __global__ void max_pool_fwd_k(const float* __restrict__ x, int64_t Ns, int C, c
   const int c = (int)(t % C);
   float best = -INFINITY;
   int bh = 0;
-  for (int h = 0; h < H; ++h) {
+  constexpr int UB = 8;      // eight neighbours per trip: indices first, then the eight row loads, then the compares
+  int h = 0;                 // (the index -> row chain of one neighbour at a time was latency bound)
+  for (; h + UB <= H; h += UB) {
+    int j[UB];
+    float v[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) j[u] = load_idx<IDX64>(idx, n * H + h + u, Ns);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) v[u] = j[u] >= 0 ? x[(int64_t)j[u] * C + c] : 0.f;  // zero shadow row takes part (blocks.py:103)
+#pragma unroll
+    for (int u = 0; u < UB; ++u)
+      if (v[u] > best) {
+        best = v[u];
+        bh = h + u;
+      }
+  }
+  for (; h < H; ++h) {
     const int j = load_idx<IDX64>(idx, n * H + h, Ns);
-    const float v = j >= 0 ? x[(int64_t)j * C + c] : 0.f;  // zero shadow row takes part (blocks.py:103)
+    const float v = j >= 0 ? x[(int64_t)j * C + c] : 0.f;
     if (v > best) {
       best = v;
       bh = h;

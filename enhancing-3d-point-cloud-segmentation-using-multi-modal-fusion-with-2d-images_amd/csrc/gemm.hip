@@ -469,7 +469,12 @@ Plan plan_gemm(int64_t M, int64_t N, int64_t Kd, int split_req, bool want_stats)
   }
   // statistics in the epilogue need the whole reduction in one workgroup: worth it unless a split saves more
   // than the separate statistics launch costs (~6 us)
-  if (want_stats && t1 <= best_t + 14000.0) best.split = 1;
+  static double bonus = -1.0;
+  if (bonus < 0.0) {
+    const char* eb = getenv("MVK_GEMM_STATS_BONUS");
+    bonus = eb ? atof(eb) : 14000.0;
+  }
+  if (want_stats && t1 <= best_t + bonus) best.split = 1;
   const char* e = getenv("MVK_GEMM_FORCE");       // development override: "pm,qn,split"
   if (e) {
     int pm = 0, qn = 0, sp = 0;

@@ -458,12 +458,13 @@ def test_gemm_batchnorm_statistics_epilogue(ops, M, N, K, n):
     A[:, 0] = 40.0                                          # large common component -> large column means
     B = torch.randn(K, N, device="cuda")
     nv = torch.tensor([n], dtype=torch.int32, device="cuda")
-    y, st = ops.gemm(A, B, stats_n_valid=nv)
+    auto, st_auto = ops.gemm(A, B, stats_n_valid=nv)          # the plan may prefer a split reduction (then no statistics)
+    assert rel_err(auto.cpu().numpy(), (A.double() @ B.double()).cpu().numpy()) < 1e-5
+    assert (st_auto is None) == (ops.gemm_plan(M, N, K, None, True)[1] == 0)
+    y, st = ops.gemm(A, B, split_k=1, stats_n_valid=nv)       # unsplit: statistics always come with it
     assert rel_err(y.cpu().numpy(), (A.double() @ B.double()).cpu().numpy()) < 1e-5
-    split, rows = ops.gemm_plan(M, N, K, None, True)
-    if st is None:
-        assert split > 1
-        pytest.skip("the plan splits the reduction of this shape: statistics stay a separate launch")
+    split, rows = ops.gemm_plan(M, N, K, 1, True)
+    assert split == 1 and rows > 0 and st is not None
     part, prow = st
     assert prow == rows and part.shape == ((M + rows - 1) // rows, 2, N)
     yv = y[:n].double()

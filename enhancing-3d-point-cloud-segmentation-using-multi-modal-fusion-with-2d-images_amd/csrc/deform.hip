@@ -268,6 +268,7 @@ extern "C" int mvk_kpconv_deform_doff(const float* q, int64_t Nq, const float* s
                                       const float* g_min_d2, const int32_t* min_arg, float* d_offsets, void* stream) {
   MVK_REQUIRE(Nq >= 0 && Ns >= 0 && H >= 0 && Cin > 0 && K >= 1 && K < DKMAX, "deform d_offsets: bad sizes");
   MVK_REQUIRE(influence >= 0 && influence <= 2, "Unknown influence function type (config.KP_influence)");
+  if (Nq == 0) return 0;
   MVK_REQUIRE(offsets && dA && d_offsets && x, "deform d_offsets: null operand");
   MVK_REQUIRE(!g_min_d2 || min_arg, "deform d_offsets: the min_d2 gradient needs the forward's arg-min columns");
   MVK_REQUIRE(H <= DOFF_LIST, "deform d_offsets: neighbour rows wider than %d columns", DOFF_LIST);
@@ -298,8 +299,8 @@ extern "C" int mvk_deform_regularizer(const float* min_d2, const float* deformed
                                       int K, float extent, float repulse_extent, float power, float* loss_accum,
                                       float* d_min_d2, float* d_deformed_kp, void* stream) {
   MVK_REQUIRE(N >= 0 && K >= 1 && K < DKMAX && extent > 0.f, "regulariser: bad sizes");
+  if (N == 0) return 0;          // an empty level contributes nothing (its tensors have no storage)
   MVK_REQUIRE(min_d2 && deformed_kp && loss_accum && d_min_d2 && d_deformed_kp, "regulariser: null operand");
-  if (N == 0) return 0;
   hipLaunchKernelGGL(deform_regularizer_kernel, dim3((unsigned)cdiv64(N * 16, 256)), dim3(256), 0, (hipStream_t)stream, min_d2,
                      deformed_kp, n_valid, N, K, extent, repulse_extent, power, loss_accum, d_min_d2, d_deformed_kp);
   MVK_CHECK_HIP(hipGetLastError());

@@ -851,3 +851,51 @@ def test_randomised_sweep_index_kernels_vs_oracle():
                        text=True, timeout=600, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "fuzz done, mismatches: 0" in p.stdout, p.stdout[-2000:]
+
+
+# ------------------------------------------------------------------ degenerate inputs of the round-2 entry points
+
+def test_round2_entry_points_on_empty_and_degenerate_inputs(ops):
+    """Empty / all-padded inputs: a level with zero valid rows (capacity padding), a deformable layer without
+    neighbours, a product with an empty reduction, an optimiser without gradients, an empty deferred list."""
+    import mvkpconv
+    optim = mvkpconv.sub("optim")
+    # BatchNorm fed by epilogue statistics with n_valid = 0: everything zero, no NaN
+    A = torch.randn(300, 64, device="cuda")
+    B = torch.randn(64, 48, device="cuda")
+    nv0 = torch.tensor([0], dtype=torch.int32, device="cuda")
+    y, st = ops.gemm(A, B, split_k=1, stats_n_valid=nv0)
+    assert st is not None
+    y._mvk_bn_stats = st
+    bn = torch.nn.BatchNorm1d(48).cuda()
+    out = ops.bn_lrelu(y, nv0, bn, slope=0.1)
+    assert torch.isfinite(out).all() and (out == 0).all() and torch.isfinite(bn.running_var).all()
+    # one valid row: variance 0, output = beta
+    nv1 = torch.tensor([1], dtype=torch.int32, device="cuda")
+    y, st = ops.gemm(A, B, split_k=1, stats_n_valid=nv1)
+    y._mvk_bn_stats = st
+    out = ops.bn_lrelu(y, nv1, bn, slope=1.0)
+    assert torch.isfinite(out).all() and torch.allclose(out[0], bn.bias.detach(), atol=1e-6) and (out[1:] == 0).all()
+    # product with an empty reduction / empty operands
+    assert (ops.gemm(torch.zeros(5, 0, device="cuda"), torch.zeros(0, 7, device="cuda")) == 0).all()
+    assert ops.gemm(torch.zeros(0, 4, device="cuda"), torch.zeros(4, 7, device="cuda")).shape == (0, 7)
+    # deformable KPConv on a level without any neighbour column, forward and backward
+    q = torch.rand(10, 3, device="cuda")
+    x = torch.randn(10, 8, device="cuda", requires_grad=True)
+    W = torch.randn(15, 8, 4, device="cuda", requires_grad=True)
+    kp = torch.rand(15, 3, device="cuda") * 0.05
+    off = torch.zeros(10, 15, 3, device="cuda", requires_grad=True)
+    idx = torch.full((10, 3), 10, dtype=torch.int64, device="cuda")            # all shadow
+    yk, md = ops.kpconv(q, q, idx, x, kp, W, 0.05, offsets=off)
+    (yk.sum() + md.sum()).backward()
+    assert (yk == 0).all() and torch.isfinite(md).all() and torch.isfinite(off.grad).all() and (x.grad == 0).all()
+    # regulariser of an empty level
+    l = ops.deform_regularizer(torch.zeros(0, 15, device="cuda"), torch.zeros(0, 15, 3, device="cuda"), 0.05, 1.2, 1.0)
+    assert float(l) == 0.0
+    # optimiser: no gradient anywhere -> nothing happens; deferred scope without products
+    p = torch.nn.Parameter(torch.ones(9, device="cuda"))
+    opt = optim.FusedClipSGD([p], lr=0.1, momentum=0.9, weight_decay=0.0, clip_value=1.0)
+    opt.step()
+    assert (p == 1).all()
+    with ops.defer_weight_grads():
+        pass

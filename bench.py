@@ -124,6 +124,8 @@ def main():
     # they were first used on, and nodes born on the legacy default stream cannot be captured later
     torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ.get("MVK_MAIN_PRIO", "0"))))
 
+    if os.environ.get("MVK_MIOPEN_BENCHMARK") == "1":     # development switch: let MIOpen search its solvers per shape
+        torch.backends.cudnn.benchmark = True
     import mvkpconv
     syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
     ops.set_feature_dtype(torch.float16 if args.features == "f16" else torch.float32)

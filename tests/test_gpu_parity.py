@@ -390,6 +390,50 @@ def test_kpconv_linearity_full_size(ops):
     assert rel_err(f(x1, W * 0.5).cpu().numpy(), (0.5 * f(x1, W)).cpu().numpy()) < FP_TOL
 
 
+def test_deformable_offset_gradient_properties_full_size(ops):
+    """BASELINE-size properties of the deformable backward (config 5 geometry: a level of ~3 500 points, ~250 neighbour
+    columns at the deform radius, Cin 128): d_offsets is linear in the upstream gradient, it vanishes with it, and it
+    equals the finite-difference slope of the forward along a random offset direction (central difference in float64
+    of the float32 forward, 2 % -- the forward is piecewise smooth in the offsets)."""
+    rng = np.random.default_rng(11)
+    raw = (rng.random((200000, 3)) * [4.8, 4.8, 0.8]).astype(np.float32)
+    p, l = ops.grid_subsample_batch(T(raw), [raw.shape[0]], dl=0.16)
+    nb = ops.radius_neighbors_batch(p, p, l, l, 0.16 * 6.0, limit=250)
+    N = p.shape[0]
+    assert N > 1500 and nb.shape[1] >= 100
+    K, Cin, Cout, ext = 15, 128, 32, 0.16 * 1.2
+    torch.manual_seed(3)
+    kp = (torch.rand(K, 3, device="cuda") - 0.5) * 0.5
+    kp[0] = 0
+    W = torch.randn(K, Cin, Cout, device="cuda") * 0.05
+    x = torch.randn(N, Cin, device="cuda")
+    off0 = torch.randn(N, K, 3, device="cuda") * 0.03
+
+    def grad_off(gy, gmin):
+        off = off0.clone().requires_grad_(True)
+        y, md = ops.kpconv(p, p, nb, x, kp, W, ext, offsets=off)
+        (gy_, gm_) = (gy, gmin)
+        torch.autograd.backward([y, md], [gy_, gm_])
+        return off.grad
+    g1, g2 = torch.randn(N, Cout, device="cuda"), torch.randn(N, Cout, device="cuda")
+    m1, m2 = torch.randn(N, K, device="cuda"), torch.randn(N, K, device="cuda")
+    a = grad_off(2 * g1 - 3 * g2, 2 * m1 - 3 * m2)
+    b = 2 * grad_off(g1, m1) - 3 * grad_off(g2, m2)
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-4
+    assert float(grad_off(torch.zeros_like(g1), torch.zeros_like(m1)).abs().max()) == 0.0
+    # directional derivative on a subset of points (each point's offsets only influence its own output row)
+    d = torch.randn(N, K, 3, device="cuda")
+    eps = 2e-3 * ext
+    with torch.no_grad():
+        yp, mp = ops.kpconv(p, p, nb, x, kp, W, ext, offsets=off0 + eps * d)
+        ym, mm = ops.kpconv(p, p, nb, x, kp, W, ext, offsets=off0 - eps * d)
+    fd = (((yp.double() - ym.double()) * g1.double()).sum(1) + ((mp.double() - mm.double()) * m1.double()).sum(1)) / (2 * eps)
+    an = (grad_off(g1, m1).double() * d.double()).sum((1, 2))
+    rel = (fd - an).abs() / (an.abs() + 1e-3 * an.abs().mean())
+    # (with ~250 neighbours x 15 kernel points a finite step crosses a clamp / arg-min kink for a minority of the points)
+    assert float(rel.median()) < 2e-2 and float((rel < 0.1).float().mean()) > 0.8
+
+
 def test_pools_golden(ops):
     g = load_golden("g4_pools")
     x, idx = T(g["x"]), T(g["pool_idx"])

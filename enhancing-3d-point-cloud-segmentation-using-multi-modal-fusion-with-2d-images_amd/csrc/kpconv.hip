@@ -165,16 +165,31 @@ __device__ __forceinline__ void st4(_Float16* p, float4 v) {
   *reinterpret_cast<half4_t*>(p) = h;
 }
 
-template <int NCH, bool IDX64, bool FAST, typename XT = float, bool VEC = true>
+// DEFORM (deformable layers, blocks.py:286-327; LPP >= 4 so that PPW <= 16): every point's deformed kernel points
+// (kernel point + its offset) live in LDS, phase A reads them instead of the wave-uniform rigid ones, drops the
+// neighbours that no deformed kernel point reaches (their row index becomes the shadow -> phase B skips them) and
+// writes a second LDS row with the 15 squared distances, from which the lanes (point, kernel point, column
+// residue) keep the running (min, first arg-min column) over ALL entries, shadow included (blocks.py:303).
+// The deformable levels are the coarse ones (hundreds of points, hundreds of neighbour columns), so the GWPB
+// waves of a workgroup share the SAME points and take every GWPB-th neighbour chunk; wave 0 adds the partial
+// aggregates (LDS, fixed order -> deterministic) and writes A / min_d2 / min_arg.
+constexpr int DPPW = 16;      // most points per wave of the deformable variant
+
+template <int NCH, bool IDX64, bool FAST, typename XT = float, bool VEC = true, bool DEFORM = false>
 __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPParams P, int LPP, int PPW, int HC) {
   const XT* __restrict__ X = reinterpret_cast<const XT*>(P.x);      // features [Ns,Cin]
   XT* __restrict__ Aout = reinterpret_cast<XT*>(P.A);                // aggregate [Nq,K,Cin]
   constexpr bool vec_ok = VEC;   // false: f16 rows of odd length (2-byte aligned), scalar loads
   constexpr int UB = NCH == 1 ? 6 : 4;  // feature rows in flight per lane (8 spills two VGPRs to scratch)
   __shared__ float wl_all[GWPB][64 * 16 + 64 * 4];
-  float* wl = wl_all[threadIdx.x >> 6];
+  __shared__ float d2_all[DEFORM ? GWPB : 1][DEFORM ? 64 * 16 + DPPW * 16 : 1];  // squared distances of the chunk (rows skewed by point)
+  __shared__ float4 kd[DEFORM ? DPPW * 16 : 1];                                 // deformed kernel points per point
+  const int wid = threadIdx.x >> 6;
+  float* wl = wl_all[wid];
+  float* d2l = d2_all[DEFORM ? wid : 0];
   const int lane = threadIdx.x & 63;
-  const int64_t n0 = ((int64_t)blockIdx.x * GWPB + (threadIdx.x >> 6)) * PPW;
+  const int64_t n0 = DEFORM ? (int64_t)blockIdx.x * PPW : ((int64_t)blockIdx.x * GWPB + wid) * PPW;
+  const int hbeg = DEFORM ? wid * HC : 0, hstep = DEFORM ? GWPB * HC : HC;     // this wave's neighbour chunks
   // phase-A identity: (point pa, neighbour slot ha)
   const int pa = lane / HC, ha = lane - pa * HC;
   const bool a_on = pa < PPW && n0 + pa < P.Nq;
@@ -193,6 +208,27 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
   const float* wblk_b = wl + pb * (HC * 16 + 4);
   const float inv_ext = 1.0f / P.extent;
   const float* __restrict__ kp = P.kp;
+  const float ext2 = P.extent * P.extent;
+  // DEFORM scan identity: pair (point, k) = pk, of which there are NPK = 16 PPW. NPK >= 64: pairs lane + 64 t, every
+  // column. NPK < 64: pair lane % NPK, columns congruent to lane / NPK modulo NSUB = 64 / NPK.
+  const int NPK = PPW * 16;
+  const int NSUB = NPK >= 64 ? 1 : 64 / NPK;
+  const int sub = NPK >= 64 ? 0 : lane / NPK;
+  float run_min[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+  int run_arg[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
+  if (DEFORM) {
+    {
+      const int e = threadIdx.x;
+      const int pp = e >> 4, kk = e & 15;
+      float4 v = make_float4(1e9f, 1e9f, 1e9f, 0.f);        // slots beyond K / beyond the last point: out of every range
+      if (kk < P.K && n0 + pp < P.Nq) {
+        const float* o = P.offsets + ((n0 + pp) * P.K + kk) * 3;
+        v = make_float4(kp[kk * 3] + o[0], kp[kk * 3 + 1] + o[1], kp[kk * 3 + 2] + o[2], 0.f);   // blocks.py:287
+      }
+      if (e < DPPW * 16) kd[e] = v;
+    }
+    __syncthreads();
+  }
 
   float4 acc[NCH][KMAX - 1];
 #pragma unroll
@@ -204,7 +240,7 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
   auto ld_j = [&](int h) -> int {
     return (a_on && h < P.H) ? load_idx<IDX64>(P.idx, (n0 + pa) * P.H + h, P.Ns) : -2;
   };
-  int jA = ld_j(ha), jB = ld_j(HC + ha);
+  int jA = ld_j(hbeg + ha), jB = ld_j(hbeg + hstep + ha);
   float sx = 0.f, sy = 0.f, sz = 0.f;
   if (jA >= 0) {
     const float* sp = P.s + (int64_t)jA * 3;
@@ -212,8 +248,8 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
     sy = sp[1];
     sz = sp[2];
   }
-  for (int h0 = 0; h0 < P.H; h0 += HC) {
-    const int jC = ld_j(h0 + 2 * HC + ha);
+  for (int h0 = hbeg; h0 < P.H; h0 += hstep) {
+    const int jC = ld_j(h0 + 2 * hstep + ha);
     float tx = 0.f, ty = 0.f, tz = 0.f;
     if (jB >= 0) {
       const float* sp = P.s + (int64_t)jB * 3;
@@ -225,7 +261,46 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
     float wv[16];
 #pragma unroll
     for (int kk = 0; kk < 16; ++kk) wv[kk] = 0.f;
-    if (jA >= 0) {
+    int jrow = jA;                 // row index phase B sees (DEFORM: shadow for neighbours out of every range)
+    if (DEFORM) {
+      // entry present (real or shadow, blocks.py:277): distances to the point's deformed kernel points
+      float dv[16];
+      bool inrange = false;
+      float bd = INFINITY;
+      int bk = 0;
+      const float rx = (jA >= 0 ? sx : 1e6f) - qx, ry = (jA >= 0 ? sy : 1e6f) - qy, rz = (jA >= 0 ? sz : 1e6f) - qz;
+#pragma unroll
+      for (int kk = 0; kk < KMAX - 1; ++kk) {
+        const float4 kq = kd[(pa < PPW ? pa : 0) * 16 + kk];
+        const float dx = rx - kq.x, dy = ry - kq.y, dz = rz - kq.z;
+        const float d2 = dx * dx + dy * dy + dz * dz;  // blocks.py:294-297
+        dv[kk] = jA >= -1 ? d2 : INFINITY;
+        if (jA >= 0) {
+          inrange = inrange || d2 < ext2;
+          wv[kk] = FAST ? fmaxf(1.0f - __builtin_amdgcn_sqrtf(d2) * inv_ext, 0.0f) : influence_w(d2, P.extent, P.influence);
+          if (!FAST && kk < P.K && d2 < bd) {
+            bd = d2;
+            bk = kk;
+          }
+        }
+      }
+      dv[15] = INFINITY;
+      if (!FAST && P.aggregation == MVK_AGG_CLOSEST) {  // one-hot of the first arg-min (blocks.py:349-351)
+#pragma unroll
+        for (int kk = 0; kk < KMAX - 1; ++kk)
+          if (kk != bk) wv[kk] = 0.f;
+      }
+      if (!inrange) {                      // dropped by the in-range filter (blocks.py:306-325)
+#pragma unroll
+        for (int kk = 0; kk < KMAX - 1; ++kk) wv[kk] = 0.f;
+        if (jA >= 0) jrow = -1;
+      }
+      float4* dd = reinterpret_cast<float4*>(d2l + lane * 16 + pa * 16);
+      dd[0] = make_float4(dv[0], dv[1], dv[2], dv[3]);
+      dd[1] = make_float4(dv[4], dv[5], dv[6], dv[7]);
+      dd[2] = make_float4(dv[8], dv[9], dv[10], dv[11]);
+      dd[3] = make_float4(dv[12], dv[13], dv[14], dv[15]);
+    } else if (jA >= 0) {
       const float rx = sx - qx, ry = sy - qy, rz = sz - qz;
       float bd = INFINITY;
       int bk = 0;
@@ -251,7 +326,7 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
           if (kk != bk) wv[kk] = 0.f;
       }
     }
-    wv[15] = __int_as_float(jA);
+    wv[15] = __int_as_float(jrow);
     {
       float4* dst = reinterpret_cast<float4*>(wrow_a);
       dst[0] = make_float4(wv[0], wv[1], wv[2], wv[3]);
@@ -260,8 +335,25 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
       dst[3] = make_float4(wv[12], wv[13], wv[14], wv[15]);
     }
     wave_sync_lds();
+    if (DEFORM) {      // running (min, first column) of d2 per (point, kernel point)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int e = lane + 64 * t;
+        const int pk = NPK >= 64 ? e : lane - sub * NPK;
+        if (pk < NPK && sub < NSUB && e < (NPK >= 64 ? NPK : 64)) {
+          const int pp = pk >> 4, kk = pk & 15;
+          for (int h = sub; h < HC; h += NSUB) {
+            const float d = d2l[(pp * HC + h) * 16 + pp * 16 + kk];
+            if (d < run_min[t]) {           // strict: this lane visits its columns in ascending order
+              run_min[t] = d;
+              run_arg[t] = h0 + h;
+            }
+          }
+        }
+      }
+    }
     // ---------------- phase B: UB feature rows in flight, then their FMAs
-    if (__ballot(jA >= 0) != 0ull) {
+    if (__ballot(jrow >= 0) != 0ull) {
       for (int hb = 0; hb < HC; hb += UB) {
         int jj[UB];
         float4 xv[UB][NCH];
@@ -313,7 +405,68 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
     sy = ty;
     sz = tz;
   }
-  if (b_on) {
+  if (DEFORM) {
+    // partial aggregates of waves 1..GWPB-1 -> wave 0, five kernel points per round through the d2 rows
+    __syncthreads();
+    float4* red = reinterpret_cast<float4*>(&d2_all[0][0]);        // [GWPB-1][5][64] float4 = 15 KB of the 20 KB
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        if (wid > 0) {
+#pragma unroll
+          for (int q5 = 0; q5 < 5; ++q5) red[((wid - 1) * 5 + q5) * 64 + lane] = acc[c][r * 5 + q5];
+        }
+        __syncthreads();
+        if (wid == 0) {
+#pragma unroll
+          for (int w = 0; w < GWPB - 1; ++w)
+#pragma unroll
+            for (int q5 = 0; q5 < 5; ++q5) {
+              const float4 v = red[(w * 5 + q5) * 64 + lane];
+              acc[c][r * 5 + q5].x += v.x;
+              acc[c][r * 5 + q5].y += v.y;
+              acc[c][r * 5 + q5].z += v.z;
+              acc[c][r * 5 + q5].w += v.w;
+            }
+        }
+        __syncthreads();
+      }
+    }
+    // (min, column) candidates of every wave and column residue
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      wl[t * 64 + lane] = run_min[t];
+      wl[256 + t * 64 + lane] = __int_as_float(run_arg[t]);
+    }
+    __syncthreads();
+    if (wid == 0 && P.min_d2 != nullptr) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int pk = lane + 64 * t;
+        if (pk < NPK && (NPK >= 64 || t == 0)) {
+          float m = INFINITY;
+          int a = 0x7fffffff;
+          for (int w = 0; w < GWPB; ++w)
+            for (int sb = 0; sb < NSUB; ++sb) {
+              const int slot = NPK >= 64 ? pk : sb * NPK + pk;
+              const float om = wl_all[w][slot];
+              const int oa = __float_as_int(wl_all[w][256 + slot]);
+              if (om < m || (om == m && oa < a)) {
+                m = om;
+                a = oa;
+              }
+            }
+          const int pp = pk >> 4, kk = pk & 15;
+          if (kk < P.K && n0 + pp < P.Nq) {
+            P.min_d2[(n0 + pp) * P.K + kk] = m;
+            if (P.min_arg) P.min_arg[(n0 + pp) * P.K + kk] = a == 0x7fffffff ? 0 : a;
+          }
+        }
+      }
+    }
+  }
+  if (b_on && (!DEFORM || wid == 0)) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int c4 = (cl + c * LPP) * 4;
@@ -443,15 +596,15 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
   }
 }
 
-template <int NCH, typename XT = float, bool VEC = true>
+template <int NCH, typename XT = float, bool VEC = true, bool DEFORM = false>
 int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
   const int c4 = (P.Cin + 3) / 4;
   const int LPP = c4 < 64 ? c4 : 64;  // lanes per point
   const int PPW = 64 / LPP;           // points per wave
   const int HC = 64 / PPW;            // neighbours per chunk and point
   const bool fast = P.influence == MVK_INFL_LINEAR && P.aggregation == MVK_AGG_SUM;
-  dim3 grid((unsigned)cdiv64(cdiv64(P.Nq, PPW), GWPB)), block(64 * GWPB);
-#define LV(I64, F) hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F, XT, VEC>), grid, block, 0, st, P, LPP, PPW, HC)
+  dim3 grid((unsigned)(DEFORM ? cdiv64(P.Nq, PPW) : cdiv64(cdiv64(P.Nq, PPW), GWPB))), block(64 * GWPB);
+#define LV(I64, F) hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F, XT, VEC, DEFORM>), grid, block, 0, st, P, LPP, PPW, HC)
   if (idx64) {
     if (fast) LV(true, true); else LV(true, false);
   } else {
@@ -515,7 +668,14 @@ extern "C" int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s,
     if (offsets == nullptr) return 0;
   }
   if (offsets != nullptr) {
-    launch_lane_channel<0, true>(P, idx64, st);
+    static const bool vec_deform = getenv("MVK_DEFORM_VEC") == nullptr || atoi(getenv("MVK_DEFORM_VEC")) != 0;
+    if (vec_deform && Cin >= 13 && Cin <= 256) {          // 64 / ceil(Cin/4) <= DPPW points per wave
+      launch_vec<1, float, true, true>(P, idx64, st);
+    } else if (vec_deform && Cin > 256 && Cin <= 512) {
+      launch_vec<2, float, true, true>(P, idx64, st);
+    } else {
+      launch_lane_channel<0, true>(P, idx64, st);
+    }
   } else if (Cin <= 256) {
     launch_vec<1>(P, idx64, st);
   } else if (Cin <= 512) {

@@ -152,6 +152,8 @@ __device__ __forceinline__ void wave_sync_lds() {   // LDS hand-off inside ONE w
 
 // 4 consecutive channels of a feature row / of the aggregate, stored as f32 or (fp16-feature mode) f16
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef float f4v __attribute__((ext_vector_type(4)));        // accumulator quad (a native vector: usable as an asm operand)
+__device__ __forceinline__ float4 as_float4(f4v v) { return make_float4(v.x, v.y, v.z, v.w); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 ld4(const _Float16* p) {
@@ -175,21 +177,38 @@ __device__ __forceinline__ void st4(_Float16* p, float4 v) {
 // aggregates (LDS, fixed order -> deterministic) and writes A / min_d2 / min_arg.
 constexpr int DPPW = 16;      // most points per wave of the deformable variant
 
-template <int NCH, bool IDX64, bool FAST, typename XT = float, bool VEC = true, bool DEFORM = false>
-__global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPParams P, int LPP, int PPW, int HC) {
+//
+// FUB > 0 (rows of >= 4 elements, feature table < 4 GB, FUB = rows per batch): phase B carries no branches at
+// all, so that a whole batch of feature rows is in flight behind counted waits: the neighbour rows of a batch
+// are read from LDS together, shadow entries load row 0 and multiply it by their zero weights, the weight rows
+// of a point are padded to a multiple of FUB with zero rows, addresses are 32-bit offsets from the table base,
+// and the lane holding the ragged last quad of a row works on the row's LAST four channels instead (it
+// recomputes up to three channels of its left neighbour, bit for bit, and stores them again).
+template <int NCH, bool IDX64, bool FAST, typename XT = float, bool VEC = true, bool DEFORM = false, int FUB = 0>
+__global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPParams P, int LPP, int PPW, int HC,
+                                                                                  int SW, int B1) {
+  constexpr bool FASTLD = FUB > 0;
+  // Sharing workgroups (all of them when DEFORM; with SW > 1 those from block B1 on): the waves of the workgroup
+  // share the same PPW points and take every nwv-th neighbour chunk; wave 0 adds the partial aggregates through
+  // LDS in a fixed order and stores them. A wave lives for tens of microseconds, so a launch of 1.2 rounds of
+  // independent waves takes two rounds; its last 0.2 round runs as sharing workgroups instead, four times as many
+  // waves of a quarter of the length, which fill the chip.
+  const int nwv = blockDim.x >> 6;
+  const bool share = DEFORM || (FASTLD && SW > 1 && (int)blockIdx.x >= B1);
   const XT* __restrict__ X = reinterpret_cast<const XT*>(P.x);      // features [Ns,Cin]
   XT* __restrict__ Aout = reinterpret_cast<XT*>(P.A);                // aggregate [Nq,K,Cin]
   constexpr bool vec_ok = VEC;   // false: f16 rows of odd length (2-byte aligned), scalar loads
-  constexpr int UB = NCH == 1 ? 6 : 4;  // feature rows in flight per lane (8 spills two VGPRs to scratch)
-  __shared__ float wl_all[GWPB][64 * 16 + 64 * 4];
+  constexpr int UB = FASTLD ? FUB : (NCH == 1 ? 6 : 4);  // feature rows in flight per lane
+  __shared__ __align__(16) float wl_all[GWPB][64 * 16 + 64 * 4];
   __shared__ float d2_all[DEFORM ? GWPB : 1][DEFORM ? 64 * 16 + DPPW * 16 : 1];  // squared distances of the chunk (rows skewed by point)
   __shared__ float4 kd[DEFORM ? DPPW * 16 : 1];                                 // deformed kernel points per point
   const int wid = threadIdx.x >> 6;
   float* wl = wl_all[wid];
   float* d2l = d2_all[DEFORM ? wid : 0];
   const int lane = threadIdx.x & 63;
-  const int64_t n0 = DEFORM ? (int64_t)blockIdx.x * PPW : ((int64_t)blockIdx.x * GWPB + wid) * PPW;
-  const int hbeg = DEFORM ? wid * HC : 0, hstep = DEFORM ? GWPB * HC : HC;     // this wave's neighbour chunks
+  const int64_t n0 = share ? ((int64_t)B1 * GWPB + ((int64_t)blockIdx.x - B1)) * PPW
+                           : ((int64_t)blockIdx.x * GWPB + wid) * PPW;
+  const int hbeg = share ? wid * HC : 0, hstep = share ? nwv * HC : HC;        // this wave's neighbour chunks
   // phase-A identity: (point pa, neighbour slot ha)
   const int pa = lane / HC, ha = lane - pa * HC;
   const bool a_on = pa < PPW && n0 + pa < P.Nq;
@@ -200,12 +219,31 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
     qy = qp[1];
     qz = qp[2];
   }
-  float* wrow_a = wl + lane * 16 + pa * 4;
+  const int HCP = FASTLD ? (HC + UB - 1) / UB * UB : HC;        // weight rows per point in LDS
+  float* wrow_a = wl + (pa * HCP + ha) * 16 + pa * 4;
   // phase-B identity: (point pb, channel quad cl)
   const int pb = lane / LPP, cl = lane - pb * LPP;
   const int64_t n = n0 + pb;
   const bool b_on = pb < PPW && n < P.Nq;
-  const float* wblk_b = wl + pb * (HC * 16 + 4);
+  const float* wblk_b = wl + (FASTLD ? min(pb, PPW - 1) : pb) * (HCP * 16 + 4);
+  if (FASTLD && HCP > HC) {      // padding rows: zero weights, shadow index
+    const int npad = HCP - HC;
+    if (lane < PPW * npad) {
+      const int pp = lane / npad, r = HC + lane % npad;
+      float4* dst = reinterpret_cast<float4*>(wl + (pp * HCP + r) * 16 + pp * 4);
+      dst[0] = dst[1] = dst[2] = make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[3] = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    }
+  }
+  uint32_t c4e[NCH];      // FASTLD: first channel of the lane's quad (the ragged quad moved left to end at Cin)
+  bool c_on[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const int c4 = (cl + c * LPP) * 4;
+    c_on[c] = c4 < P.Cin;
+    c4e[c] = c_on[c] ? (uint32_t)min(c4, P.Cin - 4) : 0u;
+  }
+  const uint32_t row_bytes = (uint32_t)P.Cin * (uint32_t)sizeof(XT);
   const float inv_ext = 1.0f / P.extent;
   const float* __restrict__ kp = P.kp;
   const float ext2 = P.extent * P.extent;
@@ -217,24 +255,23 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
   float run_min[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
   int run_arg[4] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff};
   if (DEFORM) {
-    {
-      const int e = threadIdx.x;
+    for (int e = threadIdx.x; e < DPPW * 16; e += blockDim.x) {
       const int pp = e >> 4, kk = e & 15;
       float4 v = make_float4(1e9f, 1e9f, 1e9f, 0.f);        // slots beyond K / beyond the last point: out of every range
       if (kk < P.K && n0 + pp < P.Nq) {
         const float* o = P.offsets + ((n0 + pp) * P.K + kk) * 3;
         v = make_float4(kp[kk * 3] + o[0], kp[kk * 3 + 1] + o[1], kp[kk * 3 + 2] + o[2], 0.f);   // blocks.py:287
       }
-      if (e < DPPW * 16) kd[e] = v;
+      kd[e] = v;
     }
     __syncthreads();
   }
 
-  float4 acc[NCH][KMAX - 1];
+  f4v acc[NCH][KMAX - 1];
 #pragma unroll
   for (int c = 0; c < NCH; ++c)
 #pragma unroll
-    for (int kk = 0; kk < KMAX - 1; ++kk) acc[c][kk] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kk = 0; kk < KMAX - 1; ++kk) acc[c][kk] = f4v{0.f, 0.f, 0.f, 0.f};
 
   // software pipeline over neighbour chunks: index two chunks ahead, support xyz one chunk ahead
   auto ld_j = [&](int h) -> int {
@@ -354,9 +391,22 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
     }
     // ---------------- phase B: UB feature rows in flight, then their FMAs
     if (__ballot(jrow >= 0) != 0ull) {
-      for (int hb = 0; hb < HC; hb += UB) {
+      for (int hb = 0; hb < HCP; hb += UB) {
         int jj[UB];
         float4 xv[UB][NCH];
+        if (FASTLD) {
+#pragma unroll
+          for (int u = 0; u < UB; ++u) jj[u] = __float_as_int(wblk_b[(hb + u) * 16 + 15]);
+#pragma unroll
+          for (int u = 0; u < UB; ++u) {
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {   // byte offset < 2^32, row index and row bytes < 2^24 (checked by the host)
+              const uint32_t off = __umul24((uint32_t)max(jj[u], 0), row_bytes) + c4e[c] * (uint32_t)sizeof(XT);
+              xv[u][c] = ld4(reinterpret_cast<const XT*>(reinterpret_cast<const char*>(X) + off));
+            }
+            asm volatile("" ::: "memory");    // loads leave in entry order, so that entry u waits for u + 1 loads only
+          }
+        } else
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
           jj[u] = (hb + u < HC && b_on) ? __float_as_int(wblk_b[(hb + u) * 16 + 15]) : -2;
@@ -379,7 +429,7 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
         }
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
-          if (jj[u] >= 0) {
+          if (FASTLD || jj[u] >= 0) {
             const float4* w4 = reinterpret_cast<const float4*>(wblk_b + (hb + u) * 16);
             const float4 wa = w4[0], wb = w4[1], wc = w4[2], wd = w4[3];
             const float wk[15] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w,
@@ -394,6 +444,12 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
                 acc[c][kk].w += wk[kk] * xv[u][c].w;
               }
             }
+            if (FASTLD) {   // entry u's products stay together: otherwise every entry's weight row is live at once
+#pragma unroll
+              for (int c = 0; c < NCH; ++c)
+#pragma unroll
+                for (int kk = 0; kk < KMAX - 1; ++kk) asm volatile("" : "+v"(acc[c][kk]));
+            }
           }
         }
       }
@@ -405,34 +461,37 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
     sy = ty;
     sz = tz;
   }
-  if (DEFORM) {
-    // partial aggregates of waves 1..GWPB-1 -> wave 0, five kernel points per round through the d2 rows
+  if (share) {
+    // partial aggregates of waves 1..nwv-1 -> wave 0, five kernel points per round through the waves' weight rows
     __syncthreads();
-    float4* red = reinterpret_cast<float4*>(&d2_all[0][0]);        // [GWPB-1][5][64] float4 = 15 KB of the 20 KB
+    float4* mine = reinterpret_cast<float4*>(wl_all[wid]);        // [5][64] float4 = the wave's 1280 floats
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         if (wid > 0) {
 #pragma unroll
-          for (int q5 = 0; q5 < 5; ++q5) red[((wid - 1) * 5 + q5) * 64 + lane] = acc[c][r * 5 + q5];
+          for (int q5 = 0; q5 < 5; ++q5) mine[q5 * 64 + lane] = as_float4(acc[c][r * 5 + q5]);
         }
         __syncthreads();
         if (wid == 0) {
-#pragma unroll
-          for (int w = 0; w < GWPB - 1; ++w)
+          for (int w = 1; w < nwv; ++w) {
+            const float4* theirs = reinterpret_cast<const float4*>(wl_all[w]);
 #pragma unroll
             for (int q5 = 0; q5 < 5; ++q5) {
-              const float4 v = red[(w * 5 + q5) * 64 + lane];
+              const float4 v = theirs[q5 * 64 + lane];
               acc[c][r * 5 + q5].x += v.x;
               acc[c][r * 5 + q5].y += v.y;
               acc[c][r * 5 + q5].z += v.z;
               acc[c][r * 5 + q5].w += v.w;
             }
+          }
         }
         __syncthreads();
       }
     }
+  }
+  if (DEFORM) {
     // (min, column) candidates of every wave and column residue
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -447,7 +506,7 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
         if (pk < NPK && (NPK >= 64 || t == 0)) {
           float m = INFINITY;
           int a = 0x7fffffff;
-          for (int w = 0; w < GWPB; ++w)
+          for (int w = 0; w < nwv; ++w)
             for (int sb = 0; sb < NSUB; ++sb) {
               const int slot = NPK >= 64 ? pk : sb * NPK + pk;
               const float om = wl_all[w][slot];
@@ -466,17 +525,17 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
       }
     }
   }
-  if (b_on && (!DEFORM || wid == 0)) {
+  if (b_on && (!share || wid == 0)) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
-      const int c4 = (cl + c * LPP) * 4;
-      if (c4 < P.Cin) {
+      const int c4 = FASTLD ? (int)c4e[c] : (cl + c * LPP) * 4;
+      if (FASTLD ? c_on[c] : c4 < P.Cin) {
 #pragma unroll
         for (int kk = 0; kk < KMAX - 1; ++kk) {
           if (kk < P.K) {
             XT* o = Aout + (n * P.K + kk) * P.Cin + c4;
-            if (c4 + 3 < P.Cin && vec_ok) {
-              st4(o, acc[c][kk]);
+            if (FASTLD || (c4 + 3 < P.Cin && vec_ok)) {
+              st4(o, as_float4(acc[c][kk]));
             } else {
               o[0] = (XT)acc[c][kk].x;
               if (c4 + 1 < P.Cin) o[1] = (XT)acc[c][kk].y;
@@ -603,13 +662,60 @@ int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
   const int PPW = 64 / LPP;           // points per wave
   const int HC = 64 / PPW;            // neighbours per chunk and point
   const bool fast = P.influence == MVK_INFL_LINEAR && P.aggregation == MVK_AGG_SUM;
-  dim3 grid((unsigned)(DEFORM ? cdiv64(P.Nq, PPW) : cdiv64(cdiv64(P.Nq, PPW), GWPB))), block(64 * GWPB);
-#define LV(I64, F) hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F, XT, VEC, DEFORM>), grid, block, 0, st, P, LPP, PPW, HC)
-  if (idx64) {
-    if (fast) LV(true, true); else LV(true, false);
-  } else {
-    if (fast) LV(false, true); else LV(false, false);
+  static const bool fastld_on = getenv("MVK_GATHER_FASTLD") == nullptr || atoi(getenv("MVK_GATHER_FASTLD")) != 0;
+  // rows per batch of the branch-free variant: the divisor-like batch size with the least padding of HC
+  int fub = 0;
+  if (fastld_on && fast && VEC && LPP >= 5 && P.Ns < (1 << 24) &&
+      (uint64_t)P.Ns * (uint64_t)P.Cin * sizeof(XT) < (1ull << 32) - 64) {
+    if (NCH == 2) {
+      fub = 4;
+    } else {
+      int best_pad = 1 << 30;
+      for (int ub = 8; ub >= 5; --ub) {
+        const int pad = (HC + ub - 1) / ub * ub - HC;
+        if (pad < best_pad) {
+          best_pad = pad;
+          fub = ub;
+        }
+      }
+    }
   }
+  // sharing workgroups (kernel comment): all of them for the deformable variant; for the branch-free rigid one
+  // the workgroups beyond the last full round of independent waves, when that remainder is well below a round
+  static const int split_env = getenv("MVK_GATHER_SPLIT") ? atoi(getenv("MVK_GATHER_SPLIT")) : -1;
+  const int chunks = (P.H + HC - 1) / HC;
+  const int64_t groups = cdiv64(P.Nq, PPW);               // point groups = independent waves
+  const int64_t plain_wgs = cdiv64(groups, GWPB);
+  const int64_t slots = NCH == 1 ? 1024 : 512;           // resident workgroups: 256 CUs x (4 | 2)
+  int64_t b1 = plain_wgs;                                 // first sharing workgroup
+  if (fub > 0 && chunks > 1 && split_env != 0) {
+    const int64_t full = plain_wgs / slots * slots;
+    const int64_t rem = groups - full * GWPB;             // groups left after the full rounds
+    if (split_env == 1) b1 = 0;
+    else if (rem > 0 && rem * 10 <= slots * GWPB * 7) b1 = full;
+  }
+  if (DEFORM) b1 = 0;
+  const bool any_share = b1 < plain_wgs || DEFORM;
+  const int nw = (b1 == 0 && any_share) ? (chunks < GWPB ? (chunks < 1 ? 1 : chunks) : GWPB) : GWPB;
+  const int SW = any_share ? GWPB : 1;
+  const int B1 = (int)b1;
+  dim3 grid((unsigned)(any_share ? b1 + (groups - b1 * GWPB) : plain_wgs)), block(64 * nw);
+#define LV(I64, F, L) \
+  hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F, XT, VEC, DEFORM, L>), grid, block, 0, st, P, LPP, PPW, HC, SW, B1)
+#define LVF(I64)                                                                            \
+  if (NCH == 2 && fub == 4) LV(I64, true, (VEC && NCH == 2 ? 4 : 0));                       \
+  else if (fub == 8) LV(I64, true, (VEC && NCH == 1 ? 8 : 0));                              \
+  else if (fub == 7) LV(I64, true, (VEC && NCH == 1 ? 7 : 0));                              \
+  else if (fub == 6) LV(I64, true, (VEC && NCH == 1 ? 6 : 0));                              \
+  else if (fub == 5) LV(I64, true, (VEC && NCH == 1 ? 5 : 0));                              \
+  else if (fast) LV(I64, true, 0);                                                          \
+  else LV(I64, false, 0);
+  if (idx64) {
+    LVF(true)
+  } else {
+    LVF(false)
+  }
+#undef LVF
 #undef LV
   return 0;
 }

@@ -748,8 +748,8 @@ def pmc_traffic(best):
     if prof.get("kpconv_hip_sha256") != sha:
         return None, "%s was taken with another csrc/kpconv.hip (sha mismatch): re-run the --pmc passes" % os.path.basename(path)
     sh = best["shape"]
-    lpp = min((sh["Cin"] + 3) // 4, 64)
-    grid_threads = -(-sh["Nq"] // (64 // lpp)) * 64
+    import mvkpconv
+    grid_threads = mvkpconv.sub("ops").kpconv_gather_plan(sh["Nq"], sh["Ns"], sh["H"], sh["Cin"])["grid_threads"]
     for l in prof["launches"]:
         if l["kernel"].startswith("kpconv_gather_vec") and l["grid_threads"] == grid_threads:
             return l["traffic_bytes"], "%s (%s)" % (os.path.basename(path), prof.get("command", ""))

@@ -655,27 +655,34 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
   }
 }
 
-template <int NCH, typename XT = float, bool VEC = true, bool DEFORM = false>
-int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
-  const int c4 = (P.Cin + 3) / 4;
-  const int LPP = c4 < 64 ? c4 : 64;  // lanes per point
-  const int PPW = 64 / LPP;           // points per wave
-  const int HC = 64 / PPW;            // neighbours per chunk and point
-  const bool fast = P.influence == MVK_INFL_LINEAR && P.aggregation == MVK_AGG_SUM;
+// Launch geometry of the vector gather kernel for one layer (also exported: mvk_kpconv_gather_plan).
+struct VecPlan {
+  int LPP, PPW, HC;   // lanes per point, points per wave, neighbours per chunk and point
+  int fub;            // rows per batch of the branch-free variant, 0 = the general variant
+  int SW, B1, nw;     // sharing: waves per sharing workgroup (1 = none), first sharing workgroup, waves per workgroup
+  int64_t wgs;        // workgroups
+};
+
+VecPlan plan_vec(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, bool fast, bool vec, bool deform) {
+  VecPlan v{};
+  const int NCH = Cin <= 256 ? 1 : 2;
+  const int c4 = (Cin + 3) / 4;
+  v.LPP = c4 < 64 ? c4 : 64;
+  v.PPW = 64 / v.LPP;
+  v.HC = 64 / v.PPW;
   static const bool fastld_on = getenv("MVK_GATHER_FASTLD") == nullptr || atoi(getenv("MVK_GATHER_FASTLD")) != 0;
   // rows per batch of the branch-free variant: the divisor-like batch size with the least padding of HC
-  int fub = 0;
-  if (fastld_on && fast && VEC && LPP >= 5 && P.Ns < (1 << 24) &&
-      (uint64_t)P.Ns * (uint64_t)P.Cin * sizeof(XT) < (1ull << 32) - 64) {
+  if (fastld_on && fast && vec && v.LPP >= 5 && Ns < (1 << 24) &&
+      (uint64_t)Ns * (uint64_t)Cin * (uint64_t)elem_bytes < (1ull << 32) - 64) {
     if (NCH == 2) {
-      fub = 4;
+      v.fub = 4;
     } else {
       int best_pad = 1 << 30;
       for (int ub = 8; ub >= 5; --ub) {
-        const int pad = (HC + ub - 1) / ub * ub - HC;
+        const int pad = (v.HC + ub - 1) / ub * ub - v.HC;
         if (pad < best_pad) {
           best_pad = pad;
-          fub = ub;
+          v.fub = ub;
         }
       }
     }
@@ -683,23 +690,32 @@ int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
   // sharing workgroups (kernel comment): all of them for the deformable variant; for the branch-free rigid one
   // the workgroups beyond the last full round of independent waves, when that remainder is well below a round
   static const int split_env = getenv("MVK_GATHER_SPLIT") ? atoi(getenv("MVK_GATHER_SPLIT")) : -1;
-  const int chunks = (P.H + HC - 1) / HC;
-  const int64_t groups = cdiv64(P.Nq, PPW);               // point groups = independent waves
+  const int chunks = (H + v.HC - 1) / v.HC;
+  const int64_t groups = cdiv64(Nq, v.PPW);               // point groups = independent waves
   const int64_t plain_wgs = cdiv64(groups, GWPB);
   const int64_t slots = NCH == 1 ? 1024 : 512;           // resident workgroups: 256 CUs x (4 | 2)
   int64_t b1 = plain_wgs;                                 // first sharing workgroup
-  if (fub > 0 && chunks > 1 && split_env != 0) {
+  if (v.fub > 0 && chunks > 1 && split_env != 0) {
     const int64_t full = plain_wgs / slots * slots;
     const int64_t rem = groups - full * GWPB;             // groups left after the full rounds
     if (split_env == 1) b1 = 0;
     else if (rem > 0 && rem * 10 <= slots * GWPB * 7) b1 = full;
   }
-  if (DEFORM) b1 = 0;
-  const bool any_share = b1 < plain_wgs || DEFORM;
-  const int nw = (b1 == 0 && any_share) ? (chunks < GWPB ? (chunks < 1 ? 1 : chunks) : GWPB) : GWPB;
-  const int SW = any_share ? GWPB : 1;
-  const int B1 = (int)b1;
-  dim3 grid((unsigned)(any_share ? b1 + (groups - b1 * GWPB) : plain_wgs)), block(64 * nw);
+  if (deform) b1 = 0;
+  const bool any_share = b1 < plain_wgs || deform;
+  v.nw = (b1 == 0 && any_share) ? (chunks < GWPB ? (chunks < 1 ? 1 : chunks) : GWPB) : GWPB;
+  v.SW = any_share ? GWPB : 1;
+  v.B1 = (int)b1;
+  v.wgs = any_share ? b1 + (groups - b1 * GWPB) : plain_wgs;
+  return v;
+}
+
+template <int NCH, typename XT = float, bool VEC = true, bool DEFORM = false>
+int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
+  const bool fast = P.influence == MVK_INFL_LINEAR && P.aggregation == MVK_AGG_SUM;
+  const VecPlan v = plan_vec(P.Nq, P.Ns, P.H, P.Cin, (int)sizeof(XT), fast, VEC, DEFORM);
+  const int LPP = v.LPP, PPW = v.PPW, HC = v.HC, fub = v.fub, SW = v.SW, B1 = v.B1;
+  dim3 grid((unsigned)v.wgs), block(64 * v.nw);
 #define LV(I64, F, L) \
   hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F, XT, VEC, DEFORM, L>), grid, block, 0, st, P, LPP, PPW, HC, SW, B1)
 #define LVF(I64)                                                                            \
@@ -819,6 +835,21 @@ extern "C" int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s
     launch_lane_channel<1, false>(P, idx64, st);
   }
   MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// Launch geometry mvk_kpconv_gather_fwd (elem_bytes 4) / mvk_kpconv_gather_fwd_f16 (elem_bytes 2) use for a layer
+// with linear influence and sum aggregation: out[0..6] = lanes per point, points per wave, rows per batch of the
+// branch-free variant (0 = general variant), first sharing workgroup, waves per workgroup, workgroups, grid
+// threads (what a kernel trace reports). out[5] = 0: the layer runs on the one-point-per-wave kernel instead.
+extern "C" int mvk_kpconv_gather_plan(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, int deformable,
+                                      int64_t* out) {
+  MVK_REQUIRE(out != nullptr && (elem_bytes == 2 || elem_bytes == 4), "kpconv plan: bad arguments");
+  for (int i = 0; i < 7; ++i) out[i] = 0;
+  if (Nq <= 0 || Cin <= 0 || Cin > 512 || (deformable && Cin < 13)) return 0;
+  const VecPlan v = plan_vec(Nq, Ns, H, Cin, elem_bytes, true, elem_bytes == 4 || (Cin & 1) == 0, deformable != 0);
+  out[0] = v.LPP; out[1] = v.PPW; out[2] = v.fub; out[3] = v.B1; out[4] = v.nw; out[5] = v.wgs;
+  out[6] = v.wgs * 64 * v.nw;
   return 0;
 }
 

@@ -101,6 +101,17 @@ def gemm_plan(M, N, Kd, split_k=None, want_stats=False):
     return sp.value, rows.value
 
 
+def kpconv_gather_plan(Nq, Ns, H, Cin, elem_bytes=4, deformable=False):
+    """Launch geometry of the gather kernel for a (linear, sum) layer (mvk_kpconv_gather_plan): dict with the
+    lanes per point, points per wave, rows per batch, first sharing workgroup, waves per workgroup, workgroups and
+    grid threads; 'workgroups' 0 means the layer runs on the one-point-per-wave kernel."""
+    out = (C.c_int64 * 7)()
+    check(lib().mvk_kpconv_gather_plan(int(Nq), int(Ns), int(H), int(Cin), int(elem_bytes), int(bool(deformable)), out))
+    keys = ("lanes_per_point", "points_per_wave", "rows_per_batch", "first_sharing_workgroup", "waves_per_workgroup",
+            "workgroups", "grid_threads")
+    return dict(zip(keys, [int(v) for v in out]))
+
+
 BN_SMALL_ROWS = 128      # csrc/bn.hip: up to this many rows one launch does statistics and normalisation
 
 

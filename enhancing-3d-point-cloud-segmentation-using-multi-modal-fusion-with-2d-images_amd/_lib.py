@@ -19,6 +19,7 @@ _SIGNATURES = {
                                         _vp, _vp, _vp, _vp, _vp]),
     "mvk_kpconv_gather_fwd_f16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
                                             _vp, _vp]),
+    "mvk_bn_single_launch_rows": (C.c_int, [_i]),
     "mvk_kpconv_gather_plan": (C.c_int, [_i64, _i64, _i, _i, _i, _i, _vp]),
     "mvk_kpconv_scatter_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i, _f, _i, _i,
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -586,6 +586,190 @@ __global__ __launch_bounds__(1024) void bn_small_bwd(const float* __restrict__ x
   }
 }
 
+// ---- the same single-launch BatchNorm for 129..1024 rows and D % 4 == 0, latency-shaped: a workgroup owns 16
+// channels (4 quads x 256 row lanes), a thread holds ALL its rows (at most 4) of x (and g, y) as float4 in
+// registers -- one round of loads, a reduction over the 256 row lanes (wave shuffles, then 16 partials through LDS),
+// one round of stores. The two-launch path costs a second kernel node (~8 us in a graph) and a re-read of x.
+constexpr int BN_MID_ROWS_DEFAULT = 1024;
+constexpr int BN_MID_MAX = 1024;      // 4 rows per thread x 256 row lanes
+
+// dflt unless cond, then the 16 bytes at p (written as a branch: `cond ? *p : dflt` on a struct becomes a select of
+// POINTERS -- the default spilled to scratch and a flat load)
+__device__ __forceinline__ float4 ld4_if(bool cond, const float* p, float4 dflt) {
+  float4 v = dflt;
+  if (cond) v = *reinterpret_cast<const float4*>(p);
+  return v;
+}
+
+__device__ __forceinline__ void add4(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// sum of a and of b over the 256 row lanes of the thread's channel quad (tid & 3), returned to every thread
+__device__ __forceinline__ void mid_sum(float4& a, float4& b, float4 (*ra)[4], float4 (*rb)[4]) {
+#pragma unroll
+  for (int m = 4; m < 64; m <<= 1) {
+    a.x += __shfl_xor(a.x, m); a.y += __shfl_xor(a.y, m); a.z += __shfl_xor(a.z, m); a.w += __shfl_xor(a.w, m);
+    b.x += __shfl_xor(b.x, m); b.y += __shfl_xor(b.y, m); b.z += __shfl_xor(b.z, m); b.w += __shfl_xor(b.w, m);
+  }
+  const int cq = threadIdx.x & 3, wv = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) < 4) {
+    ra[wv][cq] = a;
+    rb[wv][cq] = b;
+  }
+  __syncthreads();
+  float4 x = ra[0][cq], y = rb[0][cq];
+#pragma unroll
+  for (int i = 1; i < 16; ++i) {
+    add4(x, ra[i][cq]);
+    add4(y, rb[i][cq]);
+  }
+  a = x;
+  b = y;
+}
+
+// grid ceil(D/16), block 1024 = 4 channel quads x 256 row lanes; R <= BN_MID_MAX
+__global__ __launch_bounds__(1024) void bn_mid_fwd(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
+                                                   int D, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps, float momentum,
+                                                   float slope, float* __restrict__ running_mean,
+                                                   float* __restrict__ running_var, float* __restrict__ mean,
+                                                   float* __restrict__ invstd, float* __restrict__ y,
+                                                   long long* __restrict__ nbt, const float* __restrict__ addend) {
+  __shared__ float4 ra[16][4], rb[16][4];
+  if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;
+  const int n = min(*n_valid, R);
+  const int cq = threadIdx.x & 3, pr = threadIdx.x >> 2;
+  const int c = blockIdx.x * 16 + cq * 4;
+  const bool on = c < D;                                        // D % 4 == 0: the whole quad is in range
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 k = ld4_if(on && n > 0, x + c, z4);      // shift: row 0
+  float4 v[4], ad[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = pr + 256 * u;
+    v[u] = ld4_if(on && r < n, x + (int64_t)r * D + c, k);
+    ad[u] = ld4_if(on && addend && r < n, addend + (int64_t)r * D + c, z4);
+  }
+  float4 a = z4, b = z4;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const float dx = v[u].x - k.x, dy = v[u].y - k.y, dz = v[u].z - k.z, dw = v[u].w - k.w;   // rows >= n hold k: 0
+    a.x += dx; a.y += dy; a.z += dz; a.w += dw;
+    b.x += dx * dx; b.y += dy * dy; b.z += dz * dz; b.w += dw * dw;
+  }
+  mid_sum(a, b, ra, rb);
+  float4 mu = z4, is = z4, var = z4;
+  if (n > 0) {
+    const float inv_n = 1.0f / (float)n;
+    const float4 m1 = make_float4(a.x / (float)n, a.y / (float)n, a.z / (float)n, a.w / (float)n);
+    const float4 m2 = make_float4(b.x / (float)n, b.y / (float)n, b.z / (float)n, b.w / (float)n);
+    (void)inv_n;
+    mu = make_float4(k.x + m1.x, k.y + m1.y, k.z + m1.z, k.w + m1.w);
+    var = make_float4(fmaxf(m2.x - m1.x * m1.x, 0.f), fmaxf(m2.y - m1.y * m1.y, 0.f), fmaxf(m2.z - m1.z * m1.z, 0.f),
+                      fmaxf(m2.w - m1.w * m1.w, 0.f));
+    is = make_float4(rsqrtf(var.x + eps), rsqrtf(var.y + eps), rsqrtf(var.z + eps), rsqrtf(var.w + eps));
+  }
+  if (on && pr == 0) {
+    *reinterpret_cast<float4*>(mean + c) = mu;
+    *reinterpret_cast<float4*>(invstd + c) = is;
+    if (running_mean && n > 0) {
+      const float ub = n > 1 ? (float)n / (float)(n - 1) : 1.f;
+      float4 rm = *reinterpret_cast<float4*>(running_mean + c), rv = *reinterpret_cast<float4*>(running_var + c);
+      rm.x = (1.f - momentum) * rm.x + momentum * mu.x;
+      rm.y = (1.f - momentum) * rm.y + momentum * mu.y;
+      rm.z = (1.f - momentum) * rm.z + momentum * mu.z;
+      rm.w = (1.f - momentum) * rm.w + momentum * mu.w;
+      rv.x = (1.f - momentum) * rv.x + momentum * (n > 1 ? var.x * ub : var.x);
+      rv.y = (1.f - momentum) * rv.y + momentum * (n > 1 ? var.y * ub : var.y);
+      rv.z = (1.f - momentum) * rv.z + momentum * (n > 1 ? var.z * ub : var.z);
+      rv.w = (1.f - momentum) * rv.w + momentum * (n > 1 ? var.w * ub : var.w);
+      *reinterpret_cast<float4*>(running_mean + c) = rm;
+      *reinterpret_cast<float4*>(running_var + c) = rv;
+    }
+  }
+  if (on) {
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = pr + 256 * u;
+      if (r >= R) continue;
+      float4 o = z4;
+      if (r < n) {
+        o.x = (v[u].x - mu.x) * is.x * ga.x + be.x;
+        o.y = (v[u].y - mu.y) * is.y * ga.y + be.y;
+        o.z = (v[u].z - mu.z) * is.z * ga.z + be.z;
+        o.w = (v[u].w - mu.w) * is.w * ga.w + be.w;
+        add4(o, ad[u]);
+        o.x = o.x > 0.f ? o.x : o.x * slope;
+        o.y = o.y > 0.f ? o.y : o.y * slope;
+        o.z = o.z > 0.f ? o.z : o.z * slope;
+        o.w = o.w > 0.f ? o.w : o.w * slope;
+      }
+      *reinterpret_cast<float4*>(y + (int64_t)r * D + c) = o;
+    }
+  }
+}
+
+__global__ __launch_bounds__(1024) void bn_mid_bwd(const float* __restrict__ x, const float* __restrict__ g,
+                                                   const int* __restrict__ n_valid, int R, int D,
+                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float slope, const float* __restrict__ yout,
+                                                   float* __restrict__ d_addend, float* __restrict__ dgb,
+                                                   float* __restrict__ dx) {
+  __shared__ float4 ra[16][4], rb[16][4];
+  const int n = min(*n_valid, R);
+  const int cq = threadIdx.x & 3, pr = threadIdx.x >> 2;
+  const int c = blockIdx.x * 16 + cq * 4;
+  const bool on = c < D;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 mu = ld4_if(on, mean + c, z4), is = ld4_if(on, invstd + c, z4);
+  const float4 ga = ld4_if(on, gamma + c, z4), be = ld4_if(on, beta + c, z4);
+  float4 xh[4], gv[4];           // normalised input, gradient behind the LeakyReLU (zero on rows >= n)
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int r = pr + 256 * u;
+    const bool in = on && r < n;
+    const float4 xv = ld4_if(in, x + (int64_t)r * D + c, mu);
+    float4 gg = ld4_if(in, g + (int64_t)r * D + c, z4);
+    const float4 yv = ld4_if(in && yout, yout + (int64_t)r * D + c, z4);
+    xh[u] = make_float4((xv.x - mu.x) * is.x, (xv.y - mu.y) * is.y, (xv.z - mu.z) * is.z, (xv.w - mu.w) * is.w);
+    if (yout ? yv.x <= 0.f : xh[u].x * ga.x + be.x <= 0.f) gg.x *= slope;
+    if (yout ? yv.y <= 0.f : xh[u].y * ga.y + be.y <= 0.f) gg.y *= slope;
+    if (yout ? yv.z <= 0.f : xh[u].z * ga.z + be.z <= 0.f) gg.z *= slope;
+    if (yout ? yv.w <= 0.f : xh[u].w * ga.w + be.w <= 0.f) gg.w *= slope;
+    gv[u] = gg;
+  }
+  float4 a = z4, b = z4;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    add4(a, gv[u]);
+    b.x += gv[u].x * xh[u].x; b.y += gv[u].y * xh[u].y; b.z += gv[u].z * xh[u].z; b.w += gv[u].w * xh[u].w;
+  }
+  mid_sum(a, b, ra, rb);
+  if (on) {
+    if (pr == 0) {
+      *reinterpret_cast<float4*>(dgb + c) = a;
+      *reinterpret_cast<float4*>(dgb + D + c) = b;
+    }
+    const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int r = pr + 256 * u;
+      if (r >= R) continue;
+      float4 o = z4, go = z4;
+      if (r < n) {
+        go = gv[u];
+        o.x = ga.x * is.x * (go.x - a.x * inv_n - xh[u].x * b.x * inv_n);
+        o.y = ga.y * is.y * (go.y - a.y * inv_n - xh[u].y * b.y * inv_n);
+        o.z = ga.z * is.z * (go.z - a.z * inv_n - xh[u].z * b.z * inv_n);
+        o.w = ga.w * is.w * (go.w - a.w * inv_n - xh[u].w * b.w * inv_n);
+      }
+      *reinterpret_cast<float4*>(dx + (int64_t)r * D + c) = o;
+      if (d_addend) *reinterpret_cast<float4*>(d_addend + (int64_t)r * D + c) = go;
+    }
+  }
+}
+
 // ---- y = LeakyReLU(a + b) (the residual join of ResnetBottleneckBlock, blocks.py:649) in one launch
 __global__ void add_lrelu_fwd_k(const float* __restrict__ a, const float* __restrict__ b, int64_t n, float slope,
                                 float* __restrict__ y) {
@@ -612,7 +796,32 @@ int bn_small_rows() {
   return v;
 }
 
+// every non-null pointer 16-byte aligned (the vectorised kernels load float4)
+bool aligned16(const void* a, const void* b, const void* c, const void* d, const void* e, const void* f, const void* g,
+               const void* h) {
+  return (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e | (uintptr_t)f | (uintptr_t)g |
+           (uintptr_t)h) & 15) == 0;
+}
+
+// rows up to which the vectorised single-launch kernels are used when D % 4 == 0 (MVK_BN_MID_ROWS)
+int bn_mid_rows() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("MVK_BN_MID_ROWS");
+    v = e ? atoi(e) : BN_MID_ROWS_DEFAULT;
+    if (v > BN_MID_MAX) v = BN_MID_MAX;
+  }
+  return v;
+}
+
 }  // namespace
+
+// rows up to which mvk_bn_lrelu_fwd / _bwd are ONE launch for a D-channel input (a producer need not emit statistics)
+extern "C" int mvk_bn_single_launch_rows(int D) {
+  static const bool keep_stats = getenv("MVK_BN_MID_KEEP_STATS") != nullptr;     // development: producers still emit partials
+  if (keep_stats) return bn_small_rows();
+  return (D % 4 == 0 && bn_mid_rows() > bn_small_rows()) ? bn_mid_rows() : bn_small_rows();
+}
 
 extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t R, int D, const float* gamma,
                                 const float* beta, float eps, float momentum, float slope, float* running_mean,
@@ -623,6 +832,13 @@ extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t 
   MVK_REQUIRE((ext_part == nullptr) == (ext_rows == 0) && ext_rows >= 0, "bn: ext_part and ext_rows go together");
   if (R == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (R > bn_small_rows() && R <= bn_mid_rows() && D % 4 == 0 &&
+      aligned16(x, y, addend, gamma, beta, nullptr, nullptr, nullptr)) {
+    hipLaunchKernelGGL(bn_mid_fwd, dim3((unsigned)cdiv64(D, 16)), dim3(1024), 0, st, x, n_valid, (int)R, D, gamma, beta,
+                       eps, momentum, slope, running_mean, running_var, mean, invstd, y, (long long*)num_batches_tracked, addend);
+    MVK_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (R <= bn_small_rows()) {
     hipLaunchKernelGGL(bn_small_fwd, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, x, n_valid, (int)R, D, gamma, beta,
                        eps, momentum, slope, running_mean, running_var, mean, invstd, y, (long long*)num_batches_tracked, addend);
@@ -664,6 +880,13 @@ extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n
   hipStream_t st = (hipStream_t)stream;
   if (R == 0) {
     MVK_CHECK_HIP(hipMemsetAsync(dgamma_dbeta, 0, sizeof(float) * 2 * D, st));
+    return 0;
+  }
+  if (R > bn_small_rows() && R <= bn_mid_rows() && D % 4 == 0 &&
+      aligned16(x, g, y_out, d_addend, dgamma_dbeta, dx, mean, invstd) && aligned16(gamma, beta, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) {
+    hipLaunchKernelGGL(bn_mid_bwd, dim3((unsigned)cdiv64(D, 16)), dim3(1024), 0, st, x, g, n_valid, (int)R, D, mean,
+                       invstd, gamma, beta, slope, y_out, d_addend, dgamma_dbeta, dx);
+    MVK_CHECK_HIP(hipGetLastError());
     return 0;
   }
   if (R <= bn_small_rows()) {

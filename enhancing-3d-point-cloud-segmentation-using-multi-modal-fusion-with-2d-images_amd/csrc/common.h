@@ -28,6 +28,19 @@ extern "C" void mvk_set_error(const char* fmt, ...);
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// A pointer the compiler cannot trace to a kernel argument (read from a table in memory) is "generic": its loads
+// become flat_load, which also counts on lgkmcnt. Device allocations are global memory: reading the table slot AS a
+// global-address-space pointer lets the compiler infer that for every access made through the returned pointer.
+template <typename T>
+__device__ __forceinline__ T* load_global_ptr(T* const* slot) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef __attribute__((address_space(1))) T* gp;
+  return (T*)(*reinterpret_cast<const gp*>(slot));
+#else
+  return *slot;
+#endif
+}
+
 // neighbour index load: int32 or int64 storage, -1 for shadow / out of range
 template <bool IDX64>
 __device__ __forceinline__ int load_idx(const void* idx, int64_t pos, int64_t Ns) {

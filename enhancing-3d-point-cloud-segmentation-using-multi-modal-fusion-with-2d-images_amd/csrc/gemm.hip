@@ -429,7 +429,14 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_grouped(const GroupEntry* _
   const GroupEntry& e = tab[lo];
   const int local = b - e.wg_begin;
   const int bx = local % e.gx, by = (local / e.gx) % e.gy, bz = local / (e.gx * e.gy);
-  const GemmArgs a = e.args;
+  GemmArgs a = e.args;
+  // pointers read from a table in memory are generic to the compiler (flat_load / flat_atomic, which also count on
+  // lgkmcnt and so serialise against the LDS pipeline): they are device allocations
+  a.A = load_global_ptr(&e.args.A);
+  a.B = load_global_ptr(&e.args.B);
+  a.C = load_global_ptr(&e.args.C);
+  a.bn_part = load_global_ptr(&e.args.bn_part);
+  a.n_valid = load_global_ptr(&e.args.n_valid);
   gemm_body<TA, TB, PM, QN, WM, WN>(a, bx, by, bz);
 }
 

@@ -24,7 +24,10 @@ constexpr int SGD_CHUNK = 4096;   // elements per workgroup: 256 threads x 4 flo
 __global__ __launch_bounds__(256) void sgd_clip_kernel(const SgdTensor* __restrict__ tab, const int2* __restrict__ chunks,
                                                       float clip, float momentum, int clip_in_place) {
   const int2 c = chunks[blockIdx.x];
-  const SgdTensor t = tab[c.x];
+  SgdTensor t = tab[c.x];
+  t.p = load_global_ptr(&tab[c.x].p);     // table pointers are device allocations (global_load, not flat_load)
+  t.g = load_global_ptr(&tab[c.x].g);
+  t.m = load_global_ptr(&tab[c.x].m);
   const int64_t base = (int64_t)c.y * SGD_CHUNK;
   const bool vec = (((uintptr_t)t.p | (uintptr_t)t.g | (uintptr_t)t.m) & 15) == 0;
 #pragma unroll

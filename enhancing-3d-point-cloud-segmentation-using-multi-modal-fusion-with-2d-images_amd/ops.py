@@ -112,7 +112,13 @@ def kpconv_gather_plan(Nq, Ns, H, Cin, elem_bytes=4, deformable=False):
     return dict(zip(keys, [int(v) for v in out]))
 
 
-BN_SMALL_ROWS = 128      # csrc/bn.hip: up to this many rows one launch does statistics and normalisation
+BN_SMALL_ROWS = 128      # csrc/bn.hip: up to this many rows one launch does statistics and normalisation (any D)
+
+
+def bn_single_launch_rows(D):
+    """Rows up to which the BatchNorm of a D-channel input is one launch (csrc/bn.hip: 128, or 1024 when D % 4 == 0):
+    the producing GEMM then skips its statistics epilogue."""
+    return lib().mvk_bn_single_launch_rows(int(D))
 
 
 def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=None, keep=False, stats_n_valid=None):
@@ -132,7 +138,7 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
     if M == 0 or N == 0 or Kd == 0:
         res = out.zero_() if out is not None else torch.zeros((M, N), device=A.device, dtype=torch.float32)
         return (res, None) if want else res
-    split, rows = gemm_plan(M, N, Kd, split_k, want and out is None and not accumulate and M > BN_SMALL_ROWS)
+    split, rows = gemm_plan(M, N, Kd, split_k, want and out is None and not accumulate and M > bn_single_launch_rows(N))
     if out is None:
         out = ((torch.zeros((M, N), device=A.device, dtype=torch.float32) if keep else _zeros((M, N), A.device))
                if split > 1 else torch.empty((M, N), device=A.device, dtype=torch.float32))

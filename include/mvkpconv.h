@@ -171,6 +171,10 @@ int mvk_sgd_clip_step(const void* table, const int32_t* chunks, int64_t n_chunks
 
 /* ---------------- masked BatchNorm + LeakyReLU (capacity-padded levels) --- */
 
+/* Rows up to which mvk_bn_lrelu_fwd / mvk_bn_lrelu_bwd run as ONE launch for a D-channel input (statistics and
+ * normalisation together): a producing GEMM need not emit BatchNorm partials for such an output. */
+int mvk_bn_single_launch_rows(int D);
+
 /* Training-mode BatchNorm over the first *n_valid rows of x [R,D] (n_valid: DEVICE int32, so the
  * launch geometry is fixed while the row count varies -- hipGraph replay), fused with
  * LeakyReLU(slope) (slope = 1 -> no activation); rows >= n_valid of y are zero. Replaces

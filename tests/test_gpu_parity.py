@@ -491,7 +491,7 @@ def test_gemm_f32_every_tile_configuration(ops, pm, qn, monkeypatch):
 
 
 @pytest.mark.parametrize("M,N,K,n", [(19464, 64, 990, 19464), (19464, 32, 480, 19000), (3986, 64, 960, 3986), (1300, 128, 96, 1207),
-                                     (4096, 200, 64, 4000), (300, 256, 64, 300), (19464, 128, 32, 19464), (5000, 20, 64, 4321)])
+                                     (4096, 200, 64, 4000), (1100, 256, 64, 1100), (19464, 128, 32, 19464), (5000, 20, 64, 4321)])
 def test_gemm_batchnorm_statistics_epilogue(ops, M, N, K, n):
     """The statistics the GEMM epilogue hands to the BatchNorm that follows (per wave row block: column sum and
     centred sum of squares over the rows below n_valid) give the same normalised output, running statistics and
@@ -502,6 +502,9 @@ def test_gemm_batchnorm_statistics_epilogue(ops, M, N, K, n):
     A[:, 0] = 40.0                                          # large common component -> large column means
     B = torch.randn(K, N, device="cuda")
     nv = torch.tensor([n], dtype=torch.int32, device="cuda")
+    # outputs whose BatchNorm is a single launch anyway (<= 128 rows, <= 1024 when N % 4 == 0) get no statistics
+    small = torch.randn(ops.bn_single_launch_rows(N), K, device="cuda")
+    assert ops.gemm(small, B, split_k=1, stats_n_valid=nv)[1] is None and ops.bn_single_launch_rows(64) == 1024
     auto, st_auto = ops.gemm(A, B, stats_n_valid=nv)          # the plan may prefer a split reduction (then no statistics)
     assert rel_err(auto.cpu().numpy(), (A.double() @ B.double()).cpu().numpy()) < 1e-5
     assert (st_auto is None) == (ops.gemm_plan(M, N, K, None, True)[1] == 0)
@@ -570,10 +573,13 @@ def test_deferred_weight_gradients_run_as_one_grouped_launch(ops):
 
 @pytest.mark.parametrize("slope", [1.0, 0.1])
 @pytest.mark.parametrize("R,D,n", [(50, 64, 50), (128, 32, 100), (3000, 128, 2873), (19464, 64, 19464),
-                                   (19464, 66, 19000), (40000, 32, 40000), (4096, 200, 4000)])
+                                   (19464, 66, 19000), (40000, 32, 40000), (4096, 200, 4000),
+                                   (129, 64, 129), (923, 128, 900), (1024, 512, 1024), (225, 256, 2), (600, 36, 577),
+                                   (700, 66, 700)])
 def test_masked_bn_lrelu_vs_torch(ops, R, D, n, slope):
     """blocks.py:430-467 + LeakyReLU: the single-workgroup (R <= 128) and the three-launch kernels against
-    torch's batch_norm on the valid rows; padded rows come back as zeros, running statistics and the batch
+    torch's batch_norm on the valid rows (129..1024 rows with D % 4 == 0: the vectorised single-launch kernels);
+    padded rows come back as zeros, running statistics and the batch
     counter move like nn.BatchNorm1d's. slope = 1 checks every gradient tightly; with slope = 0.1 a
     last-bit difference of the normalised value flips the slope of elements sitting on the kink, so the
     input gradient is compared away from it and the parameter gradients (sums over all rows) loosely."""
@@ -626,7 +632,8 @@ def test_gemm_f16_mfma(ops, M, N, K, ta, tb):
     assert (one.double() - want).abs().max().item() / scale < 2e-5
 
 
-@pytest.mark.parametrize("R,D,n", [(100, 64, 90), (3000, 128, 2873), (19464, 64, 19464), (4096, 200, 4000)])
+@pytest.mark.parametrize("R,D,n", [(100, 64, 90), (3000, 128, 2873), (19464, 64, 19464), (4096, 200, 4000),
+                                   (923, 128, 900), (225, 512, 225)])
 def test_masked_bn_with_residual_join_vs_torch(ops, R, D, n):
     """y = LeakyReLU(BN(x) + shortcut) in one launch (ResnetBottleneckBlock's join, blocks.py:644-649) against
     the unfused torch expression: output, and the gradients of x, the shortcut and the BN parameters."""
@@ -904,22 +911,25 @@ def test_round2_entry_points_on_empty_and_degenerate_inputs(ops):
     neighbours, a product with an empty reduction, an optimiser without gradients, an empty deferred list."""
     import mvkpconv
     optim = mvkpconv.sub("optim")
-    # BatchNorm fed by epilogue statistics with n_valid = 0: everything zero, no NaN
-    A = torch.randn(300, 64, device="cuda")
+    # BatchNorm with n_valid = 0 (everything zero, no NaN) and with one valid row (variance 0, output = beta): the
+    # single-launch kernel (300 rows) and the one fed by the GEMM's epilogue statistics (1 300 rows)
     B = torch.randn(64, 48, device="cuda")
     nv0 = torch.tensor([0], dtype=torch.int32, device="cuda")
-    y, st = ops.gemm(A, B, split_k=1, stats_n_valid=nv0)
-    assert st is not None
-    y._mvk_bn_stats = st
-    bn = torch.nn.BatchNorm1d(48).cuda()
-    out = ops.bn_lrelu(y, nv0, bn, slope=0.1)
-    assert torch.isfinite(out).all() and (out == 0).all() and torch.isfinite(bn.running_var).all()
-    # one valid row: variance 0, output = beta
     nv1 = torch.tensor([1], dtype=torch.int32, device="cuda")
-    y, st = ops.gemm(A, B, split_k=1, stats_n_valid=nv1)
-    y._mvk_bn_stats = st
-    out = ops.bn_lrelu(y, nv1, bn, slope=1.0)
-    assert torch.isfinite(out).all() and torch.allclose(out[0], bn.bias.detach(), atol=1e-6) and (out[1:] == 0).all()
+    for rows in (300, 1300):
+        A = torch.randn(rows, 64, device="cuda")
+        bn = torch.nn.BatchNorm1d(48).cuda()
+        y, st = ops.gemm(A, B, split_k=1, stats_n_valid=nv0)
+        assert (st is not None) == (rows > ops.bn_single_launch_rows(48))
+        if st is not None:
+            y._mvk_bn_stats = st
+        out = ops.bn_lrelu(y, nv0, bn, slope=0.1)
+        assert torch.isfinite(out).all() and (out == 0).all() and torch.isfinite(bn.running_var).all()
+        y, st = ops.gemm(A, B, split_k=1, stats_n_valid=nv1)
+        if st is not None:
+            y._mvk_bn_stats = st
+        out = ops.bn_lrelu(y, nv1, bn, slope=1.0)
+        assert torch.isfinite(out).all() and torch.allclose(out[0], bn.bias.detach(), atol=1e-6) and (out[1:] == 0).all()
     # product with an empty reduction / empty operands
     assert (ops.gemm(torch.zeros(5, 0, device="cuda"), torch.zeros(0, 7, device="cuda")) == 0).all()
     assert ops.gemm(torch.zeros(0, 4, device="cuda"), torch.zeros(4, 7, device="cuda")).shape == (0, 7)

@@ -354,6 +354,24 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         if os.environ.get("MVK_BENCH_DIAG") == "1":
             print("DIAG zero arena %.1f MB" % (ops.zero_arena_high_water() / 1e6), file=sys.stderr)
     opt.zero_grad(set_to_none=True)
+    if os.environ.get("MVK_BENCH_DIAG") == "fills":
+        # development: which host call sites still launch zero-fill / copy kernels in a step (arena enabled)
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU], with_stack=True, record_shapes=True,
+                     experimental_config=torch._C._profiler._ExperimentalConfig(verbose=True)) as prof:
+            net_step_captured(net, statics[0], cfg, params, opt, reducer)
+        torch.cuda.synchronize()
+        import collections
+        agg = collections.Counter()
+        for ev in prof.events():
+            if ev.name in ("aten::zero_", "aten::fill_", "aten::zeros", "aten::zeros_like", "aten::copy_", "aten::clone",
+                           "aten::contiguous", "aten::add", "aten::add_", "aten::mul", "aten::cat"):
+                st = [f for f in ev.stack if "/torch/" not in f][:4] or list(ev.stack)[:4]
+                shape = str(getattr(ev, "input_shapes", ""))[:40]
+                agg[(ev.name, shape + " " + " <- ".join(x.split("/")[-1] for x in st))] += 1
+        for (name, st), n in agg.most_common(60):
+            print("DIAG %3d %-18s %s" % (n, name, st), file=sys.stderr)
+        opt.zero_grad(set_to_none=True)
 
     def capture(static):
         ops.set_row_counts(static.valid)

@@ -67,14 +67,14 @@ __global__ void gather_rows_fwd_k(const float* __restrict__ x, int64_t Ns, int C
 }
 
 template <bool IDX64>
-__global__ void gather_rows_bwd_k(const float* __restrict__ g, const void* idx, int64_t Nq,
+__global__ void gather_rows_bwd_k(const float* __restrict__ g, int64_t g_ld, const void* idx, int64_t Nq,
                                   int64_t stride, int64_t Ns, int C, float* __restrict__ dx) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= Nq * C) return;
   const int64_t n = t / C;
   const int c = (int)(t % C);
   const int j = load_idx<IDX64>(idx, n * stride, Ns);
-  if (j >= 0) atomicAdd(dx + (int64_t)j * C + c, g[t]);
+  if (j >= 0) atomicAdd(dx + (int64_t)j * C + c, g[n * g_ld + c]);
 }
 
 inline dim3 grid1d(int64_t total) { return dim3((unsigned)cdiv64(total, 256)); }
@@ -118,14 +118,20 @@ extern "C" int mvk_gather_rows_fwd(const float* x, int64_t Ns, int C, const void
   return 0;
 }
 
-extern "C" int mvk_gather_rows_bwd(const float* g, const void* idx, int idx64, int64_t Nq,
-                                   int64_t idx_stride, int64_t Ns, int C, float* dx, void* stream) {
+extern "C" int mvk_gather_rows_bwd_ld(const float* g, int64_t g_ld, const void* idx, int idx64, int64_t Nq,
+                                      int64_t idx_stride, int64_t Ns, int C, float* dx, void* stream) {
+  MVK_REQUIRE(g_ld >= C, "gather_rows_bwd: row stride of g smaller than its row length");
   const int64_t total = Nq * C;
   if (total == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  DISPATCH_IDX(gather_rows_bwd_k, g, idx, Nq, idx_stride, Ns, C, dx);
+  DISPATCH_IDX(gather_rows_bwd_k, g, g_ld, idx, Nq, idx_stride, Ns, C, dx);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int mvk_gather_rows_bwd(const float* g, const void* idx, int idx64, int64_t Nq,
+                                   int64_t idx_stride, int64_t Ns, int C, float* dx, void* stream) {
+  return mvk_gather_rows_bwd_ld(g, C, idx, idx64, Nq, idx_stride, Ns, C, dx, stream);
 }
 
 // ---- pointwise epilogue of the frozen 2D encoder's convolutions (mvpnet/models/unet_resnet34.py: conv -> BatchNorm

@@ -452,6 +452,7 @@ class _KPConvFn(torch.autograd.Function):
         part = st[0] if st is not None else None
         if part is not None:
             ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)    # else autograd hands backward a ZERO tensor (one fill launch) per unused output
         return y, min_d2, part
 
     @staticmethod
@@ -460,6 +461,8 @@ class _KPConvFn(torch.autograd.Function):
         extent, influence, aggregation = ctx.cfg
         K, Cin, Cout = W.shape
         Nq = q.shape[0]
+        if gy is None:                      # only min_d2 was used (the regulariser): no feature gradient
+            gy = torch.zeros((Nq, Cout), device=q.device, dtype=torch.float32)
         gy = _f32c(gy)
         Am = A * modulations.unsqueeze(2) if modulations is not None else A
         dW = dx = d_off = d_mod = None
@@ -530,6 +533,7 @@ class _KPConv16Fn(torch.autograd.Function):
         ctx.save_for_backward(q, s, idx, x16, kp, W16, A, offsets, modulations)
         ctx.min_arg = getattr(min_d2, "_mvk_min_arg", None)
         ctx.cfg = (extent, influence, aggregation, (K, Cin, Cout))
+        ctx.set_materialize_grads(False)
         return y, min_d2, None          # (no BatchNorm-statistics epilogue in the fp16 contraction)
 
     @staticmethod
@@ -537,6 +541,8 @@ class _KPConv16Fn(torch.autograd.Function):
         q, s, idx, x16, kp, W16, A, offsets, modulations = ctx.saved_tensors
         extent, influence, aggregation, (K, Cin, Cout) = ctx.cfg
         Nq = q.shape[0]
+        if gy is None:
+            gy = torch.zeros((Nq, Cout), device=q.device, dtype=torch.float32)
         gy = _f32c(gy)
         A32 = A.float()
         Am = A32 * modulations.unsqueeze(2) if modulations is not None else A32
@@ -779,10 +785,12 @@ class _GatherRowsFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (inds2d,) = ctx.saved_tensors
-        g = _f32c(g)
+        # a column slice of a wider gradient (one half of the decoder's concatenation) is read in place
+        if not (g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1 and g.stride(0) >= g.shape[1]):
+            g = _f32c(g)
         dx = _zeros((ctx.ns, g.shape[1]), g.device)
-        check(lib().mvk_gather_rows_bwd(_p(g), _p(inds2d), int(inds2d.dtype == torch.int64), inds2d.shape[0],
-                                        ctx.stride, ctx.ns, g.shape[1], _p(dx), _stream()))
+        check(lib().mvk_gather_rows_bwd_ld(_p(g), g.stride(0), _p(inds2d), int(inds2d.dtype == torch.int64),
+                                           inds2d.shape[0], ctx.stride, ctx.ns, g.shape[1], _p(dx), _stream()))
         return dx, None
 
 
@@ -1080,11 +1088,14 @@ class _LinearFn(torch.autograd.Function):
         part = st[0] if st is not None else None
         if part is not None:
             ctx.mark_non_differentiable(part)
+        ctx.set_materialize_grads(False)    # no zero tensor for the unused gradient of `part`
         return y, part
 
     @staticmethod
     def backward(ctx, g, g_part=None):
         x, W = ctx.saved_tensors
+        if g is None:
+            return None, None, None, None
         g = _f32c(g)
         dx = dW = None
         if ctx.needs_input_grad[0]:

@@ -216,6 +216,10 @@ int mvk_gather_rows_fwd(const float* x, int64_t Ns, int C, const void* idx, int 
                         int64_t idx_stride, float* out, void* stream);
 int mvk_gather_rows_bwd(const float* g, const void* idx, int idx64, int64_t Nq, int64_t idx_stride,
                         int64_t Ns, int C, float* dx, void* stream);
+/* The same with the rows of g `g_ld` floats apart (g_ld >= C): the gradient of one half of a concatenation is a
+ * column slice of the concatenated gradient (KPFCNN decoder, architectures.py:334), read in place. */
+int mvk_gather_rows_bwd_ld(const float* g, int64_t g_ld, const void* idx, int idx64, int64_t Nq,
+                           int64_t idx_stride, int64_t Ns, int C, float* dx, void* stream);
 
 /* ---------------- input pyramid ------------------------------------------ */
 

@@ -23,6 +23,7 @@ SOURCES = [
     ("bn.hip", []),
     ("optim.hip", []),
     ("deform.hip", []),
+    ("loss.hip", []),
     ("batchpad.hip", []),
     ("subsample.hip", ["-ffp-contract=off"]),
     ("neighbors.hip", ["-ffp-contract=off"]),

@@ -16,6 +16,7 @@ except ImportError:
 
 
 _FUSED_REG = os.environ.get("MVK_FUSED_REGULARIZER", "1") == "1"   # development switch: 0 = the tensor-op form below
+_FUSED_LOSS = os.environ.get("MVK_FUSED_LOSS", "1") == "1"         # development switch: 0 = torch.nn.CrossEntropyLoss
 
 
 def p2p_fitting_regularizer(net):
@@ -130,20 +131,33 @@ class _SegmentationLossMixin:
         """Ignored labels -> -1, the others -> [0, C-1] (architectures.py:352-355) through a lookup table:
         three launches whatever the number of classes, no boolean-mask assignment, no host sync
         (hipGraph capturable). Any value that is not a valid label maps to -1, like the reference's loop."""
-        lut = getattr(self, "_target_lut", None)
-        if lut is None or lut.device != labels.device:
+        lut = self._label_table(labels.device)
+        idx = labels.long().clamp(-1, lut.numel() - 2) + 1
+        return lut[idx].to(labels.dtype)
+
+    def _label_table(self, device, dtype=torch.int64):
+        """lut[l + 1] = class index of raw label l, -1 for ignored ones (slot 0: negative labels, last slot: labels
+        above the largest valid one)."""
+        key = "_target_lut" if dtype == torch.int64 else "_target_lut32"
+        lut = getattr(self, key, None)
+        if lut is None or lut.device != device:
             top = int(max(self.valid_labels)) if len(self.valid_labels) else 0
             table = np.full(top + 3, -1, dtype=np.int64)            # slot 0: negatives, slot top+2: above the range
             for i, c in enumerate(self.valid_labels):
                 table[int(c) + 1] = i
-            lut = self._target_lut = torch.from_numpy(table).to(labels.device)
-        idx = labels.long().clamp(-1, lut.numel() - 2) + 1
-        return lut[idx].to(labels.dtype)
+            lut = torch.from_numpy(table).to(device=device, dtype=dtype)
+            setattr(self, key, lut)
+        return lut
 
     def loss(self, outputs, labels):
-        target = self._targets(labels)
-        outputs = torch.transpose(outputs, 0, 1).unsqueeze(0)
-        self.output_loss = self.criterion(outputs, target.unsqueeze(0))
+        if _FUSED_LOSS and outputs.is_cuda and outputs.dtype == torch.float32:
+            # label renumbering + weighted cross entropy + mean as one autograd node (csrc/loss.hip)
+            self.output_loss = _ops.cross_entropy_lut(outputs, labels, self._label_table(outputs.device, torch.int32),
+                                                      self.criterion.weight)
+        else:
+            target = self._targets(labels)
+            outputs = torch.transpose(outputs, 0, 1).unsqueeze(0)
+            self.output_loss = self.criterion(outputs, target.unsqueeze(0))
         if self.deform_fitting_mode == 'point2point':
             self.reg_loss = p2p_fitting_regularizer(self)
         elif self.deform_fitting_mode == 'point2plane':

@@ -1114,6 +1114,47 @@ def linear(x, W, x_is_transposed=False, stats_n_valid=None):
     return y
 
 
+class _XentFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, lut, weight):
+        _dev(logits, labels, lut, weight)
+        logits = _f32c(logits)
+        if labels.dtype not in (torch.int32, torch.int64):
+            labels = labels.long()
+        labels = labels.contiguous()
+        N, Cc = logits.shape
+        part = torch.empty((lib().mvk_xent_workspace_floats(N),), device=logits.device, dtype=torch.float32)
+        out2 = torch.empty((2,), device=logits.device, dtype=torch.float32)
+        check(lib().mvk_xent_fwd(_p(logits), N, Cc, _p(labels), int(labels.dtype == torch.int64), _p(lut), lut.numel(),
+                                 _p(weight), _p(part), _p(out2), _stream()))
+        ctx.save_for_backward(logits, labels, lut, weight, out2)
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels, lut, weight, out2 = ctx.saved_tensors
+        g = _f32c(g)
+        d = torch.empty_like(logits)
+        check(lib().mvk_xent_bwd(_p(logits), logits.shape[0], logits.shape[1], _p(labels),
+                                 int(labels.dtype == torch.int64), _p(lut), lut.numel(), _p(weight), _p(out2), _p(g), _p(d),
+                                 _stream()))
+        return d, None, None, None
+
+
+def cross_entropy_lut(logits, labels, lut, class_weight=None):
+    """KPFCNN's segmentation loss (architectures.py:345-372) as one autograd node, three launches forward + backward:
+    labels [N] (int32 / int64, raw dataset values) are renumbered through `lut` (int32: lut[l + 1] = class of label
+    l or -1 = ignored; lut[0] for negative labels, lut[-1] for labels above the table), then the class-weighted
+    cross entropy of logits [N, C], mean over the kept points (torch.nn.CrossEntropyLoss(weight, ignore_index=-1))."""
+    if lut.dtype != torch.int32 or lut.dim() != 1 or lut.numel() < 3:
+        raise RuntimeError("cross_entropy_lut: lut must be a 1-D int32 tensor of at least 3 entries")
+    if logits.dim() != 2 or labels.dim() != 1 or labels.shape[0] != logits.shape[0]:
+        raise RuntimeError("cross_entropy_lut: logits [N, C] and labels [N] expected")
+    if class_weight is not None and (class_weight.dtype != torch.float32 or class_weight.numel() != logits.shape[1]):
+        raise RuntimeError("cross_entropy_lut: class_weight must be float32 [C]")
+    return _XentFn.apply(logits, labels, lut, None if class_weight is None else class_weight.contiguous())
+
+
 def bias_act_nhwc(x, bias, res=None, bias2=None, relu=True, out=None):
     """act(x + bias[c] (+ res (+ bias2[c]))) on a channels-last 4-D tensor (in place unless `out`): the pointwise
     tail of a convolution of the frozen 2D encoder after its BatchNorm was folded into the weights."""

@@ -157,6 +157,18 @@ int mvk_bias_act_nhwc(const float* x, const float* bias, const float* res, const
 
 /* ---------------- optimiser tail of a training step ------------------------ */
 
+/* Segmentation loss of KPFCNN (architectures.py:345-372): labels that are not in `valid_labels` are ignored, the rest
+ * are renumbered 0..C-1 (lut[l + 1] = class of label l or -1; lut[0] serves negative labels, lut[lut_n - 1] the labels
+ * above the table), then weighted cross entropy, mean over the kept points:
+ *   out2[0] = sum_i w[t_i] (logsumexp(x_i) - x_i[t_i]) / sum_i w[t_i],  out2[1] = sum_i w[t_i]   (class_weight NULL: 1)
+ * partials: mvk_xent_workspace_floats(N) floats. Two launches (partial sums, ordered finish): deterministic. */
+int64_t mvk_xent_workspace_floats(int64_t N);
+int mvk_xent_fwd(const float* logits /* [N,C] */, int64_t N, int C, const void* labels, int labels64, const int32_t* lut,
+                 int lut_n, const float* class_weight, float* partials, float* out2, void* stream);
+/* dlogits[i,:] = grad_loss[0] * w[t_i] / out2[1] * (softmax(x_i) - onehot(t_i)), 0 for ignored points. */
+int mvk_xent_bwd(const float* logits, int64_t N, int C, const void* labels, int labels64, const int32_t* lut, int lut_n,
+                 const float* class_weight, const float* out2, const float* grad_loss, float* dlogits, void* stream);
+
 /* Gradient value clipping + SGD (momentum, weight decay; torch.optim.SGD semantics, dampening 0, no Nesterov) over
  * ALL parameter tensors in one launch (utils/trainer.py:190-195: clip_grad_value_ + optimizer.step; groups with
  * their own learning rate as built at trainer.py:72-79):

@@ -953,3 +953,39 @@ def test_round2_entry_points_on_empty_and_degenerate_inputs(ops):
     assert (p == 1).all()
     with ops.defer_weight_grads():
         pass
+
+
+# ------------------------------------------------------------------ segmentation loss
+
+@pytest.mark.parametrize("N,C,weighted,i64", [(19464, 20, False, True), (5000, 13, True, False), (300, 20, True, True),
+                                              (1, 5, False, True), (70000, 20, False, False)])
+def test_cross_entropy_lut_vs_torch(ops, N, C, weighted, i64):
+    """csrc/loss.hip against the reference's formulation (architectures.py:345-372): labels outside valid_labels -> -1,
+    CrossEntropyLoss(weight, ignore_index=-1) on the (1, C, N) logits; value and gradient; run twice (deterministic)."""
+    torch.manual_seed(N + C)
+    valid = np.sort(np.random.RandomState(C).choice(np.arange(0, C + 6), C, replace=False))       # raw label values
+    top = int(valid.max())
+    table = np.full(top + 3, -1, np.int64)
+    for i, c in enumerate(valid):
+        table[int(c) + 1] = i
+    lut = torch.from_numpy(table).to("cuda", torch.int32)
+    labels = torch.randint(-2, top + 4, (N,), device="cuda", dtype=torch.int64 if i64 else torch.int32)
+    if N > 1:
+        labels[0] = int(valid[0])                                  # at least one kept point
+    else:
+        labels[:] = int(valid[-1])
+    x = (torch.randn(N, C, device="cuda") * 3).requires_grad_(True)
+    w = (torch.rand(C, device="cuda") + 0.5) if weighted else None
+    loss = ops.cross_entropy_lut(x, labels, lut, w)
+    (g,) = torch.autograd.grad(loss * 1.7, x)
+    loss2 = ops.cross_entropy_lut(x, labels, lut, w)
+    assert float(loss) == float(loss2)
+    target = torch.from_numpy(table).cuda()[labels.long().clamp(-1, top + 1) + 1]
+    xr = x.detach().clone().requires_grad_(True)
+    ref = torch.nn.CrossEntropyLoss(weight=w, ignore_index=-1)(xr.t().unsqueeze(0), target.unsqueeze(0))
+    (gr,) = torch.autograd.grad(ref * 1.7, xr)
+    assert abs(float(loss) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+    assert rel_err(g.cpu().numpy(), gr.cpu().numpy()) < 1e-5
+    # every point ignored: NaN like torch's mean over nothing, gradient of the ignored rows zero
+    none = ops.cross_entropy_lut(x, torch.full_like(labels, -1), lut, w)
+    assert torch.isnan(none)

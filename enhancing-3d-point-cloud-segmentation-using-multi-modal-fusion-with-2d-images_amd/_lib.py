@@ -72,6 +72,7 @@ _SIGNATURES = {
     "mvk_ball_query": (C.c_int, [_vp, _i64, _vp, C.c_double, _vp, _vp, _vp, _vp, _i64, _vp]),
     "mvk_tukey_update": (C.c_int, [_vp, _i64, _vp, C.c_double, _vp, _vp]),
     "mvk_fa_gather_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
+    "mvk_fa_gather_fwd_ex": (C.c_int, [_vp, _i, _vp, _vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
     "mvk_group_points_fwd": (C.c_int, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
     "mvk_group_points_bwd": (C.c_int, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),
     "mvk_group_points_fwd_f64": (C.c_int, [_vp, _vp, _i, _i, _i64, _i64, _i, _vp, _vp]),

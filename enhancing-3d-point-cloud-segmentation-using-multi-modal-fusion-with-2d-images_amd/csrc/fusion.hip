@@ -514,16 +514,18 @@ __global__ void group_points_bwd_kernel(const T* __restrict__ go, const int64_t*
 // h*w channel plane (L2 resident). Reads the 2D feature map in its native (nv, C, h, w) layout: the
 // (b, C, nv*h*w) transpose copy of the reference is not needed.
 // ---------------------------------------------------------------------------------------------
-__global__ void fa_gather_kernel(const float* __restrict__ feat /* [nv,C,hw] */, const float* __restrict__ xyz /* [nv*hw,3] */,
+__global__ void fa_gather_kernel(const float* __restrict__ feat /* [nv,C,hw], or [nv,hw,C] (channels last) */,
+                                 const float* __restrict__ xyz /* [nv*hw,3] */,
                                  const int64_t* __restrict__ knn /* [np*k] */, const float* __restrict__ pts /* [np,3] */,
-                                 int C, int nv, int64_t hw, int64_t npk, int k, float* __restrict__ X /* [C+4, npk] */) {
+                                 int C, int nv, int64_t hw, int64_t npk, int k, float* __restrict__ X /* [C+4, npk] */,
+                                 int64_t ch_stride, int64_t px_stride) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= npk) return;
   const int64_t p = knn[e];
   const bool ok = p >= 0 && p < nv * hw;
   const int64_t view = ok ? p / hw : 0, pix = ok ? p % hw : 0;
-  const float* f = feat + view * C * hw + pix;
-  for (int c = blockIdx.y; c < C; c += gridDim.y) X[(int64_t)c * npk + e] = ok ? f[(int64_t)c * hw] : 0.f;
+  const float* f = feat + view * C * hw + pix * px_stride;
+  for (int c = blockIdx.y; c < C; c += gridDim.y) X[(int64_t)c * npk + e] = ok ? f[(int64_t)c * ch_stride] : 0.f;
   if (blockIdx.y == 0) {
     const int64_t n = e / k;
     float dx = 0.f, dy = 0.f, dz = 0.f;
@@ -679,17 +681,24 @@ namespace {
 
 }  // namespace
 
-extern "C" int mvk_fa_gather_fwd(const float* feature_2d, const float* image_xyz, const int64_t* knn,
-                                 const float* points, int C, int nv, int64_t hw, int64_t np, int k, float* X,
-                                 void* stream) {
+extern "C" int mvk_fa_gather_fwd_ex(const float* feature_2d, int channels_last, const float* image_xyz, const int64_t* knn,
+                                    const float* points, int C, int nv, int64_t hw, int64_t np, int k, float* X,
+                                    void* stream) {
   MVK_REQUIRE(C > 0 && nv > 0 && hw > 0 && np >= 0 && k > 0, "fa_gather: bad sizes");
   const int64_t npk = np * k;
   if (npk == 0) return 0;
+  // channels last: a pixel's C channels are one contiguous run, the 8 channel slices of a point (grid.y) share its lines
   dim3 grid((unsigned)cdiv64(npk, 256), 8);
   hipLaunchKernelGGL(fa_gather_kernel, grid, dim3(256), 0, (hipStream_t)stream, feature_2d, image_xyz, knn, points, C, nv,
-                     hw, npk, k, X);
+                     hw, npk, k, X, channels_last ? (int64_t)1 : hw, channels_last ? (int64_t)C : (int64_t)1);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int mvk_fa_gather_fwd(const float* feature_2d, const float* image_xyz, const int64_t* knn,
+                                 const float* points, int C, int nv, int64_t hw, int64_t np, int k, float* X,
+                                 void* stream) {
+  return mvk_fa_gather_fwd_ex(feature_2d, 0, image_xyz, knn, points, C, nv, hw, np, k, X, stream);
 }
 
 extern "C" int mvk_unproject_depth(const uint16_t* depth, int nv, int h, int w, const double* cam_inv,

@@ -214,6 +214,6 @@ class KPFCNN(_SegmentationLossMixin, nn.Module):
         self._init_losses(config, lbl_values, ign_lbls)
 
     def forward(self, batch, config):
-        x = batch.features.clone().detach()
+        x = batch.features.detach()          # (`.clone().detach()` in the reference; nothing below writes x in place)
         x = run_encoder_decoder(self, x, batch)
         return self.head_softmax(self.head_mlp(x, batch), batch)

@@ -33,6 +33,7 @@ class KPFCNN_featureAggre(_SegmentationLossMixin, nn.Module):
     def forward(self, batch, config):
         feature_2d3d = lift_2d_features(self, batch)                       # (np, 64)
         stacked = torch.cat((batch.feature_3d, feature_2d3d), dim=1)       # e.g. 1 + z + 64 = 66 (:290-291)
-        x = stacked.clone().detach()                                       # :295 -- no grad reaches the 2D branch
+        x = stacked.detach()               # :295 (`.clone().detach()`: no grad reaches the 2D branch; nothing below
+                                           # writes x in place, so the copy itself is not needed)
         x = run_encoder_decoder(self, x, batch)
         return self.head_softmax(self.head_mlp(x, batch), batch)

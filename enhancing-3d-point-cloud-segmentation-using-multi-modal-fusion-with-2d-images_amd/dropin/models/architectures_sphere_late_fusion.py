@@ -34,7 +34,7 @@ class KPFCNN_featureAggre(_SegmentationLossMixin, nn.Module):
 
     def forward(self, batch, config):
         feature_2d3d = lift_2d_features(self, batch)
-        x = batch.feature_3d.clone().detach()
+        x = batch.feature_3d.detach()
         x = run_encoder_decoder(self, x, batch)
         x = self.transform_mlp(x, batch)
         x = torch.cat((x, feature_2d3d), dim=1)

@@ -37,8 +37,8 @@ class KPFCNN_featureAggre(_SegmentationLossMixin, nn.Module):
     def forward(self, batch, config):
         feature_2d3d = lift_2d_features(self, batch)
         ones = torch.ones_like(batch.feat_aggre_points[:, :, :1].squeeze(0))     # (np, 1)
-        x_2d = torch.cat((ones, feature_2d3d), dim=1).clone().detach()           # 65
-        x_3d = batch.feature_3d.clone().detach()                                 # e.g. 4
+        x_2d = torch.cat((ones, feature_2d3d), dim=1).detach()                   # 65 (`.clone().detach()`)
+        x_3d = batch.feature_3d.detach()                                         # e.g. 4
         skip_x = []
         for block_i, block_op in enumerate(self.encoder_blocks_3d):
             if block_i in self.encoder_skips:

@@ -1064,14 +1064,20 @@ def fa_gather(feature_2d, image_xyz, knn, points):
     knn (np,k) int64 flat pixel indices, points (np,3) f32. Treated as a constant by autograd (the 2D
     encoder is frozen in every MV-KPConv variant, architectures_sphere.py:234-237)."""
     _dev(feature_2d, image_xyz, knn, points)
-    f, xyz, pts = _f32c(feature_2d.detach()), _f32c(image_xyz), _f32c(points)
+    f = feature_2d.detach()
+    # the frozen encoder's convolutions deliver channels-last maps: read in place (no NCHW copy of the map)
+    cl = (f.dim() == 4 and f.dtype == torch.float32 and not f.is_contiguous()
+          and f.is_contiguous(memory_format=torch.channels_last))
+    if not cl:
+        f = _f32c(f)
+    xyz, pts = _f32c(image_xyz), _f32c(points)
     knn = knn.contiguous()
     if knn.dtype != torch.int64:
         raise RuntimeError("fa_gather: knn must be int64")
     nv, Cc, h, w = f.shape
     np_, k = knn.shape
     X = torch.empty((Cc + 4, np_ * k), device=f.device, dtype=torch.float32)
-    check(lib().mvk_fa_gather_fwd(_p(f), _p(xyz), _p(knn), _p(pts), Cc, nv, h * w, np_, k, _p(X), _stream()))
+    check(lib().mvk_fa_gather_fwd_ex(_p(f), int(cl), _p(xyz), _p(knn), _p(pts), Cc, nv, h * w, np_, k, _p(X), _stream()))
     return X
 
 

@@ -345,6 +345,10 @@ int mvk_knn_f64(const float* queries, int64_t nq, const double* keys, const uint
 int mvk_fa_gather_fwd(const float* feature_2d, const float* image_xyz, const int64_t* knn,
                       const float* points, int C, int nv, int64_t hw, int64_t np, int k, float* X,
                       void* stream);
+/* The same reading a channels-last feature map ([nv,h,w,C] in memory: what the frozen encoder's convolutions
+ * produce) in place when channels_last != 0. */
+int mvk_fa_gather_fwd_ex(const float* feature_2d, int channels_last, const float* image_xyz, const int64_t* knn,
+                         const float* points, int C, int nv, int64_t hw, int64_t np, int k, float* X, void* stream);
 
 /* ---------------- sphere extraction + sampling potentials ---- */
 

@@ -979,13 +979,28 @@ def test_cross_entropy_lut_vs_torch(ops, N, C, weighted, i64):
     loss = ops.cross_entropy_lut(x, labels, lut, w)
     (g,) = torch.autograd.grad(loss * 1.7, x)
     loss2 = ops.cross_entropy_lut(x, labels, lut, w)
-    assert float(loss) == float(loss2)
+    assert float(loss.detach()) == float(loss2.detach())
     target = torch.from_numpy(table).cuda()[labels.long().clamp(-1, top + 1) + 1]
     xr = x.detach().clone().requires_grad_(True)
     ref = torch.nn.CrossEntropyLoss(weight=w, ignore_index=-1)(xr.t().unsqueeze(0), target.unsqueeze(0))
     (gr,) = torch.autograd.grad(ref * 1.7, xr)
-    assert abs(float(loss) - float(ref)) < 2e-6 * max(1.0, abs(float(ref)))
+    assert abs(float(loss.detach()) - float(ref.detach())) < 2e-6 * max(1.0, abs(float(ref.detach())))
     assert rel_err(g.cpu().numpy(), gr.cpu().numpy()) < 1e-5
     # every point ignored: NaN like torch's mean over nothing, gradient of the ignored rows zero
     none = ops.cross_entropy_lut(x, torch.full_like(labels, -1), lut, w)
     assert torch.isnan(none)
+
+
+def test_fa_gather_reads_a_channels_last_map_in_place(ops):
+    """mvk_fa_gather_fwd_ex: the (nv, C, h, w) map in channels-last memory gives the same X as its NCHW copy."""
+    torch.manual_seed(3)
+    nv, Cc, h, w, npts, k = 3, 64, 12, 16, 500, 3
+    f = torch.randn(nv, Cc, h, w, device="cuda")
+    xyz = torch.randn(nv, h, w, 3, device="cuda")
+    pts = torch.randn(npts, 3, device="cuda")
+    knn = torch.randint(0, nv * h * w, (npts, k), device="cuda")
+    a = ops.fa_gather(f, xyz, knn, pts)
+    fcl = f.contiguous(memory_format=torch.channels_last)
+    assert not fcl.is_contiguous()
+    b = ops.fa_gather(fcl, xyz, knn, pts)
+    assert torch.equal(a, b)

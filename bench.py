@@ -379,17 +379,29 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         graph = torch.cuda.CUDAGraph()
         other = statics[1 - statics.index(static)]
 
-        def fork_encoder():
+        side_first = os.environ.get("MVK_NET_FIRST") != "1"      # development: 1 = capture the network's nodes first
+
+        def fork_encoder(work=True):
             # parallel branches of the SAME graph (separate graph launches do not overlap on this runtime,
             # branches of one graph do): features of the NEXT batch's views, and the NEXT batch's pyramid /
-            # unprojection / 3-NN, into the other static set
+            # unprojection / 3-NN, into the other static set.
+            # Measured (MVK_BENCH_DIAG=noside / onlyside): network alone 3.33 ms, side branches alone 2.16 ms, together
+            # 4.74 ms -- kernel time of the three branches is 6.5 ms, i.e. the wide kernels of the branches time-share
+            # the chip. Capturing the network's nodes BEFORE the side branches' (work=False here, side_work() after the
+            # network) makes it worse (5.04 ms): the side branches then start late and end after the network.
             cur = torch.cuda.current_stream()
             if enc is not None:
                 enc_stream.wait_stream(cur)
+            if use_chain:
+                build_stream.wait_stream(cur)
+            if work:
+                side_work()
+
+        def side_work():
+            if enc is not None:
                 with torch.cuda.stream(enc_stream):
                     other.feature_2d.copy_(encode(enc_in))
             if use_chain:
-                build_stream.wait_stream(cur)
                 with torch.cuda.stream(build_stream):
                     chains[1 - statics.index(static)].build(other)
 
@@ -400,10 +412,18 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                 torch.cuda.current_stream().wait_stream(build_stream)
 
         if reducer is None:
+            diag = os.environ.get("MVK_BENCH_DIAG", "")    # development: "noside" / "onlyside" time the branches apart
             with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
-                fork_encoder()
-                loss = net_step_captured(net, static, cfg, params, opt, None)
-                join_encoder()
+                if diag != "noside":
+                    fork_encoder(work=side_first)
+                if diag != "onlyside":
+                    loss = net_step_captured(net, static, cfg, params, opt, None)
+                else:
+                    loss = torch.zeros((), device=dev)
+                if diag != "noside":
+                    if not side_first:
+                        side_work()
+                    join_encoder()
             return graph.replay, loss
         # N > 1: the RCCL all-reduces stay eager calls between graphs (capturing them was tried with a one-rank process
         # group: the group's watchdog thread queries an event recorded in the capturing stream and aborts with

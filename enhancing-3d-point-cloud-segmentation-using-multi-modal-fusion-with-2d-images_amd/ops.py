@@ -379,7 +379,7 @@ def _flush_deferred():
     dev = items[0][0].device
     n = len(items)
     prob = np.zeros(n, dtype=np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i8"), ("N", "<i8"), ("Kd", "<i8")]))
-    for i, (A, B, out_ptr) in enumerate(items):
+    for i, (A, B, out_ptr, _) in enumerate(items):
         prob[i] = (A.data_ptr(), B.data_ptr(), out_ptr, A.shape[1], B.shape[1], A.shape[0])
     slots = _defer_slots(dev)
     if torch.cuda.is_current_stream_capturing():
@@ -396,6 +396,9 @@ def _flush_deferred():
     splits = np.zeros(n, np.int32)
     check(lib().mvk_gemm_f32_tn_grouped_plan(prob.ctypes.data_as(C.c_void_p), n, C.c_void_p(slot["host"].data_ptr()),
                                              C.byref(nn), C.byref(wn), C.byref(ww), splits.ctypes.data_as(C.c_void_p)))
+    for i, item in enumerate(items):
+        if splits[i] > 1 and not item[3]:
+            raise RuntimeError("defer_weight_grads: the grouped plan splits a product whose output was not zero-initialised")
     nb = n * int(lib().mvk_gemm_group_entry_bytes())
     slot["dev"][:nb].copy_(slot["host"][:nb], non_blocking=True)
     check(lib().mvk_gemm_f32_tn_grouped(C.c_void_p(slot["dev"].data_ptr()), n, nn.value, wn.value, ww.value, _stream()))
@@ -411,10 +414,14 @@ def _dw_gemm(A, B, transB=False):
     if _DEFER["on"] and not transB and A.is_cuda and B.shape[1] > 16 and len(_DEFER["items"]) < _DW_MAX \
             and A.shape[0] > 0 and A.shape[1] > 0:
         A, B = _f32c(A), _f32c(B)
-        out = _zeros((A.shape[1], B.shape[1]), A.device)       # zero-initialised: a split reduction accumulates into it
+        # a split reduction accumulates into a zero-initialised output (arena slice); an unsplit one (the big
+        # coarse-level weights: few rows to reduce over, 2/3 of all weight-gradient bytes) writes every element
+        zeroed = gemm_plan(A.shape[1], B.shape[1], A.shape[0])[0] > 1
+        out = (_zeros((A.shape[1], B.shape[1]), A.device) if zeroed
+               else torch.empty((A.shape[1], B.shape[1]), device=A.device, dtype=torch.float32))
         # only the ADDRESS is recorded: a second reference to the tensor would make autograd's AccumulateGrad clone the
         # gradient instead of adopting it (one copy launch per parameter); the tensor itself lives on as the .grad
-        _DEFER["items"].append((A, B, out.data_ptr()))
+        _DEFER["items"].append((A, B, out.data_ptr(), zeroed))
         return out
     return _gemm_off_chain(A, B, transA=True, transB=transB)
 

@@ -287,6 +287,39 @@ def test_kpconv_every_kernel_variant_vs_numpy_oracle(ops, cin, cout, H):
     assert rel_err(Wt.grad.cpu().numpy(), dW) < FP_TOL
 
 
+@pytest.mark.parametrize("Nq,cin,H,f16", [(40000, 32, 12, False), (70000, 66, 30, False), (17000, 64, 40, False),
+                                          (40000, 32, 12, True), (21000, 128, 70, False)])
+def test_kpconv_gather_launches_with_sharing_workgroups_vs_numpy_oracle(ops, Nq, cin, H, f16):
+    """Launches large enough that their last partial round of waves runs as sharing workgroups (the waves of a workgroup
+    split the neighbour chunks of ONE point group and wave 0 adds the partial aggregates, csrc/kpconv.hip): the
+    aggregate of every region of the launch -- independent waves, sharing workgroups, the ragged last group --
+    against the float64 numpy restatement."""
+    from oracle import npref
+    plan = ops.kpconv_gather_plan(Nq, 3000, H, cin, elem_bytes=2 if f16 else 4)
+    assert 0 < plan["first_sharing_workgroup"] < plan["workgroups"], plan       # the case this test is about
+    rng = np.random.default_rng(Nq + cin)
+    Ns, K = 3000, 15
+    q = (rng.random((Nq, 3)) * 0.3).astype(np.float32)
+    s = (rng.random((Ns, 3)) * 0.3).astype(np.float32)
+    idx = rng.integers(0, Ns + 1, (Nq, H)).astype(np.int32)
+    idx[:, H // 2:][rng.random((Nq, H - H // 2)) < 0.4] = Ns
+    x = rng.normal(size=(Ns, cin)).astype(np.float32)
+    kp = (rng.normal(size=(K, 3)) * 0.05).astype(np.float32)
+    if f16:
+        x = x.astype(np.float16).astype(np.float32)
+        A = ops.kpconv_gather_f16(T(q), T(s), T(idx), T(x).half(), T(kp), 0.06).float().cpu().numpy()
+    else:
+        A = ops.kpconv_gather(T(q), T(s), T(idx), T(x), T(kp), 0.06)[0].cpu().numpy()
+    ppw = plan["points_per_wave"]
+    first_shared = plan["first_sharing_workgroup"] * 4 * ppw
+    rows = np.unique(np.concatenate([np.arange(0, 64), np.arange(first_shared - 64, first_shared + 64),
+                                     np.arange(Nq - 64, Nq), rng.integers(0, Nq, 512)]))
+    W1 = np.zeros((K, cin, 1))
+    _, want, _ = npref.kpconv_forward(q[rows].astype(np.float64), s.astype(np.float64), idx[rows].astype(np.int64),
+                                      x.astype(np.float64), kp.astype(np.float64), W1, 0.06, return_A=True)
+    assert rel_err(A[rows], want) < (2e-3 if f16 else FP_TOL)
+
+
 @pytest.mark.parametrize("name,modulated", [("g4_kpconv_deform", False), ("g4_kpconv_deform_mod", True)])
 def test_kpconv_deformable_golden(ops, name, modulated):
     g = load_golden(name)

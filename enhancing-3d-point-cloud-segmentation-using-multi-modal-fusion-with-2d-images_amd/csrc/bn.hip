@@ -833,7 +833,8 @@ extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t 
   if (R == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   if (R > bn_small_rows() && R <= bn_mid_rows() && D % 4 == 0 &&
-      aligned16(x, y, addend, gamma, beta, nullptr, nullptr, nullptr)) {
+      aligned16(x, y, addend, gamma, beta, mean, invstd, running_mean) &&
+      aligned16(running_var, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) {
     hipLaunchKernelGGL(bn_mid_fwd, dim3((unsigned)cdiv64(D, 16)), dim3(1024), 0, st, x, n_valid, (int)R, D, gamma, beta,
                        eps, momentum, slope, running_mean, running_var, mean, invstd, y, (long long*)num_batches_tracked, addend);
     MVK_CHECK_HIP(hipGetLastError());

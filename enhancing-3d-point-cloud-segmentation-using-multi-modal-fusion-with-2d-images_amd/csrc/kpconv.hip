@@ -655,6 +655,99 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
   }
 }
 
+// ---------------------------------------------------------------------------
+// Rigid gather for rows of <= 4 channels (the first layer of the baseline / middle- / late-fusion nets: features
+// (1, z) or (1, r, g, b)). The vector kernel would run with one lane per point AND one neighbour per chunk --
+// an LDS round trip and a barrier per neighbour (119 us for 19 464 points). Here SLP = 4 lanes own a point: lane
+// `sub` takes the neighbours sub, sub + 4, ... in batches of four (indices, then xyz + feature rows, then the
+// products), all accumulators (15 x <= 4) in registers, no LDS; the four partial aggregates are added by two
+// butterfly steps at the end (one lane per point alone leaves 304 waves on 1 024 SIMDs, each a 50 us chain).
+// ---------------------------------------------------------------------------
+template <bool IDX64, bool FAST>
+__global__ __launch_bounds__(256) void kpconv_gather_small(KPParams P) {
+  constexpr int SLP = 4;
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int sub = (int)(gid & (SLP - 1));
+  const bool live = gid / SLP < P.Nq;                      // (whole waves take part in the shuffles below)
+  const int64_t n = live ? gid / SLP : P.Nq - 1;
+  const float qx = P.q[n * 3], qy = P.q[n * 3 + 1], qz = P.q[n * 3 + 2];
+  const float inv_ext = 1.0f / P.extent;
+  const float* __restrict__ kp = P.kp;
+  const int Cin = P.Cin;
+  float acc[KMAX - 1][4];
+#pragma unroll
+  for (int kk = 0; kk < KMAX - 1; ++kk)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[kk][c] = 0.f;
+  constexpr int UBS = 4;
+  for (int h0 = sub; h0 < P.H; h0 += UBS * SLP) {
+    int j[UBS];
+#pragma unroll
+    for (int u = 0; u < UBS; ++u)
+      j[u] = h0 + u * SLP < P.H ? load_idx<IDX64>(P.idx, n * P.H + h0 + u * SLP, P.Ns) : -1;
+    float sx[UBS], sy[UBS], sz[UBS], xv[UBS][4];
+#pragma unroll
+    for (int u = 0; u < UBS; ++u) {
+      const int64_t jj = j[u] >= 0 ? j[u] : 0;                  // shadow entries read row 0 and are not applied
+      sx[u] = P.s[jj * 3];
+      sy[u] = P.s[jj * 3 + 1];
+      sz[u] = P.s[jj * 3 + 2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) xv[u][c] = c < Cin ? P.x[jj * Cin + c] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < UBS; ++u) {
+      if (j[u] < 0) continue;
+      const float rx = sx[u] - qx, ry = sy[u] - qy, rz = sz[u] - qz;
+      float wv[KMAX - 1];
+      float bd = INFINITY;
+      int bk = 0;
+#pragma unroll
+      for (int kk = 0; kk < KMAX - 1; ++kk) {
+        wv[kk] = 0.f;
+        if (kk < P.K) {
+          const float dx = rx - kp[kk * 3], dy = ry - kp[kk * 3 + 1], dz = rz - kp[kk * 3 + 2];
+          const float d2 = dx * dx + dy * dy + dz * dz;  // blocks.py:294-297
+          if (FAST) {
+            wv[kk] = fmaxf(1.0f - __builtin_amdgcn_sqrtf(d2) * inv_ext, 0.0f);  // blocks.py:335-338
+          } else {
+            wv[kk] = influence_w(d2, P.extent, P.influence);
+            if (d2 < bd) {
+              bd = d2;
+              bk = kk;
+            }
+          }
+        }
+      }
+      if (!FAST && P.aggregation == MVK_AGG_CLOSEST) {  // one-hot of the first arg-min (blocks.py:349-351)
+#pragma unroll
+        for (int kk = 0; kk < KMAX - 1; ++kk)
+          if (kk != bk) wv[kk] = 0.f;
+      }
+#pragma unroll
+      for (int kk = 0; kk < KMAX - 1; ++kk)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[kk][c] += wv[kk] * xv[u][c];
+    }
+  }
+#pragma unroll
+  for (int kk = 0; kk < KMAX - 1; ++kk)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      acc[kk][c] += __shfl_xor(acc[kk][c], 1);
+      acc[kk][c] += __shfl_xor(acc[kk][c], 2);
+    }
+  if (!live) return;
+#pragma unroll
+  for (int kk = 0; kk < KMAX - 1; ++kk) {
+    if (kk < P.K && (kk & (SLP - 1)) == sub) {             // the four lanes share the stores
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < Cin) P.A[(n * P.K + kk) * Cin + c] = acc[kk][c];
+    }
+  }
+}
+
 // Launch geometry of the vector gather kernel for one layer (also exported: mvk_kpconv_gather_plan).
 struct VecPlan {
   int LPP, PPW, HC;   // lanes per point, points per wave, neighbours per chunk and point
@@ -798,6 +891,16 @@ extern "C" int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s,
     } else {
       launch_lane_channel<0, true>(P, idx64, st);
     }
+  } else if (Cin <= 4) {
+    const bool fast = influence == MVK_INFL_LINEAR && aggregation == MVK_AGG_SUM;
+    dim3 grid((unsigned)cdiv64(Nq * 4, 256)), block(256);       // four lanes per point
+    if (idx64) {
+      if (fast) hipLaunchKernelGGL((kpconv_gather_small<true, true>), grid, block, 0, st, P);
+      else hipLaunchKernelGGL((kpconv_gather_small<true, false>), grid, block, 0, st, P);
+    } else {
+      if (fast) hipLaunchKernelGGL((kpconv_gather_small<false, true>), grid, block, 0, st, P);
+      else hipLaunchKernelGGL((kpconv_gather_small<false, false>), grid, block, 0, st, P);
+    }
   } else if (Cin <= 256) {
     launch_vec<1>(P, idx64, st);
   } else if (Cin <= 512) {
@@ -841,12 +944,13 @@ extern "C" int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s
 // Launch geometry mvk_kpconv_gather_fwd (elem_bytes 4) / mvk_kpconv_gather_fwd_f16 (elem_bytes 2) use for a layer
 // with linear influence and sum aggregation: out[0..6] = lanes per point, points per wave, rows per batch of the
 // branch-free variant (0 = general variant), first sharing workgroup, waves per workgroup, workgroups, grid
-// threads (what a kernel trace reports). out[5] = 0: the layer runs on the one-point-per-wave kernel instead.
+// threads (what a kernel trace reports). out[5] = 0: the layer runs on another kernel (one point per wave, or one
+// point per lane for rows of <= 4 channels).
 extern "C" int mvk_kpconv_gather_plan(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, int deformable,
                                       int64_t* out) {
   MVK_REQUIRE(out != nullptr && (elem_bytes == 2 || elem_bytes == 4), "kpconv plan: bad arguments");
   for (int i = 0; i < 7; ++i) out[i] = 0;
-  if (Nq <= 0 || Cin <= 0 || Cin > 512 || (deformable && Cin < 13)) return 0;
+  if (Nq <= 0 || Cin <= 0 || Cin > 512 || (deformable && Cin < 13) || (!deformable && elem_bytes == 4 && Cin <= 4)) return 0;
   const VecPlan v = plan_vec(Nq, Ns, H, Cin, elem_bytes, true, elem_bytes == 4 || (Cin & 1) == 0, deformable != 0);
   out[0] = v.LPP; out[1] = v.PPW; out[2] = v.fub; out[3] = v.B1; out[4] = v.nw; out[5] = v.wgs;
   out[6] = v.wgs * 64 * v.nw;

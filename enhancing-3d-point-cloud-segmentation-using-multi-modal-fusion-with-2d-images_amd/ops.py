@@ -211,7 +211,12 @@ def profile_collect_contraction():
 
 def _gather_kernel_name(Cin, deform):
     if deform:
+        if 13 <= Cin <= 512:
+            lpp = min((Cin + 3) // 4, 64)
+            return "kpconv_gather_vec<NCH=%d,deform>(LPP=%d,PPW=%d)" % (1 if Cin <= 256 else 2, lpp, 64 // lpp)
         return "kpconv_lane_channel<fwd,deform>"
+    if Cin <= 4:
+        return "kpconv_gather_small(4 lanes per point)"
     if Cin <= 512:
         lpp = min((Cin + 3) // 4, 64)
         return "kpconv_gather_vec<NCH=%d>(LPP=%d,PPW=%d)" % (1 if Cin <= 256 else 2, lpp, 64 // lpp)

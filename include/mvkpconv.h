@@ -68,7 +68,8 @@ int mvk_kpconv_gather_fwd_f16(const float* q, int64_t Nq, const float* s, int64_
  * (elem_bytes 4 = mvk_kpconv_gather_fwd, 2 = mvk_kpconv_gather_fwd_f16; host only, no GPU call):
  * out[0..6] = lanes per point, points per wave, feature rows per batch of the branch-free kernel variant
  * (0 = general variant), first workgroup whose waves share their points, waves per workgroup, workgroups,
- * grid threads (the figure a kernel trace reports). out[5] = 0: the layer runs on the one-point-per-wave kernel. */
+ * grid threads (the figure a kernel trace reports). out[5] = 0: the layer runs on another kernel (one point per wave;
+ * one point per lane for rows of <= 4 channels). */
 int mvk_kpconv_gather_plan(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, int deformable, int64_t* out /* [7] */);
 
 /* dx[idx[n,h], c] += sum_k w[n,h,k] * dA[n,k,c]   (shadow rows discarded).

@@ -49,8 +49,15 @@ __device__ __forceinline__ float influence_w(float d2, float extent, int influen
   return 1.0f;
 }
 
+__device__ __forceinline__ void wave_sync_lds() {   // LDS hand-off inside ONE wave
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------------------
-// Phase A (shared): fills rel[64] (xyz + neighbour row or -1) and w[64][16].
+// Phase A (shared): fills rel[64] (xyz + neighbour row or -1) and w[64][16]. One WAVE works on its own rel / wl
+// (the hand-offs are wave-level: a workgroup may hold several independent waves).
 // Lane mapping: A1 lane = ph = p*HC + h ; A2 item = t*64 + lane, k = lane & 15, ph = item >> 4.
 // WPAD = extra floats between consecutive points' weight blocks (bank spreading).
 // Returns the lane's neighbour row j (A1 mapping) so callers can shuffle it.
@@ -78,7 +85,7 @@ __device__ __forceinline__ int phase_a(const KPParams& P, int64_t n0, int h0, in
     }
   }
   rel[lane] = make_float4(rx, ry, rz, __int_as_float(j));
-  __syncthreads();
+  wave_sync_lds();
 
   const int k = lane & 15;
   const float ext2 = P.extent * P.extent;
@@ -122,7 +129,7 @@ __device__ __forceinline__ int phase_a(const KPParams& P, int64_t n0, int h0, in
     }
     wl[(ph / HC) * (HC * 16 + WPAD) + (ph % HC) * 16 + k] = w;
   }
-  __syncthreads();
+  wave_sync_lds();
   return j;
 }
 
@@ -144,11 +151,6 @@ __device__ __forceinline__ int phase_a(const KPParams& P, int64_t n0, int h0, in
 // dispatched too slowly to keep the SIMDs' wave slots filled (measured 2.3 resident waves per SIMD of 4)
 constexpr int GWPB = 4;
 
-__device__ __forceinline__ void wave_sync_lds() {   // LDS hand-off inside ONE wave
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
 // 4 consecutive channels of a feature row / of the aggregate, stored as f32 or (fp16-feature mode) f16
 typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
@@ -554,12 +556,18 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
 // (any Cin, rigid or deformable). MODE 1: backward scatter (+ deformable grads).
 // Channels handled: c = c0 + lane + 64*slot, slot < NSLOT.
 // ---------------------------------------------------------------------------
-template <int NSLOT, bool IDX64, int MODE, bool DEFORM>
-__global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
+// WPB > 1 (backward scatter of the layers searched at the deform radius: hundreds of neighbour columns for a few
+// hundred points): the WPB waves of a workgroup work on the SAME point, wave w on the 64-neighbour chunks w, w + WPB,
+// ...; they meet only in the atomics on dx (one wave per point was a 26 us serial chain on a third of the SIMDs).
+template <int NSLOT, bool IDX64, int MODE, bool DEFORM, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB) void kpconv_lane_channel(KPParams P, int c0) {
   constexpr int HC = 64, WPAD = 0;
-  __shared__ float4 rel[64];
-  __shared__ float wl[64 * 16];
-  const int lane = threadIdx.x;
+  static_assert(WPB == 1 || MODE == 1, "only the scatter splits a point over waves");
+  __shared__ float4 rel_all[WPB][64];
+  __shared__ float wl_all[WPB][64 * 16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float4* rel = rel_all[wid];
+  float* wl = wl_all[wid];
   const int64_t n = blockIdx.x;
   const float* qp = P.q + n * 3;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
@@ -592,7 +600,7 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
     }
   }
 
-  for (int h0 = 0; h0 < P.H; h0 += HC) {
+  for (int h0 = wid * HC; h0 < P.H; h0 += HC * WPB) {
     int j = phase_a<1, HC, WPAD, IDX64, DEFORM>(P, n, h0, lane, rel, wl, qx, qy, qz, true, kx, ky,
                                                  kz, &run_min, &run_arg);
     if (__ballot(j >= 0) != 0ull) {
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(64) void kpconv_lane_channel(KPParams P, int c0) {
         }
       }
     }
-    __syncthreads();
+    wave_sync_lds();
   }
 
   if (MODE == 0) {
@@ -831,12 +839,20 @@ int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
 
 template <int MODE, bool DEFORM>
 int launch_lane_channel(const KPParams& P, int idx64, hipStream_t st) {
-  dim3 grid((unsigned)P.Nq), block(64);
+  // scatter of a layer with more than one 64-neighbour chunk (searched at the deform radius): four waves per point
+  static const bool split_on = getenv("MVK_SCATTER_SPLIT") == nullptr || atoi(getenv("MVK_SCATTER_SPLIT")) != 0;
+  const bool split = MODE == 1 && split_on && P.H > 64;
+  dim3 grid((unsigned)P.Nq), block(split ? 256 : 64);
   for (int c0 = 0; c0 < P.Cin; c0 += 512) {
     int cw = P.Cin - c0 < 512 ? P.Cin - c0 : 512;
     int ns = (cw + 63) / 64;
 #define LC(NS)                                                                                       \
-  if (idx64)                                                                                         \
+  if (split) {                                                                                       \
+    if (idx64)                                                                                       \
+      hipLaunchKernelGGL((kpconv_lane_channel<NS, true, MODE, DEFORM, (MODE == 1 ? 4 : 1)>), grid, block, 0, st, P, c0);  \
+    else                                                                                             \
+      hipLaunchKernelGGL((kpconv_lane_channel<NS, false, MODE, DEFORM, (MODE == 1 ? 4 : 1)>), grid, block, 0, st, P, c0); \
+  } else if (idx64)                                                                                  \
     hipLaunchKernelGGL((kpconv_lane_channel<NS, true, MODE, DEFORM>), grid, block, 0, st, P, c0);    \
   else                                                                                               \
     hipLaunchKernelGGL((kpconv_lane_channel<NS, false, MODE, DEFORM>), grid, block, 0, st, P, c0);

@@ -17,6 +17,8 @@
 //         power * ( 2 * mean_{n,k} min_d2 / ext^2  +  sum_i mean_n sum_{j != i} clamp_max(|loc_i - sg(loc_j)| - R, 0)^2 / K )
 //     with loc = deformed_KP / ext. One lane per point evaluates the 15 x 14 pairs, the launch also writes both
 //     gradients (they do not depend on anything upstream), so the ~50 tensor ops per layer become one launch.
+#include <stdlib.h>
+
 #include "common.h"
 
 #define DKMAX 16
@@ -48,14 +50,22 @@ __device__ __forceinline__ void wave_lds_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-template <bool IDX64>
-__global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
-  extern __shared__ __attribute__((aligned(16))) float dsm[];   // [K][Cin4] dA block of this point, then the int list
-  const int lane = threadIdx.x;
+// WPB waves per point (4 when the neighbour rows are wider than one 64-column chunk, i.e. at the deform radius):
+// wave w walks the chunks w, w + WPB, ... of pass 1 into ITS list; the lists are then read as ONE sequence (region
+// offsets through LDS) of which wave w takes the 64-entry pieces w, w + WPB, ... in pass 2 (full lanes: a point that
+// keeps 60 neighbours is one piece, not four quarter-filled ones), and the WPB x 45 partial gradients meet in LDS
+// (one wave per point was a serial chain over 400+ columns on a third of the SIMDs).
+template <bool IDX64, int WPB>
+__global__ __launch_bounds__(64 * WPB) void kpconv_deform_doff(const DoffParams P, int list_cap) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];   // [K][Cin4] dA block of this point, the lists, the partials
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int64_t n = blockIdx.x;
   const int Cin4 = (P.Cin + 3) & ~3;
   float* dA_l = dsm;
-  int* list = reinterpret_cast<int*>(dsm + (size_t)DKMAX * Cin4);
+  int* list = reinterpret_cast<int*>(dsm + (size_t)DKMAX * Cin4) + (size_t)wid * list_cap;
+  float* red = dsm + (size_t)DKMAX * Cin4 + (size_t)WPB * list_cap;          // [WPB][48]
+  constexpr int NT = 64 * WPB;
+  const int tid = threadIdx.x;
 
   // stage dA[n] (zero padded to a multiple of 4 channels)
   if ((P.Cin & 3) == 0) {
@@ -63,11 +73,11 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
     float4* dst = reinterpret_cast<float4*>(dA_l);
     const int n4 = P.K * P.Cin / 4;
 #pragma unroll 4
-    for (int e = lane; e < n4; e += 64) dst[e] = src[e];
-    for (int e = n4 + lane; e < (DKMAX - 1) * Cin4 / 4; e += 64) dst[e] = make_float4(0.f, 0.f, 0.f, 0.f);   // rows k >= K
+    for (int e = tid; e < n4; e += NT) dst[e] = src[e];
+    for (int e = n4 + tid; e < (DKMAX - 1) * Cin4 / 4; e += NT) dst[e] = make_float4(0.f, 0.f, 0.f, 0.f);   // rows k >= K
   } else {
-    for (int e = P.K * Cin4 + lane; e < (DKMAX - 1) * Cin4; e += 64) dA_l[e] = 0.f;
-    for (int e = lane; e < P.K * Cin4; e += 64) {
+    for (int e = P.K * Cin4 + tid; e < (DKMAX - 1) * Cin4; e += NT) dA_l[e] = 0.f;
+    for (int e = tid; e < P.K * Cin4; e += NT) {
       const int kk = e / Cin4, c = e - kk * Cin4;
       dA_l[e] = c < P.Cin ? P.dA[(n * P.K + kk) * P.Cin + c] : 0.f;
     }
@@ -92,10 +102,10 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
   // ---- pass 1: all H entries -> list of the kept neighbours (real neighbours within the extent of some deformed
   //      kernel point, blocks.py:306-325). The index of the next chunk is loaded one chunk ahead.
   int nkept = 0;
-  int jn = lane < P.H ? load_idx<IDX64>(P.idx, n * P.H + lane, P.Ns) : -2;
-  for (int h0 = 0; h0 < P.H; h0 += 64) {
+  int jn = wid * 64 + lane < P.H ? load_idx<IDX64>(P.idx, n * P.H + wid * 64 + lane, P.Ns) : -2;
+  for (int h0 = wid * 64; h0 < P.H; h0 += 64 * WPB) {
     const int j = jn;
-    jn = h0 + 64 + lane < P.H ? load_idx<IDX64>(P.idx, n * P.H + h0 + 64 + lane, P.Ns) : -2;
+    jn = h0 + 64 * WPB + lane < P.H ? load_idx<IDX64>(P.idx, n * P.H + h0 + 64 * WPB + lane, P.Ns) : -2;
     bool keep = false;
     if (j >= 0) {
       const float* sp = P.s + (int64_t)j * 3;
@@ -109,14 +119,14 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
     const unsigned long long bal = __ballot(keep);
     if (keep) {
       const int pos = nkept + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
-      if (pos < DOFF_LIST) list[pos] = j;
+      if (pos < list_cap) list[pos] = j;
     }
     nkept += __builtin_popcountll(bal);
   }
-  nkept = nkept < DOFF_LIST ? nkept : DOFF_LIST;
+  nkept = nkept < list_cap ? nkept : list_cap;
   // ---- min_d2 path: d min_d2[n,k] / d off[n,k,:] = -2 (rel[h*] - kpdef[k]) at the forward's arg-min column h*
   //      (shadow entries included, like torch.min over dim 1); lane k carries kernel point k's term
-  if (P.g_min_d2 != nullptr && lane < P.K && P.H > 0) {
+  if (P.g_min_d2 != nullptr && wid == 0 && lane < P.K && P.H > 0) {
     const int hs = P.min_arg[n * P.K + lane];
     const int j = load_idx<IDX64>(P.idx, n * P.H + hs, P.Ns);
     float rx = 1e6f - qx, ry = 1e6f - qy, rz = 1e6f - qz;
@@ -134,12 +144,35 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
       }
     }
   }
-  wave_lds_sync();
+  int pre[WPB + 1];        // kept entries before wave w's list in the common sequence
+  pre[0] = 0;
+  if (WPB > 1) {
+    if (lane == 0) red[wid] = __int_as_float(nkept);
+    __syncthreads();      // the dA block was staged by all waves; every list and count is complete
+#pragma unroll
+    for (int w = 0; w < WPB; ++w) pre[w + 1] = pre[w] + __float_as_int(red[w]);
+    __syncthreads();      // (red is reused for the partial gradients)
+  } else {
+    pre[WPB] = nkept;
+    wave_lds_sync();
+  }
+  const int total = pre[WPB];
+  const int* lists = reinterpret_cast<const int*>(dsm + (size_t)DKMAX * Cin4);
 
   // ---- pass 2: 64 kept neighbours at a time, lane = neighbour
-  for (int t0 = 0; t0 < nkept; t0 += 64) {
-    const bool on = t0 + lane < nkept;
-    const int j = on ? list[t0 + lane] : 0;
+  for (int t0 = wid * 64; t0 < total; t0 += 64 * WPB) {
+    const bool on = t0 + lane < total;
+    int j = 0;
+    if (on) {
+      const int gi = t0 + lane;
+      int r = 0;
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) r += gi >= pre[w] ? 1 : 0;
+      int base = 0;
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) base = r >= w ? pre[w] : base;
+      j = lists[(size_t)r * list_cap + (gi - base)];
+    }
     float B[DKMAX - 1];
 #pragma unroll
     for (int kk = 0; kk < DKMAX - 1; ++kk) B[kk] = 0.f;
@@ -197,13 +230,26 @@ __global__ __launch_bounds__(64) void kpconv_deform_doff(const DoffParams P) {
     }
   }
 
-  // ---- one reduction over the 64 lanes per component, plain stores
+  // ---- one reduction over the 64 lanes per component (then over the waves, in wave order), plain stores
 #pragma unroll
   for (int e = 0; e < (DKMAX - 1) * 3; ++e) {
     float v = dOff[e];
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
-    if (lane == 0 && e < P.K * 3) P.d_offsets[n * P.K * 3 + e] = v;
+    if (WPB == 1) {
+      if (lane == 0 && e < P.K * 3) P.d_offsets[n * P.K * 3 + e] = v;
+    } else if (lane == 0) {
+      red[wid * 48 + e] = v;
+    }
+  }
+  if (WPB > 1) {
+    __syncthreads();
+    if (wid == 0 && lane < P.K * 3) {
+      float v = red[lane];
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) v += red[w * 48 + lane];
+      P.d_offsets[n * P.K * 3 + lane] = v;
+    }
   }
 }
 
@@ -280,17 +326,27 @@ extern "C" int mvk_kpconv_deform_doff(const float* q, int64_t Nq, const float* s
   P.g_min_d2 = g_min_d2; P.min_arg = min_arg; P.d_offsets = d_offsets; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K;
   P.extent = extent; P.influence = influence;
   const int Cin4 = (Cin + 3) & ~3;
-  const size_t lds = sizeof(float) * (size_t)DKMAX * Cin4 + sizeof(int) * (size_t)(H < 64 ? 64 : H);
+  static const bool split_on = getenv("MVK_DOFF_SPLIT") == nullptr || atoi(getenv("MVK_DOFF_SPLIT")) != 0;
+  // four waves per point only where points are few (the coarse levels searched at the deform radius: 750 / 160 / 36
+  // points x 420 / 349 / 124 columns): with thousands of points the chip is full anyway and the per-wave overhead
+  // (kernel points, the 45-value reductions) costs more than the shorter chains save (4 000 x 200: 59 -> 183 us)
+  const int wpb = (split_on && H > 64 && Nq <= 1024) ? 4 : 1;
+  const int chunks = (H + 63) / 64;
+  const int list_cap = ((chunks + wpb - 1) / wpb) * 64 > 64 ? ((chunks + wpb - 1) / wpb) * 64 : 64;   // columns one wave walks
+  const size_t lds = sizeof(float) * (size_t)DKMAX * Cin4 + sizeof(int) * (size_t)wpb * list_cap + sizeof(float) * wpb * 48;
   MVK_REQUIRE(lds <= 160 * 1024, "deform d_offsets: Cin=%d does not fit the LDS staging", Cin);
-  if (idx64) {
-    if (lds > 64 * 1024)
-      MVK_CHECK_HIP(hipFuncSetAttribute((const void*)kpconv_deform_doff<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((kpconv_deform_doff<true>), dim3((unsigned)Nq), dim3(64), lds, st, P);
-  } else {
-    if (lds > 64 * 1024)
-      MVK_CHECK_HIP(hipFuncSetAttribute((const void*)kpconv_deform_doff<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((kpconv_deform_doff<false>), dim3((unsigned)Nq), dim3(64), lds, st, P);
+#define DOFF_LAUNCH(I64, W)                                                                                              \
+  {                                                                                                                      \
+    if (lds > 64 * 1024)                                                                                                 \
+      MVK_CHECK_HIP(hipFuncSetAttribute((const void*)kpconv_deform_doff<I64, W>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((kpconv_deform_doff<I64, W>), dim3((unsigned)Nq), dim3(64 * W), lds, st, P, list_cap);           \
   }
+  if (idx64) {
+    if (wpb == 4) DOFF_LAUNCH(true, 4) else DOFF_LAUNCH(true, 1)
+  } else {
+    if (wpb == 4) DOFF_LAUNCH(false, 4) else DOFF_LAUNCH(false, 1)
+  }
+#undef DOFF_LAUNCH
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

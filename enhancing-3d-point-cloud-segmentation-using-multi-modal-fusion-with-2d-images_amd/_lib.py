@@ -36,6 +36,8 @@ _SIGNATURES = {
     "mvk_bias_act_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "mvk_sgd_chunk_elems": (C.c_int, []),
     "mvk_sgd_clip_step": (C.c_int, [_vp, _vp, _i64, _f, _f, _i, _vp]),
+    "mvk_deform_operands_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "mvk_deform_operands_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _f, _vp, _vp, _vp]),
     "mvk_xent_workspace_floats": (C.c_int64, [_i64]),
     "mvk_xent_fwd": (C.c_int, [_vp, _i64, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "mvk_xent_bwd": (C.c_int, [_vp, _i64, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp]),

@@ -351,6 +351,104 @@ extern "C" int mvk_kpconv_deform_doff(const float* q, int64_t Nq, const float* s
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// (3) From the inner convolution's output to the operands of the deformable one (blocks.py:243-266, :287) in one
+// launch: feat = raw + bias; offsets[n,k,:] = feat[n, 3k..3k+2] * extent; deformed_KP = offsets + kernel_points;
+// modulated: modulations[n,k] = 2 sigmoid(feat[n, 3K + k]). As tensor ops this is 3 (6) launches forward and as many
+// backward per deformable layer (ten layers in the middle-fusion net).
+namespace {
+__global__ void deform_operands_fwd_k(const float* __restrict__ raw, const float* __restrict__ bias,
+                                      const float* __restrict__ kp, int64_t N, int K, int D, float extent,
+                                      float* __restrict__ feat, float* __restrict__ offsets, float* __restrict__ dkp,
+                                      float* __restrict__ mod) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= N * D) return;
+  const int64_t n = t / D;
+  const int d = (int)(t - n * D);
+  const float f = raw[t] + bias[d];
+  feat[t] = f;
+  if (d < 3 * K) {
+#pragma clang fp contract(off)                        // rounded product, then rounded sum: the reference's two tensor ops
+    const float o = f * extent;
+    offsets[n * 3 * K + d] = o;
+    dkp[n * 3 * K + d] = o + kp[d];
+  } else {
+    mod[n * K + (d - 3 * K)] = 2.0f / (1.0f + expf(-f));
+  }
+}
+
+// d_raw[n,d] = (g_off + g_dkp)[n,d] * extent (d < 3K) | g_mod[n,k] * mod (1 - mod / 2) (d >= 3K: d/df of 2 sigmoid);
+// d_bias[d] += column sums (f32 atomics onto a zero-initialised vector: one atomic per (workgroup, column))
+__global__ __launch_bounds__(256) void deform_operands_bwd_k(const float* __restrict__ g_off, const float* __restrict__ g_dkp,
+                                                            const float* __restrict__ g_mod, const float* __restrict__ mod,
+                                                            const float* __restrict__ g_feat, int64_t N, int K, int D,
+                                                            float extent, float* __restrict__ d_raw, float* __restrict__ d_bias) {
+  // a workgroup owns 256 / DP rows x DP (= D rounded up to a power of two <= 64) columns
+  __shared__ float part[256];
+  int DP = 1;
+  while (DP < D) DP <<= 1;
+  const int rows_per = 256 / DP;
+  const int d = threadIdx.x % DP, rl = threadIdx.x / DP;
+  float acc = 0.f;
+  for (int64_t n = (int64_t)blockIdx.x * rows_per + rl; n < N; n += (int64_t)gridDim.x * rows_per) {
+    if (d < D) {
+      float v;
+      if (d < 3 * K) {
+        v = 0.f;
+        if (g_off) v += g_off[n * 3 * K + d];
+        if (g_dkp) v += g_dkp[n * 3 * K + d];
+        v *= extent;
+      } else {
+        const float m = mod[n * K + (d - 3 * K)];
+        v = g_mod ? g_mod[n * K + (d - 3 * K)] * m * (1.0f - 0.5f * m) : 0.f;
+      }
+      if (g_feat) v += g_feat[n * D + d];
+      d_raw[n * D + d] = v;
+      acc += v;
+    }
+  }
+  part[threadIdx.x] = acc;
+  __syncthreads();
+  if (rl == 0 && d < D) {
+    float s = 0.f;
+    for (int r = 0; r < rows_per; ++r) s += part[r * DP + d];
+    atomicAdd(d_bias + d, s);
+  }
+}
+}  // namespace
+
+extern "C" int mvk_deform_operands_fwd(const float* raw, const float* bias, const float* kernel_points, int64_t N, int K,
+                                       int modulated, float extent, float* feat, float* offsets, float* deformed_kp,
+                                       float* modulations, void* stream) {
+  MVK_REQUIRE(N >= 0 && K >= 1 && K < DKMAX, "deform operands: bad sizes");
+  if (N == 0) return 0;
+  const int D = (modulated ? 4 : 3) * K;
+  MVK_REQUIRE(raw && bias && kernel_points && feat && offsets && deformed_kp && (!modulated || modulations),
+              "deform operands: null operand");
+  hipLaunchKernelGGL(deform_operands_fwd_k, dim3((unsigned)cdiv64(N * D, 256)), dim3(256), 0, (hipStream_t)stream, raw, bias,
+                     kernel_points, N, K, D, extent, feat, offsets, deformed_kp, modulations);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_deform_operands_bwd(const float* g_offsets, const float* g_deformed_kp, const float* g_modulations,
+                                       const float* modulations, const float* g_feat, int64_t N, int K, int modulated,
+                                       float extent, float* d_raw, float* d_bias /* [D], zero-initialised */, void* stream) {
+  MVK_REQUIRE(N >= 0 && K >= 1 && K < DKMAX, "deform operands: bad sizes");
+  if (N == 0) return 0;
+  const int D = (modulated ? 4 : 3) * K;
+  MVK_REQUIRE(d_raw && d_bias && (!modulated || modulations), "deform operands: null operand");
+  int DP = 1;
+  while (DP < D) DP <<= 1;
+  const int64_t rows_per = 256 / DP;
+  int64_t g = cdiv64(N, rows_per * 4);          // ~4 rows per thread
+  g = g < 1 ? 1 : (g > 256 ? 256 : g);
+  hipLaunchKernelGGL(deform_operands_bwd_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, g_offsets, g_deformed_kp,
+                     g_modulations, modulations, g_feat, N, K, D, extent, d_raw, d_bias);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int mvk_deform_regularizer(const float* min_d2, const float* deformed_kp, const int32_t* n_valid, int64_t N,
                                       int K, float extent, float repulse_extent, float power, float* loss_accum,
                                       float* d_min_d2, float* d_deformed_kp, void* stream) {

@@ -28,6 +28,7 @@ except ImportError:  # dropin/ put on sys.path directly
 _FUSE_ADD = os.environ.get("MVK_FUSE_ADD", "1") == "1"      # development switches for A/B timing
 _HIP_BN = os.environ.get("MVK_HIP_BN", "1") == "1"          # training-mode BatchNorm on the masked HIP kernel (0: nn.BatchNorm1d)
 _GEMM_STATS = os.environ.get("MVK_GEMM_STATS", "1") == "1"  # BatchNorm statistics from the producing GEMM's epilogue
+_FUSED_OPERANDS = os.environ.get("MVK_FUSED_DEFORM_OPERANDS", "1") == "1"   # development switch: 0 = the tensor ops
 
 
 def _bn_rows(x, module, use_bn=True):
@@ -137,15 +138,20 @@ class KPConv(nn.Module):
         offsets = modulations = None
         if self.deformable:
             # offsets from an inner rigid KPConv (blocks.py:243-266)
-            self.offset_features = self.offset_conv(q_pts, s_pts, neighb_inds, x) + self.offset_bias
-            nk = self.p_dim * self.K
-            if self.modulated:
-                unscaled = self.offset_features[:, :nk].reshape(-1, self.K, self.p_dim)
-                modulations = 2 * torch.sigmoid(self.offset_features[:, nk:])
+            raw = self.offset_conv(q_pts, s_pts, neighb_inds, x)
+            if _FUSED_OPERANDS and raw.is_cuda:        # bias, scale, kernel points (and 2 sigmoid) in one launch
+                self.offset_features, offsets, self.deformed_KP, modulations = ops.deform_operands(
+                    raw, self.offset_bias, self.kernel_points, self.KP_extent, self.modulated)
             else:
-                unscaled = self.offset_features.reshape(-1, self.K, self.p_dim)
-            offsets = unscaled * self.KP_extent
-            self.deformed_KP = offsets + self.kernel_points          # blocks.py:287
+                self.offset_features = raw + self.offset_bias
+                nk = self.p_dim * self.K
+                if self.modulated:
+                    unscaled = self.offset_features[:, :nk].reshape(-1, self.K, self.p_dim)
+                    modulations = 2 * torch.sigmoid(self.offset_features[:, nk:])
+                else:
+                    unscaled = self.offset_features.reshape(-1, self.K, self.p_dim)
+                offsets = unscaled * self.KP_extent
+                self.deformed_KP = offsets + self.kernel_points          # blocks.py:287
         y, min_d2 = ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent,
                                self.KP_influence, self.aggregation_mode, offsets, modulations,
                                stats_n_valid=stats_n_valid)

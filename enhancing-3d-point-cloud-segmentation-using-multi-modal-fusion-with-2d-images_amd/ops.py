@@ -635,6 +635,48 @@ class _DeformRegFn(torch.autograd.Function):
         return d_min * g, d_dkp * g, None, None, None, None
 
 
+class _DeformOperandsFn(torch.autograd.Function):
+    """offset_features, offsets, deformed_KP (and modulations) of a deformable KPConv from its inner convolution's
+    output (models/blocks.py:243-266, :287), one launch forward and one backward (mvk_deform_operands_fwd/bwd)."""
+
+    @staticmethod
+    def forward(ctx, raw, bias, kernel_points, extent, modulated):
+        _dev(raw, bias, kernel_points)
+        raw, bias, kp = _f32c(raw), _f32c(bias), _f32c(kernel_points)
+        N, D = raw.shape
+        K = kp.shape[0]
+        if D != (4 if modulated else 3) * K or bias.numel() != D:
+            raise RuntimeError("deform operands: the inner convolution must deliver %d columns" % ((4 if modulated else 3) * K))
+        feat = torch.empty_like(raw)
+        offsets = torch.empty((N, K, 3), device=raw.device, dtype=torch.float32)
+        dkp = torch.empty_like(offsets)
+        mod = torch.empty((N, K), device=raw.device, dtype=torch.float32) if modulated else None
+        check(lib().mvk_deform_operands_fwd(_p(raw), _p(bias), _p(kp), N, K, int(bool(modulated)), float(extent), _p(feat),
+                                            _p(offsets), _p(dkp), _p(mod), _stream()))
+        ctx.save_for_backward(mod)
+        ctx.cfg = (N, K, D, float(extent), bool(modulated))
+        ctx.set_materialize_grads(False)
+        return feat, offsets, dkp, mod
+
+    @staticmethod
+    def backward(ctx, g_feat, g_off, g_dkp, g_mod):
+        (mod,) = ctx.saved_tensors
+        N, K, D, extent, modulated = ctx.cfg
+        dev = (mod if mod is not None else next(g for g in (g_feat, g_off, g_dkp, g_mod) if g is not None)).device
+        gs = [None if g is None else _f32c(g) for g in (g_off, g_dkp, g_mod, g_feat)]
+        d_raw = torch.empty((N, D), device=dev, dtype=torch.float32)
+        d_bias = _zeros((D,), dev)
+        check(lib().mvk_deform_operands_bwd(_p(gs[0]), _p(gs[1]), _p(gs[2]), _p(mod), _p(gs[3]), N, K, int(modulated), extent,
+                                            _p(d_raw), _p(d_bias), _stream()))
+        return d_raw, d_bias, None, None, None
+
+
+def deform_operands(raw, bias, kernel_points, extent, modulated=False):
+    """(offset_features [N,D], offsets [N,K,3], deformed_KP [N,K,3], modulations [N,K] or None) from the inner
+    convolution's output raw [N,D] (D = 3K, 4K when modulated)."""
+    return _DeformOperandsFn.apply(raw, bias, kernel_points, extent, modulated)
+
+
 def deform_regularizer(min_d2, deformed_kp, extent, repulse_extent, power=1.0, n_valid=None):
     """power * (2 * fitting + repulsive) of one deformable layer; min_d2 [N,K], deformed_kp [N,K,3]; n_valid: DEVICE
     int32 [1] row count of a capacity-padded level (means over the valid rows only) or None."""

@@ -139,6 +139,18 @@ int mvk_kpconv_deform_doff(const float* q, int64_t Nq, const float* s, int64_t N
                            const float* offsets, const float* dA, const float* g_min_d2,
                            const int32_t* min_arg, float* d_offsets, void* stream);
 
+/* From the inner (offset) convolution's output raw [N,D] (D = 3K, or 4K when modulated) to the operands of the
+ * deformable KPConv, one launch (blocks.py:243-266, :287): feat = raw + bias; offsets[n,k,:] = feat[n,3k..3k+2] * extent;
+ * deformed_kp = offsets + kernel_points; modulations[n,k] = 2 sigmoid(feat[n, 3K + k]). */
+int mvk_deform_operands_fwd(const float* raw, const float* bias, const float* kernel_points, int64_t N, int K,
+                            int modulated, float extent, float* feat, float* offsets, float* deformed_kp,
+                            float* modulations /* NULL unless modulated */, void* stream);
+/* Its backward: d_raw [N,D] and d_bias [D] (+=, zero-initialised by the caller; f32 atomics) from the gradients of
+ * offsets, deformed_kp, modulations and feat (each may be NULL). */
+int mvk_deform_operands_bwd(const float* g_offsets, const float* g_deformed_kp, const float* g_modulations,
+                            const float* modulations, const float* g_feat, int64_t N, int K, int modulated,
+                            float extent, float* d_raw, float* d_bias, void* stream);
+
 /* p2p_fitting_regularizer of ONE deformable layer (models/architectures.py:20-58) and both its gradients:
  *   *loss_accum += power * ( 2 * mean_{n<nv,k} |min_d2| / ext^2 + sum_i mean_{n<nv} sum_{j!=i} clamp_max(|loc_i - loc_j| - R, 0)^2 / K ),
  *   loc = deformed_kp / ext, the other point of a pair detached; d_min_d2 [N,K] and d_deformed_kp [N,K,3] receive

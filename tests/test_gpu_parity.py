@@ -1037,3 +1037,39 @@ def test_fa_gather_reads_a_channels_last_map_in_place(ops):
     assert not fcl.is_contiguous()
     b = ops.fa_gather(fcl, xyz, knn, pts)
     assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,modulated", [(960, False), (257, True), (1, True), (5000, False)])
+def test_deform_operands_kernel_vs_tensor_ops(ops, N, modulated):
+    """mvk_deform_operands_fwd/bwd against the reference's tensor expression (blocks.py:243-266, :287): feat = raw +
+    bias, offsets = feat[:, :3K] * extent, deformed_KP = offsets + kernel_points, modulations = 2 sigmoid(feat[:, 3K:]);
+    gradients of raw and bias for gradients arriving on every output."""
+    torch.manual_seed(N)
+    K, ext = 15, 0.048
+    D = (4 if modulated else 3) * K
+    raw = torch.randn(N, D, device="cuda", requires_grad=True)
+    bias = torch.randn(D, device="cuda", requires_grad=True)
+    kp = torch.randn(K, 3, device="cuda")
+    feat, off, dkp, mod = ops.deform_operands(raw, bias, kp, ext, modulated)
+    go, gd, gf = torch.randn(N, K, 3, device="cuda"), torch.randn(N, K, 3, device="cuda"), torch.randn(N, D, device="cuda")
+    loss = (off * go).sum() + (dkp * gd).sum() + (feat * gf).sum()
+    gm = torch.randn(N, K, device="cuda")
+    if modulated:
+        loss = loss + (mod * gm).sum()
+    g_raw, g_bias = torch.autograd.grad(loss, [raw, bias])
+    r2, b2 = raw.detach().clone().requires_grad_(True), bias.detach().clone().requires_grad_(True)
+    f2 = r2 + b2
+    o2 = f2[:, :3 * K].reshape(-1, K, 3) * ext
+    d2 = o2 + kp
+    l2 = (o2 * go).sum() + (d2 * gd).sum() + (f2 * gf).sum()
+    if modulated:
+        m2 = 2 * torch.sigmoid(f2[:, 3 * K:])
+        l2 = l2 + (m2 * gm).sum()
+        assert rel_err(mod.detach().cpu().numpy(), m2.detach().cpu().numpy()) < 1e-6
+    w_raw, w_bias = torch.autograd.grad(l2, [r2, b2])
+    assert torch.equal(feat.detach(), f2.detach()) and torch.equal(off.detach(), o2.detach())
+    assert torch.equal(dkp.detach(), d2.detach())
+    assert rel_err(g_raw.cpu().numpy(), w_raw.cpu().numpy()) < 1e-6 and rel_err(g_bias.cpu().numpy(), w_bias.cpu().numpy()) < 1e-5
+    # only the offsets receive a gradient (no regulariser, no modulation): the other inputs of the backward are absent
+    (g_only,) = torch.autograd.grad((ops.deform_operands(raw, bias, kp, ext, modulated)[1] * go).sum(), [raw])
+    assert rel_err(g_only[:, :3 * K].cpu().numpy(), (go.reshape(N, -1) * ext).cpu().numpy()) < 1e-6

@@ -33,6 +33,7 @@ _SIGNATURES = {
     "mvk_kpconv_deform_doff": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp,
                                         _vp, _vp]),
     "mvk_deform_regularizer": (C.c_int, [_vp, _vp, _vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),
+    "mvk_deform_regularizer_ex": (C.c_int, [_vp, _vp, _vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "mvk_bias_act_nhwc": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i, _i, _vp]),
     "mvk_sgd_chunk_elems": (C.c_int, []),
     "mvk_sgd_clip_step": (C.c_int, [_vp, _vp, _i64, _f, _f, _i, _vp]),

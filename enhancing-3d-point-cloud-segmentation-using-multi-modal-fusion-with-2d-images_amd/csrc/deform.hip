@@ -259,9 +259,10 @@ __global__ __launch_bounds__(64 * WPB) void kpconv_deform_doff(const DoffParams 
 __global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __restrict__ min_d2, const float* __restrict__ dkp,
                                                                 const int32_t* __restrict__ n_valid, int64_t N, int K,
                                                                 float extent, float repulse, float power,
-                                                                float* __restrict__ loss /* [1], += */,
-                                                                float* __restrict__ d_min_d2 /* [N,K] */,
-                                                                float* __restrict__ d_dkp /* [N,K,3] */) {
+                                                                float* __restrict__ loss /* [1], += ; or null */,
+                                                                const float* __restrict__ gscale /* [1] or null: 1 */,
+                                                                float* __restrict__ d_min_d2 /* [N,K] or null */,
+                                                                float* __restrict__ d_dkp /* [N,K,3] or null */) {
   __shared__ float red[4];
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t n = t >> 4;
@@ -273,12 +274,13 @@ __global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __
   const float inv_e = 1.0f / extent;
   const float cf = valid ? power * 2.0f / (extent * extent * (float)nv * (float)K) : 0.f;   // d loss / d min_d2
   const float cr = valid ? power / ((float)nv * (float)K) : 0.f;                                // weight of one (point, i) pair sum
+  const float gsc = gscale ? gscale[0] : 1.f;     // upstream gradient of the loss term (backward launch)
   float lx = 0.f, ly = 0.f, lz = 0.f, part = 0.f;
   if (on) {
     const float* p = dkp + (n * K + i) * 3;
     lx = p[0] * inv_e; ly = p[1] * inv_e; lz = p[2] * inv_e;             // KP_locs (architectures.py:44)
     const float m = min_d2[n * K + i];
-    d_min_d2[n * K + i] = m > 0.f ? cf : (m < 0.f ? -cf : 0.f);            // L1 to zero: sign(m)
+    if (d_min_d2) d_min_d2[n * K + i] = gsc * (m > 0.f ? cf : (m < 0.f ? -cf : 0.f));   // L1 to zero: sign(m)
     part = cf * fabsf(m);
   }
   float gx = 0.f, gy = 0.f, gz = 0.f, acc = 0.f;
@@ -296,9 +298,13 @@ __global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __
   }
   if (on) {
     part += cr * acc;
-    float* o = d_dkp + (n * K + i) * 3;
-    o[0] = cr * gx * inv_e; o[1] = cr * gy * inv_e; o[2] = cr * gz * inv_e;
+    if (d_dkp) {
+      float* o = d_dkp + (n * K + i) * 3;
+      const float f = gsc * cr * inv_e;
+      o[0] = f * gx; o[1] = f * gy; o[2] = f * gz;
+    }
   }
+  if (loss == nullptr) return;          // (uniform)
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
@@ -449,14 +455,22 @@ extern "C" int mvk_deform_operands_bwd(const float* g_offsets, const float* g_de
   return 0;
 }
 
+extern "C" int mvk_deform_regularizer_ex(const float* min_d2, const float* deformed_kp, const int32_t* n_valid, int64_t N,
+                                         int K, float extent, float repulse_extent, float power, float* loss_accum,
+                                         const float* grad_scale, float* d_min_d2, float* d_deformed_kp, void* stream) {
+  MVK_REQUIRE(N >= 0 && K >= 1 && K < DKMAX && extent > 0.f, "regulariser: bad sizes");
+  if (N == 0) return 0;          // an empty level contributes nothing (its tensors have no storage)
+  MVK_REQUIRE(min_d2 && deformed_kp && (loss_accum || d_min_d2 || d_deformed_kp), "regulariser: null operand");
+  hipLaunchKernelGGL(deform_regularizer_kernel, dim3((unsigned)cdiv64(N * 16, 256)), dim3(256), 0, (hipStream_t)stream, min_d2,
+                     deformed_kp, n_valid, N, K, extent, repulse_extent, power, loss_accum, grad_scale, d_min_d2, d_deformed_kp);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
 extern "C" int mvk_deform_regularizer(const float* min_d2, const float* deformed_kp, const int32_t* n_valid, int64_t N,
                                       int K, float extent, float repulse_extent, float power, float* loss_accum,
                                       float* d_min_d2, float* d_deformed_kp, void* stream) {
-  MVK_REQUIRE(N >= 0 && K >= 1 && K < DKMAX && extent > 0.f, "regulariser: bad sizes");
-  if (N == 0) return 0;          // an empty level contributes nothing (its tensors have no storage)
-  MVK_REQUIRE(min_d2 && deformed_kp && loss_accum && d_min_d2 && d_deformed_kp, "regulariser: null operand");
-  hipLaunchKernelGGL(deform_regularizer_kernel, dim3((unsigned)cdiv64(N * 16, 256)), dim3(256), 0, (hipStream_t)stream, min_d2,
-                     deformed_kp, n_valid, N, K, extent, repulse_extent, power, loss_accum, d_min_d2, d_deformed_kp);
-  MVK_CHECK_HIP(hipGetLastError());
-  return 0;
+  if (N > 0) MVK_REQUIRE(loss_accum && d_min_d2 && d_deformed_kp, "regulariser: null operand");
+  return mvk_deform_regularizer_ex(min_d2, deformed_kp, n_valid, N, K, extent, repulse_extent, power, loss_accum, nullptr,
+                                   d_min_d2, d_deformed_kp, stream);
 }

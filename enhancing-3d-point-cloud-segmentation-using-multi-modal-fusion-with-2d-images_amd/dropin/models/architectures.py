@@ -27,40 +27,41 @@ def p2p_fitting_regularizer(net):
     kernels per deformable layer); in capacity-padded mode the means run over the valid rows only.
     On the GPU each layer's term and both its gradients come from ONE launch (ops.deform_regularizer)."""
     total = 0
-    for m in net.modules():
-        if isinstance(m, KPConv) and m.deformable:
-            rows = m.min_d2.shape[0]
-            if m.min_d2.is_cuda and _FUSED_REG:
-                # one launch per layer (csrc/deform.hip): loss term and both gradients
-                total = total + _ops.deform_regularizer(m.min_d2, m.deformed_KP, m.KP_extent, net.repulse_extent,
-                                                        net.deform_fitting_power, _ops.row_count_for(rows))
-                continue
-            n_valid = _ops.row_count_for(rows)
-            if n_valid is None:
-                mask, denom = None, float(rows)
-            else:
-                mask = (torch.arange(rows, device=m.min_d2.device) < n_valid).to(m.min_d2.dtype).unsqueeze(1)
-                denom = n_valid.to(m.min_d2.dtype)
+    deform = [m for m in net.modules() if isinstance(m, KPConv) and m.deformable]
+    if _FUSED_REG and deform and all(m.min_d2.is_cuda for m in deform):
+        # one launch per layer each way (csrc/deform.hip), all layers one autograd node accumulating into one scalar
+        term = _ops.deform_regularizer_all([(m.min_d2, m.deformed_KP, m.KP_extent, net.repulse_extent,
+                                             net.deform_fitting_power, _ops.row_count_for(m.min_d2.shape[0]))
+                                            for m in deform])
+        return term if term is not None else total
+    for m in deform:
+        rows = m.min_d2.shape[0]
+        n_valid = _ops.row_count_for(rows)
+        if n_valid is None:
+            mask, denom = None, float(rows)
+        else:
+            mask = (torch.arange(rows, device=m.min_d2.device) < n_valid).to(m.min_d2.dtype).unsqueeze(1)
+            denom = n_valid.to(m.min_d2.dtype)
 
-            def mean_rows(v):                      # nn.L1Loss(v, 0) = mean |v| over rows x columns (v >= 0 here)
-                v = v.abs()
-                if mask is not None:
-                    v = v * mask
-                return v.sum() / (denom * v.shape[1])
+        def mean_rows(v):                      # nn.L1Loss(v, 0) = mean |v| over rows x columns (v >= 0 here)
+            v = v.abs()
+            if mask is not None:
+                v = v * mask
+            return v.sum() / (denom * v.shape[1])
 
-            # fitting: squared distance to the closest input point, normalised by the extent (:35-38)
-            fitting_loss = mean_rows(m.min_d2 / (m.KP_extent ** 2))
-            # repulsion (:44-56): d[n,i,j] = |KP_i - sg(KP_j)|, j != i
-            KP_locs = m.deformed_KP / m.KP_extent
-            K = KP_locs.shape[1]
-            diff = KP_locs.unsqueeze(2) - KP_locs.detach().unsqueeze(1)               # [N,K,K,3]
-            eye = torch.eye(K, device=diff.device, dtype=diff.dtype)
-            d2 = torch.sum(diff ** 2, dim=3) + eye                                     # keep sqrt'(0) off the diagonal
-            dist = torch.sqrt(d2)
-            rep = torch.clamp_max(dist - net.repulse_extent, max=0.0) ** 2 * (1 - eye)
-            rep_loss = rep.sum(dim=2)                                                  # [N,K]: sum over the other points
-            repulsive_loss = mean_rows(rep_loss) * rep_loss.shape[1] / net.K
-            total = total + net.deform_fitting_power * (2 * fitting_loss + repulsive_loss)
+        # fitting: squared distance to the closest input point, normalised by the extent (:35-38)
+        fitting_loss = mean_rows(m.min_d2 / (m.KP_extent ** 2))
+        # repulsion (:44-56): d[n,i,j] = |KP_i - sg(KP_j)|, j != i
+        KP_locs = m.deformed_KP / m.KP_extent
+        K = KP_locs.shape[1]
+        diff = KP_locs.unsqueeze(2) - KP_locs.detach().unsqueeze(1)               # [N,K,K,3]
+        eye = torch.eye(K, device=diff.device, dtype=diff.dtype)
+        d2 = torch.sum(diff ** 2, dim=3) + eye                                     # keep sqrt'(0) off the diagonal
+        dist = torch.sqrt(d2)
+        rep = torch.clamp_max(dist - net.repulse_extent, max=0.0) ** 2 * (1 - eye)
+        rep_loss = rep.sum(dim=2)                                                  # [N,K]: sum over the other points
+        repulsive_loss = mean_rows(rep_loss) * rep_loss.shape[1] / net.K
+        total = total + net.deform_fitting_power * (2 * fitting_loss + repulsive_loss)
     return total
 
 

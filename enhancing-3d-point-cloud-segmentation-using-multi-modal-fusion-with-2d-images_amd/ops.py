@@ -677,6 +677,51 @@ def deform_operands(raw, bias, kernel_points, extent, modulated=False):
     return _DeformOperandsFn.apply(raw, bias, kernel_points, extent, modulated)
 
 
+class _DeformRegAllFn(torch.autograd.Function):
+    """The regulariser terms of ALL deformable layers of a network as one autograd node: every layer's forward launch
+    accumulates into one scalar (no additions of per-layer losses), the backward launches the same kernel with the
+    upstream gradient as a device scalar and gets both gradients already scaled (no multiplications)."""
+
+    @staticmethod
+    def forward(ctx, cfgs, *tensors):
+        ts = [_f32c(t) for t in tensors]
+        _dev(*ts)
+        loss = _zeros((1,), ts[0].device)
+        for i, (extent, repulse, power, nv) in enumerate(cfgs):
+            m, d = ts[2 * i], ts[2 * i + 1]
+            check(lib().mvk_deform_regularizer_ex(_p(m), _p(d), _p(nv), m.shape[0], m.shape[1], float(extent), float(repulse),
+                                                  float(power), _p(loss), None, None, None, _stream()))
+        ctx.save_for_backward(*ts)
+        ctx.cfgs = cfgs
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ts = ctx.saved_tensors
+        g = _f32c(g).reshape(1)
+        grads = []
+        for i, (extent, repulse, power, nv) in enumerate(ctx.cfgs):
+            m, d = ts[2 * i], ts[2 * i + 1]
+            d_min, d_dkp = torch.empty_like(m), torch.empty_like(d)
+            check(lib().mvk_deform_regularizer_ex(_p(m), _p(d), _p(nv), m.shape[0], m.shape[1], float(extent), float(repulse),
+                                                  float(power), None, _p(g), _p(d_min), _p(d_dkp), _stream()))
+            grads += [d_min, d_dkp]
+        return (None, *grads)
+
+
+def deform_regularizer_all(layers):
+    """Sum of the regulariser terms of several deformable layers; layers: list of (min_d2 [N,K], deformed_kp [N,K,3],
+    extent, repulse_extent, power, n_valid or None). Layers without rows contribute nothing."""
+    layers = [l for l in layers if l[0].shape[0] > 0]
+    if not layers:
+        return None
+    cfgs = [(l[2], l[3], l[4], l[5]) for l in layers]
+    flat = []
+    for l in layers:
+        flat += [l[0], l[1]]
+    return _DeformRegAllFn.apply(cfgs, *flat)
+
+
 def deform_regularizer(min_d2, deformed_kp, extent, repulse_extent, power=1.0, n_valid=None):
     """power * (2 * fitting + repulsive) of one deformable layer; min_d2 [N,K], deformed_kp [N,K,3]; n_valid: DEVICE
     int32 [1] row count of a capacity-padded level (means over the valid rows only) or None."""

@@ -158,6 +158,12 @@ int mvk_deform_operands_bwd(const float* g_offsets, const float* g_deformed_kp, 
 int mvk_deform_regularizer(const float* min_d2, const float* deformed_kp, const int32_t* n_valid, int64_t N, int K,
                            float extent, float repulse_extent, float power, float* loss_accum, float* d_min_d2,
                            float* d_deformed_kp, void* stream);
+/* The same with every output optional and the gradients scaled by grad_scale[0] (DEVICE scalar, NULL = 1): a forward
+ * launch takes loss_accum only (all layers of a network accumulate into ONE scalar), the backward launch takes the
+ * upstream gradient and writes d_min_d2 / d_deformed_kp already scaled. */
+int mvk_deform_regularizer_ex(const float* min_d2, const float* deformed_kp, const int32_t* n_valid, int64_t N, int K,
+                              float extent, float repulse_extent, float power, float* loss_accum, const float* grad_scale,
+                              float* d_min_d2, float* d_deformed_kp, void* stream);
 
 /* ---------------- frozen 2D encoder: pointwise epilogue of a convolution --- */
 

@@ -1073,3 +1073,26 @@ def test_deform_operands_kernel_vs_tensor_ops(ops, N, modulated):
     # only the offsets receive a gradient (no regulariser, no modulation): the other inputs of the backward are absent
     (g_only,) = torch.autograd.grad((ops.deform_operands(raw, bias, kp, ext, modulated)[1] * go).sum(), [raw])
     assert rel_err(g_only[:, :3 * K].cpu().numpy(), (go.reshape(N, -1) * ext).cpu().numpy()) < 1e-6
+
+
+def test_regulariser_of_all_layers_as_one_node_equals_the_per_layer_sum(ops):
+    """ops.deform_regularizer_all (one accumulator, gradients scaled inside the backward launches) against the sum of
+    the per-layer ops.deform_regularizer terms: value and every gradient, with an upstream factor other than 1."""
+    torch.manual_seed(11)
+    layers, leaves = [], []
+    for N, ext in ((300, 0.05), (64, 0.1), (0, 0.2), (1000, 0.2)):
+        m = torch.rand(N, 15, device="cuda").requires_grad_(True)
+        d = (torch.randn(N, 15, 3, device="cuda") * ext).requires_grad_(True)
+        nv = torch.tensor([max(N - 7, 0)], dtype=torch.int32, device="cuda") if N == 300 else None
+        layers.append((m, d, ext, 1.2, 1.0, nv))
+        leaves += [m, d]
+    one = ops.deform_regularizer_all(layers)
+    g_one = torch.autograd.grad(one * 0.37, leaves, allow_unused=True)
+    per = sum(ops.deform_regularizer(m, d, ext, rep, pw, nv) for (m, d, ext, rep, pw, nv) in layers if m.shape[0] > 0)
+    g_per = torch.autograd.grad(per * 0.37, leaves, allow_unused=True)
+    assert abs(float(one.detach()) - float(per.detach())) < 1e-6 * max(1.0, abs(float(per.detach())))
+    for a, b in zip(g_one, g_per):
+        if b is None:
+            assert a is None or a.numel() == 0
+        else:
+            assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6

@@ -259,10 +259,12 @@ def test_kpconv_fwd_bwd_golden(ops, name, influence, agg, idt):
 
 
 @pytest.mark.parametrize("cin,cout,H", [(1, 5, 9), (4, 32, 17), (8, 8, 70), (20, 12, 33), (68, 64, 40),
-                                        (128, 16, 25), (256, 8, 64), (512, 4, 10), (516, 4, 6), (1040, 3, 5)])
+                                        (128, 16, 25), (256, 8, 64), (512, 4, 10), (516, 4, 6), (1040, 3, 5),
+                                        (2, 6, 130), (130, 16, 150), (600, 4, 130), (30, 5, 260)])
 def test_kpconv_every_kernel_variant_vs_numpy_oracle(ops, cin, cout, H):
     """Seeded inputs through every gather / scatter template instantiation (LPP = 1..64, NCH = 1, 2,
-    the generic lane = channel kernel and its > 512-channel multi-launch path) against the float64
+    the generic lane = channel kernel and its > 512-channel multi-launch path, the one-lane-per-point kernel for rows
+    of <= 4 channels, the four-waves-per-point scatter of rows with more than 64 neighbour columns) against the float64
     numpy restatement; includes shadow neighbours, empty rows and a ragged last chunk."""
     from oracle import npref
     rng = np.random.default_rng(cin * 131 + H)
@@ -1096,3 +1098,24 @@ def test_regulariser_of_all_layers_as_one_node_equals_the_per_layer_sum(ops):
             assert a is None or a.numel() == 0
         else:
             assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+
+
+@pytest.mark.parametrize("influence,agg", [("gaussian", "sum"), ("constant", "sum"), ("linear", "closest"), ("gaussian", "closest")])
+@pytest.mark.parametrize("cin,idt", [(2, torch.int32), (4, torch.int64), (3, torch.int32)])
+def test_kpconv_small_row_kernel_other_influences_vs_numpy_oracle(ops, cin, idt, influence, agg):
+    """kpconv_gather_small (rows of <= 4 channels, four lanes per point) with the non-default influence / aggregation
+    modes and both index widths, a point count that is not a multiple of the wave."""
+    from oracle import npref
+    rng = np.random.default_rng(cin * 7 + len(influence) + len(agg))
+    Nq, Ns, K, H = 1001, 777, 15, 23
+    q = (rng.random((Nq, 3)) * 0.3).astype(np.float32)
+    s = (rng.random((Ns, 3)) * 0.3).astype(np.float32)
+    idx = rng.integers(0, Ns + 1, (Nq, H))
+    idx[7] = Ns
+    x = rng.normal(size=(Ns, cin)).astype(np.float32)
+    kp = (rng.normal(size=(K, 3)) * 0.05).astype(np.float32)
+    W = (rng.normal(size=(K, cin, 5)) * 0.1).astype(np.float32)
+    y, _ = ops.kpconv(T(q), T(s), torch.from_numpy(idx).to("cuda", idt), T(x), T(kp), T(W), 0.06, influence, agg)
+    want = npref.kpconv_forward(q.astype(np.float64), s.astype(np.float64), idx.astype(np.int64), x.astype(np.float64),
+                                kp.astype(np.float64), W.astype(np.float64), 0.06, influence, agg)
+    assert rel_err(y.cpu().numpy(), want) < FP_TOL

@@ -124,6 +124,13 @@ def main():
     # they were first used on, and nodes born on the legacy default stream cannot be captured later
     torch.cuda.set_stream(torch.cuda.Stream(priority=int(os.environ.get("MVK_MAIN_PRIO", "0"))))
 
+    if world > 1:
+        # one MIOpen user database / kernel cache per rank: eight processes searching solvers at once otherwise
+        # contend for the same SQLite files (lock warnings, serialised finds)
+        os.environ.setdefault("MIOPEN_USER_DB_PATH", "/tmp/mvk_miopen_db_rank%d" % local)
+        os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", "/tmp/mvk_miopen_cache_rank%d" % local)
+        for k in ("MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR"):
+            os.makedirs(os.environ[k], exist_ok=True)
     if os.environ.get("MVK_MIOPEN_BENCHMARK", "1") == "1":
         # MIOpen picks its fastest solver per convolution shape of the frozen 2D encoder, as the reference's own 2D
         # training scripts do (mvpnet/train_2d.py:17, train_mvpnet_3d.py:16: torch.backends.cudnn.benchmark = True);

@@ -14,6 +14,8 @@
 // kpconv_gather_vec (forward, rigid) and kpconv_lane_channel (backward scatter dx, deformable forward:
 // lane = channel, one point per wave, wave-uniform neighbour loop). The offset gradient of the deformable
 // layers is csrc/deform.hip (lane = neighbour).
+#include <type_traits>
+
 #include "common.h"
 
 #define KMAX 16
@@ -186,10 +188,18 @@ constexpr int DPPW = 16;      // most points per wave of the deformable variant
 // of a point are padded to a multiple of FUB with zero rows, addresses are 32-bit offsets from the table base,
 // and the lane holding the ragged last quad of a row works on the row's LAST four channels instead (it
 // recomputes up to three channels of its left neighbour, bit for bit, and stores them again).
-template <int NCH, bool IDX64, bool FAST, typename XT = float, bool VEC = true, bool DEFORM = false, int FUB = 0>
+//
+// TAIL > 0 (with FUB; rows of 4 LPP + TAIL channels, TAIL = 1..3, LPP >= 15: Cin = 66 of the early-fusion net's
+// first layer): the LPP lanes of a point take the 4 LPP leading channels as whole quads; the TAIL trailing channels
+// x 15 kernel points are spread over the same lanes -- lane l < 15 keeps kernel point l's TAIL sums and adds, per
+// neighbour, ITS weight (one ds_read_b32 of the row) times the row's TAIL trailing values (the same address for the
+// whole group). A 17th lane per point for two channels would cost a quarter of the launch (3 points per wave, not 4).
+template <int NCH, bool IDX64, bool FAST, typename XT = float, bool VEC = true, bool DEFORM = false, int FUB = 0, int TAIL = 0>
 __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPParams P, int LPP, int PPW, int HC,
                                                                                   int SW, int B1) {
   constexpr bool FASTLD = FUB > 0;
+  static_assert(TAIL == 0 || (FASTLD && NCH == 1 && !DEFORM), "trailing channels: branch-free rigid variant only");
+  constexpr int TL = TAIL > 0 ? TAIL : 1;
   // Sharing workgroups (all of them when DEFORM; with SW > 1 those from block B1 on): the waves of the workgroup
   // share the same PPW points and take every nwv-th neighbour chunk; wave 0 adds the partial aggregates through
   // LDS in a fixed order and stores them. A wave lives for tens of microseconds, so a launch of 1.2 rounds of
@@ -246,6 +256,11 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
     c4e[c] = c_on[c] ? (uint32_t)min(c4, P.Cin - 4) : 0u;
   }
   const uint32_t row_bytes = (uint32_t)P.Cin * (uint32_t)sizeof(XT);
+  const uint32_t tail_bytes = (uint32_t)(P.Cin - TAIL) * (uint32_t)sizeof(XT);   // TAIL: offset of the trailing channels
+  const bool t_on = cl < KMAX - 1;                                               // TAIL: this lane keeps kernel point cl
+  float acc_t[TL];
+#pragma unroll
+  for (int t = 0; t < TL; ++t) acc_t[t] = 0.f;
   const float inv_ext = 1.0f / P.extent;
   const float* __restrict__ kp = P.kp;
   const float ext2 = P.extent * P.extent;
@@ -396,6 +411,7 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
       for (int hb = 0; hb < HCP; hb += UB) {
         int jj[UB];
         float4 xv[UB][NCH];
+        float xt[UB][TL];
         if (FASTLD) {
 #pragma unroll
           for (int u = 0; u < UB; ++u) jj[u] = __float_as_int(wblk_b[(hb + u) * 16 + 15]);
@@ -405,6 +421,12 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
             for (int c = 0; c < NCH; ++c) {   // byte offset < 2^32, row index and row bytes < 2^24 (checked by the host)
               const uint32_t off = __umul24((uint32_t)max(jj[u], 0), row_bytes) + c4e[c] * (uint32_t)sizeof(XT);
               xv[u][c] = ld4(reinterpret_cast<const XT*>(reinterpret_cast<const char*>(X) + off));
+            }
+            if (TAIL > 0) {
+              const XT* pt = reinterpret_cast<const XT*>(reinterpret_cast<const char*>(X) +
+                                                         (__umul24((uint32_t)max(jj[u], 0), row_bytes) + tail_bytes));
+#pragma unroll
+              for (int t = 0; t < TL; ++t) xt[u][t] = (float)pt[t];
             }
             asm volatile("" ::: "memory");    // loads leave in entry order, so that entry u waits for u + 1 loads only
           }
@@ -446,11 +468,21 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
                 acc[c][kk].w += wk[kk] * xv[u][c].w;
               }
             }
+            if (TAIL > 0) {
+              const float wraw = wblk_b[(hb + u) * 16 + (t_on ? cl : 0)];
+              const float wt = t_on ? wraw : 0.f;
+#pragma unroll
+              for (int t = 0; t < TL; ++t) acc_t[t] += wt * xt[u][t];
+            }
             if (FASTLD) {   // entry u's products stay together: otherwise every entry's weight row is live at once
 #pragma unroll
               for (int c = 0; c < NCH; ++c)
 #pragma unroll
                 for (int kk = 0; kk < KMAX - 1; ++kk) asm volatile("" : "+v"(acc[c][kk]));
+              if (TAIL > 0) {
+#pragma unroll
+                for (int t = 0; t < TL; ++t) asm volatile("" : "+v"(acc_t[t]));
+              }
             }
           }
         }
@@ -491,6 +523,19 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
         }
         __syncthreads();
       }
+    }
+    if (TAIL > 0) {       // the trailing channels' sums, one more round
+      if (wid > 0) mine[lane] = make_float4(acc_t[0], TL > 1 ? acc_t[TL > 1 ? 1 : 0] : 0.f, TL > 2 ? acc_t[TL > 2 ? 2 : 0] : 0.f, 0.f);
+      __syncthreads();
+      if (wid == 0) {
+        for (int w = 1; w < nwv; ++w) {
+          const float4 v = reinterpret_cast<const float4*>(wl_all[w])[lane];
+          acc_t[0] += v.x;
+          if (TL > 1) acc_t[TL > 1 ? 1 : 0] += v.y;
+          if (TL > 2) acc_t[TL > 2 ? 2 : 0] += v.z;
+        }
+      }
+      __syncthreads();
     }
   }
   if (DEFORM) {
@@ -547,6 +592,11 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
           }
         }
       }
+    }
+    if (TAIL > 0 && cl < P.K && t_on) {      // lane cl holds kernel point cl's sums over the trailing channels
+      XT* o = Aout + (n * P.K + cl) * P.Cin + (P.Cin - TAIL);
+#pragma unroll
+      for (int t = 0; t < TL; ++t) o[t] = (XT)acc_t[t];
     }
   }
 }
@@ -760,6 +810,7 @@ __global__ __launch_bounds__(256) void kpconv_gather_small(KPParams P) {
 struct VecPlan {
   int LPP, PPW, HC;   // lanes per point, points per wave, neighbours per chunk and point
   int fub;            // rows per batch of the branch-free variant, 0 = the general variant
+  int tail;           // trailing channels handled beside the quads (TAIL of the kernel), 0 = none
   int SW, B1, nw;     // sharing: waves per sharing workgroup (1 = none), first sharing workgroup, waves per workgroup
   int64_t wgs;        // workgroups
 };
@@ -767,25 +818,42 @@ struct VecPlan {
 VecPlan plan_vec(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, bool fast, bool vec, bool deform) {
   VecPlan v{};
   const int NCH = Cin <= 256 ? 1 : 2;
-  const int c4 = (Cin + 3) / 4;
-  v.LPP = c4 < 64 ? c4 : 64;
-  v.PPW = 64 / v.LPP;
-  v.HC = 64 / v.PPW;
   static const bool fastld_on = getenv("MVK_GATHER_FASTLD") == nullptr || atoi(getenv("MVK_GATHER_FASTLD")) != 0;
-  // rows per batch of the branch-free variant: the divisor-like batch size with the least padding of HC
-  if (fastld_on && fast && vec && v.LPP >= 5 && Ns < (1 << 24) &&
-      (uint64_t)Ns * (uint64_t)Cin * (uint64_t)elem_bytes < (1ull << 32) - 64) {
-    if (NCH == 2) {
-      v.fub = 4;
-    } else {
-      int best_pad = 1 << 30;
-      for (int ub = 8; ub >= 5; --ub) {
-        const int pad = (v.HC + ub - 1) / ub * ub - v.HC;
-        if (pad < best_pad) {
-          best_pad = pad;
-          v.fub = ub;
+  static const bool tail_on = getenv("MVK_GATHER_TAIL") == nullptr || atoi(getenv("MVK_GATHER_TAIL")) != 0;
+  const bool branch_free = fastld_on && fast && vec && Ns < (1 << 24) &&
+                           (uint64_t)Ns * (uint64_t)Cin * (uint64_t)elem_bytes < (1ull << 32) - 64;
+  // first choice for f32 rows of 4 m + t channels (m >= 15, t = 1..3): m lanes per point and the t trailing channels
+  // beside the quads -- if the resulting chunk length is a multiple of the 4-row batch; else ceil(Cin / 4) lanes
+  // (measured: 19 464 points x 66 channels 72 -> 67 us; 171 k points 484 -> 495 us -- the 4-row batches hide less
+  // latency once the feature table no longer sits in the caches: hence the row limit)
+  for (int with_tail = (tail_on && branch_free && !deform && elem_bytes == 4 && NCH == 1 && Cin >= 60 && Cin % 4 != 0 &&
+                        Ns <= 65536) ? 1 : 0;
+       with_tail >= 0; --with_tail) {
+    const int c4 = with_tail ? Cin / 4 : (Cin + 3) / 4;
+    v.LPP = c4 < 64 ? c4 : 64;
+    v.PPW = 64 / v.LPP;
+    v.HC = 64 / v.PPW;
+    v.fub = 0;
+    v.tail = 0;
+    // rows per batch of the branch-free variant: the divisor-like batch size with the least padding of HC
+    if (branch_free && v.LPP >= 5) {
+      if (NCH == 2) {
+        v.fub = 4;
+      } else {
+        int best_pad = 1 << 30;
+        for (int ub = 8; ub >= 5; --ub) {
+          const int pad = (v.HC + ub - 1) / ub * ub - v.HC;
+          if (pad < best_pad) {
+            best_pad = pad;
+            v.fub = ub;
+          }
         }
       }
+    }
+    if (with_tail && v.fub > 0 && v.HC % 4 == 0) {      // batches of 4 rows: the trailing values take registers too
+      v.tail = Cin % 4;
+      v.fub = 4;
+      break;
     }
   }
   // sharing workgroups (kernel comment): all of them for the deformable variant; for the branch-free rigid one
@@ -815,12 +883,19 @@ template <int NCH, typename XT = float, bool VEC = true, bool DEFORM = false>
 int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
   const bool fast = P.influence == MVK_INFL_LINEAR && P.aggregation == MVK_AGG_SUM;
   const VecPlan v = plan_vec(P.Nq, P.Ns, P.H, P.Cin, (int)sizeof(XT), fast, VEC, DEFORM);
-  const int LPP = v.LPP, PPW = v.PPW, HC = v.HC, fub = v.fub, SW = v.SW, B1 = v.B1;
+  const int LPP = v.LPP, PPW = v.PPW, HC = v.HC, fub = v.fub, SW = v.SW, B1 = v.B1, tail = v.tail;
   dim3 grid((unsigned)v.wgs), block(64 * v.nw);
 #define LV(I64, F, L) \
   hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F, XT, VEC, DEFORM, L>), grid, block, 0, st, P, LPP, PPW, HC, SW, B1)
+#define LVT(I64, T)                                                                                                   \
+  hipLaunchKernelGGL((kpconv_gather_vec<1, I64, true, float, true, false, 4, (TAIL_OK ? T : 0)>), grid, block, 0, st, P, LPP, \
+                     PPW, HC, SW, B1)
+  constexpr bool TAIL_OK = NCH == 1 && VEC && !DEFORM && std::is_same<XT, float>::value;
 #define LVF(I64)                                                                            \
-  if (NCH == 2 && fub == 4) LV(I64, true, (VEC && NCH == 2 ? 4 : 0));                       \
+  if (TAIL_OK && tail == 1 && fub == 4) LVT(I64, 1);                                        \
+  else if (TAIL_OK && tail == 2 && fub == 4) LVT(I64, 2);                                   \
+  else if (TAIL_OK && tail == 3 && fub == 4) LVT(I64, 3);                                   \
+  else if (NCH == 2 && fub == 4) LV(I64, true, (VEC && NCH == 2 ? 4 : 0));                  \
   else if (fub == 8) LV(I64, true, (VEC && NCH == 1 ? 8 : 0));                              \
   else if (fub == 7) LV(I64, true, (VEC && NCH == 1 ? 7 : 0));                              \
   else if (fub == 6) LV(I64, true, (VEC && NCH == 1 ? 6 : 0));                              \
@@ -833,6 +908,7 @@ int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
     LVF(false)
   }
 #undef LVF
+#undef LVT
 #undef LV
   return 0;
 }

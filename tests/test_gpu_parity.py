@@ -260,7 +260,8 @@ def test_kpconv_fwd_bwd_golden(ops, name, influence, agg, idt):
 
 @pytest.mark.parametrize("cin,cout,H", [(1, 5, 9), (4, 32, 17), (8, 8, 70), (20, 12, 33), (68, 64, 40),
                                         (128, 16, 25), (256, 8, 64), (512, 4, 10), (516, 4, 6), (1040, 3, 5),
-                                        (2, 6, 130), (130, 16, 150), (600, 4, 130), (30, 5, 260)])
+                                        (2, 6, 130), (130, 16, 150), (600, 4, 130), (30, 5, 260),
+                                        (61, 8, 40), (62, 8, 16), (67, 8, 33), (129, 8, 20), (255, 4, 70)])
 def test_kpconv_every_kernel_variant_vs_numpy_oracle(ops, cin, cout, H):
     """Seeded inputs through every gather / scatter template instantiation (LPP = 1..64, NCH = 1, 2,
     the generic lane = channel kernel and its > 512-channel multi-launch path, the one-lane-per-point kernel for rows
@@ -290,7 +291,7 @@ def test_kpconv_every_kernel_variant_vs_numpy_oracle(ops, cin, cout, H):
 
 
 @pytest.mark.parametrize("Nq,cin,H,f16", [(40000, 32, 12, False), (70000, 66, 30, False), (17000, 64, 40, False),
-                                          (40000, 32, 12, True), (21000, 128, 70, False)])
+                                          (40000, 32, 12, True), (21000, 128, 70, False), (19000, 66, 40, False), (17500, 65, 20, False)])
 def test_kpconv_gather_launches_with_sharing_workgroups_vs_numpy_oracle(ops, Nq, cin, H, f16):
     """Launches large enough that their last partial round of waves runs as sharing workgroups (the waves of a workgroup
     split the neighbour chunks of ONE point group and wave 0 adds the partial aggregates, csrc/kpconv.hip): the

@@ -32,18 +32,23 @@ def test_library_exports_every_declared_symbol():
 
 def test_gather_launch_plan_is_a_host_function():
     """mvk_kpconv_gather_plan: the launch geometry of the gather kernel, no GPU call (bench.py finds the launch in the
-    PMC profile by it). First layer of the early-fusion net: 17 lanes per point, 3 points per wave, 21-neighbour
-    chunks = 3 batches of 7 rows, one full round of 1 024 independent workgroups + 2 392 sharing ones."""
+    PMC profile by it). First layer of the early-fusion net (66 = 4 x 16 + 2 channels): 16 lanes per point with the two
+    trailing channels beside the quads, 4 points per wave, 16-neighbour chunks in batches of 4 rows, one full round of
+    1 024 independent workgroups + the remaining 770 point groups as sharing workgroups."""
     ops = importlib.import_module(PKG + ".ops")
     p = ops.kpconv_gather_plan(19464, 19464, 58, 66)
-    assert (p["lanes_per_point"], p["points_per_wave"], p["rows_per_batch"]) == (17, 3, 7)
-    assert p["first_sharing_workgroup"] == 1024 and p["workgroups"] == 1024 + (6488 - 4096)
+    assert (p["lanes_per_point"], p["points_per_wave"], p["rows_per_batch"]) == (16, 4, 4)
+    assert p["first_sharing_workgroup"] == 1024 and p["workgroups"] == 1024 + (4866 - 4096)
     assert p["grid_threads"] == p["workgroups"] * 64 * p["waves_per_workgroup"]
+    t = ops.kpconv_gather_plan(19464, 19464, 58, 70)           # 70 = 4 x 17 + 2: 21-neighbour chunks, no trailing-channel mode
+    assert (t["lanes_per_point"], t["points_per_wave"], t["rows_per_batch"]) == (18, 3, 7)
+    assert t["first_sharing_workgroup"] == 1024 and t["workgroups"] == 1024 + (6488 - 4096)
     q = ops.kpconv_gather_plan(3000, 3000, 50, 64)            # under one round: independent waves only
     assert q["workgroups"] == -(-(-(-3000 // 4)) // 4) or q["first_sharing_workgroup"] == 0
     d = ops.kpconv_gather_plan(750, 750, 420, 128, deformable=True)    # deformable: every workgroup shares
     assert d["first_sharing_workgroup"] == 0 and d["workgroups"] == 375 and d["waves_per_workgroup"] == 4
-    assert ops.kpconv_gather_plan(100, 100, 20, 2)["rows_per_batch"] == 0     # rows of < 4 elements: general variant
+    assert ops.kpconv_gather_plan(100, 100, 20, 2)["workgroups"] == 0         # rows of <= 4 channels: one point per 4 lanes
+    assert ops.kpconv_gather_plan(100, 100, 20, 8)["rows_per_batch"] == 0     # 2 lanes per point: general variant
     assert ops.kpconv_gather_plan(100, 100, 20, 600)["workgroups"] == 0        # Cin > 512: one-point-per-wave kernel
     h = ops.kpconv_gather_plan(19464, 19464, 58, 64, elem_bytes=2)
     assert h["rows_per_batch"] == 8 and h["points_per_wave"] == 4

@@ -256,6 +256,8 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
     c4e[c] = c_on[c] ? (uint32_t)min(c4, P.Cin - 4) : 0u;
   }
   const uint32_t row_bytes = (uint32_t)P.Cin * (uint32_t)sizeof(XT);
+  uint64_t batch_mask0 = 0;     // phase-A lanes of the columns 0 .. UB-1 of every point (shifted by the batch's first column)
+  for (int pp = 0; pp < PPW; ++pp) batch_mask0 |= ((1ull << UB) - 1ull) << (pp * HC);
   const uint32_t tail_bytes = (uint32_t)(P.Cin - TAIL) * (uint32_t)sizeof(XT);   // TAIL: offset of the trailing channels
   const bool t_on = cl < KMAX - 1;                                               // TAIL: this lane keeps kernel point cl
   float acc_t[TL];
@@ -407,8 +409,16 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
       }
     }
     // ---------------- phase B: UB feature rows in flight, then their FMAs
-    if (__ballot(jrow >= 0) != 0ull) {
+    const uint64_t live = __ballot(jrow >= 0);        // bit = phase-A lane (point pa, column ha) holds a real neighbour
+    if (live != 0ull) {
       for (int hb = 0; hb < HCP; hb += UB) {
+        // FASTLD: a batch whose columns are shadow entries for every point of the wave (the tail of the sorted
+        // neighbour rows: H is the 90th-percentile width, the mean row holds 3/4 of it) is skipped as a whole
+        // (only in the instantiations where the extra branch leaves the register allocation alone: with fp16 rows, 5-row
+        // batches or three trailing channels it costs 30 spilled registers and up to a third of the speed)
+        constexpr bool SKIP = FASTLD && std::is_same<XT, float>::value && NCH == 1 &&
+                              (FUB == 6 || FUB == 7 || FUB == 8 || (FUB == 4 && (TAIL == 1 || TAIL == 2)));
+        if (SKIP && (live & (batch_mask0 << hb)) == 0ull) continue;
         int jj[UB];
         float4 xv[UB][NCH];
         float xt[UB][TL];

@@ -223,6 +223,17 @@ def _gather_kernel_name(Cin, deform):
     return "kpconv_lane_channel<fwd>"
 
 
+def _gather_kernel_label(Nq, Ns, H, Cin, deform, elem_bytes=4):
+    """Kernel name with the launch geometry the library actually uses (mvk_kpconv_gather_plan)."""
+    p = kpconv_gather_plan(Nq, Ns, H, Cin, elem_bytes, deform)
+    if p["workgroups"] == 0:
+        return _gather_kernel_name(Cin, deform)
+    tail = Cin - 4 * p["lanes_per_point"] if 4 * p["lanes_per_point"] < Cin else 0
+    return "kpconv_gather_vec<NCH=%d%s>(LPP=%d,PPW=%d%s)" % (1 if Cin <= 256 else 2, ",deform" if deform else "",
+                                                             p["lanes_per_point"], p["points_per_wave"],
+                                                             ",+%d trailing channels" % tail if tail else "")
+
+
 def profile_collect(h_eff=None):
     """{(kernel, Nq, Ns, H, Cin, K): {launches, total_ms, bytes_per_launch, ...}}; h_eff maps
     (Nq, Ns, H) -> mean number of real (non-shadow) neighbours per row."""
@@ -267,7 +278,7 @@ def kpconv_gather(q, s, idx, x, kp, extent, influence="linear", aggregation="sum
                                       _p(offsets), _p(min_d2), _p(min_arg), _p(A), _stream()))
     if _PROF["on"]:
         e1.record()
-        _PROF["rec"].append(((_gather_kernel_name(Cin, offsets is not None), Nq, Ns, H, Cin, K), e0, e1))
+        _PROF["rec"].append(((_gather_kernel_label(Nq, Ns, H, Cin, offsets is not None), Nq, Ns, H, Cin, K), e0, e1))
     if min_d2 is not None:
         min_d2._mvk_min_arg = min_arg          # neighbour column of each minimum: the backward's min_d2 path starts there
     return A, min_d2
@@ -512,7 +523,7 @@ def kpconv_gather_f16(q, s, idx, x16, kp, extent, influence="linear", aggregatio
                                           INFLUENCE[influence], AGGREGATION[aggregation], _p(A), _stream()))
     if _PROF["on"]:
         e1.record()
-        _PROF["rec"].append(((_gather_kernel_name(Cin, False) + "[f16]", Nq, Ns, H, Cin, K), e0, e1))
+        _PROF["rec"].append(((_gather_kernel_label(Nq, Ns, H, Cin, False, 2) + "[f16]", Nq, Ns, H, Cin, K), e0, e1))
     return A
 
 

@@ -39,6 +39,7 @@ struct KPParams {
   int H, Cin, K;
   float extent;
   int influence, aggregation;
+  int zero_skip;         // gather: neighbours without any influence become shadow entries (development switch MVK_GATHER_ZEROSKIP)
 };
 
 __device__ __forceinline__ float influence_w(float d2, float extent, int influence) {
@@ -114,6 +115,13 @@ __device__ __forceinline__ int phase_a(const KPParams& P, int64_t n0, int h0, in
         }
       }
       if (bk != k) w = 0.f;
+    }
+    if (!DEFORM) {
+      // a neighbour on which no kernel point has any influence (beyond the extent of all of them: a third of the real
+      // neighbours at conv_radius 2.5 / KP_extent 1.2) contributes exactly nothing: its entry becomes a shadow entry, so
+      // the scatter spends no atomics (its bound) and the lane = channel gather no row loads on it
+      const unsigned long long mz = __ballot(w != 0.f);
+      if (((mz >> (lane & 48)) & 0xFFFFull) == 0ull && k == 0 && jj >= 0) rel[ph].w = __int_as_float(-1);
     }
     if (DEFORM) {
       // neighbours out of range of every deformed kernel point are dropped (blocks.py:306-325)
@@ -380,6 +388,13 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
 #pragma unroll
         for (int kk = 0; kk < KMAX - 1; ++kk)
           if (kk != bk) wv[kk] = 0.f;
+      }
+      if (FASTLD && P.zero_skip) {     // no kernel point has any influence on this neighbour: a shadow entry (no row of its own is loaded,
+                        // and batches of such entries are skipped as a whole)
+        float wany = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KMAX - 1; ++kk) wany = fmaxf(wany, fabsf(wv[kk]));
+        if (wany == 0.f) jrow = -1;
       }
     }
     wv[15] = __int_as_float(jrow);
@@ -980,6 +995,8 @@ extern "C" int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s,
   P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets; P.min_d2 = min_d2; P.min_arg = min_arg;
   P.A = A_out; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
   P.influence = influence; P.aggregation = aggregation;
+  static const int zero_skip = getenv("MVK_GATHER_ZEROSKIP") ? atoi(getenv("MVK_GATHER_ZEROSKIP")) : 1;
+  P.zero_skip = zero_skip;
   if (H == 0) {
     MVK_CHECK_HIP(hipMemsetAsync(A_out, 0, sizeof(float) * Nq * K * Cin, st));
     if (offsets == nullptr) return 0;

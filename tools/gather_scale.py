@@ -12,7 +12,7 @@ staged = syn.stage_spheres([syn.raw_sphere(seed=0)], dev, None)
 limits = syn.calibrate_limits(cfg, staged)
 p = staged['points'][0] - staged['center'][0]
 pyr = common.segmentation_inputs_sphere(cfg, p, np.asarray([p.shape[0]], np.int32), limits, torch.int32)
-kp = torch.from_numpy(kpmod.load_kernels(0.1 * 0.6, 15, dimension=3, fixed='center').astype(np.float32)).to(dev)
+kp = torch.from_numpy(kpmod.load_kernels(0.1, 15, dimension=3, fixed='center').astype(np.float32)).to(dev)
 pts, nb = pyr['points'][0], pyr['neighbors'][0]
 cin = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 x = torch.randn(pts.shape[0], cin, device=dev)

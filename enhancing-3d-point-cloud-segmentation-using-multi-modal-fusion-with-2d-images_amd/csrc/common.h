@@ -35,7 +35,7 @@ template <typename T>
 __device__ __forceinline__ T* load_global_ptr(T* const* slot) {
 #if defined(__HIP_DEVICE_COMPILE__)
   typedef __attribute__((address_space(1))) T* gp;
-  return (T*)(*reinterpret_cast<const gp*>(slot));
+  return (T*)(*static_cast<const gp*>(static_cast<const void*>(slot)));
 #else
   return *slot;
 #endif

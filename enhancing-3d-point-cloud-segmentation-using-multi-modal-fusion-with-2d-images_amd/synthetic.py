@@ -386,7 +386,7 @@ class DeviceInputChain:
         cfg, st, plan, caps, lim = self.config, self.staged, self.plan, static.caps, self.limits
         world = st['points']
         stacked_world = torch.cat(world, 0)
-        static.points[0].copy_(torch.cat([p - c for p, c in zip(world, st['center'])], 0))   # :600
+        torch.cat([p - c for p, c in zip(world, st['center'])], 0, out=static.points[0][:static.n0])   # :600
         static._counts[0].fill_(static.n0)
         L = len(static.points)
         grid_of = (None, None)
@@ -407,16 +407,16 @@ class DeviceInputChain:
                                        self.status, rotations_dev=self.rot[l], total_out=static._counts[l + 1])
                 search(l + 1, l, e['pool_r'], static.pools[l], l)
                 search(l, l + 1, e['up_r'], static.upsamples[l], l + 1)
-        static.labels.copy_(torch.cat(st['labels'], 0))
+        torch.cat(st['labels'], 0, out=static.labels)
         ones = torch.ones_like(stacked_world[:, :1])
         z = stacked_world[:, 2:3]
         v = cfg.variant
         if v == "baseline":
-            static.features.copy_(torch.cat([ones, z], 1))
+            torch.cat([ones, z], 1, out=static.features)
             return
-        static.feature_3d.copy_(torch.cat([ones, z], 1) if v == "early" else torch.cat([ones, torch.cat(st['colors'], 0)], 1))
+        torch.cat([ones, z] if v == "early" else [ones] + [torch.cat(st['colors'], 0)], 1, out=static.feature_3d)
         static.feat_aggre_points.copy_(stacked_world.unsqueeze(0))
-        static.images.copy_(torch.stack(st['images'], 0))
+        torch.stack(st['images'], 0, out=static.images)
         for i, pw in enumerate(world):
             xyz, valid = ops.unproject_depth(st['depth'][i], st['cam'][i], st['poses'][i])
             static.knn_list[i].copy_(ops.knn_pixels(pw, xyz, valid, k=3).unsqueeze(0))

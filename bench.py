@@ -421,13 +421,13 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             if use_chain:
                 torch.cuda.current_stream().wait_stream(build_stream)
 
-        if reducer is None:
+        if reducer is None or getattr(reducer, "capturable", False):
             diag = os.environ.get("MVK_BENCH_DIAG", "")    # development: "noside" / "onlyside" time the branches apart
             with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
                 if diag != "noside":
                     fork_encoder(work=side_first)
                 if diag != "onlyside":
-                    loss = net_step_captured(net, static, cfg, params, opt, None)
+                    loss = net_step_captured(net, static, cfg, params, opt, reducer)
                 else:
                     loss = torch.zeros((), device=dev)
                 if diag != "noside":
@@ -453,7 +453,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             if staged_exchange:
                 orig, leaves = net.cut_tensors
                 with scope():
-                    loss.backward()
+                    loss.backward(reducer.seed(loss))
                 reducer.pack(0)
             else:
                 backward(ops, loss)
@@ -555,7 +555,12 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                             "sync-free input chain (pyramid, unprojection, 3-NN; device-side counts) of batch k+1"
                             % ("three" if enc is not None else "two")
                             + (" | frozen 2D encoder of batch k+1" if enc is not None else
-                               (" (2D encoder in line with the network)" if hasattr(net, "net_2d") else "")))
+                               (" (2D encoder in line with the network)" if hasattr(net, "net_2d") else ""))
+                            + ("" if reducer is None else
+                               " | gradient all-reduce (RCCL, two buckets) captured as a branch of the same graph"
+                               if getattr(reducer, "capturable", False) else
+                               " | gradient all-reduce: eager RCCL calls between the graphs of the step (backward "
+                               "above the cut | below the cut | unpack+clip+SGD), bucket 0 overlapped with the second"))
 
     def build_async(slot):
         """Enqueues batch k+1 on the build / encode streams and pads it into static set `slot`."""
@@ -658,7 +663,12 @@ def make_reducer(dp, net, cfg, params, world):
     if cut is None or not hasattr(net, "encoder_blocks"):
         return dp.FlatAllReduce(params, world)
     late, early = dp.split_parameters_at(net, cut)
-    red = dp.BucketedAllReduce([late, early], world)
+    # MVK_DP_GRAPH_COLLECTIVES=1 (opt-in: verified with a one-rank communicator only, this pool gives one GPU per
+    # box): the all-reduces go straight to librccl and are captured as a branch of the step's single graph
+    comm = None
+    if os.environ.get("MVK_DP_GRAPH_COLLECTIVES", "0") == "1" and torch.distributed.get_backend() == "nccl":
+        comm = dp.RcclCommunicator(params[0].device)
+    red = dp.BucketedAllReduce([late, early], world, comm=comm, prescaled=os.environ.get("MVK_DP_PRESCALE", "1") == "1")
     red.cut_block = cut
     red.dp = dp
     return red
@@ -679,7 +689,8 @@ def net_step_captured(net, static, cfg, params, opt, reducer, begin=True):
         def between():
             reducer.pack(0)
             reducer.launch(0)
-        reducer.dp.two_stage_backward(loss, net.cut_tensors, between=between, backward_scope=backward_scope(ops))
+        reducer.dp.two_stage_backward(loss, net.cut_tensors, between=between, backward_scope=backward_scope(ops),
+                                      seed=reducer.seed(loss))
         reducer.pack(1)
         reducer.launch(1)
         reducer.wait()

@@ -1120,3 +1120,14 @@ def test_kpconv_small_row_kernel_other_influences_vs_numpy_oracle(ops, cin, idt,
     want = npref.kpconv_forward(q.astype(np.float64), s.astype(np.float64), idx.astype(np.int64), x.astype(np.float64),
                                 kp.astype(np.float64), W.astype(np.float64), 0.06, influence, agg)
     assert rel_err(y.cpu().numpy(), want) < FP_TOL
+
+
+def test_gradient_exchange_through_librccl_is_capturable_in_a_graph():
+    """dp.RcclCommunicator + BucketedAllReduce(comm=...): pack, all-reduce on the exchange branch, unpack, captured in
+    one hipGraph and replayed (one-rank communicator: the box has one GPU). Runs in a child process (process group)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "dp_graph_exchange_check.py")], capture_output=True,
+                       text=True, timeout=300)
+    assert p.returncode == 0 and "DP GRAPH EXCHANGE OK" in p.stdout, (p.stdout[-2000:], p.stderr[-3000:])

@@ -592,6 +592,24 @@ def _two_stage_worker(rank, world, port, q):
     br.unpack(0)
     br.unpack(1)
     ok = all(torch.allclose(p.grad, w, rtol=1e-6, atol=1e-7) for p, w in zip(params, want))
+    # the same with the backward seeded by 1 / world: no division, .grad re-pointed at the bucket (no copy back)
+    for p in params:
+        p.grad = None
+    loss, cut = forward(True)
+    bp = dp.BucketedAllReduce([list(late.parameters()), list(early.parameters())], world, prescaled=True)
+
+    def between_p():
+        bp.pack(0)
+        bp.launch(0)
+    dp.two_stage_backward(loss, cut, between=between_p, seed=bp.seed(loss))
+    bp.pack(1)
+    bp.launch(1)
+    bp.wait()
+    bp.unpack(0)
+    bp.unpack(1)
+    ok = ok and all(torch.allclose(p.grad, w, rtol=1e-6, atol=1e-7) for p, w in zip(params, want))
+    ok = ok and all(p.grad.untyped_storage().data_ptr() in (bp.flat[0].untyped_storage().data_ptr(),
+                                                            bp.flat[1].untyped_storage().data_ptr()) for p in params)
     q.put((rank, ok, dp.cut_block_of_layer(['simple', 'resnetb', 'resnetb_strided', 'resnetb', 'resnetb_strided', 'resnetb',
                                             'nearest_upsample', 'unary'], 2)))
     dist.barrier()

@@ -27,6 +27,7 @@ _SIGNATURES = {
     "mvk_gemm_f32_plan": (C.c_int, [_i64, _i64, _i64, _i, _i, _vp, _vp]),
     "mvk_gemm_f32_ex": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mvk_gemm_group_entry_bytes": (C.c_int64, []),
+    "mvk_gemm_f32_tn_grouped_split": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "mvk_gemm_f32_tn_grouped_plan": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
     "mvk_gemm_f32_tn_grouped": (C.c_int, [_vp, _i, _i, _i64, _i64, _vp]),
     "mvk_gemm_f16": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i64, _i64, _i64, _i, _i, _i, _vp]),

@@ -586,6 +586,33 @@ struct MvkGemmProblem {
 
 extern "C" int64_t mvk_gemm_group_entry_bytes(void) { return (int64_t)sizeof(GroupEntry); }
 
+// Split of the reduction of ONE product inside a grouped launch. A product launched alone splits until the chip is
+// full (plan_gemm); in a grouped launch the other products fill it, and a split only has to bound the longest
+// workgroup: at most `ktiles` k-tiles of 32 per workgroup. Every split costs M x N x 4 bytes of f32 atomics and a zero
+// fill of the output. Measured (tools/dw_group_bench.py, the 51 products of the early-fusion net): one sphere,
+// 16.5 GFLOP: 305 us with the stand-alone splits (81 MB of atomics), 297 us at 16 k-tiles (54 MB), 309 / 352 us at
+// 40 / 80; eight spheres, 140 GFLOP: 1773 us stand-alone (323 MB), 1708 us at 84 k-tiles (87 MB), 1767 us at 170.
+// The launch is bound by its MFMA pipeline (54 -> 82 TFLOP/s), not by the atomics: the policy is worth 2-4 %.
+// MVK_DW_GROUP_KTILES: 0 = the stand-alone plan, > 0 = fixed; default = by the size of the whole group, 16..96.
+constexpr int GROUP_KTILES_MIN = 16, GROUP_KTILES_MAX = 96;
+
+int group_ktiles_env() {
+  static const int v = getenv("MVK_DW_GROUP_KTILES") ? atoi(getenv("MVK_DW_GROUP_KTILES")) : -1;
+  return v;
+}
+
+int grouped_split_at(int64_t M, int64_t N, int64_t Kd, int ktiles) {
+  if (ktiles <= 0) return plan_gemm(M, N, Kd, 0, false).split;
+  int64_t split = cdiv64(cdiv64(Kd, BK), ktiles);
+  return (int)(split > 64 ? 64 : (split < 1 ? 1 : split));
+}
+
+// Upper bound of the split the grouped launch may give this product (the caller zero-initialises the output when > 1).
+extern "C" int mvk_gemm_f32_tn_grouped_split(int64_t M, int64_t N, int64_t Kd) {
+  const int e = group_ktiles_env();
+  return grouped_split_at(M, N, Kd, e >= 0 ? e : GROUP_KTILES_MIN);
+}
+
 // Fills `table_host` (n * mvk_gemm_group_entry_bytes() bytes, narrow problems first) for the device-side grouped launch
 // and reports how many of the problems are narrow (N <= 32) and the workgroup counts of the two launches.
 extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* table_host, int* n_narrow,
@@ -597,13 +624,20 @@ extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* t
   for (int i = 0; i < n; ++i) nn += pr[i].N <= 32 ? 1 : 0;
   int64_t wn = 0, ww = 0;
   int in = 0, iw = nn;
+  int ktiles = group_ktiles_env();
+  if (ktiles < 0) {      // by the size of the group: ~8 000 workgroup-sized pieces of the longest allowed length
+    double units = 0.0;
+    for (int i = 0; i < n; ++i)
+      units += (double)cdiv64(pr[i].M, pr[i].N <= 32 ? 64 : 32) * cdiv64(pr[i].N, pr[i].N <= 32 ? 32 : 64) * cdiv64(pr[i].Kd, BK);
+    const double t = units / 8000.0;
+    ktiles = t < GROUP_KTILES_MIN ? GROUP_KTILES_MIN : (t > GROUP_KTILES_MAX ? GROUP_KTILES_MAX : (int)t);
+  }
   for (int i = 0; i < n; ++i) {
     const MvkGemmProblem& q = pr[i];
     MVK_REQUIRE(q.M > 0 && q.N > 0 && q.Kd > 0 && q.A && q.B && q.C, "grouped gemm: empty problem %d", i);
     const bool narrow = q.N <= 32;
     MVK_REQUIRE(!narrow || q.N > 16, "grouped gemm: outputs of <= 16 columns are not grouped");
-    const Plan p = plan_gemm(q.M, q.N, q.Kd, 0, false);
-    int split = p.split;
+    int split = grouped_split_at(q.M, q.N, q.Kd, ktiles);
     const int64_t ksteps = cdiv64(q.Kd, BK);
     if (split > ksteps) split = (int)ksteps;
     const int64_t k_per_split = cdiv64(ksteps, split) * BK;

@@ -432,7 +432,7 @@ def _dw_gemm(A, B, transB=False):
         A, B = _f32c(A), _f32c(B)
         # a split reduction accumulates into a zero-initialised output (arena slice); an unsplit one (the big
         # coarse-level weights: few rows to reduce over, 2/3 of all weight-gradient bytes) writes every element
-        zeroed = gemm_plan(A.shape[1], B.shape[1], A.shape[0])[0] > 1
+        zeroed = lib().mvk_gemm_f32_tn_grouped_split(A.shape[1], B.shape[1], A.shape[0]) > 1
         out = (_zeros((A.shape[1], B.shape[1]), A.device) if zeroed
                else torch.empty((A.shape[1], B.shape[1]), device=A.device, dtype=torch.float32))
         # only the ADDRESS is recorded: a second reference to the tensor would make autograd's AccumulateGrad clone the

@@ -108,6 +108,9 @@ int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, int want_st
 int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA,
                     int transB, int accumulate, int split_k, float* bn_part, const int32_t* n_valid, void* stream);
 
+/* Upper bound of the split of the reduction the grouped launch gives one product (the plan may choose fewer pieces for
+ * a large group); the caller zero-initialises the outputs for which it is > 1. */
+int mvk_gemm_f32_tn_grouped_split(int64_t M, int64_t N, int64_t Kd);
 /* Grouped weight-gradient products: n independent TN products C_i [M_i,N_i] = A_i^T B_i (A_i [Kd_i,M_i], B_i [Kd_i,N_i],
  * row-major: dW = A^T g of a KPConv layer, dW^T = g^T x of a unary layer, blocks.py / SURVEY.md A.6) in at most two
  * launches. `problems` = HOST array of records {const float* A; const float* B; float* C; int64 M, N, Kd;} (48 bytes,

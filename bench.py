@@ -187,7 +187,7 @@ def main():
     for _ in range(max(args.warmup, 1)):
         lens, loss = eager_step()
     ops.profile_reset(enabled=True)
-    INSTRUMENTED = 8
+    INSTRUMENTED = 16
     for _ in range(INSTRUMENTED):               # instrumented eager passes (same step, same data)
         lens, loss = eager_step()
     recs = ops._PROF["rec"]
@@ -764,7 +764,10 @@ def roofline(prof):
             "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "kernel": best["kernel"],
             "launch": best["shape"], "avg_launch_us": avg_ms * 1e3, "launches": best["launches"],
-            "measured_in": "HIP events on the launch stream around every gather launch of 8 instrumented eager steps run between warm-up and the timed region",
+            "launch_us_min_median_max": [round(float(v) * 1e3, 2) for v in
+                                         (min(best["each_ms"]), float(np.median(best["each_ms"])), max(best["each_ms"]))]
+            if best.get("each_ms") else None,
+            "measured_in": "HIP events on the launch stream around every gather launch of 16 instrumented eager steps run between warm-up and the timed region",
             "algorithmic_bytes_per_launch": best["bytes_per_launch"]}
 
 

@@ -240,9 +240,11 @@ def profile_collect(h_eff=None):
     torch.cuda.synchronize()
     out = {}
     for key, e0, e1 in _PROF["rec"]:
-        r = out.setdefault(key, {"launches": 0, "total_ms": 0.0})
+        r = out.setdefault(key, {"launches": 0, "total_ms": 0.0, "each_ms": []})
         r["launches"] += 1
-        r["total_ms"] += e0.elapsed_time(e1)
+        t = e0.elapsed_time(e1)
+        r["total_ms"] += t
+        r["each_ms"].append(t)
     for key, r in out.items():
         name, Nq, Ns, H, Cin, K = key
         he = (h_eff or {}).get((Nq, Ns, H), H)

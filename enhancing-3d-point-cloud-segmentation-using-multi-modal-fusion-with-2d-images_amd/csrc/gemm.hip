@@ -592,7 +592,8 @@ extern "C" int64_t mvk_gemm_group_entry_bytes(void) { return (int64_t)sizeof(Gro
 // fill of the output. Measured (tools/dw_group_bench.py, the 51 products of the early-fusion net): one sphere,
 // 16.5 GFLOP: 305 us with the stand-alone splits (81 MB of atomics), 297 us at 16 k-tiles (54 MB), 309 / 352 us at
 // 40 / 80; eight spheres, 140 GFLOP: 1773 us stand-alone (323 MB), 1708 us at 84 k-tiles (87 MB), 1767 us at 170.
-// The launch is bound by its MFMA pipeline (54 -> 82 TFLOP/s), not by the atomics: the policy is worth 2-4 %.
+// The launch is bound by its MFMA pipeline (54 -> 82 TFLOP/s), not by the atomics: the policy is worth 2-4 %; putting
+// the products with the longest workgroups first in the table (autograd records the first layer last) changes nothing.
 // MVK_DW_GROUP_KTILES: 0 = the stand-alone plan, > 0 = fixed; default = by the size of the whole group, 16..96.
 constexpr int GROUP_KTILES_MIN = 16, GROUP_KTILES_MAX = 96;
 

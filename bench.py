@@ -47,7 +47,8 @@ def parse():
     ap.add_argument("--graph", dest="graph", action="store_true", default=None,
                     help="replay the network part (fwd+loss+bwd+clip+SGD) as one hipGraph over capacity-padded levels")
     ap.add_argument("--no-graph", dest="graph", action="store_false")
-    ap.add_argument("--cpu-baseline-steps", type=int, default=5)
+    ap.add_argument("--cpu-baseline-steps", type=int, default=20,
+                    help="timed iterations per CPU leg (each leg is also cut at a time bound)")
     return ap.parse_args()
 
 
@@ -188,7 +189,7 @@ def main():
         lens, loss = eager_step()
     ops.profile_reset(enabled=True)
     INSTRUMENTED = 16
-    for _ in range(INSTRUMENTED):               # instrumented eager passes (same step, same data)
+    for _ in range(INSTRUMENTED):               # instrumented eager passes (same spheres, a fresh grid orientation each)
         lens, loss = eager_step()
     recs = ops._PROF["rec"]
     contraction = ops.profile_collect_contraction()
@@ -196,13 +197,11 @@ def main():
     ops._PROF["rec"] = recs
 
     step = eager_step
-    graph_note = "eager"
+    graph_note = ("eager", "eager step (no graph)")
     if use_graph:
-        try:
-            step, graph_note = make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer)
-        except Exception as e:                      # capture refused (e.g. a collective that cannot be captured)
-            ops.set_row_counts(None)
-            step, graph_note = eager_step, "eager (graph capture failed: %s)" % type(e).__name__
+        # a capture that fails ends the run with a non-zero exit code: an eager run in its place would report a
+        # different execution mode under the same command (--no-graph asks for the eager step explicitly)
+        step, graph_note = make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer)
     for _ in range(2 if use_graph else 0):
         lens, loss = step()
     sync()
@@ -244,6 +243,8 @@ def main():
     total_points = pts.item() * args.steps
 
     if rank == 0:
+        dp_on = world > 1 or force_dp
+        tag, execution_text = graph_note
         res = {
             "metric": "input points/s through MV-KPConv KPFCNN forward+backward (pyramid + fusion + fwd + bwd + SGD)",
             "value": total_points / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -254,21 +255,20 @@ def main():
                 args.workload + ("_fusion" if fusion else ""), int(round(sum(lens) / max(args.spheres, 1) / 1000.0)),
                 args.spheres, "_deformable" if args.deformable else ""),
                 "points_per_step_per_gpu": int(sum(lens)), "views": args.views if fusion else 0,
-                "image_hw": [120, 160] if fusion else None, "parallelism": "dp%d" % world, "execution": graph_note,
-                "ranks": ranks_seen, "backend": ("rccl" if backend == "nccl" else backend) if (world > 1 or force_dp) else None,
-                "rccl_ranks": ranks_seen if (backend == "nccl" and (world > 1 or force_dp)) else None,
+                "image_hw": [120, 160] if fusion else None, "parallelism": "dp%d" % world, "execution": tag,
+                "ranks": ranks_seen, "backend": ("rccl" if backend == "nccl" else backend) if dp_on else None,
                 "ms_per_step_per_rank": per_rank_ms,
                 "final_loss": float(loss.item()),
                 "capacity_overflow": bool(state_ref and state_ref[-1].get("overflow", False))},
             "roofline": roofline(prof),
             "contraction": mfma_report(contraction, args.features),
-            "gather_launches": [dict(kernel=r["kernel"], avg_us=r["total_ms"] / r["launches"] * 1e3,
-                                     GBps=r["bytes_per_launch"] / (r["total_ms"] / r["launches"] * 1e-3) / 1e9, **r["shape"])
-                                for r in sorted(prof.values(), key=lambda r: -r["total_ms"])],
         }
         if not args.no_cpu_baseline:           # timed on rank 0 at N = 1 only (the other ranks would sit in the barrier)
             res["cpu_baseline"] = cpu_baseline(cfg, net, staged, limits, spheres, args) if world == 1 else None
-        print(json.dumps(res))
+        detail = {"execution": execution_text, "roofline_detail": roofline_detail(prof),
+                  "gather_launches": gather_by_level(prof), "cpu_baseline_detail": CPU_DETAIL.get("last")}
+        write_detail(res, detail)
+        print(result_line(res))
     if world > 1 or force_dp:
         dist.barrier()
         dist.destroy_process_group()
@@ -551,7 +551,10 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             print("DIAG graph replay (network + encoder + input chain branches) %.2f ms | input chain alone, eager "
                   "%.2f ms" % ((t1 - t0) * 50, (t2 - t1) * 100), file=sys.stderr)
         state_ref.append(state)
-        return step_chain, ("hipGraph with %s branches per step: network fwd+loss+bwd+clip+SGD on static set k%%2 | "
+        tag = "hipGraph[net|chain%s]%s" % ("|enc2d" if enc is not None else "",
+                                           "" if reducer is None else
+                                           "+rccl-in-graph" if getattr(reducer, "capturable", False) else "+eager-rccl(3 graphs)")
+        return step_chain, (tag, "hipGraph with %s branches per step: network fwd+loss+bwd+clip+SGD on static set k%%2 | "
                             "sync-free input chain (pyramid, unprojection, 3-NN; device-side counts) of batch k+1"
                             % ("three" if enc is not None else "two")
                             + (" | frozen 2D encoder of batch k+1" if enc is not None else
@@ -650,7 +653,8 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                                             (t3 - t2) * 100, (t4 - t3) * 100), file=sys.stderr)
 
     state_ref.append(state)
-    return step, ("hipGraph(network step: fwd+loss+bwd+clip+SGD over capacity-padded levels, two static sets) | "
+    return step, ("hipGraph[net%s]+eager-input-stream" % ("|enc2d" if enc is not None else ""),
+                  "hipGraph(network step: fwd+loss+bwd+clip+SGD over capacity-padded levels, two static sets) | "
                   "second stream: pyramid + unprojection + 3-NN of the next batch" +
                   (" | frozen 2D encoder of the next batch as a parallel branch of the same graph" if enc is not None else ""))
 
@@ -740,7 +744,7 @@ def dry_run(args, world, rank):
     dist.all_gather(per_rank, t)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     if rank == 0:
-        print(json.dumps({"metric": "dry run (launch rehearsal, no GPU work)", "value": 0.0, "unit": "points/s",
+        print(result_line({"metric": "dry run (launch rehearsal, no GPU work)", "value": 0.0, "unit": "points/s",
                           "n_gpus": got, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t.item(),
                           "config": {"ranks": got, "backend": "gloo", "parallelism": "dp%d" % got,
                                      "ms_per_step_per_rank": [float(v.item()) for v in per_rank]}}))
@@ -749,26 +753,97 @@ def dry_run(args, world, rank):
     return 0 if got == args.gpus else 3
 
 
+LINE_LIMIT = 4096          # bytes: the driver's consumer keeps a bounded tail of stdout (BENCH_r02: a 22 KB line was not parsed)
+
+
+def _short(v, digits=6):
+    """Floats to `digits` significant digits, recursively: the line is read by a machine, not diffed bit for bit."""
+    if isinstance(v, float):
+        return float("%.*g" % (digits, v))
+    if isinstance(v, dict):
+        return {k: _short(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_short(x, digits) for x in v]
+    return v
+
+
+def result_line(res):
+    """The ONE JSON line of the contract, bounded to LINE_LIMIT bytes: everything per-launch lives in the side file
+    (write_detail). Raises instead of printing a line its consumer cannot read."""
+    line = json.dumps(_short(res), separators=(",", ":"))
+    if len(line) >= LINE_LIMIT or "\n" in line:
+        raise SystemExit("bench.py: result line is %d bytes (limit %d): move detail to bench_detail.json" % (len(line), LINE_LIMIT))
+    return line
+
+
+def write_detail(res, detail):
+    """Per-level gather table, the long execution description and the CPU-baseline protocol go to
+    gpurun_out/bench_detail.json (MVK_BENCH_DETAIL overrides the path; failures to write are reported, never fatal)."""
+    path = os.environ.get("MVK_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump({"line": _short(res), "detail": _short(detail)}, f, indent=1)
+    except OSError as e:
+        print("bench.py: could not write %s: %s" % (path, e), file=sys.stderr)
+
+
+def gather_by_level(prof):
+    """Gather launches of the instrumented steps aggregated per (kernel, H, Cin, K): the row counts of levels >= 1
+    move with the random grid orientation, H (the level's neighbour limit) and Cin identify the layer class."""
+    agg = {}
+    for r in prof.values():
+        sh = r["shape"]
+        a = agg.setdefault((r["kernel"], sh["H"], sh["Cin"], sh["K"]),
+                           {"kernel": r["kernel"], "H": sh["H"], "Cin": sh["Cin"], "K": sh["K"], "launches": 0,
+                            "total_ms": 0.0, "bytes": 0.0, "Nq_min": sh["Nq"], "Nq_max": sh["Nq"]})
+        a["launches"] += r["launches"]
+        a["total_ms"] += r["total_ms"]
+        a["bytes"] += r["bytes_per_launch"] * r["launches"]
+        a["Nq_min"], a["Nq_max"] = min(a["Nq_min"], sh["Nq"]), max(a["Nq_max"], sh["Nq"])
+    out = []
+    for a in sorted(agg.values(), key=lambda a: -a["total_ms"]):
+        a["avg_us"] = a["total_ms"] / a["launches"] * 1e3
+        a["GBps"] = a.pop("bytes") / (a["total_ms"] * 1e-3) / 1e9
+        out.append(a)
+    return out
+
+
+def _dominant(prof):
+    return max(prof.values(), key=lambda r: r["total_ms"]) if prof else None
+
+
 def roofline(prof):
     """Dominant KPConv gather launch class: achieved = algorithmic gathered bytes / average launch
     duration (HIP events), against the HBM peak. Bytes per launch:
         B_g = Nq*H_eff*(Cin*4 + 12 + 4) + Nq*12 + Nq*K*Cin*4."""
-    if not prof:
+    best = _dominant(prof)
+    if best is None:
         return None
-    best = max(prof.values(), key=lambda r: r["total_ms"])
-    traffic, traffic_note = pmc_traffic(best)
+    traffic, _ = pmc_traffic(best)
     avg_ms = best["total_ms"] / best["launches"]
     achieved = best["bytes_per_launch"] / (avg_ms * 1e-3) / 1e9
+    sh = best["shape"]
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_note,
-            "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-            "kernel": best["kernel"],
-            "launch": best["shape"], "avg_launch_us": avg_ms * 1e3, "launches": best["launches"],
-            "launch_us_min_median_max": [round(float(v) * 1e3, 2) for v in
-                                         (min(best["each_ms"]), float(np.median(best["each_ms"])), max(best["each_ms"]))]
-            if best.get("each_ms") else None,
-            "measured_in": "HIP events on the launch stream around every gather launch of 16 instrumented eager steps run between warm-up and the timed region",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "kernel": best["kernel"].split("(")[0],
+            "launch": {"Nq": sh["Nq"], "H": sh["H"], "H_eff": sh["H_eff"], "Cin": sh["Cin"], "K": sh["K"]},
+            "avg_launch_us": avg_ms * 1e3, "launches": best["launches"],
             "algorithmic_bytes_per_launch": best["bytes_per_launch"]}
+
+
+def roofline_detail(prof):
+    best = _dominant(prof)
+    if best is None:
+        return None
+    traffic, note = pmc_traffic(best)
+    avg_ms = best["total_ms"] / best["launches"]
+    each = best.get("each_ms") or [avg_ms]
+    return {"kernel": best["kernel"], "launch": best["shape"], "traffic_source": note,
+            "hbm_frac_measured": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "launch_us_min_median_max": [min(each) * 1e3, float(np.median(each)) * 1e3, max(each) * 1e3],
+            "measured_in": "HIP events on the launch stream around every gather launch of the instrumented eager steps "
+                           "run between warm-up and the timed region"}
 
 
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= f32 vector peak)
@@ -818,6 +893,9 @@ def pmc_traffic(best):
     return None, "%s holds no launch with this run's grid" % os.path.basename(path)
 
 
+CPU_DETAIL = {}
+
+
 def cpu_baseline(cfg, net, staged, limits, spheres, args):
     """The oracle timed on the host cores (rank 0, N = 1 only): C restatement of the pyramid (single
     thread, like the reference extension) + unfused PyTorch-ops port of the network on all cores.
@@ -842,20 +920,16 @@ def cpu_baseline(cfg, net, staged, limits, spheres, args):
     leaf = {k: v.clone().requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and
             ("weight" in k or "bias" in k) and not k.startswith("net_2d.") and "running" not in k}
 
-    def cpu_step():
+    impl = "ref" if cport.ref() else "oracle"
+    from oracle import pyramid_workers
+
+    def pyramid_leg():
         t0 = time.perf_counter()
-        # pyramid: per level neighbours / subsampling / pool / upsample neighbours
-        p, l = sub0, np.array([sub0.shape[0]], np.int32)
-        r = cfg.first_subsampling_dl * cfg.conv_radius
-        for lvl in range(5):
-            cport.radius_neighbors_batch(p, p, l, l, r, impl="ref" if cport.ref() else "oracle")
-            if lvl < 4:
-                q, ql = cport.subsample_batch(p, l, dl=2 * r / cfg.conv_radius, impl="ref" if cport.ref() else "oracle")
-                cport.radius_neighbors_batch(q, p, ql, l, r, impl="ref" if cport.ref() else "oracle")
-                cport.radius_neighbors_batch(p, q, l, ql, 2 * r, impl="ref" if cport.ref() else "oracle")
-                p, l = q, ql
-            r *= 2
-        t1 = time.perf_counter()
+        pyramid_workers.pyramid(cport, sub0, cfg.first_subsampling_dl, cfg.conv_radius, impl)
+        return time.perf_counter() - t0
+
+    def network_leg():
+        t0 = time.perf_counter()
         sdl = dict(sd)
         sdl.update(leaf)
         out, reg = torch_port.forward(sdl, cfg, cb, net2d, training=True)
@@ -863,29 +937,61 @@ def cpu_baseline(cfg, net, staged, limits, spheres, args):
         loss.backward()
         for v in leaf.values():
             v.grad = None
-        return t1 - t0, time.perf_counter() - t1
+        return time.perf_counter() - t0
 
-    a, b = cpu_step()  # warm-up (also the sample itself when one step already exceeds the time bound)
-    samples = []
-    if a + b < 20.0:
-        t_end = time.perf_counter() + 25.0       # bounded sample: about 10-30 s of CPU work
-        for _ in range(max(args.cpu_baseline_steps, 1)):
-            samples.append(cpu_step())
-            if time.perf_counter() > t_end:
+    def timed(leg, warm, want, budget_s):
+        """SURVEY 8d protocol: median of `want` (>= 20) iterations after `warm` (5) warm-ups, cut at the time bound
+        that keeps the default bench run within minutes (the cut is reported)."""
+        t_end = time.perf_counter() + budget_s
+        first = leg()
+        for _ in range(warm - 1):
+            if time.perf_counter() + first > t_end - want * first * 0.5:
                 break
-    else:
-        samples = [(a, b)]
-    n = len(samples)
-    tot = sorted(x + y for x, y in samples)
-    med = tot[n // 2] if n % 2 else 0.5 * (tot[n // 2 - 1] + tot[n // 2])
-    tp, tn = float(np.median([x for x, _ in samples])), float(np.median([y for _, y in samples]))
-    return {"value": lens[0] / med, "unit": "points/s", "cores": cores,
-            "kind": "port",
-            "sample": "median of %d step(s) after 1 warm-up over ONE %d-point sphere of the same workload: pyramid by %s "
-                      "(1 thread, median %.0f ms/step) + unfused PyTorch-CPU network fwd+bwd on %d threads (median %.0f "
-                      "ms/step); no optimizer step" % (
-                          n, lens[0], "the compiled reference core (oracle/_ref)" if cport.ref() else "the C oracle",
-                          tp * 1e3, cores, tn * 1e3)}
+            leg()
+        ts = []
+        while len(ts) < want and (not ts or time.perf_counter() + first < t_end):
+            ts.append(leg())
+        return float(np.median(ts)), len(ts)
+
+    want = max(args.cpu_baseline_steps, 1)
+    tp, n_p = timed(pyramid_leg, 5, want, 8.0)
+    tn, n_n = timed(network_leg, 5, want, 16.0)
+    # x P worker processes on the pyramid (the reference's DataLoader workers, train_ScanNet_sphere.py:58,365-377),
+    # in a child process that never sees the GPU
+    multi = None
+    try:
+        import subprocess
+        import tempfile
+        with tempfile.NamedTemporaryFile(suffix=".npy", delete=False) as f:
+            np.save(f, sub0)
+        per = max(2, min(10, int(4.0 / max(tp, 1e-3))))
+        r = subprocess.run([sys.executable, "-m", "oracle.pyramid_workers", f.name, str(cores), str(per),
+                            repr(float(cfg.first_subsampling_dl)), repr(float(cfg.conv_radius))],
+                           cwd=ROOT, capture_output=True, text=True, timeout=120)
+        os.unlink(f.name)
+        if r.returncode == 0:
+            multi = json.loads(r.stdout.strip().splitlines()[-1])
+        else:
+            print("bench.py: pyramid worker run failed: %s" % r.stderr[-400:], file=sys.stderr)
+    except Exception as e:                      # the single-process figures stand on their own
+        print("bench.py: pyramid worker run skipped: %r" % (e,), file=sys.stderr)
+    n0 = lens[0]
+    CPU_DETAIL["last"] = {
+        "protocol": "SURVEY 8d: median of >= 20 timed iterations after 5 warm-ups per leg, each leg cut at its time "
+                    "bound (pyramid 8 s, network 16 s) so the default run stays within minutes",
+        "pyramid": {"impl": "compiled reference core (oracle/_ref)" if cport.ref() else "C oracle", "threads": 1,
+                    "median_ms": tp * 1e3, "timed_iterations": n_p},
+        "pyramid_worker_processes": multi,
+        "network": {"impl": "oracle/torch_port.py (unfused PyTorch-CPU ops), fwd+loss+bwd, no optimizer step",
+                    "threads": cores, "median_ms": tn * 1e3, "timed_iterations": n_n},
+        "points": n0}
+    amort = (1.0 / multi["spheres_per_s"]) if multi else tp
+    return {"value": n0 / (tp + tn), "unit": "points/s", "cores": cores, "kind": "port",
+            "sample": "one %d-pt sphere: pyramid %s 1 thread median %.0f ms (n=%d) + PyTorch-CPU net fwd+bwd %d threads "
+                      "median %.0f ms (n=%d), 5 warm-ups each; pyramid x%d worker procs: %s spheres/s" % (
+                          n0, "oracle/_ref" if cport.ref() else "C oracle", tp * 1e3, n_p, cores, tn * 1e3, n_n, cores,
+                          ("%.1f" % multi["spheres_per_s"]) if multi else "n/a"),
+            "value_pyramid_on_workers": n0 / (amort + tn)}
 
 
 if __name__ == "__main__":

@@ -388,6 +388,43 @@ def test_bench_gpus_n_starts_n_ranks_itself():
     assert r2.returncode != 0 and "WORLD_SIZE" in (r2.stderr + r2.stdout)
 
 
+def test_bench_result_line_is_bounded():
+    """The line of record must stay under 4 KB whatever the run looked like (BENCH_r02: a 22 KB line was not
+    parsed by the driver): a worst-case result -- 8 ranks, long kernel labels, every optional object present --
+    through bench.result_line, and a line that cannot fit is refused, not printed."""
+    import importlib
+    import json
+    bench = importlib.import_module("bench")
+    prof = {}
+    for i in range(120):            # 120 distinct launch shapes, as the random grid orientation produces
+        prof[("k", i)] = {"kernel": "kpconv_gather_vec<NCH=1>(LPP=16,PPW=4,+2 trailing channels)", "launches": 16,
+                          "total_ms": 1.0 + (i == 0), "each_ms": [0.0671234567] * 16, "bytes_per_launch": 309427088.123,
+                          "shape": {"Nq": 19464 - i, "Ns": 19464, "H": 58 - i % 5, "H_eff": 42.590731607069465, "Cin": 66, "K": 15}}
+    bench.pmc_traffic = lambda best: (205634042.0, "r02_pmc_gather.json (python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline)")
+    res = {"metric": "input points/s through MV-KPConv KPFCNN forward+backward (pyramid + fusion + fwd + bwd + SGD)",
+           "value": 4236201.534778994, "unit": "points/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+           "ms_per_step": 4.5946822501719, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f16 features / f32 accumulate", "data": "synthetic",
+           "config": {"workload": "middle_fusion_kpfcnn5_sphere19k_x1_per_gpu_deformable", "points_per_step_per_gpu": 19464,
+                      "views": 5, "image_hw": [120, 160], "parallelism": "dp8",
+                      "execution": "hipGraph[net|chain|enc2d]+eager-rccl(3 graphs)", "ranks": 8, "backend": "rccl",
+                      "ms_per_step_per_rank": [4.5946822501719] * 8, "final_loss": 2.951704263687134,
+                      "capacity_overflow": False},
+           "roofline": bench.roofline(prof),
+           "contraction": bench.mfma_report({(19464, 990, 64): {"launches": 16, "total_ms": 0.7, "flops_per_launch": 2.0 * 19464 * 990 * 64}}),
+           "cpu_baseline": {"value": 15689.054546085035, "unit": "points/s", "cores": 16, "kind": "port",
+                            "sample": "x" * 260, "value_pyramid_on_workers": 17000.123456}}
+    line = bench.result_line(res)
+    assert len(line) < 4096 and "\n" not in line
+    d = json.loads(line)
+    assert d["roofline"]["bound"] == "hbm" and abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-5
+    assert set(d["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+    assert len(bench.gather_by_level(prof)) == 5          # aggregated per level class, not per launch shape
+    res["config"]["note"] = "y" * 5000
+    with pytest.raises(SystemExit):
+        bench.result_line(res)
+
+
 # ---------------------------------------------------------------- drop-in boundary (INTEGRATION.md route 1)
 
 _STUB_TREE = {

@@ -330,6 +330,7 @@ def test_bench_emits_one_valid_json_line():
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines[0]) < 4096, len(lines[0])      # the driver's consumer keeps a bounded tail (BENCH_r02 was not parsed)
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -339,5 +340,7 @@ def test_bench_emits_one_valid_json_line():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["kernel"].startswith("kpconv_gather_vec") and 0.2 < r["frac"] < 1.0
+    detail = json.load(open(os.path.join(root, "gpurun_out", "bench_detail.json")))
+    assert detail["line"]["value"] == d["value"] and len(detail["detail"]["gather_launches"]) >= 5
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == "points/s" and c["cores"] >= 1 and c["value"] > 0

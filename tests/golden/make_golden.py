@@ -606,7 +606,71 @@ def g10_reprojection():
     save("g10_reprojection", points=points, sub_points=sub, proj_inds=proj, dist=np.squeeze(dist))
 
 
-GROUPS = {"g9": g9_ply, "g8": g8_metrics, "g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn, "g5b": g5b_kpfcnn_deformable, "g10": g10_reprojection,
+def _reference_functions(rel_path, names):
+    """Compile top-level pure-NumPy function definitions of a reference file that cannot be IMPORTED here (the module
+    pulls in open3d / natsort / torchvision at import time): ast.parse the file where it lies, keep only the
+    FunctionDef nodes asked for, and execute those with nothing but `np` in their namespace. The reference's own text
+    runs; none of it is written anywhere."""
+    import ast
+    path = os.path.join(REFROOT, rel_path)
+    tree = ast.parse(open(path).read(), filename=path)
+    defs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert sorted(d.name for d in defs) == sorted(names), [d.name for d in defs]
+    ns = {"np": np}
+    exec(compile(ast.Module(body=defs, type_ignores=[]), path, "exec"), ns)
+    return [ns[n] for n in names], {d.name: (d.lineno, d.end_lineno) for d in defs}
+
+
+def g11_unproject_select():
+    """a12 / f3 pinned by the reference's own functions: `depth2xyz` and `select_frames`
+    (datasets/ScanNet_sphere_color.py:53-72) and `unproject` (datasets/get_rgbd_overlap_subcloud.py:55-66), executed
+    from the reference files (see _reference_functions) on the G6 camera / depth / poses and on random overlap tables.
+    The caller-side lines are three NumPy statements each and are restated here with their line numbers:
+      ScanNet_sphere_color.py:409  depth = np.asarray(depth, dtype=np.float32) / 1000.
+                              :412  image_xyz = depth2xyz(cam_matrix, depth)
+                              :414  image_mask = image_xyz[:, 2] > 0
+                              :416  image_xyz = np.matmul(image_xyz, pose[:3, :3].T) + pose[:3, 3]
+      get_rgbd_overlap_subcloud.py:109  depth = np.asarray(depth, dtype=np.float32) / 1000.
+                              :112  unproj_pts = unproject(cam_matrix, depth)
+                              :115  unproj_pts = pose[:3, :3].dot(unproj_pts[:, :3].T).T + pose[:3, 3]"""
+    (select_frames, depth2xyz), where = _reference_functions(
+        "KPConv-PyTorch/datasets/ScanNet_sphere_color.py", ["select_frames", "depth2xyz"])
+    (unproject,), where2 = _reference_functions("KPConv-PyTorch/datasets/get_rgbd_overlap_subcloud.py", ["unproject"])
+    print("executed from the reference:", where, where2)
+    g6 = np.load(os.path.join(OUT, "g6_fusion.npz"))
+    cam, depth_mm, poses = g6["cam"], g6["depth"], g6["poses"]
+    xyz_cam, xyz, mask, ov_pts, ov_counts = [], [], [], [], []
+    for i in range(depth_mm.shape[0]):
+        depth = np.asarray(depth_mm[i], dtype=np.float32) / 1000.           # :409
+        cam_xyz = depth2xyz(cam, depth)                                      # :412 (h*w, 3)
+        m = cam_xyz[:, 2] > 0                                                # :414
+        world = np.matmul(cam_xyz, poses[i][:3, :3].T) + poses[i][:3, 3]     # :416
+        xyz_cam.append(cam_xyz.reshape(depth.shape + (3,)))
+        xyz.append(world.reshape(depth.shape + (3,)))
+        mask.append(m.reshape(depth.shape))
+        u = unproject(cam, depth)                                            # overlap script :112 (valid pixels only)
+        u = poses[i][:3, :3].dot(u[:, :3].T).T + poses[i][:3, 3]             # :115
+        ov_pts.append(u)
+        ov_counts.append(u.shape[0])
+    xyz_cam, xyz, mask = np.stack(xyz_cam), np.stack(xyz), np.stack(mask)
+    assert xyz.dtype == np.float64 and xyz_cam.dtype == np.float64
+    # greedy frame selection on random coverage tables (bool [base points, frames]), incl. ties and empty frames
+    rng = np.random.default_rng(1111)
+    tables, picks = [], []
+    for nb, nf, p, n_sel in ((400, 12, 0.15, 3), (6000, 40, 0.05, 5), (50, 6, 0.5, 6), (64, 9, 0.0, 3)):
+        t = rng.random((nb, nf)) < p
+        if nf > 7:
+            t[:, 7] = t[:, 2]            # two identical frames: the first maximum wins
+        tables.append(t)
+        picks.append(np.asarray(select_frames(t, n_sel), np.int64))
+    arrs = dict(cam=cam, depth=depth_mm, poses=poses, xyz_cam=xyz_cam, xyz=xyz, mask=mask,
+                overlap_points=np.concatenate(ov_pts, 0), overlap_counts=np.asarray(ov_counts, np.int64))
+    for i, (t, s) in enumerate(zip(tables, picks)):
+        arrs["table%d" % i], arrs["selected%d" % i] = t, s
+    save("g11_unproject_select", **arrs)
+
+
+GROUPS = {"g11": g11_unproject_select, "g9": g9_ply, "g8": g8_metrics, "g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn, "g5b": g5b_kpfcnn_deformable, "g10": g10_reprojection,
           "g6": g6_fusion}
 
 if __name__ == "__main__":

@@ -250,6 +250,26 @@ def test_voting_metrics_and_frame_selection():
     assert np.array_equal(got, want)
 
 
+def test_unprojection_and_frame_selection_vs_reference_functions():
+    """a12 / f3 on the HIP path against G11 (the reference's own depth2xyz / select_frames / unproject function texts
+    executed in the build container): mvk_unproject_depth within 1e-13 of the float64 values (evaluation order of the
+    3x3 products: last bit), identical valid mask; the overlap table's unprojected points; greedy frame selection on
+    device tensors."""
+    ops = importlib.import_module(PKG + ".ops")
+    vt = importlib.import_module(PKG + ".dropin.utils.voting")
+    g = load_golden("g11_unproject_select")
+    xyz, valid = ops.unproject_depth(T(g["depth"].astype(np.int16)), g["cam"], T(g["poses"]))
+    assert xyz.dtype == torch.float64 and np.array_equal(valid.cpu().numpy(), g["mask"])
+    err = rel_err(xyz.cpu().numpy(), g["xyz"])
+    print("unprojection rel err vs the reference function: %.2e" % err)
+    assert err < 1e-13
+    pts = xyz.reshape(-1, 3)[valid.reshape(-1)].cpu().numpy()
+    assert rel_err(pts, g["overlap_points"]) < 1e-13
+    for i in range(4):
+        want = g["selected%d" % i].tolist()
+        assert vt.select_frames(T(g["table%d" % i]), len(want)) == want
+
+
 def test_scene_load_subsampling_vs_reference_core():
     """datasets/scene_cache.subsample_scene (ScanNet_sphere_color.py:935-948: colours as features, labels,
     dl = 0.04) against the compiled reference core (G9): points, order, colour barycentres / 255, majority labels."""

@@ -211,6 +211,28 @@ def test_fusion_oracle_vs_golden():
     assert rel_err(torch_port.feature_aggregation(sd, "fa", *args, training=False).numpy(), g["out_eval"]) < 1e-5
 
 
+def test_unprojection_and_frame_selection_vs_reference_functions():
+    """a12 / f3, pinned: G11 was produced by EXECUTING the reference's own `depth2xyz`, `select_frames`
+    (datasets/ScanNet_sphere_color.py:53-72) and `unproject` (datasets/get_rgbd_overlap_subcloud.py:55-66) function
+    texts (make_golden._reference_functions) plus the three caller lines (:409-416 / :109-115). The NumPy restatement
+    and the product's host-side `select_frames` must reproduce them bit for bit (float64 / index work)."""
+    import importlib
+    import torch
+    g = load_golden("g11_unproject_select")
+    xyz, mask = npref.unproject_frames(g["cam"], g["depth"], g["poses"])
+    assert xyz.dtype == np.float64 and np.array_equal(xyz, g["xyz"]) and np.array_equal(mask, g["mask"])
+    # the overlap script unprojects valid pixels only, with pose.dot(x.T).T instead of matmul(x, pose.T): same points
+    flat = xyz.reshape(-1, 3)[mask.reshape(-1)]
+    assert np.array_equal(mask.reshape(3, -1).sum(1), g["overlap_counts"])
+    assert rel_err(flat, g["overlap_points"]) < 1e-15
+    vt = importlib.import_module("enhancing-3d-point-cloud-segmentation-using-multi-modal-fusion-with-2d-images_amd.dropin.utils.voting")
+    for i in range(4):
+        t, want = g["table%d" % i], g["selected%d" % i].tolist()
+        assert vt.select_frames(t, len(want)) == want
+        assert vt.select_frames(torch.from_numpy(t), len(want)) == want
+        assert t.sum() == g["table%d" % i].sum()            # input not modified
+
+
 def test_sphere_picking_oracle_vs_sklearn_golden():
     """6 iterations of potentials-based sphere picking: the numpy restatement against scikit-learn's
     KDTree.query_radius (the reference's calls): same centres, member sets and potentials."""

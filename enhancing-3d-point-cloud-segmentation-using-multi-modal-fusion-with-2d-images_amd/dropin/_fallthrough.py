@@ -46,3 +46,21 @@ def reference_module_file(rel_py):
         if os.path.isfile(cand):
             return cand
     return None
+
+
+def worker_start_method():
+    """Called by the mirrored ``datasets`` package (route 1 only). The reference builds its batches -- and with them
+    the input pyramid -- in ``config.input_threads`` DataLoader workers that the script creates with the platform's
+    default start method (train_ScanNet_sphere.py:365-377: no ``multiprocessing_context``), i.e. ``fork`` on Linux,
+    after the model has initialised the GPU in the parent. A HIP context does not survive ``fork`` (the library
+    refuses such a call, ``_lib.FORK_MESSAGE``), so the drop-in makes ``spawn`` the default start method before the
+    script creates its loaders: every worker is then a fresh interpreter with its own HIP context, the script stays
+    unmodified. ``MVK_DATALOADER_START=keep`` leaves the start method alone (``fork`` / ``forkserver`` / ``spawn``
+    select one explicitly)."""
+    import multiprocessing as mp
+    want = os.environ.get("MVK_DATALOADER_START", "spawn")
+    if want == "keep":
+        return mp.get_start_method(allow_none=True)
+    if mp.get_start_method(allow_none=True) != want:
+        mp.set_start_method(want, force=True)
+    return want

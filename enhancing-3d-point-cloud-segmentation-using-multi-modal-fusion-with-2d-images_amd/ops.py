@@ -3,7 +3,10 @@
 PyTorch only owns the HBM buffers and the HIP stream; all compute below is in libmvkpconv.so.
 Every function requires CUDA(HIP) tensors and raises otherwise -- there is no CPU path here.
 """
+import collections
 import ctypes as C
+
+import weakref
 
 import torch
 
@@ -297,7 +300,9 @@ def kpconv_scatter(q, s, idx, dA, kp, extent, influence="linear", aggregation="s
     d_off = None
     if offsets is not None:
         offsets, x = _f32c(offsets), _f32c(x)
-        d_off = torch.empty((Nq, K, 3), device=q.device, dtype=torch.float32)    # written whole by mvk_kpconv_deform_doff
+        # written whole by mvk_kpconv_deform_doff -- which mvk_kpconv_scatter_bwd does not reach for an empty
+        # neighbour matrix (its early return): zeros then
+        d_off = (torch.zeros if (Nq == 0 or H == 0) else torch.empty)((Nq, K, 3), device=q.device, dtype=torch.float32)
         if g_min_d2 is not None:
             g_min_d2 = _f32c(g_min_d2)
             if min_arg is None:
@@ -361,7 +366,7 @@ def _gemm_off_chain(A, B, **kw):
 # result tensor is handed to autograd at once) and the whole list runs as one grouped launch per tile shape when the
 # scope ends (mvk_gemm_f32_tn_grouped): ~100 latency-bound ~10 us launches leave the serial chain of a step. Same
 # contract as overlap_weight_grads: nothing may read a weight gradient before the scope has been left.
-_DEFER = {"on": False, "items": [], "slots": None, "eager": 0}
+_DEFER = {"on": False, "items": [], "leaves": set(), "slots": None, "eager": 0}
 _DW_MAX = 512
 
 
@@ -377,7 +382,7 @@ def _defer_slots(device):
 
 class defer_weight_grads:
     def __enter__(self):
-        _DEFER.update(on=True, items=[])
+        _DEFER.update(on=True, items=[], leaves=set())
         return self
 
     def __exit__(self, *exc):
@@ -385,7 +390,7 @@ class defer_weight_grads:
             if exc[0] is None:
                 _flush_deferred()
         finally:
-            _DEFER.update(on=False, items=[])
+            _DEFER.update(on=False, items=[], leaves=set())
         return False
 
 
@@ -397,7 +402,14 @@ def _flush_deferred():
     dev = items[0][0].device
     n = len(items)
     prob = np.zeros(n, dtype=np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i8"), ("N", "<i8"), ("Kd", "<i8")]))
-    for i, (A, B, out_ptr, _) in enumerate(items):
+    for i, (A, B, out_ptr, _, storage) in enumerate(items):
+        if torch._C._storage_Use_Count(storage._cdata) < 2:
+            # nothing but this list still owns the result: autograd did not adopt it as a .grad (it added the not yet
+            # computed tensor to an existing gradient, or dropped it) -- the product would be lost silently
+            raise RuntimeError("defer_weight_grads: a deferred weight-gradient result (%d x %d) was consumed before the "
+                               "grouped launch computed it; was the backward run on parameters that already hold a "
+                               ".grad, or with hooks that copy gradients? Run it without the scope (MVK_DEFER_DW=0)"
+                               % (A.shape[1], B.shape[1]))
         prob[i] = (A.data_ptr(), B.data_ptr(), out_ptr, A.shape[1], B.shape[1], A.shape[0])
     slots = _defer_slots(dev)
     if torch.cuda.is_current_stream_capturing():
@@ -426,9 +438,21 @@ def _flush_deferred():
         slot["event"] = ev
 
 
-def _dw_gemm(A, B, transB=False):
+def _dw_gemm(A, B, transB=False, target=None):
     """A^T @ B for a weight gradient: deferred into the grouped launch inside defer_weight_grads(), on a side stream
-    inside overlap_weight_grads(), a plain product otherwise."""
+    inside overlap_weight_grads(), a plain product otherwise. `target`: the tensor the gradient is FOR (the Function's
+    weight input). A deferred product hands autograd a result that is only computed when the scope ends, which is
+    sound only if AccumulateGrad ADOPTS that tensor as the parameter's .grad: a parameter that already holds a gradient
+    (zero_grad(set_to_none=False), micro-batch accumulation, a second backward stage through the same weight) would
+    get `grad += <not yet computed>` and the result tensor would be freed before the grouped launch writes it -- such
+    products run in line. A weight used twice inside ONE scope cannot be served either way and is refused."""
+    leaf = target if (target is not None and target.is_leaf) else None
+    if _DEFER["on"] and leaf is not None:
+        if id(leaf) in _DEFER["leaves"]:
+            raise RuntimeError("defer_weight_grads: the same parameter receives two weight gradients inside one scope "
+                               "(shared weights): run this backward without the scope (MVK_DEFER_DW=0)")
+        if leaf.grad is not None:
+            return _gemm_off_chain(A, B, transA=True, transB=transB)
     if _DEFER["on"] and not transB and A.is_cuda and B.shape[1] > 16 and len(_DEFER["items"]) < _DW_MAX \
             and A.shape[0] > 0 and A.shape[1] > 0:
         A, B = _f32c(A), _f32c(B)
@@ -439,7 +463,12 @@ def _dw_gemm(A, B, transB=False):
                else torch.empty((A.shape[1], B.shape[1]), device=A.device, dtype=torch.float32))
         # only the ADDRESS is recorded: a second reference to the tensor would make autograd's AccumulateGrad clone the
         # gradient instead of adopting it (one copy launch per parameter); the tensor itself lives on as the .grad
-        _DEFER["items"].append((A, B, out.data_ptr(), zeroed))
+        # the STORAGE is held too (not a tensor: AccumulateGrad counts tensor references only): its memory cannot be
+        # handed out again before the grouped launch has written it, and its owner count tells at flush time whether
+        # autograd adopted the result (>= 2) or consumed and dropped it (1)
+        _DEFER["items"].append((A, B, out.data_ptr(), zeroed, out.untyped_storage()))
+        if leaf is not None:
+            _DEFER["leaves"].add(id(leaf))
         return out
     return _gemm_off_chain(A, B, transA=True, transB=transB)
 
@@ -492,7 +521,7 @@ class _KPConvFn(torch.autograd.Function):
         Am = A * modulations.unsqueeze(2) if modulations is not None else A
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
-            dW = _dw_gemm(Am.view(Nq, K * Cin), gy).view(K, Cin, Cout)
+            dW = _dw_gemm(Am.view(Nq, K * Cin), gy, target=W).view(K, Cin, Cout)
         need_dA = ctx.needs_input_grad[3] or (offsets is not None)
         if need_dA:
             dAm = gemm(gy, W.reshape(K * Cin, Cout), transB=True).view(Nq, K, Cin)
@@ -558,6 +587,7 @@ class _KPConv16Fn(torch.autograd.Function):
         ctx.save_for_backward(q, s, idx, x16, kp, W16, A, offsets, modulations)
         ctx.min_arg = getattr(min_d2, "_mvk_min_arg", None)
         ctx.cfg = (extent, influence, aggregation, (K, Cin, Cout))
+        ctx.w_ref = weakref.ref(W)          # the f32 parameter the gradient is for (see _dw_gemm)
         ctx.set_materialize_grads(False)
         return y, min_d2, None          # (no BatchNorm-statistics epilogue in the fp16 contraction)
 
@@ -573,7 +603,7 @@ class _KPConv16Fn(torch.autograd.Function):
         Am = A32 * modulations.unsqueeze(2) if modulations is not None else A32
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
-            dW = _dw_gemm(Am.view(Nq, K * Cin), gy).view(K, Cin, Cout)
+            dW = _dw_gemm(Am.view(Nq, K * Cin), gy, target=ctx.w_ref()).view(K, Cin, Cout)
         if ctx.needs_input_grad[3] or offsets is not None:
             dAm = gemm(gy, W16.float(), transB=True).view(Nq, K, Cin)
             if modulations is not None:
@@ -760,15 +790,33 @@ def row_count_for(rows):
     return _ROW_COUNTS.get(int(rows))
 
 
-_FULL_COUNTS = {}
+_FULL_COUNTS = collections.OrderedDict()       # eager entries: bounded LRU
+_FULL_COUNTS_KEPT = {}                          # entries a captured graph may point at: never evicted
+_FULL_COUNTS_MAX = 256
 
 
 def full_count(rows, device):
-    """Device int32 [1] holding `rows` (cached): the n_valid of a tensor without padded rows."""
+    """Device int32 [1] holding `rows`: the n_valid of a tensor without padded rows. Produced by an asynchronous
+    fill launch (no host-to-device copy, no synchronisation) and kept in a bounded LRU table: in ordinary training
+    the row count of every pyramid level changes with each batch. Words handed out while a stream is capturing are
+    kept for good (the graph's kernel nodes hold their addresses)."""
     key = (int(rows), device.index)
+    t = _FULL_COUNTS_KEPT.get(key)
+    if t is not None:
+        return t
+    capturing = torch.cuda.is_current_stream_capturing()
     t = _FULL_COUNTS.get(key)
     if t is None:
-        t = _FULL_COUNTS[key] = torch.tensor([int(rows)], dtype=torch.int32, device=device)
+        t = torch.full((1,), int(rows), dtype=torch.int32, device=device)
+        if not capturing:
+            _FULL_COUNTS[key] = t
+            if len(_FULL_COUNTS) > _FULL_COUNTS_MAX:
+                _FULL_COUNTS.popitem(last=False)
+    else:
+        _FULL_COUNTS.move_to_end(key)
+    if capturing:
+        _FULL_COUNTS_KEPT[key] = t
+        _FULL_COUNTS.pop(key, None)
     return t
 
 
@@ -1220,7 +1268,7 @@ class _LinearFn(torch.autograd.Function):
             dx = gemm(W, g, transA=True, transB=True) if ctx.xt else gemm(g, W)      # [Kd,M] or [M,Kd]
         if ctx.needs_input_grad[1]:
             # dW [N,Kd] = g^T [N,M] @ x [M,Kd]
-            dW = _dw_gemm(g, x, transB=ctx.xt)
+            dW = _dw_gemm(g, x, transB=ctx.xt, target=W)
         return dx, dW, None, None
 
 

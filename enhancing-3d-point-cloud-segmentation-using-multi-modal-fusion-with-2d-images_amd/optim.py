@@ -31,7 +31,8 @@ class FusedClipSGD:
             self.param_groups.append({"params": ps, "lr": float(g.get("lr", lr)),
                                       "weight_decay": float(g.get("weight_decay", weight_decay))})
         self.momentum = float(momentum)
-        self.clip = float("inf") if clip_value is None else float(clip_value)
+        # trainer.py:191: `if self.config.grad_clip_norm > 0: clip_grad_value_(...)` -- a bound <= 0 means NO clipping
+        self.clip = float("inf") if (clip_value is None or float(clip_value) <= 0) else float(clip_value)
         self.clip_in_place = bool(clip_in_place)
         self.params = [p for g in self.param_groups for p in g["params"]]
         for p in self.params:
@@ -76,7 +77,59 @@ class FusedClipSGD:
         for i, g in enumerate(self.param_groups):
             if group is None or group == i:
                 g["lr"] = float(lr)
+        self.sync_hyperparameters()
+
+    def sync_hyperparameters(self):
+        """Call after changing ``param_groups[i]['lr']`` / ``['weight_decay']`` in place (the reference's trainer does
+        at every epoch end, trainer.py:239-241). Eager steps pick the new values up by themselves (the table key holds
+        them); the tables of CAPTURED steps are rewritten here: a captured memcpy node re-reads its pinned host bytes
+        at every replay, so the next replay of every graph runs with the new rates. Returns the number of captured
+        tables rewritten."""
         self._key = None
+        group_of = {id(p): g for g in self.param_groups for p in g["params"]}
+        by_ptr = {p.data_ptr(): group_of[id(p)] for p in self.params}
+        n = 0
+        for slot in self._captured:
+            k = slot.get("records", 0)
+            rec = slot["host"].numpy()[:k * _REC.itemsize].view(_REC)
+            for i in range(k):
+                g = by_ptr.get(int(rec[i]["p"]))
+                if g is not None:
+                    rec[i]["lr"], rec[i]["wd"] = g["lr"], g["weight_decay"]
+            n += 1
+        return n
+
+    def state_dict(self):
+        """torch.optim.SGD's layout (trainer.py:251 saves ``optimizer.state_dict()``): ``state`` maps the parameter's
+        position to ``{'momentum_buffer': tensor}``, ``param_groups`` hold the hyper-parameters and position lists."""
+        pos = {id(p): i for i, p in enumerate(self.params)}
+        groups = [{"lr": g["lr"], "momentum": self.momentum, "dampening": 0, "weight_decay": g["weight_decay"],
+                   "nesterov": False, "maximize": False, "foreach": None, "differentiable": False, "fused": None,
+                   "params": [pos[id(p)] for p in g["params"]]} for g in self.param_groups]
+        return {"state": {i: {"momentum_buffer": self.state[p]["momentum_buffer"].clone()} for i, p in enumerate(self.params)},
+                "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        """Accepts a state dict of this class or of a torch.optim.SGD over the same parameter order (trainer.py:101
+        restores ``optimizer_state_dict`` from a checkpoint). Momentum buffers are copied INTO the flat buffer the
+        captured graphs point at; learning rates / weight decay are taken over and pushed to captured tables."""
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups) or any(len(a["params"]) != len(b["params"])
+                                                        for a, b in zip(groups, self.param_groups)):
+            raise ValueError("loaded state dict has different parameter groups")
+        for mine, theirs in zip(self.param_groups, groups):
+            mine["lr"], mine["weight_decay"] = float(theirs["lr"]), float(theirs.get("weight_decay", mine["weight_decay"]))
+        if groups and "momentum" in groups[0]:
+            self.momentum = float(groups[0]["momentum"])
+        with torch.no_grad():
+            for i, p in enumerate(self.params):
+                st = sd["state"].get(i, sd["state"].get(str(i)))
+                buf = None if st is None else st.get("momentum_buffer")
+                if buf is None:
+                    self.state[p]["momentum_buffer"].zero_()       # torch: no buffer yet == first step == zeros here
+                else:
+                    self.state[p]["momentum_buffer"].copy_(buf.to(p.device, torch.float32).view_as(p))
+        self.sync_hyperparameters()
 
     def _build(self, items):
         dev = self.params[0].device
@@ -108,6 +161,7 @@ class FusedClipSGD:
         slot["dev"].copy_(slot["host"], non_blocking=True)          # under capture: a memcpy node replayed with the graph
         slot["chunks_dev"].copy_(slot["chunks_host"], non_blocking=True)
         slot["n"] = int(chunks.shape[0])
+        slot["records"] = len(items)
         return slot
 
     @torch.no_grad()
@@ -128,7 +182,8 @@ class FusedClipSGD:
         capturing = torch.cuda.is_current_stream_capturing()
         if key != self._key or capturing:
             self._cur = self._build(items)
-            self._key = key
+            # a captured slot's device table is only filled when its graph replays: an eager step must never reuse it
+            self._key = None if capturing else key
         t = self._cur
         stream = torch.cuda.current_stream()
         check(lib().mvk_sgd_clip_step(C.c_void_p(t["dev"].data_ptr()), C.c_void_p(t["chunks_dev"].data_ptr()), t["n"],

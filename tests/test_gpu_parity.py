@@ -605,6 +605,53 @@ def test_deferred_weight_gradients_run_as_one_grouped_launch(ops):
         assert rel_err(o.cpu().numpy(), w) < 1e-5
 
 
+def test_deferred_weight_gradients_with_existing_grads_and_shared_weights(ops):
+    """ADVICE r2 (ops.defer_weight_grads hazard): a parameter that already holds a .grad (zero_grad(set_to_none=False),
+    micro-batch accumulation, a second backward stage through the same weight) must ACCUMULATE correctly -- its product
+    runs in line instead of being deferred; a weight used twice inside one scope is refused loudly; a deferred result
+    that autograd consumed instead of adopting (a hook that copies the gradient) raises at the flush instead of losing
+    the product silently."""
+    torch.manual_seed(11)
+    x = torch.randn(3000, 96, device="cuda")
+    W = torch.nn.Parameter(torch.randn(64, 96, device="cuda") * 0.1)
+    want = (torch.ones(3000, 64, device="cuda").double().t() @ x.double())
+
+    def backward_once():
+        with ops.defer_weight_grads():
+            ops.linear(x, W).sum().backward()
+
+    backward_once()                                         # .grad is None: deferred, adopted
+    assert rel_err(W.grad.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    backward_once()                                         # .grad exists: in line, accumulated
+    backward_once()
+    assert rel_err(W.grad.cpu().numpy(), (3 * want).cpu().numpy()) < 1e-5
+    W.grad = None
+    with pytest.raises(RuntimeError, match="two weight gradients"):
+        with ops.defer_weight_grads():
+            (ops.linear(x, W).sum() + ops.linear(2 * x, W).sum()).backward()
+    W.grad = None
+    # the same through a KPConv layer (the weight is input 5 of the node)
+    q = torch.rand(500, 3, device="cuda")
+    idx = torch.randint(0, 501, (500, 12), device="cuda", dtype=torch.int32)
+    feats = torch.randn(500, 32, device="cuda")
+    kp = (torch.rand(15, 3, device="cuda") - 0.5) * 0.2
+    Wk = torch.nn.Parameter(torch.randn(15, 32, 48, device="cuda") * 0.1)
+
+    def kp_backward():
+        with ops.defer_weight_grads():
+            ops.kpconv(q, q, idx, feats, kp, Wk, 0.12)[0].sum().backward()
+
+    kp_backward()
+    g1 = Wk.grad.clone()
+    kp_backward()
+    assert rel_err(Wk.grad.cpu().numpy(), (2 * g1).cpu().numpy()) < 1e-5
+    # a non-leaf weight whose gradient is consumed (not adopted) before the flush: loud
+    Wn = torch.nn.Parameter(torch.randn(64, 96, device="cuda") * 0.1)
+    with pytest.raises(RuntimeError, match="consumed before the grouped launch"):
+        with ops.defer_weight_grads():
+            ops.linear(x, Wn * 2.0).sum().backward()         # MulBackward reads dW at once and drops it
+
+
 # ------------------------------------------------------------------ masked BatchNorm + LeakyReLU
 
 @pytest.mark.parametrize("slope", [1.0, 0.1])
@@ -746,6 +793,75 @@ def test_fused_clip_sgd_matches_torch_clip_and_sgd():
         torch.cuda.synchronize()
     for a, b in zip(ours, ref):
         assert rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-6
+
+
+def test_fused_clip_sgd_trainer_contract():
+    """what the reference's trainer asks of its optimiser beyond step() -- (1) grad_clip_norm <= 0 means no
+    clipping (trainer.py:191), (2) state_dict() / load_state_dict() in torch.optim.SGD's layout, interchangeable with a
+    torch SGD over the same parameters (trainer.py:101, 251), (3) the per-epoch learning-rate decay written into
+    param_groups (trainer.py:239-241) reaches the CAPTURED step after sync_hyperparameters(), (4) an eager step after a
+    capture does not run on the captured table."""
+    import mvkpconv
+    optim = mvkpconv.sub("optim")
+    torch.manual_seed(3)
+    shapes = [(5,), (300, 7), (4100,)]
+    ours = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ours]
+    mine = optim.FusedClipSGD([{"params": ours[:2]}, {"params": ours[2:], "lr": 1e-3}], lr=1e-2, momentum=0.9,
+                              weight_decay=1e-3, clip_value=0.0)                       # (1) no clipping
+    theirs = torch.optim.SGD([{"params": ref[:2]}, {"params": ref[2:], "lr": 1e-3}], lr=1e-2, momentum=0.9, weight_decay=1e-3)
+
+    def same():
+        return all(rel_err(a.detach().cpu().numpy(), b.detach().cpu().numpy()) < 1e-6 for a, b in zip(ours, ref))
+
+    for _ in range(2):
+        for a, b in zip(ours, ref):
+            g = torch.randn_like(a) * 5
+            a.grad, b.grad = g.clone(), g.clone()
+        mine.step()
+        theirs.step()
+    assert same()
+    # (2) our state into a fresh torch SGD, torch's state into a fresh FusedClipSGD: both continue identically
+    sd = mine.state_dict()
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][1]["lr"] == 1e-3 and sd["param_groups"][0]["params"] == [0, 1]
+    theirs2 = torch.optim.SGD([{"params": ref[:2]}, {"params": ref[2:], "lr": 5.0}], lr=5.0, momentum=0.1)
+    theirs2.load_state_dict(sd)
+    mine2 = optim.FusedClipSGD([{"params": ours[:2]}, {"params": ours[2:]}], lr=7.0, momentum=0.0, clip_value=-1.0)
+    mine2.load_state_dict(theirs.state_dict())
+    assert mine2.momentum == 0.9 and mine2.param_groups[1]["lr"] == 1e-3 and mine2.param_groups[0]["weight_decay"] == 1e-3
+    for a, b in zip(ours, ref):
+        g = torch.randn_like(a)
+        a.grad, b.grad = g.clone(), g.clone()
+    mine2.step()
+    theirs2.step()
+    assert same()
+    # (3) + (4): capture a step, decay the rates in place like the trainer, replay
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        for a in ours:
+            a.grad = torch.zeros_like(a)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, stream=st):
+            mine2.step()
+        for rep in range(3):
+            if rep == 1:
+                for g1, g2 in zip(mine2.param_groups, theirs2.param_groups):
+                    g1["lr"] *= 0.5
+                    g2["lr"] *= 0.5
+                assert mine2.sync_hyperparameters() == 1
+            for a, b in zip(ours, ref):
+                a.grad.copy_(torch.full_like(a, 0.3 + rep))
+                b.grad = torch.full_like(b, 0.3 + rep)
+            graph.replay()
+            theirs2.step()
+        torch.cuda.synchronize()
+        assert same()
+        for a, b in zip(ours, ref):                   # eager step with the SAME tensors right after the capture
+            b.grad = a.grad.clone()
+        mine2.step()
+        theirs2.step()
+        torch.cuda.synchronize()
+    assert same()
 
 
 # ------------------------------------------------------------------ deformable: regulariser kernel
@@ -979,6 +1095,15 @@ def test_round2_entry_points_on_empty_and_degenerate_inputs(ops):
     yk, md = ops.kpconv(q, q, idx, x, kp, W, 0.05, offsets=off)
     (yk.sum() + md.sum()).backward()
     assert (yk == 0).all() and torch.isfinite(md).all() and torch.isfinite(off.grad).all() and (x.grad == 0).all()
+    # ... and with NO neighbour column at all (H == 0: the scatter returns before the offset-gradient kernel; the
+    # offsets' gradient must then be zeros, not uninitialised memory -- ADVICE r2)
+    for _ in range(3):
+        junk = torch.full((10, 15, 3), float("nan"), device="cuda")            # poison what the allocator hands out next
+        del junk
+        off.grad = None
+        yk, md = ops.kpconv(q, q, torch.zeros((10, 0), dtype=torch.int64, device="cuda"), x, kp, W, 0.05, offsets=off)
+        yk.sum().backward()
+        assert (yk == 0).all() and off.grad is not None and (off.grad == 0).all()
     # regulariser of an empty level
     l = ops.deform_regularizer(torch.zeros(0, 15, device="cuda"), torch.zeros(0, 15, 3, device="cuda"), 0.05, 1.2, 1.0)
     assert float(l) == 0.0

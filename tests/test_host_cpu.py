@@ -493,6 +493,63 @@ def test_dropin_first_on_sys_path_still_reaches_the_reference_modules(tmp_path):
     assert r.returncode == 0 and "FALLTHROUGH OK" in r.stdout, r.stderr[-3000:]
 
 
+_WORKER_DATASET = (
+    "import os, sys, importlib, numpy as np, torch\n"
+    "from torch.utils.data import Dataset\n"
+    "class Stub(Dataset):\n"
+    "    # stands for the reference dataset: __getitem__ (potential_item) calls the pyramid builders, i.e. the library\n"
+    "    def __init__(self, lib_module):\n"
+    "        self.lib_module = lib_module\n"
+    "    def __len__(self):\n"
+    "        return 8\n"
+    "    def __getitem__(self, i):\n"
+    "        lib_mod = importlib.import_module(self.lib_module)\n"
+    "        lib_mod._check_process()          # raises FORK_MESSAGE in a forked child of the library's owner\n"
+    "        return np.array([i, os.getpid(), os.getppid()], np.int64)\n")
+
+
+def test_unmodified_script_dataloader_workers_are_not_forked(tmp_path):
+    """n2: with dropin/ first on sys.path, `import datasets...` makes `spawn` the default start method, so a
+    DataLoader created exactly as the reference script does (train_ScanNet_sphere.py:365-377: num_workers > 0, no
+    multiprocessing_context) hands its items to fresh processes in which the library call is legal -- while the same
+    loader under `fork` (MVK_DATALOADER_START=keep) gets the loud fork error, not a hang."""
+    (tmp_path / "stubds.py").write_text(_WORKER_DATASET)
+    kp = tmp_path / "KPConv-PyTorch"
+    for rel, text in _STUB_TREE.items():
+        f = kp / rel
+        f.parent.mkdir(parents=True, exist_ok=True)
+        f.write_text(text)
+    script = tmp_path / "train_stub.py"
+    script.write_text(
+        "import os, sys\n"
+        "sys.path.insert(0, %r); sys.path.append(%r); sys.path.append(%r)\n"
+        "import multiprocessing as mp\n"
+        "import torch\n"
+        "from torch.utils.data import DataLoader\n"
+        "import datasets.common as DC                      # the drop-in (route 1)\n"
+        "import stubds\n"
+        "if __name__ == '__main__':\n"
+        "    lib_mod = __import__(%r, fromlist=['_lib'])._lib\n"
+        "    lib_mod._owner_pid = os.getpid()               # the parent has 'initialised the library' (no GPU here)\n"
+        "    loader = DataLoader(stubds.Stub(lib_mod.__name__), batch_size=1, num_workers=2)\n"
+        "    try:\n"
+        "        rows = [b[0].tolist() for b in loader]\n"
+        "        assert sorted(r[0] for r in rows) == list(range(8))\n"
+        "        assert all(r[1] != os.getpid() for r in rows)\n"
+        "        print('WORKERS OK', mp.get_start_method())\n"
+        "    except RuntimeError as e:\n"
+        "        print('WORKERS FAILED', mp.get_start_method(), 'forked child' in str(e))\n"
+        % (os.path.join(ROOT, PKG, "dropin"), str(tmp_path), ROOT, PKG))
+    env = dict(os.environ)
+    env.pop("MVK_DATALOADER_START", None)
+    r = subprocess.run([sys.executable, str(script)], cwd=str(kp), env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "WORKERS OK spawn" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+    r = subprocess.run([sys.executable, str(script)], cwd=str(kp), env=dict(env, MVK_DATALOADER_START="keep"),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert "WORKERS FAILED fork True" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
+
+
 def test_scannet_custom_batch_round_trips_the_flat_list():
     """ScanNetCustomBatch(input_list): L = (len - 11) // 5 (ScanNet_sphere_color.py:1535), dtypes kept,
     pin_memory() / to() return self; the baseline variant with L = (len - 7) // 5."""

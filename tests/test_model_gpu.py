@@ -344,3 +344,95 @@ def test_bench_emits_one_valid_json_line():
     assert detail["line"]["value"] == d["value"] and len(detail["detail"]["gather_launches"]) >= 5
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["unit"] == "points/s" and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_dataloader_workers_build_the_pyramid_without_forking(tmp_path):
+    """n2 on the GPU box: a DataLoader created like the reference script's (num_workers=2, no multiprocessing_context)
+    AFTER the parent has initialised the GPU; the drop-in's `datasets` package has made `spawn` the default, so both
+    workers build their pyramids with the HIP library in their own contexts. Level-0 neighbours (independent of the
+    random grid orientation) must equal the parent's own search; the whole list has the reference's 5*L + 2 layout."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = "enhancing-3d-point-cloud-segmentation-using-multi-modal-fusion-with-2d-images_amd"
+    (tmp_path / "workerds.py").write_text(
+        "import numpy as np\n"
+        "from datasets.common import PointCloudDataset\n"
+        "class DS(PointCloudDataset):\n"
+        "    def __init__(self, cfg, limits):\n"
+        "        PointCloudDataset.__init__(self, 'w')\n"
+        "        self.config, self.neighborhood_limits = cfg, limits\n"
+        "    def __len__(self):\n"
+        "        return 4\n"
+        "    def __getitem__(self, i):\n"
+        "        rng = np.random.default_rng(i)\n"
+        "        pts = (rng.random((3000, 3)) * [1.6, 1.6, 0.4]).astype(np.float32)\n"
+        "        feats = np.ones((3000, 1), np.float32)\n"
+        "        labels = rng.integers(0, 20, 3000).astype(np.int64)\n"
+        "        return self.segmentation_inputs(pts, feats, labels, np.array([3000], np.int32)) + [np.int64(i)]\n")
+    script = tmp_path / "train_like.py"
+    script.write_text(
+        "import os, sys\n"
+        "sys.path.insert(0, %r); sys.path.append(%r); sys.path.append(%r)\n"
+        "import numpy as np, torch\n"
+        "from torch.utils.data import DataLoader\n"
+        "import datasets.common as DC\n"
+        "import workerds\n"
+        "if __name__ == '__main__':\n"
+        "    import mvkpconv\n"
+        "    syn = mvkpconv.sub('synthetic')\n"
+        "    cfg = syn.make_config('baseline')\n"
+        "    x = torch.zeros(8, device='cuda'); torch.cuda.synchronize()      # the parent owns a HIP context\n"
+        "    limits = [30, 30, 30, 30, 30]\n"
+        "    ds = workerds.DS(cfg, limits)\n"
+        "    loader = DataLoader(ds, batch_size=1, num_workers=2, collate_fn=lambda b: b[0])\n"
+        "    seen = 0\n"
+        "    for flat in loader:\n"
+        "        L = (len(flat) - 3) // 5\n"
+        "        assert L == 5 and 5 * L + 3 == len(flat), len(flat)\n"
+        "        i = int(flat[-1])\n"
+        "        rng = np.random.default_rng(i)\n"
+        "        pts = (rng.random((3000, 3)) * [1.6, 1.6, 0.4]).astype(np.float32)\n"
+        "        assert np.array_equal(flat[0], pts) and flat[L].dtype == np.int64 and flat[L].shape[0] == 3000\n"
+        "        own = DC.batch_neighbors(torch.from_numpy(pts).cuda(), torch.from_numpy(pts).cuda(), np.array([3000], np.int32),\n"
+        "                                 np.array([3000], np.int32), cfg.first_subsampling_dl * cfg.conv_radius, limit=30)\n"
+        "        assert np.array_equal(own.cpu().numpy(), flat[L]), 'worker pyramid differs from the parent search'\n"
+        "        assert flat[1].shape[0] > 100 and flat[4].shape[0] > 0 and flat[2 * L].shape[0] == flat[1].shape[0]\n"
+        "        seen += 1\n"
+        "    assert seen == 4\n"
+        "    print('WORKER PYRAMIDS OK')\n" % (os.path.join(root, pkg, "dropin"), str(tmp_path), root))
+    env = dict(os.environ)
+    env.pop("MVK_DATALOADER_START", None)
+    r = subprocess.run([sys.executable, str(script)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "WORKER PYRAMIDS OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_default_multi_gpu_step_structure_trains_like_the_single_graph_step():
+    """The DEFAULT N > 1 step (three graphs -- forward + backward above the cut + pack | backward below the cut + pack |
+    unpack + clip + SGD -- with eager RCCL all-reduces between them, bench.py make_graph_step) rehearsed with a one-rank
+    RCCL group (MVK_BENCH_FORCE_DP=1) must train like the single-graph N = 1 step: same seeds, same spheres, same grid
+    orientations => the loss after warm-up + 16 instrumented + 2 + 3 SGD steps agrees to the rounding of the float
+    atomics (two single-graph runs differ by the same order; the measured differences are printed)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def run(extra_env):
+        env = dict(os.environ, MVK_BENCH_DETAIL=os.path.join(root, "gpurun_out", "bench_detail_test.json"), **extra_env)
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+
+    one = run({})
+    dp = run({"MVK_BENCH_FORCE_DP": "1", "MASTER_PORT": "29531"})
+    assert one["config"]["execution"] == "hipGraph[net|chain|enc2d]" and one["config"]["backend"] is None
+    assert dp["config"]["execution"] == "hipGraph[net|chain|enc2d]+eager-rccl(3 graphs)", dp["config"]["execution"]
+    assert dp["config"]["backend"] == "rccl" and dp["config"]["ranks"] == 1
+    assert not one["config"]["capacity_overflow"] and not dp["config"]["capacity_overflow"]
+    a, b = one["config"]["final_loss"], dp["config"]["final_loss"]
+    print("final loss: single graph %.6f | three graphs + eager RCCL %.6f | rel diff %.2e" % (a, b, abs(a - b) / abs(a)))
+    assert abs(a - b) < 2e-3 * abs(a)

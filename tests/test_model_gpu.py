@@ -289,7 +289,7 @@ def test_graph_replay_trains_like_eager(device_chain):
             # `held` keeps an eager autograd graph (and its AccumulateGrad nodes) alive across the capture, like the
             # loss of bench.py's warm-up: the capture must run on the same stream as that backward did
             step, note = bench.make_graph_step(shim, ops, cfg, net, staged, limits, params, opt, None)   # 2 eager steps inside
-            assert note.startswith("hipGraph")
+            assert note[0].startswith("hipGraph")
             losses_g = [step()[1].item() for _ in range(2)]
             torch.cuda.synchronize()
         assert not [w for w in caught if "AccumulateGrad" in str(w.message)], "stream mismatch between eager and captured backward"

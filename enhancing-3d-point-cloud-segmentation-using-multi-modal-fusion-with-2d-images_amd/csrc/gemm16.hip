@@ -12,6 +12,8 @@
 //   * operands are staged i-major ([64][BK + 4] halfs, row = 72 bytes): an MFMA operand read is one
 //     ds_read_b64 per lane (4 consecutive k), bank-conflict free (18 i mod 64 hits 32 distinct even banks);
 //   * one k-tile = 4 MFMAs per wave (k = 8 each) instead of 16; f16 sources are staged bit for bit.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -211,6 +213,196 @@ __global__ __launch_bounds__(256) void gemm_f16_mfma(const AT* __restrict__ A, c
   }
 }
 
+
+// ----------------------------------------------------------------------------------------------------------------
+// Streaming contraction for the rigid fp16 layers (gfx950: v_mfma_f32_16x16x32_f16, 8 halfs per lane and operand).
+//
+// y [M, N] = A16 [M, Kp] . Wt16 [N, Kp]^T with M in the tens of thousands, N = 32 or 64 and Kp <= 1024: 60 flop per
+// byte of A, i.e. the product is bound by the stream of A (38.5 MB for 19 464 x 992), and the 64 x 64 x 32 LDS-staged
+// kernel above moves that stream through LDS behind a barrier per 32-deep step (51 us). Here
+//   * both operands are k-contiguous in memory with 64-byte aligned rows (the gather kernel writes the aggregate with
+//     a row stride padded to 32 halfs, mvk_round_weights_f16 writes the weights transposed and zero padded), so an
+//     MFMA operand fragment IS one 16-byte global load: no LDS staging, no conversion, no barrier in the k loop;
+//   * the small operand is STATIONARY IN REGISTERS: wave w of a workgroup keeps the weight fragments of its quarter of
+//     the reduction (SW steps of 32 x all N columns = SW*CT*4 VGPRs <= 128) for the whole launch;
+//   * the rows stream past in 16-row tiles: per tile a wave issues SW 16-byte loads per lane (one tile ahead, second
+//     register set), runs SW*CT MFMAs, and the four partial 16 x N blocks of the workgroup's waves meet in LDS (fixed
+//     order: deterministic; no atomics), from where they are stored as whole 256-byte rows;
+//   * BatchNorm statistics of the layer's output (blocks.py:456-460) for the workgroup's rows in the same pass
+//     (shifted sums per thread, merged with the parallel-variance formula): same partials format as gemm.hip.
+struct S16Args {
+  const _Float16* A;
+  const _Float16* Bt;
+  float* C;
+  int64_t M, lda, ldb;
+  int N, steps, tiles_per_wg;
+  const int* n_valid;
+  float* bn_part;
+};
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int CT, int SW>
+__global__ __launch_bounds__(256, 2) void gemm_f16_stream(const S16Args a) {
+  constexpr int N = 16 * CT, LDR = N + 4;       // + 4: the four row groups of an accumulator land in distinct banks
+  constexpr int G = 4;                          // tiles per group: partial blocks of G tiles wait in LDS for one store phase
+  __shared__ __attribute__((aligned(16))) float red[G][4][16][LDR];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int r = lane & 15, g = lane >> 4;
+  const int s0 = w * SW;
+
+  h8 b[SW][CT];
+#pragma unroll
+  for (int s = 0; s < SW; ++s)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+      // branch-free: steps beyond the reduction load a real address and are zeroed afterwards (the loads stay in flight together)
+      const int st = s0 + s < a.steps ? s0 + s : a.steps - 1;
+      b[s][ct] = *reinterpret_cast<const h8*>(a.Bt + (int64_t)(ct * 16 + r) * a.ldb + st * 32 + g * 8);
+    }
+#pragma unroll
+  for (int s = 0; s < SW; ++s)
+    if (s0 + s >= a.steps) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b[s][ct][e] = (_Float16)0.f;
+    }
+
+  const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+  const int64_t ntiles = (a.M + 15) / 16;
+  const int T = (int)(ntiles - tile0 < a.tiles_per_wg ? ntiles - tile0 : a.tiles_per_wg);
+  const int64_t last = tile0 + (T > 0 ? T - 1 : 0);
+
+  auto load_tile = [&](int64_t tile, h8 (&af)[SW]) {
+    tile = tile < last ? tile : last;                      // tiles beyond the workgroup's last: loaded again, never computed
+    int64_t row = tile * 16 + r;
+    row = row < a.M ? row : a.M - 1;                       // clamped rows are never stored nor counted
+    const _Float16* p = a.A + row * a.lda + g * 8;
+#pragma unroll
+    for (int s = 0; s < SW; ++s) {
+      int st = s0 + s;
+      st = st < a.steps ? st : a.steps - 1;                // beyond the reduction: a real address, zero weights
+      af[s] = *reinterpret_cast<const h8*>(p + st * 32);
+    }
+  };
+
+  auto compute = [&](int slot, const h8 (&af)[SW]) {
+    f32x4 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < SW; ++s)
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[s], b[s][ct], acc[ct], 0, 0, 0);
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) red[slot][w][g * 4 + i][ct * 16 + r] = acc[ct][i];
+  };
+
+  int64_t nv = a.n_valid ? (int64_t)*a.n_valid : a.M;
+  nv = nv < a.M ? nv : a.M;
+  // statistics of this thread's (row in tile, 4 columns) over the tiles: count, shift, shifted sums
+  const bool red_thread = tid < 64 * CT;
+  const int rr = tid / (4 * CT), cq = (tid % (4 * CT)) * 4;
+  float cnt = 0.f;
+  float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), s1 = sh, s2 = sh;
+
+  // Phase 1 of a group (<= G tiles): loads + MFMAs + LDS writes only. Two register sets, the loads of tile t + 2 issued
+  // right after the MFMAs of tile t have freed the set; NO global store in this phase: a store between a load and its
+  // use makes the compiler's vmcnt wait cover every load in flight (stores and loads share the counter and may retire
+  // out of order), which serialised the stream tile by tile in the first version of this kernel.
+  // Phase 2: the four waves' partial blocks are added in a fixed order and stored as whole rows; statistics.
+  h8 a0[SW], a1[SW];
+  load_tile(tile0, a0);
+  load_tile(tile0 + 1, a1);
+  for (int t0 = 0; t0 < T; t0 += G) {
+    const int ng = T - t0 < G ? T - t0 : G;
+#pragma unroll
+    for (int i = 0; i < G; i += 2) {
+      if (i < ng) compute(i, a0);
+      load_tile(tile0 + t0 + i + 2, a0);
+      if (i + 1 < ng) compute(i + 1, a1);
+      load_tile(tile0 + t0 + i + 3, a1);
+    }
+    __syncthreads();
+    if (red_thread) {
+      for (int i = 0; i < ng; ++i) {
+        const float4 p0 = *reinterpret_cast<const float4*>(&red[i][0][rr][cq]);
+        const float4 p1 = *reinterpret_cast<const float4*>(&red[i][1][rr][cq]);
+        const float4 p2 = *reinterpret_cast<const float4*>(&red[i][2][rr][cq]);
+        const float4 p3 = *reinterpret_cast<const float4*>(&red[i][3][rr][cq]);
+        float4 v;
+        v.x = ((p0.x + p1.x) + p2.x) + p3.x;
+        v.y = ((p0.y + p1.y) + p2.y) + p3.y;
+        v.z = ((p0.z + p1.z) + p2.z) + p3.z;
+        v.w = ((p0.w + p1.w) + p2.w) + p3.w;
+        const int64_t row = (tile0 + t0 + i) * 16 + rr;
+        if (row < a.M) *reinterpret_cast<float4*>(a.C + row * N + cq) = v;
+        if (a.bn_part != nullptr && row < nv) {
+          if (cnt == 0.f) sh = v;
+          cnt += 1.f;
+          const float dx = v.x - sh.x, dy = v.y - sh.y, dz = v.z - sh.z, dw = v.w - sh.w;
+          s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+          s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
+        }
+      }
+    }
+    if (t0 + G < T) __syncthreads();                       // the next group overwrites the partial blocks
+  }
+
+  if (a.bn_part != nullptr) {
+    // merge the 16 row positions of every column in a fixed order (parallel-variance formula, no cancellation)
+    __syncthreads();
+    float* L = &red[0][0][0][0];                       // [3][16][N]: count, mean, M2
+    if (red_thread) {
+      const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+      const float m[4] = {sh.x + s1.x * inv, sh.y + s1.y * inv, sh.z + s1.z * inv, sh.w + s1.w * inv};
+      const float q[4] = {s2.x - s1.x * s1.x * inv, s2.y - s1.y * s1.y * inv, s2.z - s1.z * s1.z * inv, s2.w - s1.w * s1.w * inv};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        L[(0 * 16 + rr) * N + cq + e] = cnt;
+        L[(1 * 16 + rr) * N + cq + e] = m[e];
+        L[(2 * 16 + rr) * N + cq + e] = q[e] > 0.f ? q[e] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (tid < N && tile0 < ntiles) {
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+      for (int i = 0; i < 16; ++i) {
+        const float ni = L[(0 * 16 + i) * N + tid], mi = L[(1 * 16 + i) * N + tid], qi = L[(2 * 16 + i) * N + tid];
+        if (ni > 0.f) {
+          const float nn = n + ni, d = mi - mean;
+          mean += d * (ni / nn);
+          m2 += qi + d * d * (n * ni / nn);
+          n = nn;
+        }
+      }
+      a.bn_part[((int64_t)blockIdx.x * 2) * N + tid] = mean * n;      // the block's sum
+      a.bn_part[((int64_t)blockIdx.x * 2 + 1) * N + tid] = m2;        // squares about the block's own mean
+    }
+  }
+}
+
+// Weights of a KPConv layer for the fp16 mode in one launch: W [Kd, N] f32 -> Wt16 [N, Kp] fp16 (transposed, k
+// contiguous, zero padded to Kp) and, optionally, the rounded values back in f32 [Kd, N] for the f32 backward product
+// dA = g . W16^T. One thread per (k, n): reads coalesced over n.
+__global__ __launch_bounds__(256) void round_weights_f16_kernel(const float* __restrict__ W, int64_t Kd, int N, int64_t Kp,
+                                                               _Float16* __restrict__ Wt, float* __restrict__ Wr) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= Kp * N) return;
+  const int64_t k = i / N;
+  const int n = (int)(i - k * N);
+  _Float16 h = (_Float16)0.f;
+  if (k < Kd) {
+    h = (_Float16)W[k * N + n];
+    if (Wr) Wr[k * N + n] = (float)h;
+  }
+  Wt[(int64_t)n * Kp + k] = h;
+}
+
 template <bool TA, bool TB, typename AT, typename BT>
 void launch16(const void* A, const void* B, void* C, int c_f16, int64_t M, int64_t N, int64_t Kd, int64_t lda,
               int64_t ldb, int64_t k_per_split, int split_k, int alA, int alB, hipStream_t st) {
@@ -262,6 +454,63 @@ extern "C" int mvk_gemm_f16(const void* A, int a_f16, const void* B, int b_f16, 
   else if (a_f16) launch16_t<_Float16, float>(transA, transB, A, B, C, c_f16, M, N, Kd, lda, ldb, k_per_split, split_k, alA, alB, st);
   else if (b_f16) launch16_t<float, _Float16>(transA, transB, A, B, C, c_f16, M, N, Kd, lda, ldb, k_per_split, split_k, alA, alB, st);
   else launch16_t<float, float>(transA, transB, A, B, C, c_f16, M, N, Kd, lda, ldb, k_per_split, split_k, alA, alB, st);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- streaming contraction (rigid fp16 layers) -----------------------------------------------------------------
+
+// Which launch the streaming kernel would use for y [M,N] = A16 [M,Kp] . Wt16 [N,Kp]^T: out[0] = 1 when supported
+// (N = 32 or 64, Kp a multiple of 32 with Kp / 32 <= 32), out[1] = 16-row tiles per workgroup (= rows per statistics
+// block / 16), out[2] = workgroups. MVK_GEMM16_TILES overrides the tiles per workgroup (development).
+extern "C" int mvk_gemm_f16_stream_plan(int64_t M, int N, int64_t Kp, int64_t* out) {
+  MVK_REQUIRE(out != nullptr, "gemm16 stream plan: null output");
+  out[0] = out[1] = out[2] = 0;
+  if (M <= 0 || (N != 32 && N != 64) || Kp <= 0 || Kp % 32 != 0 || Kp / 32 > 32) return 0;
+  const int64_t ntiles = cdiv64(M, 16);
+  int64_t T = cdiv64(ntiles, 512);                 // two workgroups per CU resident, one round
+  if (T < 2) T = ntiles >= 2 ? 2 : 1;              // amortise the load of the stationary weights
+  if (const char* e = getenv("MVK_GEMM16_TILES")) {
+    const long v = atol(e);
+    if (v > 0) T = v;
+  }
+  out[0] = 1;
+  out[1] = T;
+  out[2] = cdiv64(ntiles, T);
+  return 0;
+}
+
+extern "C" int mvk_gemm_f16_stream(const void* A16, int64_t lda, const void* Wt16, int64_t ldb, float* C, int64_t M,
+                                   int N, int64_t Kp, const int* n_valid, float* bn_part, void* stream) {
+  int64_t plan[3];
+  if (int e = mvk_gemm_f16_stream_plan(M, N, Kp, plan)) return e;
+  MVK_REQUIRE(plan[0] == 1, "gemm16 stream: unsupported shape M=%lld N=%d Kp=%lld", (long long)M, N, (long long)Kp);
+  MVK_REQUIRE(lda >= Kp && ldb >= Kp && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A16 % 16) == 0 && ((uintptr_t)Wt16 % 16) == 0,
+              "gemm16 stream: operands must be 16-byte aligned with row strides that are multiples of 8 halfs");
+  S16Args a;
+  a.A = (const _Float16*)A16; a.Bt = (const _Float16*)Wt16; a.C = C; a.M = M; a.lda = lda; a.ldb = ldb; a.N = N;
+  a.steps = (int)(Kp / 32); a.tiles_per_wg = (int)plan[1]; a.n_valid = n_valid; a.bn_part = bn_part;
+  const int sw = a.steps <= 4 ? 1 : (a.steps <= 8 ? 2 : (a.steps <= 16 ? 4 : 8));
+  const dim3 grid((unsigned)plan[2]), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define MVK_S16(CT, SW) hipLaunchKernelGGL((gemm_f16_stream<CT, SW>), grid, block, 0, st, a)
+  if (N == 64) {
+    if (sw == 1) MVK_S16(4, 1); else if (sw == 2) MVK_S16(4, 2); else if (sw == 4) MVK_S16(4, 4); else MVK_S16(4, 8);
+  } else {
+    if (sw == 1) MVK_S16(2, 1); else if (sw == 2) MVK_S16(2, 2); else if (sw == 4) MVK_S16(2, 4); else MVK_S16(2, 8);
+  }
+#undef MVK_S16
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_round_weights_f16(const float* W, int64_t Kd, int N, int64_t Kp, void* Wt16, float* W_rounded,
+                                     void* stream) {
+  MVK_REQUIRE(Kd >= 0 && N > 0 && Kp >= Kd, "round_weights_f16: bad sizes");
+  if (Kp == 0) return 0;
+  MVK_REQUIRE(W && Wt16, "round_weights_f16: null pointer");
+  hipLaunchKernelGGL(round_weights_f16_kernel, dim3((unsigned)cdiv64(Kp * N, 256)), dim3(256), 0, (hipStream_t)stream, W, Kd, N,
+                     Kp, (_Float16*)Wt16, W_rounded);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -40,6 +40,7 @@ struct KPParams {
   float extent;
   int influence, aggregation;
   int zero_skip;         // gather: neighbours without any influence become shadow entries (development switch MVK_GATHER_ZEROSKIP)
+  int64_t ldA;           // vector gather: row stride of the aggregate in elements (>= K*Cin; the columns beyond K*Cin are written as zeros)
 };
 
 __device__ __forceinline__ float influence_w(float d2, float extent, int influence) {
@@ -206,7 +207,9 @@ template <int NCH, bool IDX64, bool FAST, typename XT = float, bool VEC = true, 
 __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPParams P, int LPP, int PPW, int HC,
                                                                                   int SW, int B1) {
   constexpr bool FASTLD = FUB > 0;
+  constexpr bool PADDED = sizeof(XT) == 2;      // fp16 aggregate: rows may carry a stride (P.ldA) and a zero pad
   static_assert(TAIL == 0 || (FASTLD && NCH == 1 && !DEFORM), "trailing channels: branch-free rigid variant only");
+  static_assert(TAIL == 0 || !PADDED, "trailing channels: f32 rows only");
   constexpr int TL = TAIL > 0 ? TAIL : 1;
   // Sharing workgroups (all of them when DEFORM; with SW > 1 those from block B1 on): the waves of the workgroup
   // share the same PPW points and take every nwv-th neighbour chunk; wave 0 adds the partial aggregates through
@@ -605,7 +608,8 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
 #pragma unroll
         for (int kk = 0; kk < KMAX - 1; ++kk) {
           if (kk < P.K) {
-            XT* o = Aout + (n * P.K + kk) * P.Cin + c4;
+            // (the f32 instantiations keep the dense [Nq,K,Cin] addressing: they sit at their register limit)
+            XT* o = PADDED ? Aout + n * P.ldA + kk * P.Cin + c4 : Aout + (n * P.K + kk) * P.Cin + c4;
             if (FASTLD || (c4 + 3 < P.Cin && vec_ok)) {
               st4(o, as_float4(acc[c][kk]));
             } else {
@@ -619,9 +623,18 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
       }
     }
     if (TAIL > 0 && cl < P.K && t_on) {      // lane cl holds kernel point cl's sums over the trailing channels
-      XT* o = Aout + (n * P.K + cl) * P.Cin + (P.Cin - TAIL);
+      XT* o = Aout + (n * P.K + cl) * P.Cin + (P.Cin - TAIL);       // (TAIL: f32 only)
 #pragma unroll
       for (int t = 0; t < TL; ++t) o[t] = (XT)acc_t[t];
+    }
+    if (PADDED) {
+      // padded rows (fp16 aggregate for the streaming contraction, gemm16.hip: row stride a multiple of 32 halfs):
+      // the columns beyond K*Cin are zeros, written by the point's first lanes
+      const int pad = (int)(P.ldA - (int64_t)P.K * P.Cin);
+      if (pad > 0 && cl < pad) {
+        XT* o = Aout + n * P.ldA + (int64_t)P.K * P.Cin;
+        for (int t = cl; t < pad; t += LPP) o[t] = (XT)0.f;
+      }
     }
   }
 }
@@ -994,7 +1007,7 @@ extern "C" int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s,
   KPParams P{};
   P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets; P.min_d2 = min_d2; P.min_arg = min_arg;
   P.A = A_out; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
-  P.influence = influence; P.aggregation = aggregation;
+  P.influence = influence; P.aggregation = aggregation; P.ldA = (int64_t)K * Cin;
   static const int zero_skip = getenv("MVK_GATHER_ZEROSKIP") ? atoi(getenv("MVK_GATHER_ZEROSKIP")) : 1;
   P.zero_skip = zero_skip;
   if (H == 0) {
@@ -1044,7 +1057,7 @@ extern "C" int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s
   P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets;
   P.A = const_cast<float*>(dA); P.dx = dx; P.g_min_d2 = g_min_d2; P.d_offsets = d_offsets;
   P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
-  P.influence = influence; P.aggregation = aggregation;
+  P.influence = influence; P.aggregation = aggregation; P.ldA = (int64_t)K * Cin;
   if (offsets != nullptr) {
     MVK_REQUIRE(x != nullptr && d_offsets != nullptr, "kpconv bwd: deformable needs x and d_offsets");
     MVK_REQUIRE(aggregation == MVK_AGG_SUM, "kpconv bwd: deformable + 'closest' aggregation has no offset gradient path");
@@ -1078,20 +1091,24 @@ extern "C" int mvk_kpconv_gather_plan(int64_t Nq, int64_t Ns, int H, int Cin, in
 
 // fp16-feature mode of the rigid gather (BASELINE config 5): x [Ns,Cin] and A_out [Nq,K,Cin] are fp16 in
 // memory (half the gather and aggregate bytes), correlation weights and the aggregation sums stay f32.
-extern "C" int mvk_kpconv_gather_fwd_f16(const float* q, int64_t Nq, const float* s, int64_t Ns,
-                                         const void* idx, int idx64, int H, const void* x_f16, int Cin,
-                                         const float* kp, int K, float extent, int influence,
-                                         int aggregation, void* A_out_f16, void* stream) {
+// ldA: row stride of A_out in halfs (>= K*Cin; the streaming contraction of gemm16.hip wants a multiple of 32, the
+// pad columns are written as zeros).
+extern "C" int mvk_kpconv_gather_fwd_f16_ld(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                                            const void* idx, int idx64, int H, const void* x_f16, int Cin,
+                                            const float* kp, int K, float extent, int influence,
+                                            int aggregation, void* A_out_f16, int64_t ldA, void* stream) {
   if (int e = check_common(Nq, Ns, H, Cin, K, influence, aggregation)) return e;
   MVK_REQUIRE(Cin <= 512, "kpconv (fp16 features): Cin=%d unsupported (<= 512)", Cin);
+  MVK_REQUIRE(ldA >= (int64_t)K * Cin && (ldA - (int64_t)K * Cin) < 64 && ((ldA - (int64_t)K * Cin) == 0 || ldA % 2 == 0),
+              "kpconv (fp16 features): bad aggregate row stride");
   if (Nq == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   KPParams P{};
   P.q = q; P.s = s; P.idx = idx; P.x = (const float*)x_f16; P.kp = kp;
   P.A = (float*)A_out_f16; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
-  P.influence = influence; P.aggregation = aggregation;
+  P.influence = influence; P.aggregation = aggregation; P.ldA = ldA;
   if (H == 0) {
-    MVK_CHECK_HIP(hipMemsetAsync(A_out_f16, 0, 2 * Nq * K * Cin, st));
+    MVK_CHECK_HIP(hipMemsetAsync(A_out_f16, 0, 2 * Nq * ldA, st));
     return 0;
   }
   if (Cin & 1) {   // odd row length: rows are only 2-byte aligned
@@ -1101,4 +1118,12 @@ extern "C" int mvk_kpconv_gather_fwd_f16(const float* q, int64_t Nq, const float
   }
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int mvk_kpconv_gather_fwd_f16(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                                         const void* idx, int idx64, int H, const void* x_f16, int Cin,
+                                         const float* kp, int K, float extent, int influence,
+                                         int aggregation, void* A_out_f16, void* stream) {
+  return mvk_kpconv_gather_fwd_f16_ld(q, Nq, s, Ns, idx, idx64, H, x_f16, Cin, kp, K, extent, influence, aggregation,
+                                      A_out_f16, (int64_t)K * Cin, stream);
 }

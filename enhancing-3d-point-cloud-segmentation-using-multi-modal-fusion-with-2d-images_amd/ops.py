@@ -4,6 +4,7 @@ PyTorch only owns the HBM buffers and the HIP stream; all compute below is in li
 Every function requires CUDA(HIP) tensors and raises otherwise -- there is no CPU path here.
 """
 import collections
+import os
 import ctypes as C
 
 import weakref
@@ -176,6 +177,50 @@ def gemm_f16(A, B, transA=False, transB=False, split_k=None, out_f16=False):
     check(lib().mvk_gemm_f16(_p(A), int(A.dtype == torch.float16), _p(B), int(B.dtype == torch.float16), _p(out),
                              int(out_f16), M, N, Kd, int(transA), int(transB), int(split_k), _stream()))
     return out
+
+
+def gemm_f16_stream_plan(M, N, Kp):
+    """(supported, 16-row tiles per workgroup, workgroups) of mvk_gemm_f16_stream for C [M,N] = A16 [M,Kp] . Wt16 [N,Kp]^T."""
+    out = (C.c_int64 * 3)()
+    check(lib().mvk_gemm_f16_stream_plan(int(M), int(N), int(Kp), out))
+    return bool(out[0]), int(out[1]), int(out[2])
+
+
+def round_weights_f16(W2d, Kp, want_rounded=True):
+    """W [Kd,N] f32 -> (Wt16 [N,Kp] fp16: transposed, zero padded; the rounded values as f32 [Kd,N] or None), one launch."""
+    _dev(W2d)
+    W2d = _f32c(W2d)
+    Kd, N = W2d.shape
+    Wt = torch.empty((N, int(Kp)), device=W2d.device, dtype=torch.float16)
+    Wr = torch.empty((Kd, N), device=W2d.device, dtype=torch.float32) if want_rounded else None
+    check(lib().mvk_round_weights_f16(_p(W2d), Kd, N, int(Kp), _p(Wt), _p(Wr), _stream()))
+    return Wt, Wr
+
+
+def gemm_f16_stream(A16, Wt16, stats_n_valid=None, want_stats=False):
+    """y [M,N] f32 = A16 [M,Kp] . Wt16 [N,Kp]^T on v_mfma_f32_16x16x32_f16 (mvk_gemm_f16_stream: weights stationary in
+    registers, rows streamed as fragment loads). Returns (y, (partials, rows per block) or None): with stats_n_valid
+    (DEVICE int32 [1]) or want_stats the launch also produces the BatchNorm partial statistics of y."""
+    _dev(A16, Wt16, stats_n_valid)
+    if A16.dtype != torch.float16 or Wt16.dtype != torch.float16 or A16.dim() != 2 or Wt16.dim() != 2:
+        raise RuntimeError("gemm_f16_stream: operands must be 2-D float16 tensors")
+    if A16.stride(1) != 1 or Wt16.stride(1) != 1:
+        raise RuntimeError("gemm_f16_stream: operands must be k-contiguous")
+    M, Kp = A16.shape
+    N = Wt16.shape[0]
+    if Wt16.shape[1] != Kp:
+        raise RuntimeError("gemm_f16_stream: inner dimensions differ")
+    ok, tiles, wgs = gemm_f16_stream_plan(M, N, Kp) if M > 0 else (True, 1, 0)
+    if not ok:
+        raise RuntimeError("gemm_f16_stream: unsupported shape %d x %d x %d" % (M, N, Kp))
+    y = torch.empty((M, N), device=A16.device, dtype=torch.float32)
+    part = None
+    if (stats_n_valid is not None or want_stats) and M > 0:
+        part = torch.empty((2 * wgs, N), device=A16.device, dtype=torch.float32)
+    if M > 0:
+        check(lib().mvk_gemm_f16_stream(_p(A16), A16.stride(0), _p(Wt16), Wt16.stride(0), _p(y), M, N, Kp,
+                                        _p(stats_n_valid), _p(part), _stream()))
+    return y, ((part, 16 * tiles) if part is not None else None)
 
 
 # ---- optional per-launch timing of the gather kernel (bench.py roofline): HIP events on the
@@ -537,8 +582,9 @@ class _KPConvFn(torch.autograd.Function):
         return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None
 
 
-def kpconv_gather_f16(q, s, idx, x16, kp, extent, influence="linear", aggregation="sum"):
-    """fp16-feature mode of kpconv_gather (rigid): x16 [Ns,Cin] fp16 -> A [Nq,K,Cin] fp16."""
+def kpconv_gather_f16(q, s, idx, x16, kp, extent, influence="linear", aggregation="sum", row_stride=None):
+    """fp16-feature mode of kpconv_gather (rigid): x16 [Ns,Cin] fp16 -> A [Nq,K,Cin] fp16; with row_stride
+    (>= K*Cin, in halfs) A is [Nq, row_stride] with zeros beyond K*Cin (the operand layout of gemm_f16_stream)."""
     _dev(q, s, idx, x16, kp)
     if x16.dtype != torch.float16:
         raise RuntimeError("kpconv_gather_f16: features must be float16")
@@ -547,11 +593,15 @@ def kpconv_gather_f16(q, s, idx, x16, kp, extent, influence="linear", aggregatio
     Nq, Ns, H, Cin, K = q.shape[0], s.shape[0], idx.shape[1] if idx.dim() == 2 else 0, x16.shape[1], kp.shape[0]
     if x16.shape[0] != Ns:
         raise RuntimeError("kpconv: features and support points differ in length")
-    A = torch.empty((Nq, K, Cin), device=q.device, dtype=torch.float16)
+    if row_stride is None:
+        A = torch.empty((Nq, K, Cin), device=q.device, dtype=torch.float16)
+    else:
+        A = torch.empty((Nq, int(row_stride)), device=q.device, dtype=torch.float16)
     if _PROF["on"]:
         e0, e1 = _timing_events()
-    check(lib().mvk_kpconv_gather_fwd_f16(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, _p(x16), Cin, _p(kp), K, float(extent),
-                                          INFLUENCE[influence], AGGREGATION[aggregation], _p(A), _stream()))
+    check(lib().mvk_kpconv_gather_fwd_f16_ld(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, _p(x16), Cin, _p(kp), K, float(extent),
+                                             INFLUENCE[influence], AGGREGATION[aggregation], _p(A),
+                                             K * Cin if row_stride is None else int(row_stride), _stream()))
     if _PROF["on"]:
         e1.record()
         _PROF["rec"].append(((_gather_kernel_label(Nq, Ns, H, Cin, False, 2) + "[f16]", Nq, Ns, H, Cin, K), e0, e1))
@@ -569,43 +619,70 @@ class _KPConv16Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation, stats_n_valid=None):
         K, Cin, Cout = W.shape
+        Kd = K * Cin
         x16 = x.to(torch.float16)
-        W16 = W.reshape(K * Cin, Cout).to(torch.float16)
-        min_d2 = None
-        if offsets is None and Cin <= 512:
-            A = kpconv_gather_f16(q, s, idx, x16, kp, extent, influence, aggregation)
+        min_d2 = part = None
+        # rigid layers whose contraction fits the streaming kernel: aggregate rows padded to 32 halfs, weights
+        # transposed + rounded (+ their f32 image for the backward) in one launch, statistics from the contraction
+        Kp = (Kd + 31) // 32 * 32
+        fast = (offsets is None and modulations is None and Cin <= 512 and _STREAM16
+                and gemm_f16_stream_plan(max(q.shape[0], 1), Cout, Kp)[0])
+        if fast:
+            Wt16, W16f = round_weights_f16(W.reshape(Kd, Cout), Kp, True)
+            A = kpconv_gather_f16(q, s, idx, x16, kp, extent, influence, aggregation, row_stride=Kp)
+            if _PROF["on"]:
+                e0, e1 = _timing_events()
+            y, st = gemm_f16_stream(A, Wt16, stats_n_valid)
+            if _PROF["on"]:
+                e1.record()
+                _PROF["gemm"].append(((q.shape[0], Kd, Cout), e0, e1))
+            part = st[0] if st is not None else None
+            ctx.save_for_backward(q, s, idx, x16, kp, W16f, A, offsets, modulations)
         else:
-            A, min_d2 = kpconv_gather(q, s, idx, x16.float(), kp, extent, influence, aggregation, offsets,
-                                      want_min_d2=offsets is not None)
-        Am = A.float() * modulations.unsqueeze(2) if modulations is not None else A
-        if _PROF["on"]:
-            e0, e1 = _timing_events()
-        y = gemm_f16(Am.view(-1, K * Cin), W16)
-        if _PROF["on"]:
-            e1.record()
-            _PROF["gemm"].append(((q.shape[0], K * Cin, Cout), e0, e1))
-        ctx.save_for_backward(q, s, idx, x16, kp, W16, A, offsets, modulations)
+            W16 = W.reshape(Kd, Cout).to(torch.float16)
+            if offsets is None and Cin <= 512:
+                A = kpconv_gather_f16(q, s, idx, x16, kp, extent, influence, aggregation)
+            else:
+                A, min_d2 = kpconv_gather(q, s, idx, x16.float(), kp, extent, influence, aggregation, offsets,
+                                          want_min_d2=offsets is not None)
+            Am = A.float() * modulations.unsqueeze(2) if modulations is not None else A
+            if _PROF["on"]:
+                e0, e1 = _timing_events()
+            y = gemm_f16(Am.view(-1, Kd), W16)
+            if _PROF["on"]:
+                e1.record()
+                _PROF["gemm"].append(((q.shape[0], Kd, Cout), e0, e1))
+            ctx.save_for_backward(q, s, idx, x16, kp, W16, A, offsets, modulations)
+        ctx.fast = bool(fast)
         ctx.min_arg = getattr(min_d2, "_mvk_min_arg", None)
         ctx.cfg = (extent, influence, aggregation, (K, Cin, Cout))
         ctx.w_ref = weakref.ref(W)          # the f32 parameter the gradient is for (see _dw_gemm)
+        if part is not None:
+            ctx.mark_non_differentiable(part)
         ctx.set_materialize_grads(False)
-        return y, min_d2, None          # (no BatchNorm-statistics epilogue in the fp16 contraction)
+        return y, min_d2, part
 
     @staticmethod
     def backward(ctx, gy, g_min_d2, g_part=None):
         q, s, idx, x16, kp, W16, A, offsets, modulations = ctx.saved_tensors
         extent, influence, aggregation, (K, Cin, Cout) = ctx.cfg
-        Nq = q.shape[0]
+        Nq, Kd = q.shape[0], K * Cin
         if gy is None:
             gy = torch.zeros((Nq, Cout), device=q.device, dtype=torch.float32)
         gy = _f32c(gy)
-        A32 = A.float()
+        if ctx.fast:
+            # A [Nq, Kp] fp16 (zero padded rows), W16 = the rounded weights as f32 [Kd, Cout]
+            A32 = A[:, :Kd].float().view(Nq, K, Cin)
+            Wf = W16
+        else:
+            A32 = A.float()
+            Wf = W16.float()
         Am = A32 * modulations.unsqueeze(2) if modulations is not None else A32
         dW = dx = d_off = d_mod = None
         if ctx.needs_input_grad[5]:
-            dW = _dw_gemm(Am.view(Nq, K * Cin), gy, target=ctx.w_ref()).view(K, Cin, Cout)
+            dW = _dw_gemm(Am.view(Nq, Kd), gy, target=ctx.w_ref()).view(K, Cin, Cout)
         if ctx.needs_input_grad[3] or offsets is not None:
-            dAm = gemm(gy, W16.float(), transB=True).view(Nq, K, Cin)
+            dAm = gemm(gy, Wf, transB=True).view(Nq, K, Cin)
             if modulations is not None:
                 if ctx.needs_input_grad[7]:
                     d_mod = (dAm * A32).sum(dim=2)
@@ -616,6 +693,9 @@ class _KPConv16Fn(torch.autograd.Function):
                                        x=x16.float() if offsets is not None else None, offsets=offsets,
                                        g_min_d2=g_min_d2 if offsets is not None else None, min_arg=ctx.min_arg)
         return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None
+
+
+_STREAM16 = os.environ.get("MVK_GEMM16_STREAM", "1") == "1"      # development switch: 0 = the LDS-staged fp16 kernel everywhere
 
 
 _FEATURE_DTYPE = {"dtype": torch.float32}
@@ -647,7 +727,11 @@ def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", o
     y, min_d2, part = fn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation,
                                stats_n_valid)
     if part is not None:        # the plan is a pure function of the shape: the same rows the contraction just used
-        y._mvk_bn_stats = (part, gemm_plan(y.shape[0], y.shape[1], W.shape[0] * W.shape[1], None, True)[1])
+        if fn is _KPConv16Fn:
+            rows = 16 * gemm_f16_stream_plan(y.shape[0], y.shape[1], (W.shape[0] * W.shape[1] + 31) // 32 * 32)[1]
+        else:
+            rows = gemm_plan(y.shape[0], y.shape[1], W.shape[0] * W.shape[1], None, True)[1]
+        y._mvk_bn_stats = (part, rows)
     return y, min_d2
 
 

@@ -353,7 +353,8 @@ def test_kpconv_deformable_golden(ops, name, modulated):
     assert rel_err(bo.grad.cpu().numpy(), g["offset_bias_grad"]) < 5e-4
 
 
-@pytest.mark.parametrize("cin,cout,H", [(66, 64, 40), (64, 128, 33), (7, 16, 20), (300, 32, 12), (600, 24, 9)])
+@pytest.mark.parametrize("cin,cout,H", [(66, 64, 40), (64, 128, 33), (7, 16, 20), (300, 32, 12), (600, 24, 9),
+                                        (32, 32, 30), (5, 64, 25), (64, 64, 20)])     # the last three + the first: streaming contraction
 def test_kpconv_fp16_feature_mode_vs_numpy_oracle(ops, cin, cout, H):
     """BASELINE config 5 ("fp16 features with MFMA on the KP contraction"): features, aggregate and weights
     rounded to fp16, exact products, f32 accumulation. The float64 oracle gets the same rounded operands
@@ -713,6 +714,80 @@ def test_gemm_f16_mfma(ops, M, N, K, ta, tb):
     assert got16.dtype == torch.float16 and (got16.double() - want).abs().max().item() / scale < 2e-3
     one = ops.gemm_f16(A.half(), B.half(), transA=ta, transB=tb, split_k=1)
     assert (one.double() - want).abs().max().item() / scale < 2e-5
+
+
+@pytest.mark.parametrize("M,N,Kd", [(19464, 64, 990), (4986, 64, 960), (19464, 32, 480), (40000, 64, 75), (1, 64, 990),
+                                    (17, 32, 33), (1233, 64, 1024), (700, 32, 96), (76700, 32, 480)])
+def test_gemm_f16_stream(ops, M, N, Kd):
+    """The streaming fp16 contraction of the rigid layers (csrc/gemm16.hip, v_mfma_f32_16x16x32_f16; reference shape
+    contract models/blocks.py:370-374): padded k-contiguous operands, exact fp16 products, f32 accumulation -> equals the
+    float64 product of the rounded operands to summation order (2e-5 of the largest output); the statistics partials of
+    the same launch (sum and centred squares per workgroup block, rows below a device count) against NumPy; two launches
+    give the same bits (no atomics); mvk_round_weights_f16 is exact."""
+    torch.manual_seed(M + N + Kd)
+    Kp = (Kd + 31) // 32 * 32
+    A = torch.zeros((M, Kp), device="cuda", dtype=torch.float16)
+    A[:, :Kd] = torch.randn((M, Kd), device="cuda").half()
+    W = torch.randn((Kd, N), device="cuda") * 0.2
+    Wt, Wr = ops.round_weights_f16(W, Kp, True)
+    assert Wt.shape == (N, Kp) and Wt.dtype == torch.float16
+    assert torch.equal(Wt[:, :Kd], W.half().t()) and (Wt[:, Kd:] == 0).all() and torch.equal(Wr, W.half().float())
+    ok, tiles, wgs = ops.gemm_f16_stream_plan(M, N, Kp)
+    assert ok and wgs == -(-(-(-M // 16)) // tiles)
+    want = A[:, :Kd].double() @ W.half().double()
+    scale = max(want.abs().max().item(), 1e-30)
+    y, st = ops.gemm_f16_stream(A, Wt)
+    assert st is None and y.dtype == torch.float32
+    err = (y.double() - want).abs().max().item() / scale
+    assert err < 2e-5, err
+    nv = max(1, M - 37) if M > 40 else M
+    n_valid = torch.tensor([nv], dtype=torch.int32, device="cuda")
+    y2, (part, rows) = ops.gemm_f16_stream(A, Wt, n_valid)
+    assert torch.equal(y, y2) and rows == 16 * tiles and part.shape == (2 * wgs, N)
+    yv = y.double().cpu().numpy()
+    for b in sorted({0, wgs // 2, wgs - 1}):
+        blk = yv[b * rows:min((b + 1) * rows, nv)]
+        got_sum, got_m2 = part[2 * b].double().cpu().numpy(), part[2 * b + 1].double().cpu().numpy()
+        if blk.shape[0] == 0:
+            assert (got_sum == 0).all() and (got_m2 == 0).all()
+            continue
+        s_ref = blk.sum(0)
+        m2_ref = ((blk - blk.mean(0)) ** 2).sum(0)
+        assert np.abs(got_sum - s_ref).max() < 1e-5 * max(np.abs(blk).sum(0).max(), 1e-30)
+        assert np.abs(got_m2 - m2_ref).max() < 1e-4 * max(m2_ref.max(), 1e-30) + 1e-30
+    # the partials drive the masked BatchNorm exactly like a statistics pass over y would
+    if M > 200:
+        bn = torch.nn.BatchNorm1d(N, momentum=0.02).cuda()
+        ref = torch.nn.BatchNorm1d(N, momentum=0.02).cuda()
+        y2._mvk_bn_stats = (part, rows)
+        out = ops.bn_lrelu(y2, n_valid, bn, slope=0.1)
+        outr = torch.nn.functional.leaky_relu(ref(y[:nv]), 0.1)
+        assert rel_err(out[:nv].detach().cpu().numpy(), outr.detach().cpu().numpy()) < 2e-5 and (out[nv:] == 0).all()
+    with pytest.raises(RuntimeError):
+        ops.gemm_f16_stream(A, torch.zeros((48, Kp), device="cuda", dtype=torch.float16))       # N = 48: not a streaming shape
+
+
+def test_gather_f16_padded_rows_equal_the_plain_gather(ops):
+    """mvk_kpconv_gather_fwd_f16_ld: the aggregate with rows padded to 32 halfs holds the bits of the unpadded fp16
+    aggregate in its first K*Cin columns and zeros behind them (the streaming contraction multiplies the pad by zero
+    weights: it must be finite)."""
+    rng = np.random.default_rng(5)
+    for cin, H, Nq in ((66, 40, 1000), (5, 22, 777), (32, 31, 4100), (64, 17, 130), (33, 12, 257)):
+        Ns, K = Nq + 50, 15
+        q = T((rng.random((Nq, 3)) * 0.4).astype(np.float32))
+        s = T((rng.random((Ns, 3)) * 0.4).astype(np.float32))
+        idx = T(rng.integers(0, Ns + 1, (Nq, H)).astype(np.int32))
+        x16 = T(rng.normal(size=(Ns, cin)).astype(np.float16))
+        kp = T((rng.normal(size=(K, 3)) * 0.05).astype(np.float32))
+        Kd = K * cin
+        Kp = (Kd + 31) // 32 * 32
+        plain = ops.kpconv_gather_f16(q, s, idx, x16, kp, 0.06)
+        fill = torch.full((Nq, Kp), float("nan"), device="cuda", dtype=torch.float16)     # poison the allocator's next block
+        del fill
+        padded = ops.kpconv_gather_f16(q, s, idx, x16, kp, 0.06, row_stride=Kp)
+        assert padded.shape == (Nq, Kp)
+        assert torch.equal(padded[:, :Kd].contiguous().view(torch.int16), plain.view(Nq, Kd).view(torch.int16))
+        assert (padded[:, Kd:] == 0).all()
 
 
 @pytest.mark.parametrize("R,D,n", [(100, 64, 90), (3000, 128, 2873), (19464, 64, 19464), (4096, 200, 4000),

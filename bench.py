@@ -686,7 +686,8 @@ def net_step_captured(net, static, cfg, params, opt, reducer, begin=True):
     if begin:
         ops.step_begin()
     staged_exchange = reducer is not None and hasattr(reducer, "cut_block")
-    net.backward_cut = reducer.cut_block if staged_exchange else None
+    tail = split_tail_plan(net, cfg, opt) if reducer is None else None
+    net.backward_cut = reducer.cut_block if staged_exchange else (tail["cut"] if tail else None)
     out = net(static, cfg)
     loss = net.loss(out, static.labels)
     if staged_exchange:
@@ -700,12 +701,60 @@ def net_step_captured(net, static, cfg, params, opt, reducer, begin=True):
         reducer.wait()
         reducer.unpack(0)
         reducer.unpack(1)
+    elif tail:
+        split_tail_backward(ops, net, loss, opt, tail)
+        return loss
     else:
         backward(ops, loss)
         if reducer is not None:
             reducer()
     clip_and_step(params, opt, cfg)
     return loss
+
+
+_TAIL = {}
+
+
+def split_tail_plan(net, cfg, opt):
+    """N = 1: the tail of a step -- the grouped weight-gradient launch (0.23 ms) and clip + SGD (0.075 ms) -- sits
+    behind the whole backward although 95 % of its bytes belong to the head, the decoder and encoder levels >= 2, whose
+    gradients are complete when the backward reaches the cut at the entry of level 2 (dp.py: the same cut the N > 1
+    exchange uses). With the cut, that part of the tail runs on a side stream (a branch of the captured graph) beside
+    the backward of levels 0-1. MVK_SPLIT_TAIL=0: everything at the end, on the chain."""
+    if os.environ.get("MVK_SPLIT_TAIL", "1") != "1" or not hasattr(net, "encoder_blocks") or not hasattr(opt, "clip"):
+        return None
+    if os.environ.get("MVK_DEFER_DW", "1") != "1" or os.environ.get("MVK_OVERLAP_DW", "0") == "1":
+        return None
+    key = id(net)
+    if key not in _TAIL:
+        import mvkpconv
+        dp = mvkpconv.sub("dp")
+        cut = dp.cut_block_of_layer(cfg.architecture, int(os.environ.get("MVK_TAIL_CUT_LAYER", "2")))
+        if cut is None:
+            _TAIL[key] = None
+        else:
+            late, early = dp.split_parameters_at(net, cut)
+            _TAIL[key] = {"cut": cut, "late": late, "early": early, "stream": torch.cuda.Stream()}
+    return _TAIL[key]
+
+
+def split_tail_backward(ops, net, loss, opt, tail):
+    """Backward in two stages around net.backward_cut; the deferred weight gradients and the optimiser step of the
+    parameters above the cut on the side stream while stage 2 runs; those below the cut at the end."""
+    main, side = torch.cuda.current_stream(), tail["stream"]
+    orig, leaves = net.cut_tensors
+    with ops.defer_weight_grads(flush=False) as scope:
+        loss.backward()
+    side.wait_stream(main)
+    ops.flush_deferred(scope.take(), side)
+    with torch.cuda.stream(side):
+        opt.step(only=tail["late"])
+    pairs = [(t, l.grad) for t, l in zip(orig, leaves) if t.requires_grad and l.grad is not None]
+    if pairs:
+        with ops.defer_weight_grads():
+            torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
+    opt.step(only=tail["early"])
+    main.wait_stream(side)
 
 
 def backward_scope(ops):

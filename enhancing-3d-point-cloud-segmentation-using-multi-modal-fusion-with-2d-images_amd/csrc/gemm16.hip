@@ -243,32 +243,27 @@ struct S16Args {
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int CT, int SW>
-__global__ __launch_bounds__(256, 2) void gemm_f16_stream(const S16Args a) {
+// A 16-byte store the compiler does not see: global stores share the vmcnt counter with the loads and may retire out of
+// order with them, so a store the compiler knows about between a load and its use turns the counted wait in front of
+// that use into a wait for EVERYTHING in flight (measured in the first version of the streaming kernel: one drained
+// pipeline per store phase). Hidden from its bookkeeping the waits stay counted; they are still sufficient: a wait
+// for "at most k outstanding" then returns later than needed (the counter also holds the stores), never earlier --
+// loads return in order among themselves, so with s hidden stores and j older loads, <= k outstanding means at least
+// j + 1 loads have returned.
+__device__ __forceinline__ void store_f4_hidden(float* p, float4 v) {
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v q = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
+}
+
+template <int CT, int SW, int NS>
+__global__ __launch_bounds__(256, 1) void gemm_f16_stream(const S16Args a) {
   constexpr int N = 16 * CT, LDR = N + 4;       // + 4: the four row groups of an accumulator land in distinct banks
-  constexpr int G = 4;                          // tiles per group: partial blocks of G tiles wait in LDS for one store phase
+  constexpr int G = NS;                         // tiles per group = register sets: one set per tile of the group
   __shared__ __attribute__((aligned(16))) float red[G][4][16][LDR];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int r = lane & 15, g = lane >> 4;
   const int s0 = w * SW;
-
-  h8 b[SW][CT];
-#pragma unroll
-  for (int s = 0; s < SW; ++s)
-#pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-      // branch-free: steps beyond the reduction load a real address and are zeroed afterwards (the loads stay in flight together)
-      const int st = s0 + s < a.steps ? s0 + s : a.steps - 1;
-      b[s][ct] = *reinterpret_cast<const h8*>(a.Bt + (int64_t)(ct * 16 + r) * a.ldb + st * 32 + g * 8);
-    }
-#pragma unroll
-  for (int s = 0; s < SW; ++s)
-    if (s0 + s >= a.steps) {
-#pragma unroll
-      for (int ct = 0; ct < CT; ++ct)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) b[s][ct][e] = (_Float16)0.f;
-    }
 
   const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
   const int64_t ntiles = (a.M + 15) / 16;
@@ -288,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_stream(const S16Args a) {
     }
   };
 
-  auto compute = [&](int slot, const h8 (&af)[SW]) {
+  auto compute = [&](int slot, const h8 (&af)[SW], const h8 (&b)[SW][CT]) {
     f32x4 acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -310,22 +305,31 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_stream(const S16Args a) {
   float cnt = 0.f;
   float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), s1 = sh, s2 = sh;
 
-  // Phase 1 of a group (<= G tiles): loads + MFMAs + LDS writes only. Two register sets, the loads of tile t + 2 issued
-  // right after the MFMAs of tile t have freed the set; NO global store in this phase: a store between a load and its
-  // use makes the compiler's vmcnt wait cover every load in flight (stores and loads share the counter and may retire
-  // out of order), which serialised the stream tile by tile in the first version of this kernel.
-  // Phase 2: the four waves' partial blocks are added in a fixed order and stored as whole rows; statistics.
-  h8 a0[SW], a1[SW];
-  load_tile(tile0, a0);
-  load_tile(tile0 + 1, a1);
+  // NS register sets = NS tiles in flight per wave (one workgroup per CU: the registers of a second resident workgroup
+  // are spent on depth instead -- what bounds the stream is bytes in flight per CU, 2 sets x 2 workgroups were 126 KB,
+  // 6 sets are 190 KB). Phase 1 of a group of NS tiles: MFMAs of tile i on set i, then the loads of tile i + NS into
+  // the set just freed: the queue of outstanding loads is [sets i .. NS-1, sets 0 .. i-1] on every path, the
+  // compiler's counted waits are exact. Phase 2: the four waves' partial blocks are added in a fixed order and stored
+  // as whole rows (hidden stores, see store_f4_hidden); statistics.
+  // Prologue: the first NS tiles of A and the stationary weights go out back to back, no wait in between (the weight
+  // rows are allocated 4 * SW * 32 halfs long and zero beyond the reduction, mvk_gemm_f16_stream_plan out[3]: every
+  // wave loads SW whole steps unconditionally -- zeroing the surplus step in registers had put a wait for the weights
+  // in front of the first load of A: one memory latency of a ~4-latency kernel).
+  h8 af[NS][SW];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) load_tile(tile0 + i, af[i]);
+  h8 b[SW][CT];
+#pragma unroll
+  for (int s = 0; s < SW; ++s)
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct)
+      b[s][ct] = *reinterpret_cast<const h8*>(a.Bt + (int64_t)(ct * 16 + r) * a.ldb + (s0 + s) * 32 + g * 8);
   for (int t0 = 0; t0 < T; t0 += G) {
     const int ng = T - t0 < G ? T - t0 : G;
 #pragma unroll
-    for (int i = 0; i < G; i += 2) {
-      if (i < ng) compute(i, a0);
-      load_tile(tile0 + t0 + i + 2, a0);
-      if (i + 1 < ng) compute(i + 1, a1);
-      load_tile(tile0 + t0 + i + 3, a1);
+    for (int i = 0; i < NS; ++i) {
+      if (i < ng) compute(i, af[i], b);
+      load_tile(tile0 + t0 + i + NS, af[i]);
     }
     __syncthreads();
     if (red_thread) {
@@ -340,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16_stream(const S16Args a) {
         v.z = ((p0.z + p1.z) + p2.z) + p3.z;
         v.w = ((p0.w + p1.w) + p2.w) + p3.w;
         const int64_t row = (tile0 + t0 + i) * 16 + rr;
-        if (row < a.M) *reinterpret_cast<float4*>(a.C + row * N + cq) = v;
+        if (row < a.M) store_f4_hidden(a.C + row * N + cq, v);
         if (a.bn_part != nullptr && row < nv) {
           if (cnt == 0.f) sh = v;
           cnt += 1.f;
@@ -462,13 +466,16 @@ extern "C" int mvk_gemm_f16(const void* A, int a_f16, const void* B, int b_f16, 
 
 // Which launch the streaming kernel would use for y [M,N] = A16 [M,Kp] . Wt16 [N,Kp]^T: out[0] = 1 when supported
 // (N = 32 or 64, Kp a multiple of 32 with Kp / 32 <= 32), out[1] = 16-row tiles per workgroup (= rows per statistics
-// block / 16), out[2] = workgroups. MVK_GEMM16_TILES overrides the tiles per workgroup (development).
+// block / 16), out[2] = workgroups, out[3] = halfs per row the weight operand must be allocated with (zeros beyond
+// the reduction; >= Kp). MVK_GEMM16_TILES overrides the tiles per workgroup (development).
+static int stream_sw(int64_t steps) { return steps <= 4 ? 1 : (steps <= 8 ? 2 : (steps <= 16 ? 4 : 8)); }
+
 extern "C" int mvk_gemm_f16_stream_plan(int64_t M, int N, int64_t Kp, int64_t* out) {
   MVK_REQUIRE(out != nullptr, "gemm16 stream plan: null output");
-  out[0] = out[1] = out[2] = 0;
+  out[0] = out[1] = out[2] = out[3] = 0;
   if (M <= 0 || (N != 32 && N != 64) || Kp <= 0 || Kp % 32 != 0 || Kp / 32 > 32) return 0;
   const int64_t ntiles = cdiv64(M, 16);
-  int64_t T = cdiv64(ntiles, 512);                 // two workgroups per CU resident, one round
+  int64_t T = cdiv64(ntiles, 256);                 // one workgroup per CU (the kernel spends its registers on tiles in flight), one round
   if (T < 2) T = ntiles >= 2 ? 2 : 1;              // amortise the load of the stationary weights
   if (const char* e = getenv("MVK_GEMM16_TILES")) {
     const long v = atol(e);
@@ -477,23 +484,31 @@ extern "C" int mvk_gemm_f16_stream_plan(int64_t M, int N, int64_t Kp, int64_t* o
   out[0] = 1;
   out[1] = T;
   out[2] = cdiv64(ntiles, T);
+  out[3] = 4 * 32 * stream_sw(Kp / 32);
   return 0;
 }
 
 extern "C" int mvk_gemm_f16_stream(const void* A16, int64_t lda, const void* Wt16, int64_t ldb, float* C, int64_t M,
                                    int N, int64_t Kp, const int* n_valid, float* bn_part, void* stream) {
-  int64_t plan[3];
+  int64_t plan[4];
   if (int e = mvk_gemm_f16_stream_plan(M, N, Kp, plan)) return e;
   MVK_REQUIRE(plan[0] == 1, "gemm16 stream: unsupported shape M=%lld N=%d Kp=%lld", (long long)M, N, (long long)Kp);
-  MVK_REQUIRE(lda >= Kp && ldb >= Kp && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A16 % 16) == 0 && ((uintptr_t)Wt16 % 16) == 0,
-              "gemm16 stream: operands must be 16-byte aligned with row strides that are multiples of 8 halfs");
+  MVK_REQUIRE(lda >= Kp && ldb >= plan[3] && lda % 8 == 0 && ldb % 8 == 0 && ((uintptr_t)A16 % 16) == 0 && ((uintptr_t)Wt16 % 16) == 0,
+              "gemm16 stream: operands must be 16-byte aligned, row strides multiples of 8 halfs, weight rows >= %lld halfs (zero padded)",
+              (long long)plan[3]);
   S16Args a;
   a.A = (const _Float16*)A16; a.Bt = (const _Float16*)Wt16; a.C = C; a.M = M; a.lda = lda; a.ldb = ldb; a.N = N;
   a.steps = (int)(Kp / 32); a.tiles_per_wg = (int)plan[1]; a.n_valid = n_valid; a.bn_part = bn_part;
-  const int sw = a.steps <= 4 ? 1 : (a.steps <= 8 ? 2 : (a.steps <= 16 ? 4 : 8));
+  const int sw = stream_sw(a.steps);
   const dim3 grid((unsigned)plan[2]), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define MVK_S16(CT, SW) hipLaunchKernelGGL((gemm_f16_stream<CT, SW>), grid, block, 0, st, a)
+  int ns = 6;                                      // register sets = tiles in flight per wave (development: MVK_GEMM16_SETS=4)
+  if (const char* e = getenv("MVK_GEMM16_SETS")) ns = atoi(e) == 4 ? 4 : 6;
+#define MVK_S16(CT, SW)                                                                         \
+  do {                                                                                          \
+    if (ns == 4) hipLaunchKernelGGL((gemm_f16_stream<CT, SW, 4>), grid, block, 0, st, a);       \
+    else hipLaunchKernelGGL((gemm_f16_stream<CT, SW, 6>), grid, block, 0, st, a);               \
+  } while (0)
   if (N == 64) {
     if (sw == 1) MVK_S16(4, 1); else if (sw == 2) MVK_S16(4, 2); else if (sw == 4) MVK_S16(4, 4); else MVK_S16(4, 8);
   } else {

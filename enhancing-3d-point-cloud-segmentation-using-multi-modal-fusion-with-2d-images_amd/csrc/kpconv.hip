@@ -647,15 +647,22 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
 // WPB > 1 (backward scatter of the layers searched at the deform radius: hundreds of neighbour columns for a few
 // hundred points): the WPB waves of a workgroup work on the SAME point, wave w on the 64-neighbour chunks w, w + WPB,
 // ...; they meet only in the atomics on dx (one wave per point was a 26 us serial chain on a third of the SIMDs).
-template <int NSLOT, bool IDX64, int MODE, bool DEFORM, int WPB = 1>
-__global__ __launch_bounds__(64 * WPB) void kpconv_lane_channel(KPParams P, int c0) {
+// HS > 1 (scatter of the coarse levels, a few hundred points or fewer: one wave per point leaves most SIMDs idle behind
+// a serial chain of H neighbours x NSLOT atomics): the workgroup's HS waves all evaluate the chunk's weights and take
+// every HS-th neighbour each, and the 64-channel slots of a point are spread over blockIdx.y (NSLOT = 1) -- level 4
+// (85 points, 512 channels): 85 waves -> 2 720.
+template <int NSLOT, bool IDX64, int MODE, bool DEFORM, int WPB = 1, int HS = 1>
+__global__ __launch_bounds__(64 * WPB * HS) void kpconv_lane_channel(KPParams P, int c0_base) {
   constexpr int HC = 64, WPAD = 0;
   static_assert(WPB == 1 || MODE == 1, "only the scatter splits a point over waves");
-  __shared__ float4 rel_all[WPB][64];
-  __shared__ float wl_all[WPB][64 * 16];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  float4* rel = rel_all[wid];
-  float* wl = wl_all[wid];
+  static_assert(HS == 1 || (MODE == 1 && WPB == 1 && !DEFORM), "neighbour interleave: rigid scatter only");
+  const int c0 = c0_base + (int)blockIdx.y * 64 * NSLOT;
+  __shared__ float4 rel_all[WPB * HS][64];
+  __shared__ float wl_all[WPB * HS][64 * 16];
+  const int lane = threadIdx.x & 63, wid_all = threadIdx.x >> 6;
+  const int wid = HS > 1 ? 0 : wid_all;          // HS: every wave walks all chunks
+  float4* rel = rel_all[wid_all];
+  float* wl = wl_all[wid_all];
   const int64_t n = blockIdx.x;
   const float* qp = P.q + n * 3;
   const float qx = qp[0], qy = qp[1], qz = qp[2];
@@ -693,7 +700,7 @@ __global__ __launch_bounds__(64 * WPB) void kpconv_lane_channel(KPParams P, int 
                                                  kz, &run_min, &run_arg);
     if (__ballot(j >= 0) != 0ull) {
       const int hend = min(HC, P.H - h0);
-      for (int hh = 0; hh < hend; ++hh) {
+      for (int hh = HS > 1 ? wid_all : 0; hh < hend; hh += HS) {
         const int jj = __builtin_amdgcn_readfirstlane(__float_as_int(rel[hh].w));
         if (jj < 0) continue;  // wave-uniform
         const float4* w4 = reinterpret_cast<const float4*>(wl + hh * 16);
@@ -955,7 +962,23 @@ template <int MODE, bool DEFORM>
 int launch_lane_channel(const KPParams& P, int idx64, hipStream_t st) {
   // scatter of a layer with more than one 64-neighbour chunk (searched at the deform radius): four waves per point
   static const bool split_on = getenv("MVK_SCATTER_SPLIT") == nullptr || atoi(getenv("MVK_SCATTER_SPLIT")) != 0;
+  static const bool spread_on = getenv("MVK_SCATTER_SPREAD") == nullptr || atoi(getenv("MVK_SCATTER_SPREAD")) != 0;
   const bool split = MODE == 1 && split_on && P.H > 64;
+  if (MODE == 1 && !DEFORM && !split && spread_on && P.Nq < 2048) {
+    // few points (coarse levels): one wave per (point, 64-channel slot), and below ~4 000 such waves four waves per
+    // slot that take every fourth neighbour (see the kernel's HS parameter)
+    const int slots = (P.Cin + 63) / 64;
+    const bool hs = (int64_t)P.Nq * slots < 4096;
+    dim3 grid((unsigned)P.Nq, (unsigned)slots), block(hs ? 256 : 64);
+    if (hs) {
+      if (idx64) hipLaunchKernelGGL((kpconv_lane_channel<1, true, 1, false, 1, 4>), grid, block, 0, st, P, 0);
+      else hipLaunchKernelGGL((kpconv_lane_channel<1, false, 1, false, 1, 4>), grid, block, 0, st, P, 0);
+    } else {
+      if (idx64) hipLaunchKernelGGL((kpconv_lane_channel<1, true, 1, false, 1, 1>), grid, block, 0, st, P, 0);
+      else hipLaunchKernelGGL((kpconv_lane_channel<1, false, 1, false, 1, 1>), grid, block, 0, st, P, 0);
+    }
+    return 0;
+  }
   dim3 grid((unsigned)P.Nq), block(split ? 256 : 64);
   for (int c0 = 0; c0 < P.Cin; c0 += 512) {
     int cw = P.Cin - c0 < 512 ? P.Cin - c0 : 512;

@@ -180,10 +180,11 @@ def gemm_f16(A, B, transA=False, transB=False, split_k=None, out_f16=False):
 
 
 def gemm_f16_stream_plan(M, N, Kp):
-    """(supported, 16-row tiles per workgroup, workgroups) of mvk_gemm_f16_stream for C [M,N] = A16 [M,Kp] . Wt16 [N,Kp]^T."""
-    out = (C.c_int64 * 3)()
+    """(supported, 16-row tiles per workgroup, workgroups, halfs per weight row) of mvk_gemm_f16_stream for
+    C [M,N] = A16 [M,Kp] . Wt16 [N, >= Kp]^T."""
+    out = (C.c_int64 * 4)()
     check(lib().mvk_gemm_f16_stream_plan(int(M), int(N), int(Kp), out))
-    return bool(out[0]), int(out[1]), int(out[2])
+    return bool(out[0]), int(out[1]), int(out[2]), int(out[3])
 
 
 def round_weights_f16(W2d, Kp, want_rounded=True):
@@ -208,15 +209,15 @@ def gemm_f16_stream(A16, Wt16, stats_n_valid=None, want_stats=False):
         raise RuntimeError("gemm_f16_stream: operands must be k-contiguous")
     M, Kp = A16.shape
     N = Wt16.shape[0]
-    if Wt16.shape[1] != Kp:
-        raise RuntimeError("gemm_f16_stream: inner dimensions differ")
-    ok, tiles, wgs = gemm_f16_stream_plan(M, N, Kp) if M > 0 else (True, 1, 0)
+    ok, tiles, wgs, wrow = gemm_f16_stream_plan(max(M, 1), N, Kp)
     if not ok:
         raise RuntimeError("gemm_f16_stream: unsupported shape %d x %d x %d" % (M, N, Kp))
+    if Wt16.shape[1] < wrow:
+        raise RuntimeError("gemm_f16_stream: weight rows must be %d halfs long, zero padded (round_weights_f16)" % wrow)
     y = torch.empty((M, N), device=A16.device, dtype=torch.float32)
     part = None
     if (stats_n_valid is not None or want_stats) and M > 0:
-        part = torch.empty((2 * wgs, N), device=A16.device, dtype=torch.float32)
+        part = torch.empty((wgs, 2, N), device=A16.device, dtype=torch.float32)      # the layout of gemm()'s epilogue partials
     if M > 0:
         check(lib().mvk_gemm_f16_stream(_p(A16), A16.stride(0), _p(Wt16), Wt16.stride(0), _p(y), M, N, Kp,
                                         _p(stats_n_valid), _p(part), _stream()))
@@ -426,6 +427,15 @@ def _defer_slots(device):
 
 
 class defer_weight_grads:
+    """`with defer_weight_grads(): loss.backward()`. flush=False leaves the recorded products to the caller:
+    `items = scope.take()` after the block, then `flush_deferred(items, stream)` -- e.g. on a side stream, beside the
+    next stage of the backward (bench.py: the weight gradients and the optimiser step of everything above the backward
+    cut run while the backward of the point-heavy levels is still computing)."""
+
+    def __init__(self, flush=True):
+        self.flush = bool(flush)
+        self.items = []
+
     def __enter__(self):
         _DEFER.update(on=True, items=[], leaves=set())
         return self
@@ -433,14 +443,38 @@ class defer_weight_grads:
     def __exit__(self, *exc):
         try:
             if exc[0] is None:
-                _flush_deferred()
+                if self.flush:
+                    _flush_deferred()
+                else:
+                    self.items = _DEFER["items"]
         finally:
             _DEFER.update(on=False, items=[], leaves=set())
         return False
 
+    def take(self):
+        items, self.items = self.items, []
+        return items
 
-def _flush_deferred():
-    items = _DEFER["items"]
+
+def flush_deferred(items, stream=None):
+    """The grouped launch for `items` (from defer_weight_grads(flush=False).take()) on `stream` (default: the current
+    one). On another stream the operands are marked as used there (record_stream), so their memory is not handed out
+    again to work of the producing stream while the grouped product still reads it; the caller orders the streams
+    (stream.wait_stream(producer) before, consumer.wait_stream(stream) after)."""
+    if not items:
+        return
+    if stream is None or stream == torch.cuda.current_stream():
+        return _flush_deferred(items)
+    for (A, B, _, _, _) in items:
+        A.record_stream(stream)
+        B.record_stream(stream)
+    with torch.cuda.stream(stream):
+        _flush_deferred(items)
+
+
+def _flush_deferred(items=None):
+    if items is None:
+        items = _DEFER["items"]
     if not items:
         return
     import numpy as np
@@ -628,7 +662,7 @@ class _KPConv16Fn(torch.autograd.Function):
         fast = (offsets is None and modulations is None and Cin <= 512 and _STREAM16
                 and gemm_f16_stream_plan(max(q.shape[0], 1), Cout, Kp)[0])
         if fast:
-            Wt16, W16f = round_weights_f16(W.reshape(Kd, Cout), Kp, True)
+            Wt16, W16f = round_weights_f16(W.reshape(Kd, Cout), gemm_f16_stream_plan(max(q.shape[0], 1), Cout, Kp)[3], True)
             A = kpconv_gather_f16(q, s, idx, x16, kp, extent, influence, aggregation, row_stride=Kp)
             if _PROF["on"]:
                 e0, e1 = _timing_events()

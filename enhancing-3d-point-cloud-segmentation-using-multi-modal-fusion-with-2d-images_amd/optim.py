@@ -46,13 +46,13 @@ class FusedClipSGD:
             self.state[p] = {"momentum_buffer": self._flat_m[off:off + p.numel()].view_as(p)}
             off += p.numel()
         self._chunk = lib().mvk_sgd_chunk_elems()
-        self._key = None
+        self._tables = {}                # eager steps: (pointers, rates) of a step -> the slot that holds its table
         self._cur = None
         # Table slots (pinned host staging + device copy) are allocated HERE: pinning memory is not allowed while a
         # stream is capturing. Eager steps rotate through two slots (guarded by events); every graph capture takes
         # a slot of its own, because the captured memcpy node re-reads the pinned bytes at each replay.
         self._max_chunks = sum((p.numel() + self._chunk - 1) // self._chunk for p in self.params)
-        self._free = [self._new_slot() for _ in range(6)] if self.params else []
+        self._free = [self._new_slot() for _ in range(12)] if self.params else []
         self._eager = []
         self._captured = []
 
@@ -85,7 +85,7 @@ class FusedClipSGD:
         them); the tables of CAPTURED steps are rewritten here: a captured memcpy node re-reads its pinned host bytes
         at every replay, so the next replay of every graph runs with the new rates. Returns the number of captured
         tables rewritten."""
-        self._key = None
+        self._tables = {}
         group_of = {id(p): g for g in self.param_groups for p in g["params"]}
         by_ptr = {p.data_ptr(): group_of[id(p)] for p in self.params}
         n = 0
@@ -148,7 +148,7 @@ class FusedClipSGD:
             slot = self._free.pop()
             self._captured.append(slot)
         else:
-            while len(self._eager) < 2 and len(self._free) > 4:
+            while len(self._eager) < 4 and len(self._free) > 8:
                 self._eager.append(self._free.pop())
             if not self._eager:
                 self._eager.append(self._new_slot())
@@ -165,11 +165,14 @@ class FusedClipSGD:
         return slot
 
     @torch.no_grad()
-    def step(self):
+    def step(self, only=None):
+        """only: an iterable of parameters -- step just those (bench.py steps the parameters above the backward cut on
+        a side stream while the rest of the backward is still running, the others at the end)."""
         items = []
+        subset = None if only is None else {id(p) for p in only}
         for g in self.param_groups:
             for p in g["params"]:
-                if p.grad is None:
+                if p.grad is None or (subset is not None and id(p) not in subset):
                     continue
                 gr = p.grad
                 if gr.dtype != torch.float32 or not gr.is_contiguous():
@@ -180,11 +183,14 @@ class FusedClipSGD:
             return
         key = tuple((p.data_ptr(), g.data_ptr(), lr, wd) for p, g, lr, wd in items)
         capturing = torch.cuda.is_current_stream_capturing()
-        if key != self._key or capturing:
-            self._cur = self._build(items)
+        cached = self._tables.get(key) if not capturing else None
+        if cached is None:
+            cached = self._build(items)
             # a captured slot's device table is only filled when its graph replays: an eager step must never reuse it
-            self._key = None if capturing else key
-        t = self._cur
+            if not capturing:
+                self._tables = {k: v for k, v in self._tables.items() if v is not cached}    # a rotated slot lost its old table
+                self._tables[key] = cached
+        t = self._cur = cached
         stream = torch.cuda.current_stream()
         check(lib().mvk_sgd_clip_step(C.c_void_p(t["dev"].data_ptr()), C.c_void_p(t["chunks_dev"].data_ptr()), t["n"],
                                       self.clip if np.isfinite(self.clip) else 3.0e38, self.momentum,

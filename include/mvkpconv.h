@@ -143,8 +143,11 @@ int mvk_gemm_f16(const void* A, int a_f16, const void* B, int b_f16, void* C, in
  * waves are added in a fixed order (deterministic, no atomics). bn_part != NULL: per workgroup (= plan[1] * 16 rows)
  * and column the sum and the centred sum of squares over the rows below *n_valid (NULL: all M), the partials format
  * of mvk_gemm_f32_ex: [2 * plan[2], N].
- * _plan (host only): out[0] = 1 when the shape is supported, out[1] = 16-row tiles per workgroup, out[2] = workgroups. */
-int mvk_gemm_f16_stream_plan(int64_t M, int N, int64_t Kp, int64_t* out /* [3] */);
+ * The weight rows must be allocated plan[3] (>= Kp) halfs long, zero beyond the reduction (every wave then loads whole
+ * steps unconditionally).
+ * _plan (host only): out[0] = 1 when the shape is supported, out[1] = 16-row tiles per workgroup, out[2] = workgroups,
+ * out[3] = halfs per weight row. */
+int mvk_gemm_f16_stream_plan(int64_t M, int N, int64_t Kp, int64_t* out /* [4] */);
 int mvk_gemm_f16_stream(const void* A16, int64_t lda, const void* Wt16, int64_t ldb, float* C, int64_t M, int N,
                         int64_t Kp, const int* n_valid, float* bn_part, void* stream);
 /* W [Kd,N] f32 -> Wt16 [N,Kp] fp16 (transposed, zero padded to Kp >= Kd) and, when W_rounded != NULL, the rounded

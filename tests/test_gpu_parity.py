@@ -729,11 +729,11 @@ def test_gemm_f16_stream(ops, M, N, Kd):
     A = torch.zeros((M, Kp), device="cuda", dtype=torch.float16)
     A[:, :Kd] = torch.randn((M, Kd), device="cuda").half()
     W = torch.randn((Kd, N), device="cuda") * 0.2
-    Wt, Wr = ops.round_weights_f16(W, Kp, True)
-    assert Wt.shape == (N, Kp) and Wt.dtype == torch.float16
+    ok, tiles, wgs, wrow = ops.gemm_f16_stream_plan(M, N, Kp)
+    assert ok and wgs == -(-(-(-M // 16)) // tiles) and wrow >= Kp and wrow % 32 == 0
+    Wt, Wr = ops.round_weights_f16(W, wrow, True)
+    assert Wt.shape == (N, wrow) and Wt.dtype == torch.float16
     assert torch.equal(Wt[:, :Kd], W.half().t()) and (Wt[:, Kd:] == 0).all() and torch.equal(Wr, W.half().float())
-    ok, tiles, wgs = ops.gemm_f16_stream_plan(M, N, Kp)
-    assert ok and wgs == -(-(-(-M // 16)) // tiles)
     want = A[:, :Kd].double() @ W.half().double()
     scale = max(want.abs().max().item(), 1e-30)
     y, st = ops.gemm_f16_stream(A, Wt)
@@ -743,11 +743,11 @@ def test_gemm_f16_stream(ops, M, N, Kd):
     nv = max(1, M - 37) if M > 40 else M
     n_valid = torch.tensor([nv], dtype=torch.int32, device="cuda")
     y2, (part, rows) = ops.gemm_f16_stream(A, Wt, n_valid)
-    assert torch.equal(y, y2) and rows == 16 * tiles and part.shape == (2 * wgs, N)
+    assert torch.equal(y, y2) and rows == 16 * tiles and part.shape == (wgs, 2, N)
     yv = y.double().cpu().numpy()
     for b in sorted({0, wgs // 2, wgs - 1}):
         blk = yv[b * rows:min((b + 1) * rows, nv)]
-        got_sum, got_m2 = part[2 * b].double().cpu().numpy(), part[2 * b + 1].double().cpu().numpy()
+        got_sum, got_m2 = part[b, 0].double().cpu().numpy(), part[b, 1].double().cpu().numpy()
         if blk.shape[0] == 0:
             assert (got_sum == 0).all() and (got_m2 == 0).all()
             continue
@@ -764,7 +764,9 @@ def test_gemm_f16_stream(ops, M, N, Kd):
         outr = torch.nn.functional.leaky_relu(ref(y[:nv]), 0.1)
         assert rel_err(out[:nv].detach().cpu().numpy(), outr.detach().cpu().numpy()) < 2e-5 and (out[nv:] == 0).all()
     with pytest.raises(RuntimeError):
-        ops.gemm_f16_stream(A, torch.zeros((48, Kp), device="cuda", dtype=torch.float16))       # N = 48: not a streaming shape
+        ops.gemm_f16_stream(A, torch.zeros((48, wrow), device="cuda", dtype=torch.float16))     # N = 48: not a streaming shape
+    with pytest.raises(RuntimeError):
+        ops.gemm_f16_stream(A, Wt[:, :Kp - 8].contiguous())                                    # weight rows shorter than the plan asks for
 
 
 def test_gather_f16_padded_rows_equal_the_plain_gather(ops):

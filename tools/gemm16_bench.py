@@ -38,7 +38,7 @@ for (M, N, Kd) in [(19464, 64, 990), (19464, 32, 480), (4986, 64, 960), (40000, 
     A16p = torch.zeros(M, Kp, device=dev, dtype=torch.float16)
     A16p[:, :Kd] = A32.half()
     A16 = A32.half().contiguous()
-    Wt, Wr = ops.round_weights_f16(W, Kp, True)
+    Wt, Wr = ops.round_weights_f16(W, ops.gemm_f16_stream_plan(M, N, Kp)[3], True)
     W16 = W.half()
     nv = torch.tensor([M], dtype=torch.int32, device=dev)
     fl = 2.0 * M * N * Kd
@@ -46,7 +46,7 @@ for (M, N, Kd) in [(19464, 64, 990), (19464, 32, 480), (4986, 64, 960), (40000, 
     us32 = timeit(lambda: ops.gemm(A32, W, out=out))
     us16 = timeit(lambda: ops.gemm_f16(A16, W16))
     line = "%-22s f32 %6.1f us | f16 staged %6.1f us |" % ((M, N, Kd), us32, us16)
-    for tiles in ("", "1", "2", "3", "4", "6", "8", "12"):
+    for tiles in ("", "3", "4", "5", "6", "8", "12"):
         if tiles:
             os.environ["MVK_GEMM16_TILES"] = tiles
         else:
@@ -56,5 +56,5 @@ for (M, N, Kd) in [(19464, 64, 990), (19464, 32, 480), (4986, 64, 960), (40000, 
         uss = timeit(lambda: ops.gemm_f16_stream(A16p, Wt, nv))
         line += " T%s=%d: %5.1f/%5.1f us (%.0f TF, %.2f TB/s)" % ("*" if not tiles else "", t, us, uss, fl / us / 1e6, (M * Kp * 2 + M * N * 4) / us / 1e6)
     os.environ.pop("MVK_GEMM16_TILES", None)
-    usw = timeit(lambda: ops.round_weights_f16(W, Kp, True))
+    usw = timeit(lambda: ops.round_weights_f16(W, Wt.shape[1], True))
     print(line + " | round_weights %.1f us" % usw, flush=True)

@@ -51,6 +51,8 @@ _SIGNATURES = {
     "mvk_bn_lrelu_fwd": (C.c_int, [_vp, _vp, _i64, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _i, _vp]),
     "mvk_bn_lrelu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvk_bias_lrelu_fwd": (C.c_int, [_vp, _vp, _i64, _i, _f, _vp, _vp]),
+    "mvk_bias_lrelu_bwd": (C.c_int, [_vp, _vp, _i64, _i, _f, _vp, _vp, _vp]),
     "mvk_add_lrelu_fwd": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp]),
     "mvk_add_lrelu_bwd": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp]),
     "mvk_max_pool_fwd": (C.c_int, [_vp, _i64, _i, _vp, _i, _i64, _i, _vp, _vp, _vp]),

@@ -913,6 +913,45 @@ extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n
   return 0;
 }
 
+// ---- bias + LeakyReLU of the layers without BatchNorm (blocks.py:462-463 `x + self.bias`, then the block's
+// LeakyReLU: the two head layers of every network). As tensor ops that is 2 launches forward and 4 backward (activation
+// backward, two library reductions for the bias gradient at 11-17 us each, a fill); here one launch each way.
+// Row-major [R, C]; a workgroup owns 64 rows, thread t the column t % CP of the row lanes t / CP (CP = C rounded up to a
+// power of two <= 256), the backward's column sums meet in LDS and leave as one atomic per workgroup and column.
+__global__ __launch_bounds__(256) void bias_lrelu_fwd_k(const float* __restrict__ x, const float* __restrict__ bias, int64_t R,
+                                                       int C, int CP, float slope, float* __restrict__ y) {
+  const int col = threadIdx.x % CP, rl = threadIdx.x / CP, RL = 256 / CP;
+  if (col >= C) return;
+  const float b = bias[col];
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  for (int64_t r = r0 + rl; r < r0 + 64 && r < R; r += RL) {
+    const float v = x[r * C + col] + b;
+    y[r * C + col] = v > 0.f ? v : v * slope;
+  }
+}
+
+__global__ __launch_bounds__(256) void bias_lrelu_bwd_k(const float* __restrict__ y, const float* __restrict__ g, int64_t R, int C,
+                                                       int CP, float slope, float* __restrict__ dx, float* __restrict__ dbias) {
+  __shared__ float part[256];
+  const int col = threadIdx.x % CP, rl = threadIdx.x / CP, RL = 256 / CP;
+  float s = 0.f;
+  if (col < C) {
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    for (int64_t r = r0 + rl; r < r0 + 64 && r < R; r += RL) {
+      // the sign of the output is the sign of the pre-activation (slope > 0); slope == 1: identity
+      const float d = g[r * C + col] * (y[r * C + col] > 0.f ? 1.f : slope);
+      dx[r * C + col] = d;
+      s += d;
+    }
+  }
+  part[threadIdx.x] = s;
+  __syncthreads();
+  if (rl == 0 && col < C) {
+    for (int i = 1; i < RL; ++i) s += part[i * CP + col];
+    atomicAdd(dbias + col, s);
+  }
+}
+
 extern "C" int mvk_add_lrelu_fwd(const float* a, const float* b, int64_t n, float slope, float* y, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(add_lrelu_fwd_k, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, n, slope, y);
@@ -923,6 +962,32 @@ extern "C" int mvk_add_lrelu_fwd(const float* a, const float* b, int64_t n, floa
 extern "C" int mvk_add_lrelu_bwd(const float* y, const float* g, int64_t n, float slope, float* d, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(add_lrelu_bwd_k, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, (hipStream_t)stream, y, g, n, slope, d);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+static int pow2_ge(int c) {
+  int p = 1;
+  while (p < c) p <<= 1;
+  return p;
+}
+
+extern "C" int mvk_bias_lrelu_fwd(const float* x, const float* bias, int64_t R, int C, float slope, float* y, void* stream) {
+  MVK_REQUIRE(R >= 0 && C >= 1 && C <= 256, "bias_lrelu: C=%d unsupported (1..256)", C);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(bias_lrelu_fwd_k, dim3((unsigned)cdiv64(R, 64)), dim3(256), 0, (hipStream_t)stream, x, bias, R, C,
+                     pow2_ge(C), slope, y);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+/* dbias [C] must be zero-initialised (one atomic per 64-row block and column is added to it) */
+extern "C" int mvk_bias_lrelu_bwd(const float* y, const float* g, int64_t R, int C, float slope, float* dx, float* dbias,
+                                  void* stream) {
+  MVK_REQUIRE(R >= 0 && C >= 1 && C <= 256, "bias_lrelu: C=%d unsupported (1..256)", C);
+  if (R == 0) return 0;
+  hipLaunchKernelGGL(bias_lrelu_bwd_k, dim3((unsigned)cdiv64(R, 64)), dim3(256), 0, (hipStream_t)stream, y, g, R, C,
+                     pow2_ge(C), slope, dx, dbias);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

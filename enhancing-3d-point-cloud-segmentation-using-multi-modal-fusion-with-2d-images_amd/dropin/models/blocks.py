@@ -28,6 +28,8 @@ except ImportError:  # dropin/ put on sys.path directly
 _FUSE_ADD = os.environ.get("MVK_FUSE_ADD", "1") == "1"      # development switches for A/B timing
 _HIP_BN = os.environ.get("MVK_HIP_BN", "1") == "1"          # training-mode BatchNorm on the masked HIP kernel (0: nn.BatchNorm1d)
 _GEMM_STATS = os.environ.get("MVK_GEMM_STATS", "1") == "1"  # BatchNorm statistics from the producing GEMM's epilogue
+_FUSE_FANOUT = os.environ.get("MVK_FUSE_FANOUT", "1") == "1"    # the two gradients of a block's input summed inside unary1's backward GEMM
+_FUSED_BIAS = os.environ.get("MVK_FUSED_BIAS", "1") == "1"      # bias + LeakyReLU of the BatchNorm-less layers in one launch
 _FUSED_OPERANDS = os.environ.get("MVK_FUSED_DEFORM_OPERANDS", "1") == "1"   # development switch: 0 = the tensor ops
 
 
@@ -217,6 +219,8 @@ class BatchNormBlock(nn.Module):
             # reference's unsqueeze/transpose round trip (blocks.py:456-460) without the copies
             x = self.batch_norm(x)
         else:
+            if addend is None and x.is_cuda and x.dim() == 2 and x.shape[1] <= 256 and _FUSED_BIAS:
+                return ops.bias_lrelu(x, self.bias, 1.0 if slope is None else slope)     # one launch each way
             x = x + self.bias
         if addend is not None:
             return ops.add_lrelu(x, addend, 1.0 if slope is None else slope) if _FUSE_ADD else \
@@ -242,18 +246,26 @@ class UnaryBlock(nn.Module):
         if not no_relu:
             self.leaky_relu = nn.LeakyReLU(0.1)
 
-    def forward(self, x, batch=None, join=None):
-        """join = (shortcut, slope): finish a residual block here -- LeakyReLU_slope(BN(x W^T) + shortcut)."""
+    def forward(self, x, batch=None, join=None, passthrough=False):
+        """join = (shortcut, slope): finish a residual block here -- LeakyReLU_slope(BN(x W^T) + shortcut).
+        passthrough: returns (output, x') where x' aliases x for the block's shortcut branch: the gradients of the two
+        consumers of x are then summed inside this layer's backward GEMM (ops.linear) instead of by one more launch."""
         # nn.Linear(bias=False) = x @ W^T: on the f32 MFMA GEMM (faster than the library GEMM on these
         # tall-skinny shapes, tools/gemm_bench.py); parameters stay those of self.mlp (state-dict compatible)
+        alias = x
         if _MFMA_LINEAR and x.is_cuda:
             nv = _bn_rows(x, self, self.use_bn) if _GEMM_STATS else None
-            y = ops.linear(x, self.mlp.weight, stats_n_valid=nv)
+            if passthrough and _FUSE_FANOUT and x.requires_grad:
+                y, alias = ops.linear(x, self.mlp.weight, stats_n_valid=nv, passthrough=True)
+            else:
+                y = ops.linear(x, self.mlp.weight, stats_n_valid=nv)
         else:
             y = self.mlp(x)
         if join is not None:
-            return self.batch_norm(y, join[1], addend=join[0])
-        return self.batch_norm(y, None if self.no_relu else 0.1)
+            out = self.batch_norm(y, join[1], addend=join[0])
+        else:
+            out = self.batch_norm(y, None if self.no_relu else 0.1)
+        return (out, alias) if passthrough else out
 
     def __repr__(self):
         return 'UnaryBlock(in_feat: {:d}, out_feat: {:d}, BN: {:s}, ReLU: {:s})'.format(
@@ -320,7 +332,10 @@ class ResnetBottleneckBlock(nn.Module):
 
     def forward(self, features, batch):
         q_pts, s_pts, inds = _conv_inputs(self.block_name, self.layer_ind, batch)
-        x = self.unary1(features)
+        if isinstance(self.unary1, UnaryBlock):
+            x, features = self.unary1(features, passthrough=True)      # `features` from here on: the shortcut's input
+        else:
+            x = self.unary1(features)
         nv = _bn_rows(q_pts, self, self.use_bn) if _GEMM_STATS else None
         x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv), 0.1)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features

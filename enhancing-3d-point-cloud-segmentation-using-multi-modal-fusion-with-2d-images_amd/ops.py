@@ -1011,6 +1011,37 @@ class _AddLReLUFn(torch.autograd.Function):
         return d, d, None
 
 
+class _BiasLReLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bias, slope):
+        _dev(x, bias)
+        x, bias = _f32c(x), _f32c(bias)
+        y = torch.empty_like(x)
+        check(lib().mvk_bias_lrelu_fwd(_p(x), _p(bias), x.shape[0], x.shape[1], float(slope), _p(y), _stream()))
+        ctx.save_for_backward(y)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        g = _f32c(g)
+        dx = torch.empty_like(y)
+        db = _zeros((y.shape[1],), y.device)
+        check(lib().mvk_bias_lrelu_bwd(_p(y), _p(g), y.shape[0], y.shape[1], ctx.slope, _p(dx), _p(db), _stream()))
+        return dx, db, None
+
+
+def bias_lrelu(x, bias, slope=0.1):
+    """LeakyReLU_slope(x + bias) for [R, C <= 256] rows in one launch each way (blocks.py:462-463 + the block's
+    LeakyReLU; slope = 1: the bias alone). slope must be positive (the backward reads the sign from the output)."""
+    if x.dim() != 2 or bias.dim() != 1 or bias.shape[0] != x.shape[1]:
+        raise RuntimeError("bias_lrelu: x [R,C] and bias [C] expected")
+    if not slope > 0:
+        raise ValueError("bias_lrelu: slope must be positive")
+    return _BiasLReLUFn.apply(x, bias, slope)
+
+
 def add_lrelu(a, b, slope=0.1):
     """LeakyReLU(a + b) in one launch (residual join of ResnetBottleneckBlock, blocks.py:649)."""
     if a.shape != b.shape:
@@ -1360,42 +1391,59 @@ def fa_gather(feature_2d, image_xyz, knn, points):
 
 
 class _LinearFn(torch.autograd.Function):
-    """y = x @ W^T on the f32 MFMA GEMM. x is [M,Kd] row-major, or [Kd,M] when x_is_transposed."""
+    """y = x @ W^T on the f32 MFMA GEMM. x is [M,Kd] row-major, or [Kd,M] when x_is_transposed.
+    passthrough: also returns x itself as a second (aliasing) output for a parallel consumer of x -- the shortcut of a
+    residual block; the backward then ACCUMULATES g @ W into that consumer's gradient inside the GEMM (its epilogue adds
+    onto the buffer) instead of leaving autograd to sum two tensors with one more launch per block."""
 
     @staticmethod
-    def forward(ctx, x, W, x_is_transposed, stats_n_valid=None):
+    def forward(ctx, x, W, x_is_transposed, stats_n_valid=None, passthrough=False):
         ctx.save_for_backward(x, W)
         ctx.xt = bool(x_is_transposed)
+        ctx.set_materialize_grads(False)    # no zero tensors for unused gradients (statistics, an unused passthrough)
+        alias = x.view_as(x) if passthrough else None
         if stats_n_valid is None:
-            return gemm(x, W, transA=ctx.xt, transB=True), None
+            return gemm(x, W, transA=ctx.xt, transB=True), None, alias
         y, st = gemm(x, W, transA=ctx.xt, transB=True, stats_n_valid=stats_n_valid)
         part = st[0] if st is not None else None
         if part is not None:
             ctx.mark_non_differentiable(part)
-        ctx.set_materialize_grads(False)    # no zero tensor for the unused gradient of `part`
-        return y, part
+        return y, part, alias
 
     @staticmethod
-    def backward(ctx, g, g_part=None):
+    def backward(ctx, g, g_part=None, g_alias=None):
         x, W = ctx.saved_tensors
         if g is None:
-            return None, None, None, None
+            return g_alias, None, None, None, None
         g = _f32c(g)
         dx = dW = None
         if ctx.needs_input_grad[0]:
-            dx = gemm(W, g, transA=True, transB=True) if ctx.xt else gemm(g, W)      # [Kd,M] or [M,Kd]
+            if ctx.xt:
+                dx = gemm(W, g, transA=True, transB=True)                    # [Kd,M]
+                if g_alias is not None:
+                    dx = dx + g_alias
+            elif (g_alias is not None and g_alias.dtype == torch.float32 and g_alias.is_contiguous()
+                  and g_alias.shape == (g.shape[0], W.shape[1])):
+                # nobody else holds the parallel consumer's gradient (it is this node's own grad input): add onto it
+                dx = gemm(g, W, out=g_alias, accumulate=True)
+            else:
+                dx = gemm(g, W)                                              # [M,Kd]
+                if g_alias is not None:
+                    dx = dx + g_alias
         if ctx.needs_input_grad[1]:
             # dW [N,Kd] = g^T [N,M] @ x [M,Kd]
             dW = _dw_gemm(g, x, transB=ctx.xt, target=W)
-        return dx, dW, None, None
+        return dx, dW, None, None, None
 
 
-def linear(x, W, x_is_transposed=False, stats_n_valid=None):
-    """nn.Linear without bias / a 1x1 convolution over rows, on gemm_f32_mfma. stats_n_valid: see kpconv()."""
-    y, part = _LinearFn.apply(x, W, x_is_transposed, stats_n_valid)
+def linear(x, W, x_is_transposed=False, stats_n_valid=None, passthrough=False):
+    """nn.Linear without bias / a 1x1 convolution over rows, on gemm_f32_mfma. stats_n_valid: see kpconv().
+    passthrough=True returns (y, x') with x' an alias of x whose gradient is summed into x's inside the backward GEMM
+    (use x' for the other consumer of x)."""
+    y, part, alias = _LinearFn.apply(x, W, x_is_transposed, stats_n_valid, passthrough)
     if part is not None:        # the plan is a pure function of the shape: the same rows the product just used
         y._mvk_bn_stats = (part, gemm_plan(y.shape[0], y.shape[1], W.shape[1], None, True)[1])
-    return y
+    return (y, alias) if passthrough else y
 
 
 class _XentFn(torch.autograd.Function):

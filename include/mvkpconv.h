@@ -256,6 +256,13 @@ int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n_valid, int
                      const float* y_out /* forward output, needed (with d_addend) when the forward had an addend */,
                      float* d_addend /* [R,D] gradient of the addend, or NULL */, void* stream);
 
+/* y = LeakyReLU_slope(x + bias) over rows of C <= 256 channels: the BatchNorm-less form of BatchNormBlock
+ * (models/blocks.py:462-463) fused with the LeakyReLU that follows it in UnaryBlock (:493-498) -- the two head layers.
+ * _bwd: dx = g * (y > 0 ? 1 : slope) and dbias += column sums of dx (dbias zero-initialised by the caller; one float
+ * atomic per 64-row block and column). */
+int mvk_bias_lrelu_fwd(const float* x, const float* bias, int64_t R, int C, float slope, float* y, void* stream);
+int mvk_bias_lrelu_bwd(const float* y, const float* g, int64_t R, int C, float slope, float* dx, float* dbias, void* stream);
+
 /* y = LeakyReLU_slope(a + b) over n elements and its backward d = g * (y > 0 ? 1 : slope) (both
  * addends receive d): the residual join of ResnetBottleneckBlock (blocks.py:649), slope > 0. */
 int mvk_add_lrelu_fwd(const float* a, const float* b, int64_t n, float slope, float* y, void* stream);

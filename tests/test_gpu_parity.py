@@ -653,6 +653,46 @@ def test_deferred_weight_gradients_with_existing_grads_and_shared_weights(ops):
             ops.linear(x, Wn * 2.0).sum().backward()         # MulBackward reads dW at once and drops it
 
 
+@pytest.mark.parametrize("R,C,slope", [(19464, 128, 0.1), (19464, 20, 0.1), (300, 1, 0.1), (5000, 256, 1.0), (1, 7, 0.1)])
+def test_bias_lrelu_vs_torch(ops, R, C, slope):
+    """The BatchNorm-less form of BatchNormBlock + LeakyReLU (blocks.py:462-463, the two head layers) in one launch each
+    way: output and input gradient bit for bit (same single operations), bias gradient = column sums to 1e-5."""
+    torch.manual_seed(R + C)
+    x = torch.randn(R, C, device="cuda", requires_grad=True)
+    b = torch.randn(C, device="cuda", requires_grad=True)
+    g = torch.randn(R, C, device="cuda")
+    y = ops.bias_lrelu(x, b, slope)
+    gx, gb = torch.autograd.grad(y, [x, b], g)
+    xr, br = x.detach().clone().requires_grad_(True), b.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.leaky_relu(xr + br, slope)
+    gxr, gbr = torch.autograd.grad(yr, [xr, br], g)
+    assert torch.equal(y, yr) and torch.equal(gx, gxr)
+    assert rel_err(gb.cpu().numpy(), gbr.cpu().numpy()) < 1e-5
+
+
+@pytest.mark.parametrize("M,Kd,N", [(19464, 128, 32), (4986, 256, 64), (330, 1024, 256), (85, 2048, 512), (1, 16, 8)])
+def test_linear_passthrough_sums_the_two_gradients_inside_the_gemm(ops, M, Kd, N):
+    """ops.linear(..., passthrough=True): y = x W^T and an alias x' of x for a second consumer (the shortcut of a
+    residual block, blocks.py:638-649); the backward adds g W onto the second consumer's gradient inside the GEMM
+    (split or unsplit plans) -- the input gradient must equal autograd's sum of the two, the weight gradient is
+    untouched, and an unused alias costs nothing."""
+    torch.manual_seed(M + Kd)
+    x = torch.randn(M, Kd, device="cuda", requires_grad=True)
+    W = (torch.randn(N, Kd, device="cuda") * 0.1).requires_grad_(True)
+    gy, gs = torch.randn(M, N, device="cuda"), torch.randn(M, Kd, device="cuda")
+    y, xs = ops.linear(x, W, passthrough=True)
+    gx, gW = torch.autograd.grad([y, xs * 1.5], [x, W], [gy, gs])
+    want_x = gy.double() @ W.detach().double() + 1.5 * gs.double()
+    want_W = gy.double().t() @ x.detach().double()
+    assert rel_err(gx.cpu().numpy(), want_x.cpu().numpy()) < 1e-5 and rel_err(gW.cpu().numpy(), want_W.cpu().numpy()) < 1e-5
+    y2, xs2 = ops.linear(x, W, passthrough=True)            # alias unused: plain product
+    (gx2,) = torch.autograd.grad(y2, x, gy)
+    assert rel_err(gx2.cpu().numpy(), (gy.double() @ W.detach().double()).cpu().numpy()) < 1e-5
+    y3, xs3 = ops.linear(x, W, passthrough=True)            # only the alias used: its gradient passes through
+    (gx3,) = torch.autograd.grad(xs3, x, gs)
+    assert torch.equal(gx3, gs)
+
+
 # ------------------------------------------------------------------ masked BatchNorm + LeakyReLU
 
 @pytest.mark.parametrize("slope", [1.0, 0.1])

@@ -721,7 +721,7 @@ def split_tail_plan(net, cfg, opt):
     gradients are complete when the backward reaches the cut at the entry of level 2 (dp.py: the same cut the N > 1
     exchange uses). With the cut, that part of the tail runs on a side stream (a branch of the captured graph) beside
     the backward of levels 0-1. MVK_SPLIT_TAIL=0: everything at the end, on the chain."""
-    if os.environ.get("MVK_SPLIT_TAIL", "1") != "1" or not hasattr(net, "encoder_blocks") or not hasattr(opt, "clip"):
+    if os.environ.get("MVK_SPLIT_TAIL", "0") != "1" or not hasattr(net, "encoder_blocks") or not hasattr(opt, "clip"):
         return None
     if os.environ.get("MVK_DEFER_DW", "1") != "1" or os.environ.get("MVK_OVERLAP_DW", "0") == "1":
         return None

@@ -338,7 +338,7 @@ def test_bench_emits_one_valid_json_line():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["unit"] == "points/s" and d["vs_baseline"] is None
     assert d["value"] > 5e4 and d["config"]["execution"].startswith("hipGraph") and d["config"]["capacity_overflow"] is False
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5     # (6 significant digits in the line)
     assert r["kernel"].startswith("kpconv_gather_vec") and 0.2 < r["frac"] < 1.0
     detail = json.load(open(os.path.join(root, "gpurun_out", "bench_detail.json")))
     assert detail["line"]["value"] == d["value"] and len(detail["detail"]["gather_launches"]) >= 5
@@ -428,13 +428,13 @@ def test_default_multi_gpu_step_structure_trains_like_the_single_graph_step():
         return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
 
     one = run({})
-    plain = run({"MVK_SPLIT_TAIL": "0"})           # grouped dW + SGD at the end of the chain instead of the side branch
+    plain = run({"MVK_SPLIT_TAIL": "1"})           # opt-in: grouped dW + SGD of everything above the backward cut on a side branch
     dp = run({"MVK_BENCH_FORCE_DP": "1", "MASTER_PORT": "29531"})
     assert one["config"]["execution"] == "hipGraph[net|chain|enc2d]" and one["config"]["backend"] is None
     assert dp["config"]["execution"] == "hipGraph[net|chain|enc2d]+eager-rccl(3 graphs)", dp["config"]["execution"]
     assert dp["config"]["backend"] == "rccl" and dp["config"]["ranks"] == 1
     assert not one["config"]["capacity_overflow"] and not dp["config"]["capacity_overflow"]
     a, b, c = one["config"]["final_loss"], dp["config"]["final_loss"], plain["config"]["final_loss"]
-    print("final loss: single graph %.6f (tail on the chain %.6f) | three graphs + eager RCCL %.6f | rel diff %.2e / %.2e"
+    print("final loss: single graph %.6f (tail on a side branch %.6f) | three graphs + eager RCCL %.6f | rel diff %.2e / %.2e"
           % (a, c, b, abs(a - c) / abs(a), abs(a - b) / abs(a)))
     assert abs(a - b) < 2e-3 * abs(a) and abs(a - c) < 2e-3 * abs(a)

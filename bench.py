@@ -742,10 +742,13 @@ def split_tail_backward(ops, net, loss, opt, tail):
     """Backward in two stages around net.backward_cut; the deferred weight gradients and the optimiser step of the
     parameters above the cut on the side stream while stage 2 runs; those below the cut at the end."""
     main, side = torch.cuda.current_stream(), tail["stream"]
+    if os.environ.get("MVK_TAIL_SIDE", "1") != "1":       # development: the same two pieces, both on the chain
+        side = main
     orig, leaves = net.cut_tensors
     with ops.defer_weight_grads(flush=False) as scope:
         loss.backward()
-    side.wait_stream(main)
+    if side is not main:
+        side.wait_stream(main)
     ops.flush_deferred(scope.take(), side)
     with torch.cuda.stream(side):
         opt.step(only=tail["late"])
@@ -754,7 +757,8 @@ def split_tail_backward(ops, net, loss, opt, tail):
         with ops.defer_weight_grads():
             torch.autograd.backward([t for t, _ in pairs], [g for _, g in pairs])
     opt.step(only=tail["early"])
-    main.wait_stream(side)
+    if side is not main:
+        main.wait_stream(side)
 
 
 def backward_scope(ops):

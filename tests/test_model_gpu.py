@@ -12,16 +12,20 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-def _run(variant, deformable=False, modulated=False, spheres=1):
+def _run(variant, deformable=False, modulated=False, spheres=1, nv=3, radius=0.6, density=2500.0, hw=(60, 80),
+         gradients=True):
     import mvkpconv
     from oracle import torch_port
+    from util import check_err
+    tag = "%s%s%s x%d nv%d r%.1f" % (variant, " deform" if deformable else "", " mod" if modulated else "", spheres, nv, radius)
     syn = mvkpconv.sub("synthetic")
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     np.random.seed(0)
     cfg = syn.make_config(variant, deformable=deformable, modulated=modulated)
-    sph = [syn.raw_sphere(seed=i, radius=0.6, density=2500.0) for i in range(spheres)]
-    views = [syn.sphere_views(s, nv=3, h=60, w=80) for s in sph] if variant != "baseline" else None
+    sph = [syn.raw_sphere(seed=i, radius=radius, density=density) if density else syn.raw_sphere(seed=i, radius=radius)
+           for i in range(spheres)]
+    views = [syn.sphere_views(s, nv=nv, h=hw[0], w=hw[1]) for s in sph] if variant != "baseline" else None
     staged = syn.stage_spheres(sph, dev, views)
     limits = syn.calibrate_limits(cfg, staged)
     batch, lens = syn.build_batch(cfg, staged, limits, torch.int64)
@@ -39,7 +43,8 @@ def _run(variant, deformable=False, modulated=False, spheres=1):
                     p.normal_(0, 0.05)
     out = net(batch, cfg)
     loss = net.loss(out, batch.labels)
-    loss.backward()
+    if gradients:
+        loss.backward()
     sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
     leaf = {k: sd[k].clone().requires_grad_(True) for k, p in net.named_parameters() if p.requires_grad}
     sdl = dict(sd)
@@ -49,10 +54,12 @@ def _run(variant, deformable=False, modulated=False, spheres=1):
         cb["feature_2d"] = seen["f"]
     ref, reg = torch_port.forward(sdl, cfg, cb, None, True)
     ref_loss = torch_port.loss_fn(ref, cb["labels"], reg, cfg)
-    ref_loss.backward()
     rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
-    assert rel(out.detach().cpu(), ref.detach()) < 1e-3
-    assert abs(loss.item() - ref_loss.item()) < 1e-4 * max(1.0, abs(ref_loss.item()))
+    check_err("network %s (%d points): logits vs CPU port" % (tag, lens[0]), rel(out.detach().cpu(), ref.detach()), 1e-3)
+    check_err("network %s: loss vs CPU port (rel)" % tag, abs(loss.item() - ref_loss.item()) / max(1.0, abs(ref_loss.item())), 1e-4)
+    if not gradients:
+        return net
+    ref_loss.backward()
     pairs = []
     for name, p in net.named_parameters():
         if not p.requires_grad:
@@ -66,7 +73,8 @@ def _run(variant, deformable=False, modulated=False, spheres=1):
     assert len(pairs) > 50
     scale = max(b.norm().item() for _, _, b in pairs)
     A, Bv = torch.cat([a for _, a, _ in pairs]), torch.cat([b for _, _, b in pairs])
-    assert (A @ Bv).item() / (A.norm().item() * Bv.norm().item()) > 0.999        # whole gradient
+    check_err("network %s: 1 - cosine of the whole gradient" % tag, 1.0 - (A @ Bv).item() / (A.norm().item() * Bv.norm().item()), 1e-3)
+    worst_cos, worst_ratio = 0.0, 0.0
     for name, a, b in pairs:
         if b.norm().item() < 1e-3 * scale:
             # analytically ~0 gradients (e.g. a BatchNorm bias whose shift the next BatchNorm removes):
@@ -75,7 +83,10 @@ def _run(variant, deformable=False, modulated=False, spheres=1):
             continue
         cos = (a @ b).item() / (a.norm().item() * b.norm().item())
         ratio = a.norm().item() / b.norm().item()
+        worst_cos, worst_ratio = max(worst_cos, 1 - cos), max(worst_ratio, abs(ratio - 1))
         assert cos > 0.99 and abs(ratio - 1) < 5e-2, "%s grad cos %.6f norm ratio %.4f" % (name, cos, ratio)
+    check_err("network %s: worst per-parameter 1 - cosine" % tag, worst_cos, 1e-2)
+    check_err("network %s: worst per-parameter |norm ratio - 1|" % tag, worst_ratio, 5e-2)
     return net
 
 
@@ -94,6 +105,26 @@ def test_deformable_middle_fusion_vs_cpu_port():
 
 def test_deformable_modulated_late_fusion_vs_cpu_port():
     _run("late", deformable=True, modulated=True)
+
+
+def test_five_view_middle_fusion_vs_cpu_port():
+    """BASELINE configs[3]'s per-rank workload (middle fusion, deformable architecture, FIVE views) against the CPU
+    port: logits, loss, gradients."""
+    _run("middle", deformable=True, nv=5)
+
+
+def test_full_size_early_fusion_forward_vs_cpu_port():
+    """BASELINE configs[2] at its own size -- one ~19.5 k-point sphere (radius 1.2), 3 views of 120 x 160 -- through the
+    HIP path against the unfused CPU port on the same weights: logits and loss (the forward only: the port's backward
+    at this size takes minutes; gradients are covered at 2.3 k points above and per layer in test_gpu_parity.py)."""
+    net = _run("early", radius=1.2, density=None, hw=(120, 160), gradients=False)
+    assert net is not None
+
+
+def test_full_size_late_fusion_deformable_40k_forward_vs_cpu_port():
+    """BASELINE configs[4]'s geometry (late fusion, deformable + modulated, sphere of radius 1.7: ~55 k points on the
+    synthetic room) forward against the CPU port, f32."""
+    _run("late", deformable=True, modulated=True, radius=1.7, density=None, hw=(120, 160), gradients=False)
 
 
 def test_state_dict_keys_follow_the_reference_names():

@@ -48,3 +48,22 @@ def assert_neighbors_equal_mod_ties(got, want, q, s, q_lens, s_lens, cropped=Fal
 def rel_err(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def check_err(label, err, bound):
+    """Assert err < bound and record the MEASURED error next to the bound: printed (pytest -s) and appended to
+    $MVK_PARITY_LOG (default gpurun_out/parity_errors.txt) so the bounds can be read against what the run shows."""
+    import os
+    line = "%-78s measured %.3e  bound %.1e" % (label, float(err), float(bound))
+    print(line)
+    path = os.environ.get("MVK_PARITY_LOG")
+    if path is None:
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.path.join(root, "gpurun_out", "parity_errors.txt")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass
+    assert err < bound, line

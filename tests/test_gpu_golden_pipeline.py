@@ -12,7 +12,7 @@ from util import bits_equal, rel_err, check_err
 from test_oracle_vs_golden import check_pyramid, g5_config, g5b_config, g5_batch, _Cfg
 
 pytestmark = pytest.mark.gpu
-G5_GRAD_TOL = 2e-3      # lowered to ~3x the measured worst case below (profiles/r03_parity_errors.txt)
+G5_GRAD_TOL = 1e-3      # round 3: ~3x the measured worst case (2.9e-4 on G5, 5.6e-5 on G5b; profiles/r03_parity_errors.txt); was 2e-3
 PKG = "enhancing-3d-point-cloud-segmentation-using-multi-modal-fusion-with-2d-images_amd"
 
 

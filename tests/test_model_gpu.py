@@ -1,10 +1,12 @@
 """GPU: the drop-in networks (HIP kernels) end to end against the unfused CPU port with identical
 weights -- logits, loss and parameter gradients, for every fusion variant and for the deformable
-architecture. Tolerances: 1e-3 relative on logits, 1e-4 on the loss. Gradients through ~36 layers
-with train-mode BatchNorm over layers that hold only a handful of points are ill-conditioned: the
-CPU port ALONE moves by up to 3e-2 (max-relative) between float32 and float64 on this input, so
-the end-to-end gradient check is a wiring check (cosine > 0.99, norm ratio within 5 %); the tight
-1e-4 gradient checks are the per-layer golden tests in test_gpu_parity.py."""
+architecture. Tolerances (round 3: set to ~3-10x what the runs show, profiles/r03_parity_errors.txt): 1e-4
+relative on logits (measured <= 7e-6), 1e-5 on the loss (<= 2e-7). Gradients through ~36 layers with
+train-mode BatchNorm over layers that hold only a handful of points are ill-conditioned: the CPU port
+ALONE moves by up to 3e-2 (max-relative) between float32 and float64 on this input, so the end-to-end
+gradient check is per parameter tensor a cosine > 0.999 (measured 1 - cos <= 2e-4) and a norm ratio within
+3 % (measured <= 0.94 %, the deformable + modulated late-fusion net); the tight 1e-4 gradient checks are
+the per-layer golden tests in test_gpu_parity.py."""
 import numpy as np
 import pytest
 import torch
@@ -55,8 +57,8 @@ def _run(variant, deformable=False, modulated=False, spheres=1, nv=3, radius=0.6
     ref, reg = torch_port.forward(sdl, cfg, cb, None, True)
     ref_loss = torch_port.loss_fn(ref, cb["labels"], reg, cfg)
     rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
-    check_err("network %s (%d points): logits vs CPU port" % (tag, lens[0]), rel(out.detach().cpu(), ref.detach()), 1e-3)
-    check_err("network %s: loss vs CPU port (rel)" % tag, abs(loss.item() - ref_loss.item()) / max(1.0, abs(ref_loss.item())), 1e-4)
+    check_err("network %s (%d points): logits vs CPU port" % (tag, lens[0]), rel(out.detach().cpu(), ref.detach()), 1e-4)
+    check_err("network %s: loss vs CPU port (rel)" % tag, abs(loss.item() - ref_loss.item()) / max(1.0, abs(ref_loss.item())), 1e-5)
     if not gradients:
         return net
     ref_loss.backward()
@@ -73,7 +75,7 @@ def _run(variant, deformable=False, modulated=False, spheres=1, nv=3, radius=0.6
     assert len(pairs) > 50
     scale = max(b.norm().item() for _, _, b in pairs)
     A, Bv = torch.cat([a for _, a, _ in pairs]), torch.cat([b for _, _, b in pairs])
-    check_err("network %s: 1 - cosine of the whole gradient" % tag, 1.0 - (A @ Bv).item() / (A.norm().item() * Bv.norm().item()), 1e-3)
+    check_err("network %s: 1 - cosine of the whole gradient" % tag, 1.0 - (A @ Bv).item() / (A.norm().item() * Bv.norm().item()), 5e-4)
     worst_cos, worst_ratio = 0.0, 0.0
     for name, a, b in pairs:
         if b.norm().item() < 1e-3 * scale:
@@ -84,9 +86,9 @@ def _run(variant, deformable=False, modulated=False, spheres=1, nv=3, radius=0.6
         cos = (a @ b).item() / (a.norm().item() * b.norm().item())
         ratio = a.norm().item() / b.norm().item()
         worst_cos, worst_ratio = max(worst_cos, 1 - cos), max(worst_ratio, abs(ratio - 1))
-        assert cos > 0.99 and abs(ratio - 1) < 5e-2, "%s grad cos %.6f norm ratio %.4f" % (name, cos, ratio)
-    check_err("network %s: worst per-parameter 1 - cosine" % tag, worst_cos, 1e-2)
-    check_err("network %s: worst per-parameter |norm ratio - 1|" % tag, worst_ratio, 5e-2)
+        assert cos > 0.999 and abs(ratio - 1) < 3e-2, "%s grad cos %.6f norm ratio %.4f" % (name, cos, ratio)
+    check_err("network %s: worst per-parameter 1 - cosine" % tag, worst_cos, 1e-3)
+    check_err("network %s: worst per-parameter |norm ratio - 1|" % tag, worst_ratio, 3e-2)
     return net
 
 
@@ -390,10 +392,13 @@ def test_dataloader_workers_build_the_pyramid_without_forking(tmp_path):
     (tmp_path / "workerds.py").write_text(
         "import numpy as np\n"
         "from datasets.common import PointCloudDataset\n"
+        "def first(b):\n"
+        "    return b[0]                      # (spawned workers unpickle the collate function: module level, like ScanNetCollate)\n"
         "class DS(PointCloudDataset):\n"
-        "    def __init__(self, cfg, limits):\n"
-        "        PointCloudDataset.__init__(self, 'w')\n"
-        "        self.config, self.neighborhood_limits = cfg, limits\n"
+        "    def __init__(self, fields, limits):\n"
+        "        PointCloudDataset.__init__(self, 'w')      # self.config = the (picklable, module-level) Config class\n"
+        "        self.config.__dict__.update(fields)\n"
+        "        self.neighborhood_limits = limits\n"
         "    def __len__(self):\n"
         "        return 4\n"
         "    def __getitem__(self, i):\n"
@@ -416,8 +421,9 @@ def test_dataloader_workers_build_the_pyramid_without_forking(tmp_path):
         "    cfg = syn.make_config('baseline')\n"
         "    x = torch.zeros(8, device='cuda'); torch.cuda.synchronize()      # the parent owns a HIP context\n"
         "    limits = [30, 30, 30, 30, 30]\n"
-        "    ds = workerds.DS(cfg, limits)\n"
-        "    loader = DataLoader(ds, batch_size=1, num_workers=2, collate_fn=lambda b: b[0])\n"
+        "    fields = {k: getattr(cfg, k) for k in ('architecture', 'first_subsampling_dl', 'conv_radius', 'deform_radius', 'num_layers')}\n"
+        "    ds = workerds.DS(fields, limits)\n"
+        "    loader = DataLoader(ds, batch_size=1, num_workers=2, collate_fn=workerds.first)\n"
         "    seen = 0\n"
         "    for flat in loader:\n"
         "        L = (len(flat) - 3) // 5\n"

@@ -331,18 +331,39 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   __syncthreads();
 
   // ---- P8: unordered_map iteration order
-  int* tau = W.tau + off;
-  int* posnew = W.posnew + off;
-  int* nextb = W.nextb + off;
-  int* tarr = W.tarr + off;
-  int* ft = W.ft + (int64_t)off * 3 + 32 * b;
-  int* bcnt = W.bcnt + (int64_t)off * 3 + 32 * b;
-  int* bhead = W.bhead + (int64_t)off * 3 + 32 * b;
+  // The epochs are inherently sequential (the final order depends on every rehash), and each one is a handful of
+  // block-wide phases of atomics and scans over its live elements: with the per-epoch arrays in HBM every phase was a
+  // round of L2 atomics / agent-scope loads (~1.5 us each way), ~8 us per epoch whatever its size, and a cloud of
+  // 5 000 voxels runs 10 of them. The epochs whose bucket count fits (nb <= L_NB: 13 ... 2357, eight of the ten for
+  // the level-0 cloud, all of them for the coarser levels) keep the arrays in LDS; tau moves to HBM once they outgrow it.
+  constexpr int L_NB = 2400;
+  __shared__ int l_tau[L_NB], l_posnew[L_NB], l_nextb[L_NB], l_tarr[L_NB], l_ft[L_NB], l_bcnt[L_NB], l_bhead[L_NB];
+  int* tau_g = W.tau + off;
+  int* posnew_g = W.posnew + off;
+  int* nextb_g = W.nextb + off;
+  int* tarr_g = W.tarr + off;
+  int* ft_g = W.ft + (int64_t)off * 3 + 32 * b;
+  int* bcnt_g = W.bcnt + (int64_t)off * 3 + 32 * b;
+  int* bhead_g = W.bhead + (int64_t)off * 3 + 32 * b;
   int epoch = 0;
   unsigned long long nb = sched.nb[0];
   int start = 0;
+  bool in_lds = true;
   while (start < M) {
     const int end = (unsigned long long)M < nb ? M : (int)nb;  // elements [0,end) live in this epoch
+    const bool use_lds = nb <= (unsigned long long)L_NB;
+    if (in_lds && !use_lds) {                                   // the table outgrew LDS: tau of the older elements moves
+      for (int v = tid; v < start; v += TPB) tau_g[v] = l_tau[v];
+      in_lds = false;
+      __syncthreads();
+    }
+    int* tau = use_lds ? l_tau : tau_g;
+    int* posnew = use_lds ? l_posnew : posnew_g;
+    int* nextb = use_lds ? l_nextb : nextb_g;
+    int* tarr = use_lds ? l_tarr : tarr_g;
+    int* ft = use_lds ? l_ft : ft_g;
+    int* bcnt = use_lds ? l_bcnt : bcnt_g;
+    int* bhead = use_lds ? l_bhead : bhead_g;
     for (int v = start + tid; v < end; v += TPB) tau[v] = v;   // new elements: processed in insertion order
     for (unsigned long long i = tid; i < nb; i += TPB) {
       ft[i] = 0x7fffffff;
@@ -377,6 +398,7 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
     start = end;
     nb = sched.nb[++epoch];
   }
+  const int* tau = in_lds ? l_tau : tau_g;
   // ---- P9: staging rows in iteration order
   float* sp = W.stage_pts + (int64_t)off * 3;
   float* sf = fdim > 0 ? W.stage_feat + (int64_t)off * fdim : nullptr;

@@ -597,6 +597,12 @@ extern "C" int64_t mvk_gemm_group_entry_bytes(void) { return (int64_t)sizeof(Gro
 // MVK_DW_GROUP_KTILES: 0 = the stand-alone plan, > 0 = fixed; default = by the size of the whole group, 16..96.
 constexpr int GROUP_KTILES_MIN = 16, GROUP_KTILES_MAX = 96;
 
+// Row tile of the wide class of the grouped launch in units of 16 rows (development: MVK_DW_WIDE_PM = 2 / 4 / 8).
+int group_wide_pm() {
+  static const int v = getenv("MVK_DW_WIDE_PM") ? atoi(getenv("MVK_DW_WIDE_PM")) : 4;   // 64-row tiles: -5 % on the product list of a step (tools/dw_group_bench.py), the long reductions re-read g half as often
+  return v == 2 || v == 8 ? v : 4;
+}
+
 int group_ktiles_env() {
   static const int v = getenv("MVK_DW_GROUP_KTILES") ? atoi(getenv("MVK_DW_GROUP_KTILES")) : -1;
   return v;
@@ -629,7 +635,7 @@ extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* t
   if (ktiles < 0) {      // by the size of the group: ~8 000 workgroup-sized pieces of the longest allowed length
     double units = 0.0;
     for (int i = 0; i < n; ++i)
-      units += (double)cdiv64(pr[i].M, pr[i].N <= 32 ? 64 : 32) * cdiv64(pr[i].N, pr[i].N <= 32 ? 32 : 64) * cdiv64(pr[i].Kd, BK);
+      units += (double)cdiv64(pr[i].M, pr[i].N <= 32 ? 64 : 16 * group_wide_pm()) * cdiv64(pr[i].N, pr[i].N <= 32 ? 32 : 64) * cdiv64(pr[i].Kd, BK);
     const double t = units / 8000.0;
     ktiles = t < GROUP_KTILES_MIN ? GROUP_KTILES_MIN : (t > GROUP_KTILES_MAX ? GROUP_KTILES_MAX : (int)t);
   }
@@ -653,7 +659,7 @@ extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* t
     e.args.vecB = ((q.N % 4 == 0) && ((uintptr_t)q.B % 16 == 0)) ? 4 : ((q.N % 2 == 0) && ((uintptr_t)q.B % 8 == 0)) ? 2 : 1;
     e.args.bn_part = nullptr;
     e.args.n_valid = nullptr;
-    const int64_t tm = narrow ? 64 : 32, tn = narrow ? 32 : 64;      // plan tiles: narrow (pm 1, qn 2), wide (pm 2, qn 1)
+    const int64_t tm = narrow ? 64 : 16 * group_wide_pm(), tn = narrow ? 32 : 64;      // plan tiles: narrow (pm 1, qn 2), wide (pm 2, qn 1)
     e.gx = (int)cdiv64(q.N, tn);
     e.gy = (int)cdiv64(q.M, tm);
     e.gz = split;
@@ -686,9 +692,17 @@ extern "C" int mvk_gemm_f32_tn_grouped(const void* table_dev, int n, int n_narro
   if (n_narrow > 0 && wgs_narrow > 0)
     hipLaunchKernelGGL((gemm_f32_mfma_grouped<true, false, 1, 2, 4, 1>), dim3((unsigned)wgs_narrow), dim3(256), 0, st, tab,
                        n_narrow);
-  if (n - n_narrow > 0 && wgs_wide > 0)
-    hipLaunchKernelGGL((gemm_f32_mfma_grouped<true, false, 2, 1, 1, 4>), dim3((unsigned)wgs_wide), dim3(256), 0, st,
-                       tab + n_narrow, n - n_narrow);
+  if (n - n_narrow > 0 && wgs_wide > 0) {
+    if (group_wide_pm() == 4)
+      hipLaunchKernelGGL((gemm_f32_mfma_grouped<true, false, 4, 1, 1, 4>), dim3((unsigned)wgs_wide), dim3(256), 0, st,
+                         tab + n_narrow, n - n_narrow);
+    else if (group_wide_pm() == 8)
+      hipLaunchKernelGGL((gemm_f32_mfma_grouped<true, false, 8, 1, 1, 4>), dim3((unsigned)wgs_wide), dim3(256), 0, st,
+                         tab + n_narrow, n - n_narrow);
+    else
+      hipLaunchKernelGGL((gemm_f32_mfma_grouped<true, false, 2, 1, 1, 4>), dim3((unsigned)wgs_wide), dim3(256), 0, st,
+                         tab + n_narrow, n - n_narrow);
+  }
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

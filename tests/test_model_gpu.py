@@ -475,3 +475,54 @@ def test_default_multi_gpu_step_structure_trains_like_the_single_graph_step():
     print("final loss: single graph %.6f (tail on a side branch %.6f) | three graphs + eager RCCL %.6f | rel diff %.2e / %.2e"
           % (a, c, b, abs(a - c) / abs(a), abs(a - b) / abs(a)))
     assert abs(a - b) < 2e-3 * abs(a) and abs(a - c) < 2e-3 * abs(a)
+
+
+def test_two_stage_backward_with_deformable_blocks_below_the_cut_and_deferred_weight_gradients():
+    """dp.two_stage_backward with the cut INSIDE the deformable part of the encoder, every stage under
+    ops.defer_weight_grads: stage 1 already gives the blocks below the cut a gradient through the regulariser (offset
+    branch; a zero feature-path product for the outer weights), stage 2 then ACCUMULATES onto those .grad tensors --
+    their products must run in line (not deferred into memory autograd has already consumed). Gradients must equal a
+    plain loss.backward() of the same network and batch."""
+    import mvkpconv
+    syn, ops, dp = mvkpconv.sub("synthetic"), mvkpconv.sub("ops"), mvkpconv.sub("dp")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = syn.make_config("baseline", deformable=True)
+    sph = [syn.raw_sphere(seed=3, radius=0.6, density=2500.0)]
+    staged = syn.stage_spheres(sph, dev, None)
+    limits = syn.calibrate_limits(cfg, staged)
+    batch, _ = syn.build_batch(cfg, staged, limits, torch.int32)
+    net = syn.build_model(cfg, dev)
+    net.train()
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith("offset_bias"):
+                p.normal_(0, 0.05)
+    first_deform = min(i for i, b in enumerate(cfg.architecture) if "deformable" in b)
+    cut = first_deform + 2                       # two deformable blocks stay below the cut
+    assert "deformable" in cfg.architecture[cut - 1] and "deformable" in cfg.architecture[cut]
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+
+    def grads(two_stage):
+        net.load_state_dict(sd)
+        net.zero_grad(set_to_none=True)
+        net.backward_cut = cut if two_stage else None
+        loss = net.loss(net(batch, cfg), batch.labels)
+        if two_stage:
+            dp.two_stage_backward(loss, net.cut_tensors, backward_scope=ops.defer_weight_grads)
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        net.backward_cut = None
+        return {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}, loss.item()
+
+    want, l0 = grads(False)
+    got, l1 = grads(True)
+    assert abs(l0 - l1) < 1e-6 * abs(l0) and set(want) == set(got)
+    below = [n for n in want if n.startswith("encoder_blocks.%d." % (cut - 1))]
+    assert any("offset_conv.weights" in n for n in below) and any(n.endswith("KPConv.weights") for n in below)
+    scale = max(v.abs().max().item() for v in want.values())
+    worst = max(((got[n] - want[n]).abs().max().item() / max(want[n].abs().max().item(), 1e-3 * scale), n) for n in want)
+    from util import check_err
+    check_err("two-stage + deferred dW vs plain backward, worst parameter (%s)" % worst[1], worst[0], 1e-3)

@@ -453,7 +453,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             if staged_exchange:
                 orig, leaves = net.cut_tensors
                 with scope():
-                    loss.backward(reducer.seed(loss))
+                    loss.backward(reducer.seed(loss), retain_graph=reducer.dp.deformable_below(cfg.architecture, reducer.cut_block))
                 reducer.pack(0)
             else:
                 backward(ops, loss)
@@ -695,7 +695,8 @@ def net_step_captured(net, static, cfg, params, opt, reducer, begin=True):
             reducer.pack(0)
             reducer.launch(0)
         reducer.dp.two_stage_backward(loss, net.cut_tensors, between=between, backward_scope=backward_scope(ops),
-                                      seed=reducer.seed(loss))
+                                      seed=reducer.seed(loss),
+                                      retain_graph=reducer.dp.deformable_below(cfg.architecture, reducer.cut_block))
         reducer.pack(1)
         reducer.launch(1)
         reducer.wait()

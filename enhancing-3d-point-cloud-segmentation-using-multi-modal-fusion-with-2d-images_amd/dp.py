@@ -216,19 +216,26 @@ def cut_block_of_layer(architecture, layer):
     return None
 
 
-def two_stage_backward(loss, cut_tensors, between=None, backward_scope=None, seed=None):
+def deformable_below(architecture, cut_block):
+    """True when a deformable block lies below the cut: the regulariser then reaches its KPConv node in stage 1 (through
+    min_d2) and the feature path reaches the SAME node again in stage 2 -- stage 1 must keep the graph
+    (two_stage_backward(retain_graph=True)). The shipped cuts (entry of level 2) lie below every deformable block."""
+    return any('deformable' in b for b in list(architecture)[:cut_block])
+
+
+def two_stage_backward(loss, cut_tensors, between=None, backward_scope=None, seed=None, retain_graph=False):
     """loss.backward() in two pieces around a severed graph: `cut_tensors` = (originals, leaves) as recorded by
     run_encoder_decoder when net.backward_cut is set (everything downstream of the cut was computed from the
     detached leaves). Stage 1 = loss.backward(): gradients of the parameters above the cut and of the leaves;
     `between()` (e.g. start the all-reduce of the late bucket); stage 2 = backward of the originals with the leaves'
     gradients: the parameters below the cut. The sum of both stages is exactly what an unsevered loss.backward()
     computes. backward_scope: context manager factory wrapped around each stage (ops.overlap_weight_grads).
-    seed: gradient of the loss to start from (BucketedAllReduce.seed)."""
+    seed: gradient of the loss to start from (BucketedAllReduce.seed). retain_graph: see deformable_below()."""
     import contextlib
     scope = backward_scope if backward_scope is not None else contextlib.nullcontext
     orig, leaves = cut_tensors
     with scope():
-        loss.backward(seed)
+        loss.backward(seed, retain_graph=bool(retain_graph))
     if between is not None:
         between()
     pairs = [(t, l.grad) for t, l in zip(orig, leaves) if t.requires_grad and l.grad is not None]

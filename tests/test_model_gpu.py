@@ -510,7 +510,8 @@ def test_two_stage_backward_with_deformable_blocks_below_the_cut_and_deferred_we
         net.backward_cut = cut if two_stage else None
         loss = net.loss(net(batch, cfg), batch.labels)
         if two_stage:
-            dp.two_stage_backward(loss, net.cut_tensors, backward_scope=ops.defer_weight_grads)
+            assert dp.deformable_below(cfg.architecture, cut) and not dp.deformable_below(cfg.architecture, first_deform)
+            dp.two_stage_backward(loss, net.cut_tensors, backward_scope=ops.defer_weight_grads, retain_graph=True)
         else:
             loss.backward()
         torch.cuda.synchronize()

@@ -540,4 +540,4 @@ def test_two_stage_backward_with_deformable_blocks_below_the_cut_and_deferred_we
     scale = max(v.abs().max().item() for v in want.values())
     worst = max(((got[n] - want[n]).abs().max().item() / max(want[n].abs().max().item(), 1e-3 * scale), n) for n in want)
     from util import check_err
-    check_err("two-stage + deferred dW vs plain backward, worst parameter (%s)" % worst[1], worst[0], 1e-3)
+    check_err("two-stage + deferred dW vs plain backward, worst parameter (%s)" % worst[1], worst[0], 1e-4)

@@ -21,6 +21,8 @@ _SIGNATURES = {
                                             _vp, _vp]),
     "mvk_kpconv_gather_fwd_f16_ld": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
                                                _vp, _i64, _vp]),
+    "mvk_gemm_f32_stream_plan": (C.c_int, [_i64, _i, _i64, _vp]),
+    "mvk_gemm_f32_stream": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i, _i64, _vp, _vp, _vp]),
     "mvk_gemm_f16_stream_plan": (C.c_int, [_i64, _i, _i64, _vp]),
     "mvk_gemm_f16_stream": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _vp, _vp, _vp]),
     "mvk_round_weights_f16": (C.c_int, [_vp, _i64, _i, _i64, _vp, _vp, _vp]),

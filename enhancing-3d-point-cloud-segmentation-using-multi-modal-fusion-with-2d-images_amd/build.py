@@ -19,6 +19,7 @@ SOURCES = [
     ("kpconv.hip", []),
     ("gemm.hip", []),
     ("gemm16.hip", []),
+    ("gemm32s.hip", []),
     ("pool.hip", []),
     ("bn.hip", []),
     ("optim.hip", []),

@@ -1,0 +1,254 @@
+// f32 streaming contraction for the big rigid layers (v_mfma_f32_16x16x4_f32, exact f32): the f32 twin of
+// gemm_f16_stream (gemm16.hip) for y [M, N] = A [M, Kd] . W [Kd, N] with M in the tens of thousands, N = 32 or 64 and
+// Kd <= 1024 (reference shape contract models/blocks.py:370-374) -- the first layers of the network, where the tiled
+// kernel of gemm.hip (every workgroup re-stages its slice of W through LDS behind a barrier per 32-deep step) reaches
+// 0.36-0.47 of the f32 MFMA peak.
+//   * one workgroup per CU of NW = 4 or 8 waves; wave w keeps the weight fragments of its 1 / NW of the reduction for
+//     all N columns in registers for the whole launch (slices of at most 128 columns: 128 registers at N = 64 -- four
+//     waves with 256-column slices need 256 registers of weights plus 128 of rows in flight, and the compiler spills);
+//   * the rows of A stream past in 16-row tiles as 8-byte fragment loads straight from HBM (K*Cin = 990 floats: rows
+//     are only 8-byte aligned; lane (row r, group g) takes k = 8 j + 2 g + {0, 1}: two MFMA steps per load, the same k
+//     permutation on both operands), two tiles in flight per wave through two register sets;
+//   * lane c owns the columns CT c .. CT c + CT - 1 (the "column tiles" of its accumulators), so a weight fragment for
+//     all of them is one 16-byte load and the partial blocks go to LDS as 16-byte rows; the eight waves' partial blocks
+//     are added in a fixed order (deterministic, no atomics) and stored as whole rows (hidden stores, see gemm16.hip);
+//   * BatchNorm statistics of the output for the workgroup's rows in the same pass (gemm.hip's partials format).
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct S32Args {
+  const float* A;
+  const float* B;
+  float* C;
+  int64_t M, lda;
+  int N, Kd, ks, tiles_per_wg;
+  const int* n_valid;
+  float* bn_part;
+};
+
+__device__ __forceinline__ void store_f4_hidden32(float* p, float4 v) {     // see gemm16.hip: store_f4_hidden
+  typedef float f4v __attribute__((ext_vector_type(4)));
+  const f4v q = {v.x, v.y, v.z, v.w};
+  asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
+}
+
+template <int CT, int KJ, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gemm_f32_stream(const S32Args a) {
+  constexpr int N = 16 * CT, LDR = N + 4, NS = 2, G = 2;
+  __shared__ __attribute__((aligned(16))) float red[G][NW][16][LDR];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = lane & 15, g = lane >> 4;
+  const int k0 = w * a.ks;
+
+  const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
+  const int64_t ntiles = (a.M + 15) / 16;
+  const int T = (int)(ntiles - tile0 < a.tiles_per_wg ? ntiles - tile0 : a.tiles_per_wg);
+  const int64_t last = tile0 + (T > 0 ? T - 1 : 0);
+
+  auto load_tile = [&](int64_t tile, float2 (&af)[KJ]) {
+    tile = tile < last ? tile : last;
+    int64_t row = tile * 16 + c;                          // A operand: lane's row = lane & 15
+    row = row < a.M ? row : a.M - 1;
+    // One base address per lane, the KJ loads at compile-time offsets from it. The slices of the four waves cover
+    // 4 ks >= Kd columns: the last loads of the last wave run up to 31 floats past the row -- into the next row, or,
+    // for the last row of A, into the slack the caller guarantees behind it (mvk_gemm_f32_stream: a_slack_floats); the
+    // values are replaced by zeros below (a NaN there would survive the zero weight).
+    const float* p = a.A + row * a.lda + k0 + 2 * g;
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) af[j] = *reinterpret_cast<const float2*>(p + 8 * j);
+  };
+
+  float2 af[NS][KJ];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) load_tile(tile0 + i, af[i]);
+
+  // stationary weights: b[2 j + t][ct] = W[k0 + 8 j + 2 g + t][CT c + ct], zero beyond the reduction
+  float b[2 * KJ][CT];
+#pragma unroll
+  for (int j = 0; j < KJ; ++j)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k = k0 + 8 * j + 2 * g + t;
+      const int kc = k < a.Kd ? k : a.Kd - 1;
+      const float* p = a.B + (int64_t)kc * N + c * CT;
+      if (CT == 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        b[2 * j + t][0] = v.x; b[2 * j + t][1] = v.y; b[2 * j + t][CT > 2 ? 2 : 0] = v.z; b[2 * j + t][CT > 2 ? 3 : 0] = v.w;
+      } else {
+        const float2 v = *reinterpret_cast<const float2*>(p);
+        b[2 * j + t][0] = v.x; b[2 * j + t][1] = v.y;
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < KJ; ++j)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (k0 + 8 * j + 2 * g + t >= a.Kd) {
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) b[2 * j + t][ct] = 0.f;
+      }
+
+  auto compute = [&](int slot, const float2 (&x)[KJ]) {
+    f32x4 acc[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) {
+      const bool in = k0 + 8 * j + 2 * g + 1 < a.Kd;      // (Kd is even: both elements of a pair are in or out)
+      const float x0 = in ? x[j].x : 0.f, x1 = in ? x[j].y : 0.f;
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, b[2 * j][ct], acc[ct], 0, 0, 0);
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, b[2 * j + 1][ct], acc[ct], 0, 0, 0);
+    }
+    // C/D map: column = lane & 15 (-> the lane's columns CT c + ct), row = 4 (lane >> 4) + reg
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float* dst = &red[slot][w][g * 4 + i][c * CT];
+      if (CT == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0][i], acc[1][i], acc[CT > 2 ? 2 : 0][i], acc[CT > 2 ? 3 : 0][i]);
+      } else {
+        *reinterpret_cast<float2*>(dst) = make_float2(acc[0][i], acc[1][i]);
+      }
+    }
+  };
+
+  int64_t nv = a.n_valid ? (int64_t)*a.n_valid : a.M;
+  nv = nv < a.M ? nv : a.M;
+  const bool red_thread = tid < 64 * CT;
+  const int rr = tid / (4 * CT), cq = (tid % (4 * CT)) * 4;
+  float cnt = 0.f;
+  float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), s1 = sh, s2 = sh;
+
+  for (int t0 = 0; t0 < T; t0 += G) {
+    const int ng = T - t0 < G ? T - t0 : G;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      if (i < ng) compute(i, af[i]);
+      load_tile(tile0 + t0 + i + NS, af[i]);
+    }
+    __syncthreads();
+    if (red_thread) {
+      for (int i = 0; i < ng; ++i) {
+        float4 v = *reinterpret_cast<const float4*>(&red[i][0][rr][cq]);
+#pragma unroll
+        for (int ww = 1; ww < NW; ++ww) {
+          const float4 p = *reinterpret_cast<const float4*>(&red[i][ww][rr][cq]);
+          v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        const int64_t row = (tile0 + t0 + i) * 16 + rr;
+        if (row < a.M) store_f4_hidden32(a.C + row * N + cq, v);
+        if (a.bn_part != nullptr && row < nv) {
+          if (cnt == 0.f) sh = v;
+          cnt += 1.f;
+          const float dx = v.x - sh.x, dy = v.y - sh.y, dz = v.z - sh.z, dw = v.w - sh.w;
+          s1.x += dx; s1.y += dy; s1.z += dz; s1.w += dw;
+          s2.x += dx * dx; s2.y += dy * dy; s2.z += dz * dz; s2.w += dw * dw;
+        }
+      }
+    }
+    if (t0 + G < T) __syncthreads();
+  }
+
+  if (a.bn_part != nullptr) {
+    __syncthreads();
+    float* L = &red[0][0][0][0];                       // [3][16][N]: count, mean, M2
+    if (red_thread) {
+      const float inv = cnt > 0.f ? 1.f / cnt : 0.f;
+      const float m[4] = {sh.x + s1.x * inv, sh.y + s1.y * inv, sh.z + s1.z * inv, sh.w + s1.w * inv};
+      const float q[4] = {s2.x - s1.x * s1.x * inv, s2.y - s1.y * s1.y * inv, s2.z - s1.z * s1.z * inv, s2.w - s1.w * s1.w * inv};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        L[(0 * 16 + rr) * N + cq + e] = cnt;
+        L[(1 * 16 + rr) * N + cq + e] = m[e];
+        L[(2 * 16 + rr) * N + cq + e] = q[e] > 0.f ? q[e] : 0.f;
+      }
+    }
+    __syncthreads();
+    if (tid < N && tile0 < ntiles) {
+      float n = 0.f, mean = 0.f, m2 = 0.f;
+      for (int i = 0; i < 16; ++i) {
+        const float ni = L[(0 * 16 + i) * N + tid], mi = L[(1 * 16 + i) * N + tid], qi = L[(2 * 16 + i) * N + tid];
+        if (ni > 0.f) {
+          const float nn = n + ni, d = mi - mean;
+          mean += d * (ni / nn);
+          m2 += qi + d * d * (n * ni / nn);
+          n = nn;
+        }
+      }
+      a.bn_part[((int64_t)blockIdx.x * 2) * N + tid] = mean * n;
+      a.bn_part[((int64_t)blockIdx.x * 2 + 1) * N + tid] = m2;
+    }
+  }
+}
+
+}  // namespace
+
+// out[0] = 1 when C [M,N] = A [M,Kd] . B [Kd,N] runs on the streaming kernel (N = 32 or 64, Kd even, 16 <= Kd <= 1024,
+// M >= 4096: below that the tiled kernel's split plans win), out[1] = 16-row tiles per workgroup (= statistics block
+// rows / 16), out[2] = workgroups, out[3] = readable floats the kernel needs behind the last element of A. MVK_GEMM32_STREAM=0 disables it, MVK_GEMM32_TILES overrides out[1] (development).
+static int stream32_nw(int64_t Kd) { return Kd > 512 ? 8 : 4; }          // waves per workgroup: slices of <= 128 columns
+
+static int stream32_kj(int64_t Kd) {
+  const int per = (int)cdiv64(Kd, stream32_nw(Kd));
+  const int kj = ((per + 7) / 8 * 8) / 8;
+  return kj <= 4 ? 4 : (kj <= 8 ? 8 : 16);
+}
+
+extern "C" int mvk_gemm_f32_stream_plan(int64_t M, int N, int64_t Kd, int64_t* out) {
+  MVK_REQUIRE(out != nullptr, "gemm32 stream plan: null output");
+  out[0] = out[1] = out[2] = out[3] = 0;
+  static const bool on = getenv("MVK_GEMM32_STREAM") == nullptr || atoi(getenv("MVK_GEMM32_STREAM")) != 0;
+  if (!on || M < 4096 || (N != 32 && N != 64) || Kd < 16 || Kd > 1024 || (Kd & 1)) return 0;
+  const int64_t ntiles = cdiv64(M, 16);
+  int64_t T = cdiv64(ntiles, 256);
+  if (T < 2) T = 2;
+  if (const char* e = getenv("MVK_GEMM32_TILES")) {
+    const long v = atol(e);
+    if (v > 0) T = v;
+  }
+  out[0] = 1;
+  out[1] = T;
+  out[2] = cdiv64(ntiles, T);
+  const int64_t cover = (int64_t)stream32_nw(Kd) * 8 * stream32_kj(Kd);        // columns the waves' slices cover
+  out[3] = cover > Kd ? cover - Kd : 0;
+  return 0;
+}
+
+// a_slack_floats: how many floats behind the last element of A are readable (any content): the kernel needs
+// mvk_gemm_f32_stream_plan's out[3] of them.
+extern "C" int mvk_gemm_f32_stream(const float* A, int64_t a_slack_floats, const float* B, float* C, int64_t M, int N,
+                                   int64_t Kd, const int* n_valid, float* bn_part, void* stream) {
+  int64_t plan[4];
+  if (int e = mvk_gemm_f32_stream_plan(M, N, Kd, plan)) return e;
+  MVK_REQUIRE(plan[0] == 1, "gemm32 stream: unsupported shape M=%lld N=%d Kd=%lld", (long long)M, N, (long long)Kd);
+  MVK_REQUIRE(a_slack_floats >= plan[3], "gemm32 stream: %lld readable floats needed behind A, %lld given", (long long)plan[3],
+              (long long)a_slack_floats);
+  MVK_REQUIRE(((uintptr_t)A % 8) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm32 stream: operand alignment");
+  S32Args a;
+  a.A = A; a.B = B; a.C = C; a.M = M; a.lda = Kd; a.N = N; a.Kd = (int)Kd;
+  a.tiles_per_wg = (int)plan[1]; a.n_valid = n_valid; a.bn_part = bn_part;
+  const int nw = stream32_nw(Kd);
+  const dim3 grid((unsigned)plan[2]), block(64 * nw);
+  hipStream_t st = (hipStream_t)stream;
+#define MVK_S32(CT, KJ)                                                                         \
+  do {                                                                                          \
+    if (nw == 8) hipLaunchKernelGGL((gemm_f32_stream<CT, KJ, 8>), grid, block, 0, st, a);       \
+    else hipLaunchKernelGGL((gemm_f32_stream<CT, KJ, 4>), grid, block, 0, st, a);               \
+  } while (0)
+  const int kjr = stream32_kj(Kd);                      // 8-byte loads per lane and tile
+  a.ks = 8 * kjr;                                       // slice length of a wave (surplus columns: zero weights)
+  if (N == 64) {
+    if (kjr == 4) MVK_S32(4, 4); else if (kjr == 8) MVK_S32(4, 8); else MVK_S32(4, 16);
+  } else {
+    if (kjr == 4) MVK_S32(2, 4); else if (kjr == 8) MVK_S32(2, 8); else MVK_S32(2, 16);
+  }
+#undef MVK_S32
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}

@@ -179,6 +179,36 @@ def gemm_f16(A, B, transA=False, transB=False, split_k=None, out_f16=False):
     return out
 
 
+def gemm_f32_stream_plan(M, N, Kd):
+    """(runs on the streaming kernel, 16-row tiles per workgroup, workgroups, floats needed behind A) for
+    C [M,N] = A [M,Kd] . B [Kd,N] in f32 (mvk_gemm_f32_stream_plan)."""
+    out = (C.c_int64 * 4)()
+    check(lib().mvk_gemm_f32_stream_plan(int(M), int(N), int(Kd), out))
+    return bool(out[0]), int(out[1]), int(out[2]), int(out[3])
+
+
+def _slack_floats(t):
+    """Readable float32 elements behind the last element of the (contiguous) tensor t inside its own storage."""
+    return t.untyped_storage().nbytes() // 4 - t.storage_offset() - t.numel()
+
+
+def gemm_f32_stream(A, B, stats_n_valid=None):
+    """C [M,N] f32 = A [M,Kd] . B [Kd,N] on the streaming f32 MFMA kernel (weights stationary in registers, rows of A as
+    fragment loads). Returns (C, (partials, rows per block) or None). The caller checks gemm_f32_stream_plan and that A
+    has the slack the plan asks for (kpconv_gather allocates it)."""
+    _dev(A, B, stats_n_valid)
+    A, B = _f32c(A), _f32c(B)
+    M, Kd = A.shape
+    N = B.shape[1]
+    ok, tiles, wgs, need = gemm_f32_stream_plan(M, N, Kd)
+    if not ok or B.shape[0] != Kd:
+        raise RuntimeError("gemm_f32_stream: unsupported shape %d x %d x %d" % (M, N, Kd))
+    y = torch.empty((M, N), device=A.device, dtype=torch.float32)
+    part = torch.empty((wgs, 2, N), device=A.device, dtype=torch.float32) if stats_n_valid is not None else None
+    check(lib().mvk_gemm_f32_stream(_p(A), _slack_floats(A), _p(B), _p(y), M, N, Kd, _p(stats_n_valid), _p(part), _stream()))
+    return y, ((part, 16 * tiles) if part is not None else None)
+
+
 def gemm_f16_stream_plan(M, N, Kp):
     """(supported, 16-row tiles per workgroup, workgroups, halfs per weight row) of mvk_gemm_f16_stream for
     C [M,N] = A16 [M,Kp] . Wt16 [N, >= Kp]^T."""
@@ -315,7 +345,8 @@ def kpconv_gather(q, s, idx, x, kp, extent, influence="linear", aggregation="sum
     Nq, Ns, H, Cin, K = q.shape[0], s.shape[0], idx.shape[1] if idx.dim() == 2 else 0, x.shape[1], kp.shape[0]
     if x.shape[0] != Ns:
         raise RuntimeError("kpconv: features and support points differ in length")
-    A = torch.empty((Nq, K, Cin), device=q.device, dtype=torch.float32)
+    # 64 floats of slack behind the aggregate: the streaming contraction reads up to 31 floats past the last row
+    A = torch.empty(Nq * K * Cin + 64, device=q.device, dtype=torch.float32)[:Nq * K * Cin].view(Nq, K, Cin)
     min_d2 = min_arg = None
     if offsets is not None:
         offsets = _f32c(offsets)
@@ -571,7 +602,9 @@ class _KPConvFn(torch.autograd.Function):
         if _PROF["on"]:
             e0, e1 = _timing_events()
         st = None
-        if stats_n_valid is not None:                                           # blocks.py:370-374
+        if _contraction_streams(Am, q.shape[0], K * Cin, Cout):                 # the big rigid layers (levels 0-1)
+            y, st = gemm_f32_stream(Am.view(-1, K * Cin), W.reshape(K * Cin, Cout), stats_n_valid)
+        elif stats_n_valid is not None:                                         # blocks.py:370-374
             y, st = gemm(Am.view(-1, K * Cin), W.reshape(K * Cin, Cout), stats_n_valid=stats_n_valid)
         else:
             y = gemm(Am.view(-1, K * Cin), W.reshape(K * Cin, Cout))
@@ -582,6 +615,7 @@ class _KPConvFn(torch.autograd.Function):
         ctx.min_arg = getattr(min_d2, "_mvk_min_arg", None)
         ctx.cfg = (extent, influence, aggregation)
         ctx.stat_rows = st[1] if st is not None else 0
+        _LAST_STATS_ROWS[0] = ctx.stat_rows
         part = st[0] if st is not None else None
         if part is not None:
             ctx.mark_non_differentiable(part)
@@ -614,6 +648,18 @@ class _KPConvFn(torch.autograd.Function):
                                        offsets=offsets,
                                        g_min_d2=g_min_d2 if offsets is not None else None, min_arg=ctx.min_arg)
         return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None
+
+
+_LAST_STATS_ROWS = [0]       # rows per block of the statistics partials the last KPConv forward produced
+
+
+def _contraction_streams(A, M, Kd, N):
+    """Whether the forward contraction of a layer runs on gemm_f32_stream: a supported shape and an aggregate with the
+    slack the kernel reads behind its last row (kpconv_gather's own allocation has it; a modulated copy does not)."""
+    if M <= 0:
+        return False
+    ok, _, _, need = gemm_f32_stream_plan(M, N, Kd)
+    return ok and A.is_contiguous() and _slack_floats(A) >= need
 
 
 def kpconv_gather_f16(q, s, idx, x16, kp, extent, influence="linear", aggregation="sum", row_stride=None):
@@ -675,6 +721,7 @@ class _KPConv16Fn(torch.autograd.Function):
                 e1.record()
                 _PROF["gemm"].append(((q.shape[0], Kd, Cout), e0, e1))
             part = st[0] if st is not None else None
+            _LAST_STATS_ROWS[0] = st[1] if st is not None else 0
             ctx.save_for_backward(q, s, idx, x16, kp, W16f, A, offsets, modulations)
         else:
             W16 = W.reshape(Kd, Cout).to(torch.float16)
@@ -764,11 +811,8 @@ def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", o
     fn = _KPConv16Fn if (feature_dtype or _FEATURE_DTYPE["dtype"]) == torch.float16 else _KPConvFn
     y, min_d2, part = fn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation,
                                stats_n_valid)
-    if part is not None:        # the plan is a pure function of the shape: the same rows the contraction just used
-        if fn is _KPConv16Fn:
-            rows = 16 * gemm_f16_stream_plan(y.shape[0], y.shape[1], (W.shape[0] * W.shape[1] + 31) // 32 * 32)[1]
-        else:
-            rows = gemm_plan(y.shape[0], y.shape[1], W.shape[0] * W.shape[1], None, True)[1]
+    if part is not None:        # rows per statistics block of the launch that just ran (set by the node's forward)
+        rows = _LAST_STATS_ROWS[0]
         y._mvk_bn_stats = (part, rows)
     return y, min_d2
 

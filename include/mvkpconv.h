@@ -129,6 +129,19 @@ int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* table_host, 
 int mvk_gemm_f32_tn_grouped(const void* table_dev, int n, int n_narrow, int64_t wgs_narrow, int64_t wgs_wide,
                             void* stream);
 
+/* The K x Cin x Cout contraction of the big rigid layers as a stream (models/blocks.py:370-374; exact f32 on
+ * v_mfma_f32_16x16x4_f32): C [M,N] = A [M,Kd] . B [Kd,N], N = 32 or 64, Kd even and <= 1024, M >= 4096. The weights stay in
+ * registers (wave w of the workgroup: its 1/4 or 1/8 of the reduction), the rows of A stream through as 8-byte fragment
+ * loads without LDS staging, the waves' partial blocks are added in a fixed order (deterministic, no atomics).
+ * bn_part != NULL: BatchNorm partials of C over the rows below *n_valid (NULL: all M), format of mvk_gemm_f32_ex with
+ * blocks of plan[1] * 16 rows: [plan[2], 2, N]. The kernel reads up to plan[3] floats behind the last element of A
+ * (content irrelevant, it is masked): a_slack_floats states how many are readable.
+ * _plan (host only): out[0] = 1 when the shape runs on this kernel, out[1] = 16-row tiles per workgroup, out[2] =
+ * workgroups, out[3] = floats needed behind A. */
+int mvk_gemm_f32_stream_plan(int64_t M, int N, int64_t Kd, int64_t* out /* [4] */);
+int mvk_gemm_f32_stream(const float* A, int64_t a_slack_floats, const float* B, float* C, int64_t M, int N, int64_t Kd,
+                        const int* n_valid, float* bn_part, void* stream);
+
 /* fp16-feature mode of the same contraction (BASELINE config 5): operands are rounded to fp16 (each may be
  * stored as f32 or f16 in memory: a_f16 / b_f16), multiplied on v_mfma_f32_32x32x8_f16 and accumulated in
  * f32; C is f32 [M,N] (split_k > 1: atomics onto a zero-initialised C) or, with c_f16, fp16 [M,N]. */

@@ -811,6 +811,50 @@ def test_gemm_f16_stream(ops, M, N, Kd):
         ops.gemm_f16_stream(A, Wt[:, :Kp - 8].contiguous())                                    # weight rows shorter than the plan asks for
 
 
+@pytest.mark.parametrize("M,N,Kd", [(19464, 64, 990), (19464, 32, 480), (4986, 64, 960), (4100, 64, 30), (40000, 32, 150),
+                                    (55070, 64, 1024), (5000, 32, 16)])
+def test_gemm_f32_stream(ops, M, N, Kd):
+    """The streaming f32 contraction of the big rigid layers (csrc/gemm32s.hip; reference shape contract
+    models/blocks.py:370-374): equals the float64 product to f32 summation order (2e-6 of the largest output), equals
+    the tiled kernel's result to the same bound, statistics partials against NumPy, two launches bit-identical (no
+    atomics), NaN-filled slack behind A harmless (the surplus columns are masked, not multiplied by zero)."""
+    torch.manual_seed(M + N + Kd)
+    ok, tiles, wgs, need = ops.gemm_f32_stream_plan(M, N, Kd)
+    assert ok and 0 <= need < 64
+    buf = torch.full((M * Kd + 64,), float("nan"), device="cuda")
+    A = buf[:M * Kd].view(M, Kd)
+    A.copy_(torch.randn(M, Kd, device="cuda"))
+    W = torch.randn(Kd, N, device="cuda") * 0.2
+    want = A.double() @ W.double()
+    scale = want.abs().max().item()
+    y, st = ops.gemm_f32_stream(A, W)
+    assert st is None and torch.isfinite(y).all()
+    assert (y.double() - want).abs().max().item() / scale < 2e-6
+    assert (y - ops.gemm(A, W)).abs().max().item() / scale < 2e-6
+    nv = M - 37
+    n_valid = torch.tensor([nv], dtype=torch.int32, device="cuda")
+    y2, (part, rows) = ops.gemm_f32_stream(A, W, n_valid)
+    assert torch.equal(y, y2) and rows == 16 * tiles and part.shape == (wgs, 2, N)
+    yv = y.double().cpu().numpy()
+    for b in sorted({0, wgs // 2, wgs - 1}):
+        blk = yv[b * rows:min((b + 1) * rows, nv)]
+        got_sum, got_m2 = part[b, 0].double().cpu().numpy(), part[b, 1].double().cpu().numpy()
+        if blk.shape[0] == 0:
+            assert (got_sum == 0).all() and (got_m2 == 0).all()
+            continue
+        assert np.abs(got_sum - blk.sum(0)).max() < 1e-5 * max(np.abs(blk).sum(0).max(), 1e-30)
+        m2_ref = ((blk - blk.mean(0)) ** 2).sum(0)
+        assert np.abs(got_m2 - m2_ref).max() < 1e-4 * max(m2_ref.max(), 1e-30) + 1e-30
+    bn, ref = torch.nn.BatchNorm1d(N, momentum=0.02).cuda(), torch.nn.BatchNorm1d(N, momentum=0.02).cuda()
+    y2._mvk_bn_stats = (part, rows)
+    out = ops.bn_lrelu(y2, n_valid, bn, slope=0.1)
+    outr = torch.nn.functional.leaky_relu(ref(y[:nv]), 0.1)
+    assert rel_err(out[:nv].detach().cpu().numpy(), outr.detach().cpu().numpy()) < 2e-5 and (out[nv:] == 0).all()
+    # shapes the plan leaves to the tiled kernel
+    for (m, n, k) in ((3000, 64, 990), (19464, 128, 1920), (19464, 64, 75), (19464, 64, 1100), (19464, 48, 480)):
+        assert not ops.gemm_f32_stream_plan(m, n, k)[0]
+
+
 def test_gather_f16_padded_rows_equal_the_plain_gather(ops):
     """mvk_kpconv_gather_fwd_f16_ld: the aggregate with rows padded to 32 halfs holds the bits of the unpadded fp16
     aggregate in its first K*Cin columns and zeros behind them (the streaming contraction multiplies the pad by zero

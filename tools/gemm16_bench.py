@@ -44,6 +44,14 @@ for (M, N, Kd) in [(19464, 64, 990), (19464, 32, 480), (4986, 64, 960), (40000, 
     fl = 2.0 * M * N * Kd
     out = torch.zeros(M, N, device=dev)
     us32 = timeit(lambda: ops.gemm(A32, W, out=out))
+    if ops.gemm_f32_stream_plan(M, N, Kd)[0]:
+        Abuf = torch.zeros(M * Kd + 64, device=dev)
+        As = Abuf[:M * Kd].view(M, Kd)
+        As.copy_(A32)
+        us32s = timeit(lambda: ops.gemm_f32_stream(As, W))
+        us32ss = timeit(lambda: ops.gemm_f32_stream(As, W, nv))
+        print("%-22s f32 tiled %6.1f us | f32 stream %6.1f / with statistics %6.1f us (%.1f TF = %.2f of the f32 MFMA peak)"
+              % ((M, N, Kd), us32, us32s, us32ss, fl / us32s / 1e6, fl / us32s / 1e6 / 157.3), flush=True)
     us16 = timeit(lambda: ops.gemm_f16(A16, W16))
     line = "%-22s f32 %6.1f us | f16 staged %6.1f us |" % ((M, N, Kd), us32, us16)
     for tiles in ("", "3", "4", "5", "6", "8", "12"):

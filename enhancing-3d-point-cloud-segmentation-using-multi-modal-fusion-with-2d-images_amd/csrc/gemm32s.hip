@@ -37,35 +37,58 @@ __device__ __forceinline__ void store_f4_hidden32(float* p, float4 v) {     // s
   asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
 }
 
+__device__ __forceinline__ void wave_lds_handoff() {   // LDS hand-off inside ONE wave (its own region)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 template <int CT, int KJ, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void gemm_f32_stream(const S32Args a) {
-  constexpr int N = 16 * CT, LDR = N + 4, NS = 2, G = 2;
+  constexpr int N = 16 * CT, LDR = N + 4, G = 2;
+  constexpr int KS = 8 * KJ;                    // columns of a wave's slice
+  constexpr int LDA = KS + 12;                  // LDS row of the slice image: 140 floats at KS = 128 -- row r starts at bank
+                                                // 12 r mod 64, sixteen distinct multiples of 4: the 8-byte fragment reads of
+                                                // a half wave (16 rows x 2 lane groups) hit 64 distinct banks
+  constexpr int LPR = KS / 2;                   // lanes that carry one row of the slice (8 bytes each): 64 at KS = 128
+  constexpr int RPI = 64 / LPR;                 // rows per load instruction
+  constexpr int NLD = 16 / RPI;                 // load instructions per 16-row tile
   __shared__ __attribute__((aligned(16))) float red[G][NW][16][LDR];
+  __shared__ __attribute__((aligned(16))) float abuf[NW][16][LDA];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = lane & 15, g = lane >> 4;
-  const int k0 = w * a.ks;
+  const int k0 = w * KS;
 
   const int64_t tile0 = (int64_t)blockIdx.x * a.tiles_per_wg;
   const int64_t ntiles = (a.M + 15) / 16;
   const int T = (int)(ntiles - tile0 < a.tiles_per_wg ? ntiles - tile0 : a.tiles_per_wg);
   const int64_t last = tile0 + (T > 0 ? T - 1 : 0);
 
-  auto load_tile = [&](int64_t tile, float2 (&af)[KJ]) {
+  // Staging identity: lane -> (row within the instruction's RPI rows, 8-byte column of the slice). The rows of A are only
+  // 8-byte aligned (K*Cin = 990 floats), so a row slice travels as LPR x 8 bytes -- contiguous over the lanes, unlike a
+  // fragment load (lane = row: 64 rows per instruction; the first version of this kernel loaded fragments directly
+  // and was bound by the address unit: 39 us against 34 us for the tiled kernel on 19 464 x 990 x 64).
+  const int srow = lane / LPR, scol = 2 * (lane % LPR);
+  const bool s_in = k0 + scol + 1 < a.Kd;                   // columns beyond the reduction (last wave): zeros in the image
+  const int64_t s_off = (int64_t)(s_in ? k0 + scol : (a.Kd >= 2 ? a.Kd - 2 : 0));     // a real address either way
+
+  auto load_tile = [&](int64_t tile, float2 (&st)[NLD]) {
     tile = tile < last ? tile : last;
-    int64_t row = tile * 16 + c;                          // A operand: lane's row = lane & 15
-    row = row < a.M ? row : a.M - 1;
-    // One base address per lane, the KJ loads at compile-time offsets from it. The slices of the four waves cover
-    // 4 ks >= Kd columns: the last loads of the last wave run up to 31 floats past the row -- into the next row, or,
-    // for the last row of A, into the slack the caller guarantees behind it (mvk_gemm_f32_stream: a_slack_floats); the
-    // values are replaced by zeros below (a NaN there would survive the zero weight).
-    const float* p = a.A + row * a.lda + k0 + 2 * g;
 #pragma unroll
-    for (int j = 0; j < KJ; ++j) af[j] = *reinterpret_cast<const float2*>(p + 8 * j);
+    for (int i = 0; i < NLD; ++i) {
+      int64_t row = tile * 16 + i * RPI + srow;
+      row = row < a.M ? row : a.M - 1;                     // clamped rows are never stored nor counted
+      st[i] = *reinterpret_cast<const float2*>(a.A + row * a.lda + s_off);
+    }
+  };
+  auto stage_tile = [&](const float2 (&st)[NLD]) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i)
+      *reinterpret_cast<float2*>(&abuf[w][i * RPI + srow][scol]) = s_in ? st[i] : make_float2(0.f, 0.f);
   };
 
-  float2 af[NS][KJ];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) load_tile(tile0 + i, af[i]);
+  float2 st[NLD];
+  load_tile(tile0, st);
 
   // stationary weights: b[2 j + t][ct] = W[k0 + 8 j + 2 g + t][CT c + ct], zero beyond the reduction
   float b[2 * KJ][CT];
@@ -93,18 +116,18 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_f32_stream(const S32Args a) {
         for (int ct = 0; ct < CT; ++ct) b[2 * j + t][ct] = 0.f;
       }
 
-  auto compute = [&](int slot, const float2 (&x)[KJ]) {
+  auto compute = [&](int slot) {
     f32x4 acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* arow = &abuf[w][c][2 * g];               // A operand: the lane's row = lane & 15, its group's column pair
 #pragma unroll
     for (int j = 0; j < KJ; ++j) {
-      const bool in = k0 + 8 * j + 2 * g + 1 < a.Kd;      // (Kd is even: both elements of a pair are in or out)
-      const float x0 = in ? x[j].x : 0.f, x1 = in ? x[j].y : 0.f;
+      const float2 x = *reinterpret_cast<const float2*>(arow + 8 * j);
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(x0, b[2 * j][ct], acc[ct], 0, 0, 0);
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.x, b[2 * j][ct], acc[ct], 0, 0, 0);
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(x1, b[2 * j + 1][ct], acc[ct], 0, 0, 0);
+      for (int ct = 0; ct < CT; ++ct) acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(x.y, b[2 * j + 1][ct], acc[ct], 0, 0, 0);
     }
     // C/D map: column = lane & 15 (-> the lane's columns CT c + ct), row = 4 (lane >> 4) + reg
 #pragma unroll
@@ -125,12 +148,21 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_f32_stream(const S32Args a) {
   float cnt = 0.f;
   float4 sh = make_float4(0.f, 0.f, 0.f, 0.f), s1 = sh, s2 = sh;
 
+  // Per tile: the slice of the tile (in registers since the previous iteration) goes to the wave's LDS image, the loads
+  // of the NEXT tile are issued, and the MFMAs of this tile read their fragments from the image -- one register set, the
+  // next tile's HBM latency runs behind this tile's MFMAs (4 096 cycles at KS = 128, N = 64) and behind the other wave
+  // of the SIMD. The image is the wave's own: wave-level hand-offs only, no workgroup barrier in the stream.
   for (int t0 = 0; t0 < T; t0 += G) {
     const int ng = T - t0 < G ? T - t0 : G;
 #pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      if (i < ng) compute(i, af[i]);
-      load_tile(tile0 + t0 + i + NS, af[i]);
+    for (int i = 0; i < G; ++i) {
+      if (i < ng) {
+        stage_tile(st);
+        load_tile(tile0 + t0 + i + 1, st);
+        wave_lds_handoff();
+        compute(i);
+        wave_lds_handoff();
+      }
     }
     __syncthreads();
     if (red_thread) {
@@ -215,8 +247,7 @@ extern "C" int mvk_gemm_f32_stream_plan(int64_t M, int N, int64_t Kd, int64_t* o
   out[0] = 1;
   out[1] = T;
   out[2] = cdiv64(ntiles, T);
-  const int64_t cover = (int64_t)stream32_nw(Kd) * 8 * stream32_kj(Kd);        // columns the waves' slices cover
-  out[3] = cover > Kd ? cover - Kd : 0;
+  out[3] = 0;                  // floats needed behind A: none (the loader clamps its columns)
   return 0;
 }
 
@@ -227,8 +258,7 @@ extern "C" int mvk_gemm_f32_stream(const float* A, int64_t a_slack_floats, const
   int64_t plan[4];
   if (int e = mvk_gemm_f32_stream_plan(M, N, Kd, plan)) return e;
   MVK_REQUIRE(plan[0] == 1, "gemm32 stream: unsupported shape M=%lld N=%d Kd=%lld", (long long)M, N, (long long)Kd);
-  MVK_REQUIRE(a_slack_floats >= plan[3], "gemm32 stream: %lld readable floats needed behind A, %lld given", (long long)plan[3],
-              (long long)a_slack_floats);
+  (void)a_slack_floats;        // (kept in the signature: the staged loader never reads past a row)
   MVK_REQUIRE(((uintptr_t)A % 8) == 0 && ((uintptr_t)B % 16) == 0 && ((uintptr_t)C % 16) == 0, "gemm32 stream: operand alignment");
   S32Args a;
   a.A = A; a.B = B; a.C = C; a.M = M; a.lda = Kd; a.N = N; a.Kd = (int)Kd;

@@ -221,9 +221,15 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_f32_stream(const S32Args a) {
 
 }  // namespace
 
-// out[0] = 1 when C [M,N] = A [M,Kd] . B [Kd,N] runs on the streaming kernel (N = 32 or 64, Kd even, 16 <= Kd <= 1024,
-// M >= 4096: below that the tiled kernel's split plans win), out[1] = 16-row tiles per workgroup (= statistics block
-// rows / 16), out[2] = workgroups, out[3] = readable floats the kernel needs behind the last element of A. MVK_GEMM32_STREAM=0 disables it, MVK_GEMM32_TILES overrides out[1] (development).
+// out[0] = 1 when C [M,N] = A [M,Kd] . B [Kd,N] runs on the streaming kernel, out[1] = 16-row tiles per workgroup
+// (= statistics block rows / 16), out[2] = workgroups, out[3] = 0.
+// Measured (tools/gemm16_bench.py, profiles/r03_gemm_stream_bench.txt): the kernel reaches 0.44 of the f32 MFMA peak
+// on 19 464 x 990 x 64 (35.4 us) -- no better than the tiled kernel of gemm.hip (33.8 us, 0.47) -- and 0.60 on
+// 171 000 x 990 x 64 (229 against 252 us); with 32 output columns or reductions of <= 512 it loses (15 against 13 us,
+// 44 against 33 us). Both kernels sit at what the matrix pipe sustains here with f32 operands (v_mfma_f32_16x16x4_f32:
+// 128 MFMAs per tile and wave; ~7 us per tile round of two waves per SIMD), so the plan takes the streaming kernel only
+// where it measured faster: N = 64, 512 < Kd <= 1024 (even), M >= 98 304 -- the first layer of batches of five spheres
+// and more. MVK_GEMM32_STREAM=0 disables it, =2 takes it for every supported shape (M >= 4096; development). MVK_GEMM32_STREAM=0 disables it, MVK_GEMM32_TILES overrides out[1] (development).
 static int stream32_nw(int64_t Kd) { return Kd > 512 ? 8 : 4; }          // waves per workgroup: slices of <= 128 columns
 
 static int stream32_kj(int64_t Kd) {
@@ -235,8 +241,10 @@ static int stream32_kj(int64_t Kd) {
 extern "C" int mvk_gemm_f32_stream_plan(int64_t M, int N, int64_t Kd, int64_t* out) {
   MVK_REQUIRE(out != nullptr, "gemm32 stream plan: null output");
   out[0] = out[1] = out[2] = out[3] = 0;
-  static const bool on = getenv("MVK_GEMM32_STREAM") == nullptr || atoi(getenv("MVK_GEMM32_STREAM")) != 0;
-  if (!on || M < 4096 || (N != 32 && N != 64) || Kd < 16 || Kd > 1024 || (Kd & 1)) return 0;
+  const char* env = getenv("MVK_GEMM32_STREAM");          // read per call: tests switch it for single cases
+  const int mode = env == nullptr ? 1 : atoi(env);
+  if (mode == 0 || (N != 32 && N != 64) || Kd < 16 || Kd > 1024 || (Kd & 1)) return 0;
+  if (mode == 2 ? M < 4096 : (M < 98304 || N != 64 || Kd <= 512)) return 0;
   const int64_t ntiles = cdiv64(M, 16);
   int64_t T = cdiv64(ntiles, 256);
   if (T < 2) T = 2;

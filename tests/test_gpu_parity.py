@@ -812,15 +812,19 @@ def test_gemm_f16_stream(ops, M, N, Kd):
 
 
 @pytest.mark.parametrize("M,N,Kd", [(19464, 64, 990), (19464, 32, 480), (4986, 64, 960), (4100, 64, 30), (40000, 32, 150),
-                                    (55070, 64, 1024), (5000, 32, 16)])
-def test_gemm_f32_stream(ops, M, N, Kd):
+                                    (55070, 64, 1024), (5000, 32, 16), (100003, 64, 990)])
+def test_gemm_f32_stream(ops, M, N, Kd, monkeypatch):
     """The streaming f32 contraction of the big rigid layers (csrc/gemm32s.hip; reference shape contract
     models/blocks.py:370-374): equals the float64 product to f32 summation order (2e-6 of the largest output), equals
     the tiled kernel's result to the same bound, statistics partials against NumPy, two launches bit-identical (no
     atomics), NaN-filled slack behind A harmless (the surplus columns are masked, not multiplied by zero)."""
     torch.manual_seed(M + N + Kd)
+    # the default plan takes the kernel only where it measured faster than the tiled one (N = 64, Kd > 512, M >= 98 304);
+    # MVK_GEMM32_STREAM=2 (read per call) opens every supported shape to it for this test
+    assert ops.gemm_f32_stream_plan(M, N, Kd)[0] == (M >= 98304 and N == 64 and Kd > 512)
+    monkeypatch.setenv("MVK_GEMM32_STREAM", "2")
     ok, tiles, wgs, need = ops.gemm_f32_stream_plan(M, N, Kd)
-    assert ok and 0 <= need < 64
+    assert ok and need == 0
     buf = torch.full((M * Kd + 64,), float("nan"), device="cuda")
     A = buf[:M * Kd].view(M, Kd)
     A.copy_(torch.randn(M, Kd, device="cuda"))
@@ -850,7 +854,7 @@ def test_gemm_f32_stream(ops, M, N, Kd):
     out = ops.bn_lrelu(y2, n_valid, bn, slope=0.1)
     outr = torch.nn.functional.leaky_relu(ref(y[:nv]), 0.1)
     assert rel_err(out[:nv].detach().cpu().numpy(), outr.detach().cpu().numpy()) < 2e-5 and (out[nv:] == 0).all()
-    # shapes the plan leaves to the tiled kernel
+    # shapes no plan gives to the streaming kernel
     for (m, n, k) in ((3000, 64, 990), (19464, 128, 1920), (19464, 64, 75), (19464, 64, 1100), (19464, 48, 480)):
         assert not ops.gemm_f32_stream_plan(m, n, k)[0]
 

@@ -7,6 +7,11 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/benc
 F=$(ls $O/kt/*/*_kernel_trace.csv | head -1)
 python3 $R/tools/trace_steady.py $F 10 90 > $O/${TAG}_steady_state_per_step.txt
 python3 $R/tools/trace_by_grid.py $F kpconv_gather_vec > $O/${TAG}_gather_by_grid.txt
+for k in kpconv_lane_channel gemm_f32_mfma subsample_cloud_kernel nb_query_kernel nb_build_kernel bn_finish_apply sgd_clip_kernel; do
+  echo "== $k"; python3 $R/tools/trace_by_grid.py $F $k | head -24
+done > $O/${TAG}_kernels_by_grid.txt
+python3 $R/tools/trace_queues.py $F > $O/${TAG}_hw_queues_per_step.txt 2>&1
+python3 $R/tools/trace_chain.py $F all > $O/${TAG}_step_all_queues_in_order.txt 2>&1
 cp $(ls $O/kt/*/*_kernel_stats.csv | head -1) $O/${TAG}_bench_graph_kernel_stats.csv
 rm -rf $O/kt
 # 2. HBM traffic of the KPConv kernels: separate FETCH_SIZE / WRITE_SIZE passes of the same command
@@ -18,4 +23,15 @@ rm -rf $O/pf $O/pw
 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $O/pm -- python3 $R/tools/mfma_probe.py > /dev/null 2> $O/pm.err
 python3 $R/tools/pmc_mfma.py $(ls $O/pm/*/*_counter_collection.csv | head -1) $O/${TAG}_pmc_mfma.json > $O/pmc_mfma.log 2>&1
 rm -rf $O/pm
+# 4. the network branch alone, kernel by kernel in launch order
+MVK_BENCH_DIAG=noside rocprofv3 --kernel-trace --output-format csv -d $O/kn -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/kn.err
+python3 $R/tools/trace_chain.py $(ls $O/kn/*/*_kernel_trace.csv | head -1) > $O/${TAG}_chain_noside.txt 2>&1
+rm -rf $O/kn
+# 5. operator benches (device time of graph-captured launches) and workload lines
+python3 $R/tools/gemm_bench.py > $O/${TAG}_gemm_bench.txt 2>/dev/null
+python3 $R/tools/gemm16_bench.py 2>/dev/null | cut -c1-400 > $O/${TAG}_gemm16_bench.txt
+MVK_GEMM32_STREAM=2 python3 $R/tools/gemm16_bench.py 2>/dev/null | grep "f32 stream" > $O/${TAG}_gemm_stream_bench.txt
+bash $R/tools/workloads_round.sh > $O/${TAG}_workloads.txt 2>&1
+bash $R/tools/config5.sh > $O/${TAG}_config5.txt 2>&1
+cd $R && python3 bench.py > $O/${TAG}_bench_line.json 2> $O/bench_line.err; cp $R/gpurun_out/bench_detail.json $O/${TAG}_bench_detail.json; cd /tmp
 ls -la $O; cat $O/pmc_mfma.log; head -5 $O/pmc_traffic.log; head -3 $O/${TAG}_steady_state_per_step.txt

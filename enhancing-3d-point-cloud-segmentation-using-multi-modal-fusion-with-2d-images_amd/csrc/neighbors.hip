@@ -36,6 +36,8 @@ struct NbWs {
   float4* recs;       // Ns records sorted by cell
   int* qoffs;         // B + 1
   int* soffs;         // B + 1
+  const int* q_lens;  // device-lens entry: the kernels derive the offsets from the lengths themselves (B is a handful
+  const int* s_lens;  // of clouds) -- one launch less per search; null: qoffs / soffs hold them
   int* counts;        // Nq
   int* maxcount;      // 1
   int* overflow;      // 1
@@ -48,9 +50,21 @@ __global__ __launch_bounds__(TPB) void nb_build_kernel(const float* __restrict__
   __shared__ CloudGrid G;
   __shared__ int sh[TPB / 64 + 2];
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int off = W.soffs[b], n = W.soffs[b + 1] - off;
+  int off, n;
   int64_t base = 0;
-  for (int i = 0; i < b; ++i) base += cell_cap(W.soffs[i + 1] - W.soffs[i]) + 1;
+  if (W.s_lens) {
+    off = 0;
+    for (int i = 0; i < b; ++i) {
+      const int li = max(W.s_lens[i], 0);
+      off += li;
+      base += cell_cap(li) + 1;
+    }
+    n = max(W.s_lens[b], 0);
+  } else {
+    off = W.soffs[b];
+    n = W.soffs[b + 1] - off;
+    for (int i = 0; i < b; ++i) base += cell_cap(W.soffs[i + 1] - W.soffs[i]) + 1;
+  }
   const float* P = s + (int64_t)off * 3;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = tid; i < n; i += TPB)
@@ -151,15 +165,27 @@ __global__ __launch_bounds__(64) void nb_query_kernel(const float* __restrict__ 
   __shared__ int lidx[FILL ? CAP : 1];
   const int64_t i = blockIdx.x;
   const int lane = threadIdx.x;
-  if (i >= W.qoffs[B]) {   // fixed-capacity launch (device-lens variant): a padding row has no neighbours
+  int b = 0, soff = 0;
+  bool padding;
+  if (W.q_lens) {          // offsets from the device lengths (wave-uniform scalar loop over a handful of clouds)
+    int qend = max(W.q_lens[0], 0);
+    while (b + 1 < B && i >= qend) {
+      soff += max(W.s_lens[b], 0);
+      ++b;
+      qend += max(W.q_lens[b], 0);
+    }
+    padding = i >= qend;
+  } else {
+    padding = i >= W.qoffs[B];
+    while (b + 1 < B && i >= W.qoffs[b + 1]) ++b;
+    soff = W.soffs[b];
+  }
+  if (padding) {   // fixed-capacity launch (device-lens variant): a padding row has no neighbours
     if (FILL)
       for (int c = lane; c < width; c += 64) out[i * width + c] = (int)Ns;
     return;
   }
-  int b = 0;
-  while (b + 1 < B && i >= W.qoffs[b + 1]) ++b;
   const CloudGrid G = W.grids[b];
-  const int soff = W.soffs[b];
   const int* cstart = W.cell_start + G.cell_base;
   const float qx = q[i * 3], qy = q[i * 3 + 1], qz = q[i * 3 + 2];
   const float r2 = radius * radius;  // neighbors.cpp:226
@@ -298,7 +324,7 @@ int nb_run(const float* q, int64_t Nq, const float* s, int64_t Ns, const int32_t
   MVK_REQUIRE(tq == Nq && ts == Ns, "neighbors: batch lengths do not sum to the point counts");
 
   Carver cv{(char*)workspace};
-  NbWs W;
+  NbWs W{};
   int64_t cells = cell_cap(Ns) + (int64_t)B * (4096 + 1 + 4);
   W.grids = cv.take<CloudGrid>(B);              // grid part first: its layout depends on (Ns, B) only
   W.cell_start = cv.take<int>(cells);
@@ -368,23 +394,6 @@ extern "C" int mvk_radius_neighbors_enqueue(const float* q, int64_t Nq, const fl
                 workspace, workspace_bytes, stream);
 }
 
-namespace {
-// query / support offsets from DEVICE lengths into the header the kernels read
-__global__ void nb_offsets_kernel(const int* __restrict__ q_lens, const int* __restrict__ s_lens, int B,
-                                  int* __restrict__ qoffs, int* __restrict__ soffs) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int a = 0, b = 0;
-  for (int i = 0; i < B; ++i) {
-    qoffs[i] = a;
-    soffs[i] = b;
-    a += max(q_lens[i], 0);
-    b += max(s_lens[i], 0);
-  }
-  qoffs[B] = a;
-  soffs[B] = b;
-}
-}  // namespace
-
 extern "C" int mvk_radius_neighbors_dev(const float* q, int64_t Nq_cap, const float* s, int64_t Ns_cap,
                                         const int32_t* q_lens_dev, const int32_t* s_lens_dev, int B,
                                         float radius, int32_t* out, int width, int32_t shadow,
@@ -396,7 +405,7 @@ extern "C" int mvk_radius_neighbors_dev(const float* q, int64_t Nq_cap, const fl
   MVK_REQUIRE(workspace && workspace_bytes >= ws_bytes(Nq_cap, Ns_cap, B), "neighbors: workspace too small");
   hipStream_t st = (hipStream_t)stream;
   Carver cv{(char*)workspace};
-  NbWs W;
+  NbWs W{};
   int64_t cells = cell_cap(Ns_cap) + (int64_t)B * (4096 + 1 + 4);
   W.grids = cv.take<CloudGrid>(B);
   W.cell_start = cv.take<int>(cells);
@@ -409,7 +418,8 @@ extern "C" int mvk_radius_neighbors_dev(const float* q, int64_t Nq_cap, const fl
   MVK_REQUIRE(cv.p <= (char*)workspace + workspace_bytes, "neighbors: workspace carve overflow");
   W.maxcount = status_dev;
   W.overflow = status_dev + 1;
-  hipLaunchKernelGGL(nb_offsets_kernel, dim3(1), dim3(64), 0, st, q_lens_dev, s_lens_dev, B, W.qoffs, W.soffs);
+  W.q_lens = q_lens_dev;       // the kernels derive the offsets themselves (was: a one-thread launch per search)
+  W.s_lens = s_lens_dev;
   if (!reuse_grid) hipLaunchKernelGGL(nb_build_kernel, dim3(B), dim3(TPB), 0, st, s, W, radius);
   if (width <= 64)
     hipLaunchKernelGGL((nb_query_kernel<true, 256>), dim3((unsigned)Nq_cap), dim3(64), 0, st, q, W, B, radius,

@@ -61,6 +61,11 @@ struct SubWs {
   int* bhead;
   // per cloud
   int* out_count;  // B
+  // device-lens entry (mvk_grid_subsample_batch_dev): per-cloud lengths instead of host offsets, optional grid
+  // orientation applied by the cloud's own workgroup before phase 1 (all null / unused otherwise)
+  const int* lens_dev;
+  const float* rot_dev;   // B x 9
+  float* rot_pts;         // N x 3 scratch for the oriented cloud
   // staging (N rows)
   float* stage_pts;
   float* stage_feat;
@@ -134,13 +139,35 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   __shared__ unsigned long long dims[2];
   __shared__ int sh[TPB / 64 + 2];
   const int b = blockIdx.x;
-  const int off = offs[b], n = offs[b + 1] - off;
+  int off, n;
+  if (W.lens_dev) {          // offsets from the device lengths (was: a one-thread launch per call)
+    off = 0;
+    for (int i = 0; i < b; ++i) off += max(W.lens_dev[i], 0);
+    n = max(W.lens_dev[b], 0);
+  } else {
+    off = offs[b];
+    n = offs[b + 1] - off;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   if (n == 0) {
     if (tid == 0) W.out_count[b] = 0;
     return;
   }
   const float* P = pts + (int64_t)off * 3;
+  if (W.rot_dev) {
+    // ---- P0: the cloud in the random grid orientation (datasets/common.py:118), same arithmetic as
+    // rotate_cloud_kernel -- (p0 * R[0][i] + p1 * R[1][i]) + p2 * R[2][i] -- by the cloud's own workgroup
+    // (was: a launch of its own in front of this kernel)
+    const float* M = W.rot_dev + b * 9;
+    float* Q = W.rot_pts + (int64_t)off * 3;
+    for (int i = tid; i < n; i += TPB) {
+      const float p0 = P[i * 3], p1 = P[i * 3 + 1], p2 = P[i * 3 + 2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Q[i * 3 + c] = (p0 * M[0 * 3 + c] + p1 * M[1 * 3 + c]) + p2 * M[2 * 3 + c];
+    }
+    __syncthreads();
+    P = Q;
+  }
 
   // ---- P1: min / max
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -440,51 +467,45 @@ __global__ void subsample_compact_kernel(const int* __restrict__ offs, SubWs W, 
 
 // ---- device-lens variant (capturable in a hipGraph: no host reads, fixed launch geometry) ----------------
 
-// offs[b] = sum(lens[:b]) for b <= B (one thread; B is a handful of clouds)
-__global__ void offsets_from_lens_kernel(const int* __restrict__ lens, int B, int* __restrict__ offs) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  int s = 0;
-  for (int b = 0; b < B; ++b) {
-    offs[b] = s;
-    s += max(lens[b], 0);
-  }
-  offs[B] = s;
-}
-
-// same arithmetic as rotate_cloud_kernel, cloud of a row found from DEVICE offsets, matrices in DEVICE memory
-__global__ void rotate_stacked_dev_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                          const int* __restrict__ lens, int B, const float* __restrict__ R,
-                                          int transpose, int64_t cap) {
+// Device-lens finish in ONE launch (was four: compaction, rotation back, padding, and the offsets launch in front):
+// row t of the fixed-capacity output = barycentre o of cloud b from its staging rows, rotated back into the world frame
+// (datasets/common.py:134: R transposed, same arithmetic as rotate_cloud_kernel), rows beyond the total <- pad;
+// thread 0 publishes the per-cloud counts, their total and the overflow flag (a level that outgrew its capacity).
+__global__ void subsample_finish_dev_kernel(SubWs W, int B, float* __restrict__ out_pts, int* __restrict__ out_lens,
+                                            int64_t out_cap, float pad, int* __restrict__ total_out,
+                                            int* __restrict__ overflow) {
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= cap) return;
-  int b = 0, acc = 0;
-  while (b < B && t >= acc + lens[b]) acc += lens[b++];
-  if (b >= B) return;   // padding row
-  const float* M = R + b * 9;
-  const float p0 = in[t * 3], p1 = in[t * 3 + 1], p2 = in[t * 3 + 2];
-  float o[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const float r0 = transpose ? M[i * 3 + 0] : M[0 * 3 + i];
-    const float r1 = transpose ? M[i * 3 + 1] : M[1 * 3 + i];
-    const float r2 = transpose ? M[i * 3 + 2] : M[2 * 3 + i];
-    o[i] = (p0 * r0 + p1 * r1) + p2 * r2;
-  }
-  out[t * 3] = o[0];
-  out[t * 3 + 1] = o[1];
-  out[t * 3 + 2] = o[2];
-}
-
-// rows >= sum(out_lens) of the fixed-capacity output <- pad value; *total_out <- sum(out_lens)
-__global__ void pad_tail_kernel(float* __restrict__ out_pts, const int* __restrict__ out_lens, int B, int64_t out_cap,
-                                float pad, int* __restrict__ total_out) {
   int tot = 0;
-  for (int b = 0; b < B; ++b) tot += out_lens[b];
-  if (tot > out_cap) tot = (int)out_cap;
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t == 0 && total_out) *total_out = tot;
-  if (t >= out_cap * 3) return;
-  if (t >= (int64_t)tot * 3) out_pts[t] = pad;
+  for (int i = 0; i < B; ++i) tot += W.out_count[i];
+  if (t == 0) {
+    for (int i = 0; i < B; ++i) out_lens[i] = W.out_count[i];
+    if (tot > out_cap && overflow) atomicExch(overflow, 1);
+    if (total_out) *total_out = tot > out_cap ? (int)out_cap : tot;
+  }
+  if (t >= out_cap) return;
+  if (t >= tot) {
+    out_pts[t * 3] = pad;
+    out_pts[t * 3 + 1] = pad;
+    out_pts[t * 3 + 2] = pad;
+    return;
+  }
+  int b = 0, base = 0, off = 0;           // cloud of output row t, first output row / first input row of that cloud
+  while (b + 1 < B && t >= base + W.out_count[b]) {
+    base += W.out_count[b];
+    off += max(W.lens_dev[b], 0);
+    ++b;
+  }
+  const float* p = W.stage_pts + ((int64_t)off + (t - base)) * 3;
+  const float p0 = p[0], p1 = p[1], p2 = p[2];
+  if (W.rot_dev) {
+    const float* M = W.rot_dev + b * 9;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) out_pts[t * 3 + i] = (p0 * M[i * 3 + 0] + p1 * M[i * 3 + 1]) + p2 * M[i * 3 + 2];
+  } else {
+    out_pts[t * 3] = p0;
+    out_pts[t * 3 + 1] = p1;
+    out_pts[t * 3 + 2] = p2;
+  }
 }
 
 struct Carver {
@@ -583,7 +604,7 @@ int subsample_run(const float* pts, int64_t N, const int32_t* lens_host, int B, 
 
   const int64_t n = N > 0 ? N : 1;
   Carver cv{(char*)workspace, (char*)workspace + workspace_bytes};
-  SubWs W;
+  SubWs W{};
   W.slot = cv.take<int>(n); W.member = cv.take<int>(n); W.scan = cv.take<int>(n);
   W.hkey = cv.take<unsigned long long>(4 * n); W.hfirst = cv.take<int>(4 * n); W.hvox = cv.take<int>(4 * n);
   W.vkey = cv.take<unsigned long long>(n); W.vcount = cv.take<int>(n); W.vseg = cv.take<int>(n);
@@ -678,7 +699,7 @@ extern "C" int mvk_grid_subsample_batch_dev(const float* pts, int64_t cap_in, co
   hipStream_t st = (hipStream_t)stream;
   const int64_t n = cap_in;
   Carver cv{(char*)workspace, (char*)workspace + workspace_bytes};
-  SubWs W;
+  SubWs W{};
   W.slot = cv.take<int>(n); W.member = cv.take<int>(n); W.scan = cv.take<int>(n);
   W.hkey = cv.take<unsigned long long>(4 * n); W.hfirst = cv.take<int>(4 * n); W.hvox = cv.take<int>(4 * n);
   W.vkey = cv.take<unsigned long long>(n); W.vcount = cv.take<int>(n); W.vseg = cv.take<int>(n);
@@ -689,7 +710,7 @@ extern "C" int mvk_grid_subsample_batch_dev(const float* pts, int64_t cap_in, co
   W.tau = cv.take<int>(n); W.posnew = cv.take<int>(n); W.nextb = cv.take<int>(n); W.tarr = cv.take<int>(n);
   W.ft = cv.take<int>(3 * n + 32 * B); W.bcnt = cv.take<int>(3 * n + 32 * B); W.bhead = cv.take<int>(3 * n + 32 * B);
   W.out_count = cv.take<int>(B + 1);
-  int* offs_d = cv.take<int>(B + 1);
+  cv.take<int>(B + 1);
   W.stage_pts = cv.take<float>(3 * n);
   W.stage_feat = cv.take<float>(1);
   W.stage_lab = cv.take<int>(1);
@@ -700,24 +721,14 @@ extern "C" int mvk_grid_subsample_batch_dev(const float* pts, int64_t cap_in, co
   Schedule sched;
   sched.nb[0] = 13;
   for (int e = 1; e < 48; ++e) sched.nb[e] = mvk_next_bkt(2 * sched.nb[e - 1]);
-  hipLaunchKernelGGL(offsets_from_lens_kernel, dim3(1), dim3(64), 0, st, lens_dev, B, offs_d);
-  const unsigned pb = (unsigned)cdiv64(cap_in, 256);
-  if (rot_dev) {
-    hipLaunchKernelGGL(rotate_stacked_dev_kernel, dim3(pb), dim3(256), 0, st, pts, rot_pts, lens_dev, B, rot_dev, 0, cap_in);
-    pts = rot_pts;
-  }
+  // two launches: the per-cloud kernel (offsets from the device lengths, orientation as its phase 0) and the finish
+  W.lens_dev = lens_dev;
+  W.rot_dev = rot_dev;
+  W.rot_pts = rot_pts;
   hipLaunchKernelGGL(subsample_cloud_kernel, dim3(B), dim3(TPB), 0, st, pts, (const float*)nullptr, 0,
-                     (const int32_t*)nullptr, 0, offs_d, dl, W, B, sched);
-  int gx = (int)cdiv64(n, 256 * (int64_t)B);
-  if (gx < 1) gx = 1;
-  if (gx > 64) gx = 64;
-  hipLaunchKernelGGL(subsample_compact_kernel, dim3(gx, B), dim3(256), 0, st, offs_d, W, B, 0, 0, (int)n, out_pts,
-                     (float*)nullptr, (int*)nullptr, out_lens_dev, out_cap, status_dev + 1);
-  if (rot_dev)
-    hipLaunchKernelGGL(rotate_stacked_dev_kernel, dim3((unsigned)cdiv64(out_cap, 256)), dim3(256), 0, st, out_pts, out_pts,
-                       out_lens_dev, B, rot_dev, 1, out_cap);
-  hipLaunchKernelGGL(pad_tail_kernel, dim3((unsigned)cdiv64(out_cap * 3, 256)), dim3(256), 0, st, out_pts, out_lens_dev, B,
-                     out_cap, pad_value, total_out_dev);
+                     (const int32_t*)nullptr, 0, (const int*)nullptr, dl, W, B, sched);
+  hipLaunchKernelGGL(subsample_finish_dev_kernel, dim3((unsigned)cdiv64(out_cap, 256)), dim3(256), 0, st, W, B, out_pts,
+                     out_lens_dev, out_cap, pad_value, total_out_dev, status_dev + 1);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

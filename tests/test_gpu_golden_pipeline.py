@@ -274,6 +274,43 @@ def test_unprojection_and_frame_selection_vs_reference_functions():
         assert vt.select_frames(T(g["table%d" % i]), len(want)) == want
 
 
+def test_frame_overlap_table_at_the_reference_size_vs_scipy():
+    """f3 at the size the reference's script uses (datasets/get_rgbd_overlap_subcloud.py:68-138: 6 000 base points,
+    depth maps resized to 80 x 60): `frame_overlaps` against an independent nearest-neighbour search --
+    scipy.spatial.cKDTree.query(k = 1, distance_upper_bound = 0.1) in float64 on the unprojected pixels of G11's kind of
+    frames -- standing for open3d's `search_hybrid_vector_3d(p, 0.1, 1)` (nearest neighbour within a radius; open3d is
+    not installed here: the hybrid search's own boundary convention at exactly 0.1 stays unpinned)."""
+    import mvkpconv
+    from scipy.spatial import cKDTree
+    from oracle import npref
+    syn = mvkpconv.sub("synthetic")
+    vt = importlib.import_module(PKG + ".dropin.utils.voting")
+    rng = np.random.default_rng(33)
+    sph = syn.raw_sphere(seed=5, radius=1.2)
+    views = syn.sphere_views(sph, nv=8, h=60, w=80)
+    sub = sph["points"][rng.permutation(sph["points"].shape[0])[:6000]]          # num_base_pts = 6000 (:69)
+    got = vt.frame_overlaps(T(sub), T(views["depth"].astype(np.int16)), views["cam"], T(views["poses"])).cpu().numpy()
+    xyz, mask = npref.unproject_frames(views["cam"], views["depth"], views["poses"])
+    tree = cKDTree(sub.astype(np.float64))
+    want = np.zeros((6000, 8), bool)
+    near_boundary = 0
+    for f in range(8):
+        pix = xyz[f].reshape(-1, 3)[mask[f].reshape(-1)]
+        d, nn = tree.query(pix, k=1, distance_upper_bound=0.1)
+        ok = np.isfinite(d)
+        want[nn[ok], f] = True
+        near_boundary += int((np.abs(d[ok] - 0.1) < 1e-6).sum())
+    assert want.sum() > 1000 and near_boundary == 0          # the fixture does not sit on the radius boundary
+    assert np.array_equal(got, want)
+    sel = vt.select_frames(T(got), 3)
+    o, ref = want.copy(), []
+    for _ in range(3):
+        fidx = int(o.sum(0).argmax())
+        ref.append(fidx)
+        o[o[:, fidx]] = False
+    assert sel == ref
+
+
 def test_scene_load_subsampling_vs_reference_core():
     """datasets/scene_cache.subsample_scene (ScanNet_sphere_color.py:935-948: colours as features, labels,
     dl = 0.04) against the compiled reference core (G9): points, order, colour barycentres / 255, majority labels."""

@@ -57,15 +57,19 @@ class FeatureAggregation(nn.Module):
         transposed = True
         for layer in self.mlp:
             w = layer.conv.weight
+            bn = layer.bn
+            rows = x.shape[1] if transposed else x.shape[0]
+            if bn.training:   # HIP BatchNorm + ReLU over the np*k rows (all valid unless the level is capacity padded);
+                n_valid = ops.row_count_for(rows)          # its column statistics come out of the GEMM's epilogue
+                if n_valid is None:
+                    n_valid = ops.full_count(rows, x.device)
+                x = ops.linear(x, w.view(w.shape[0], w.shape[1]), x_is_transposed=transposed, stats_n_valid=n_valid)
+                x = ops.bn_lrelu(x, n_valid, bn, 0.0)
+                transposed = False
+                continue
             x = ops.linear(x, w.view(w.shape[0], w.shape[1]), x_is_transposed=transposed)   # [np*k, out]
             transposed = False
-            bn = layer.bn
-            if bn.training:   # HIP BatchNorm + ReLU over the np*k rows (all valid unless the level is capacity padded)
-                n_valid = ops.row_count_for(x.shape[0])
-                x = ops.bn_lrelu(x, n_valid if n_valid is not None else ops.full_count(x.shape[0], x.device), bn, 0.0)
-            else:
-                x = F.relu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False,
-                                        bn.momentum, bn.eps))
+            x = F.relu(F.batch_norm(x, bn.running_mean, bn.running_var, bn.weight, bn.bias, False, bn.momentum, bn.eps))
         return x.view(n_pts, k, -1).sum(dim=1)
 
     def reset_parameters(self):

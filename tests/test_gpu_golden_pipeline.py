@@ -286,11 +286,15 @@ def test_frame_overlap_table_at_the_reference_size_vs_scipy():
     syn = mvkpconv.sub("synthetic")
     vt = importlib.import_module(PKG + ".dropin.utils.voting")
     rng = np.random.default_rng(33)
-    sph = syn.raw_sphere(seed=5, radius=1.2)
-    views = syn.sphere_views(sph, nv=8, h=60, w=80)
+    sph = syn.raw_sphere(seed=5, radius=2.0, density=3000.0)
+    views = syn.sphere_views(sph, nv=8, h=120, w=160)
+    depth = np.ascontiguousarray(views["depth"][:, ::2, ::2])                    # nearest-neighbour resize to 80 x 60 (:107)
+    cam = views["cam"].copy()
+    cam[0] /= 2                                                                  # intrinsics follow the resize (:87-88)
+    cam[1] /= 2
     sub = sph["points"][rng.permutation(sph["points"].shape[0])[:6000]]          # num_base_pts = 6000 (:69)
-    got = vt.frame_overlaps(T(sub), T(views["depth"].astype(np.int16)), views["cam"], T(views["poses"])).cpu().numpy()
-    xyz, mask = npref.unproject_frames(views["cam"], views["depth"], views["poses"])
+    got = vt.frame_overlaps(T(sub), T(depth.astype(np.int16)), cam, T(views["poses"])).cpu().numpy()
+    xyz, mask = npref.unproject_frames(cam, depth, views["poses"])
     tree = cKDTree(sub.astype(np.float64))
     want = np.zeros((6000, 8), bool)
     near_boundary = 0
@@ -300,7 +304,7 @@ def test_frame_overlap_table_at_the_reference_size_vs_scipy():
         ok = np.isfinite(d)
         want[nn[ok], f] = True
         near_boundary += int((np.abs(d[ok] - 0.1) < 1e-6).sum())
-    assert want.sum() > 1000 and near_boundary == 0          # the fixture does not sit on the radius boundary
+    assert want.sum() > 500 and near_boundary == 0          # the fixture does not sit on the radius boundary
     assert np.array_equal(got, want)
     sel = vt.select_frames(T(got), 3)
     o, ref = want.copy(), []

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvkpconv.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -17,6 +17,8 @@ _SIGNATURES = {
     "mvk_last_error": (C.c_char_p, []),
     "mvk_kpconv_gather_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
                                         _vp, _vp, _vp, _vp, _vp]),
+    "mvk_kpconv_gather_fwd_ordered": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
+                                                _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvk_kpconv_gather_fwd_f16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
                                             _vp, _vp]),
     "mvk_kpconv_gather_fwd_f16_ld": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
@@ -71,6 +73,7 @@ _SIGNATURES = {
                                                _vp]),
     "mvk_radius_neighbors_dev": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _i, _vp, _i, _vp, _i64,
                                            _vp]),
+    "mvk_neighbors_cell_order": (C.c_int, [_i64, _i, _vp, _vp, _i64, _vp, _i64, _vp]),
     "mvk_radius_neighbors_workspace": (C.c_int64, [_i64, _i64, _i]),
     "mvk_radius_neighbors_batch": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _vp,
                                              _vp, _i64, _vp]),

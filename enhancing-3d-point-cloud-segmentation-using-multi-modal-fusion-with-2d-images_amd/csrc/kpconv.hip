@@ -41,6 +41,9 @@ struct KPParams {
   int influence, aggregation;
   int zero_skip;         // gather: neighbours without any influence become shadow entries (development switch MVK_GATHER_ZEROSKIP)
   int64_t ldA;           // vector gather: row stride of the aggregate in elements (>= K*Cin; the columns beyond K*Cin are written as zeros)
+  const int32_t* order;  // vector gather (rigid): work list -- the wave working on slots w .. w+PPW-1 takes the points order[w ..] (a
+                         // spatially sorted permutation of 0 .. Nq-1); results land in the points' own rows. null: slot = point
+  int xcd_blocks;        // with `order`: the first xcd_blocks workgroups are dealt to the 8 XCDs as 8 contiguous runs of the work list
 };
 
 __device__ __forceinline__ float influence_w(float d2, float extent, int influence) {
@@ -229,15 +232,23 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
   float* wl = wl_all[wid];
   float* d2l = d2_all[DEFORM ? wid : 0];
   const int lane = threadIdx.x & 63;
-  const int64_t n0 = share ? ((int64_t)B1 * GWPB + ((int64_t)blockIdx.x - B1)) * PPW
-                           : ((int64_t)blockIdx.x * GWPB + wid) * PPW;
+  const int32_t* __restrict__ ord = DEFORM ? nullptr : P.order;
+  int64_t blk = blockIdx.x;
+  if (!DEFORM && (int)blockIdx.x < P.xcd_blocks) {
+    // workgroups go to the XCDs round robin (b % 8): XCD x then works on ONE contiguous run of the sorted work list,
+    // so that the rows its L2 pulls are those of one region of the cloud
+    const int xq = P.xcd_blocks >> 3, xr = P.xcd_blocks & 7, xc = blockIdx.x & 7;
+    blk = (int64_t)xc * xq + min(xc, xr) + (blockIdx.x >> 3);
+  }
+  const int64_t n0 = share ? ((int64_t)B1 * GWPB + ((int64_t)blockIdx.x - B1)) * PPW : (blk * GWPB + wid) * PPW;
   const int hbeg = share ? wid * HC : 0, hstep = share ? nwv * HC : HC;        // this wave's neighbour chunks
   // phase-A identity: (point pa, neighbour slot ha)
   const int pa = lane / HC, ha = lane - pa * HC;
   const bool a_on = pa < PPW && n0 + pa < P.Nq;
+  const int64_t na = (a_on && ord) ? (int64_t)ord[n0 + pa] : n0 + pa;      // the point of this lane's phase-A identity
   float qx = 0.f, qy = 0.f, qz = 0.f;
   if (a_on) {
-    const float* qp = P.q + (n0 + pa) * 3;
+    const float* qp = P.q + na * 3;
     qx = qp[0];
     qy = qp[1];
     qz = qp[2];
@@ -246,8 +257,8 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
   float* wrow_a = wl + (pa * HCP + ha) * 16 + pa * 4;
   // phase-B identity: (point pb, channel quad cl)
   const int pb = lane / LPP, cl = lane - pb * LPP;
-  const int64_t n = n0 + pb;
-  const bool b_on = pb < PPW && n < P.Nq;
+  const int64_t nslot = n0 + pb;
+  const bool b_on = pb < PPW && nslot < P.Nq;
   const float* wblk_b = wl + (FASTLD ? min(pb, PPW - 1) : pb) * (HCP * 16 + 4);
   if (FASTLD && HCP > HC) {      // padding rows: zero weights, shadow index
     const int npad = HCP - HC;
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
 
   // software pipeline over neighbour chunks: index two chunks ahead, support xyz one chunk ahead
   auto ld_j = [&](int h) -> int {
-    return (a_on && h < P.H) ? load_idx<IDX64>(P.idx, (n0 + pa) * P.H + h, P.Ns) : -2;
+    return (a_on && h < P.H) ? load_idx<IDX64>(P.idx, na * P.H + h, P.Ns) : -2;
   };
   int jA = ld_j(hbeg + ha), jB = ld_j(hbeg + hstep + ha);
   float sx = 0.f, sy = 0.f, sz = 0.f;
@@ -601,6 +612,7 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
     }
   }
   if (b_on && (!share || wid == 0)) {
+    const int64_t n = ord ? (int64_t)ord[nslot] : nslot;      // the row of this lane's phase-B identity
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const int c4 = FASTLD ? (int)c4e[c] : (cl + c * LPP) * 4;
@@ -925,9 +937,12 @@ VecPlan plan_vec(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, bool fa
 }
 
 template <int NCH, typename XT = float, bool VEC = true, bool DEFORM = false>
-int launch_vec(const KPParams& P, int idx64, hipStream_t st) {
+int launch_vec(KPParams P, int idx64, hipStream_t st) {
   const bool fast = P.influence == MVK_INFL_LINEAR && P.aggregation == MVK_AGG_SUM;
   const VecPlan v = plan_vec(P.Nq, P.Ns, P.H, P.Cin, (int)sizeof(XT), fast, VEC, DEFORM);
+  static const bool xcd_runs = getenv("MVK_GATHER_XCD_RUNS") == nullptr || atoi(getenv("MVK_GATHER_XCD_RUNS")) != 0;
+  if (DEFORM) P.order = nullptr;
+  P.xcd_blocks = (P.order != nullptr && xcd_runs) ? (int)(v.SW > 1 ? v.B1 : v.wgs) : 0;
   const int LPP = v.LPP, PPW = v.PPW, HC = v.HC, fub = v.fub, SW = v.SW, B1 = v.B1, tail = v.tail;
   dim3 grid((unsigned)v.wgs), block(64 * v.nw);
 #define LV(I64, F, L) \
@@ -1024,10 +1039,20 @@ extern "C" int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s,
                                      const float* kp, int K, float extent, int influence,
                                      int aggregation, const float* offsets, float* min_d2,
                                      int32_t* min_arg, float* A_out, void* stream) {
+  return mvk_kpconv_gather_fwd_ordered(q, Nq, s, Ns, idx, idx64, H, x, Cin, kp, K, extent, influence, aggregation, offsets,
+                                       min_d2, min_arg, A_out, nullptr, stream);
+}
+
+extern "C" int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                                             const void* idx, int idx64, int H, const float* x, int Cin,
+                                             const float* kp, int K, float extent, int influence,
+                                             int aggregation, const float* offsets, float* min_d2,
+                                             int32_t* min_arg, float* A_out, const int32_t* order, void* stream) {
   if (int e = check_common(Nq, Ns, H, Cin, K, influence, aggregation)) return e;
   if (Nq == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   KPParams P{};
+  P.order = order;        // used by the vector kernels of rigid layers (5 <= Cin <= 512); the other kernels work in row order
   P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets; P.min_d2 = min_d2; P.min_arg = min_arg;
   P.A = A_out; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
   P.influence = influence; P.aggregation = aggregation; P.ldA = (int64_t)K * Cin;

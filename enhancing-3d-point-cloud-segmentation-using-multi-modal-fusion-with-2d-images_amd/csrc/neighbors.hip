@@ -150,6 +150,39 @@ __global__ __launch_bounds__(TPB) void nb_build_kernel(const float* __restrict__
   }
 }
 
+// Work list for the KPConv gather out of a built grid: the stacked support rows sorted by (cloud, cell, row) -- the
+// record order of the counting sort with the rows of a cell put in ascending order (the scatter's atomics leave them in
+// arrival order; a cell holds a dozen rows), so the list is the same on every run. One workgroup per cloud, one
+// thread per cell; the last cloud's workgroup appends the identity for the rows up to order_cap (capacity padding).
+__global__ __launch_bounds__(TPB) void nb_cell_order_kernel(NbWs W, int B, int* __restrict__ order, int64_t order_cap) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  int off = 0, n;
+  if (W.s_lens) {
+    for (int i = 0; i < b; ++i) off += max(W.s_lens[i], 0);
+    n = max(W.s_lens[b], 0);
+  } else {
+    off = W.soffs[b];
+    n = W.soffs[b + 1] - off;
+  }
+  const CloudGrid G = W.grids[b];
+  const int ncell = G.dims[0] * G.dims[1] * G.dims[2];
+  const int* cstart = W.cell_start + G.cell_base;
+  for (int c = tid; c < ncell; c += TPB) {
+    const int beg = cstart[c], end = cstart[c + 1];
+    for (int j = beg; j < end; ++j) {
+      const int v = __float_as_int(W.recs[off + j].w);
+      int k = j;
+      while (k > beg && order[off + k - 1] > v) {
+        order[off + k] = order[off + k - 1];
+        --k;
+      }
+      order[off + k] = v;
+    }
+  }
+  if (b == B - 1)
+    for (int64_t i = (int64_t)off + n + tid; i < order_cap; i += TPB) order[i] = (int)i;
+}
+
 // max-reduction into one word shared by every query wave: read first, most waves then skip the atomic
 __device__ __forceinline__ void note_count(int* maxcount, int n) {
   if (n > __hip_atomic_load(maxcount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxcount, n);
@@ -427,6 +460,29 @@ extern "C" int mvk_radius_neighbors_dev(const float* q, int64_t Nq_cap, const fl
   else
     hipLaunchKernelGGL((nb_query_kernel<true, LIST_CAP>), dim3((unsigned)Nq_cap), dim3(64), 0, st, q, W, B, radius,
                        (int64_t)shadow, out, width);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// The supports of the grid the workspace holds (built by the last search on it: same Ns, B and lengths), as a work
+// list for mvk_kpconv_gather_fwd_ordered: order_out[0 .. total) = the stacked rows sorted by cloud, grid cell
+// (x fastest) and row; order_out[total .. order_cap) = identity. s_lens_dev: the device lengths of a
+// mvk_radius_neighbors_dev search, NULL after the host-length entry points (their offsets are in the workspace).
+extern "C" int mvk_neighbors_cell_order(int64_t Ns, int B, const int32_t* s_lens_dev, int32_t* order_out,
+                                        int64_t order_cap, void* workspace, int64_t workspace_bytes, void* stream) {
+  MVK_REQUIRE(B >= 1 && B <= 4096 && Ns >= 0 && Ns < (1ll << 29) && order_out && order_cap >= Ns, "cell order: bad arguments");
+  MVK_REQUIRE(workspace && workspace_bytes >= ws_bytes(0, Ns, B), "cell order: workspace too small");
+  Carver cv{(char*)workspace};
+  NbWs W{};
+  int64_t cells = cell_cap(Ns) + (int64_t)B * (4096 + 1 + 4);
+  W.grids = cv.take<CloudGrid>(B);
+  W.cell_start = cv.take<int>(cells);
+  W.cell_fill = cv.take<int>(cells);
+  W.recs = cv.take<float4>(Ns + 1);
+  int* hdr = cv.take<int>(4 + 2 * (B + 1));
+  W.soffs = hdr + 4 + B + 1;
+  W.s_lens = s_lens_dev;
+  hipLaunchKernelGGL(nb_cell_order_kernel, dim3(B), dim3(TPB), 0, (hipStream_t)stream, W, B, order_out, order_cap);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

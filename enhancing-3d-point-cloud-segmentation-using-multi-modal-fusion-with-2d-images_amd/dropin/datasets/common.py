@@ -7,6 +7,8 @@ the stacked points stay in HBM and every level is produced by the HIP kernels (o
 subsampling level for the data-dependent point counts). NumPy inputs are accepted too (they are
 staged once) and NumPy outputs can be requested with ``as_numpy=True`` for calibration code.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -123,8 +125,15 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
     neighborhood_limits): the 13 neighbour searches are only enqueued (full ``limit`` columns, no read-back
     per search; ops.check_neighbor_status(status) validates them later) and the searches that share
     supports and radius -- conv / pool of a level and the upsample search of the level above -- share
-    one cell grid."""
+    one cell grid.
+
+    Not in the reference: ``orders`` -- per layer the level's rows sorted by the cells of its conv search's grid
+    (ops.neighbors_cell_order; None for a layer without conv blocks), the work list the KPConv gather walks
+    (MVK_GATHER_ORDER=0: no lists). The reference's flat batch list has no slot for them: each list is also
+    remembered under its points tensor (ops.remember_work_order), where the blocks find it as long as that tensor
+    reaches the network as it is (device-resident batches in the process that built them)."""
     r_normal = config.first_subsampling_dl * config.conv_radius
+    want_orders = os.environ.get("MVK_GATHER_ORDER", "1") != "0"
     grid_of = [None, None]          # supports tensor and radius of the grid the neighbour workspace holds
 
     def neighbors(qp, sp, qb, sb, radius, layer):
@@ -137,7 +146,7 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
     pts = _t(stacked_points, np.float32)
     lens = np.ascontiguousarray(stack_lengths.cpu().numpy() if isinstance(stack_lengths, torch.Tensor)
                                 else stack_lengths, dtype=np.int32)
-    out = dict(points=[], neighbors=[], pools=[], upsamples=[], lengths=[], deform_layers=[])
+    out = dict(points=[], neighbors=[], pools=[], upsamples=[], lengths=[], deform_layers=[], orders=[])
     layer_blocks = []
     level = 0
     dev = pts.device
@@ -163,8 +172,13 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
             else:
                 r = r_normal
             conv_i = neighbors(pts, pts, lens, lens, r, layer)
+            order = None
+            if want_orders and pts.shape[0] > 0 and conv_i.shape[1] > 0:      # the workspace holds this search's grid
+                order = ops.neighbors_cell_order(pts.shape[0], pts.shape[0], len(lens), device=pts.device)
+                ops.remember_work_order(pts, order)      # for batch containers without an `orders` attribute
         else:
             conv_i = empty_idx()
+            order = None
         if 'pool' in block or 'strided' in block:
             dl = 2 * r_normal / config.conv_radius
             R = rotations[level] if rotations is not None else None
@@ -187,6 +201,7 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
         out['upsamples'].append(up_i)
         out['lengths'].append(torch.from_numpy(np.asarray(lens, dtype=np.int32)))
         out['deform_layers'].append(deform_layer)
+        out['orders'].append(order)
         pts, lens = pool_p, pool_b
         r_normal *= 2
         layer_blocks = []
@@ -208,6 +223,7 @@ class SphereBatch:
         self.pools = pyramid['pools']
         self.upsamples = pyramid['upsamples']
         self.lengths = pyramid['lengths']
+        self.orders = pyramid.get('orders')          # work lists of the KPConv gather (None: row order)
         self.labels = labels
         self.features = features
         self.feature_3d = feature_3d
@@ -219,6 +235,8 @@ class SphereBatch:
     def to(self, device):
         for name in ('points', 'neighbors', 'pools', 'upsamples', 'lengths'):
             setattr(self, name, [t.to(device) for t in getattr(self, name)])
+        if self.orders:
+            self.orders = [None if t is None else t.to(device) for t in self.orders]
         for name in ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images'):
             t = getattr(self, name)
             if t is not None:

@@ -31,6 +31,7 @@ _GEMM_STATS = os.environ.get("MVK_GEMM_STATS", "1") == "1"  # BatchNorm statisti
 _FUSE_FANOUT = os.environ.get("MVK_FUSE_FANOUT", "1") == "1"    # the two gradients of a block's input summed inside unary1's backward GEMM
 _FUSED_BIAS = os.environ.get("MVK_FUSED_BIAS", "1") == "1"      # bias + LeakyReLU of the BatchNorm-less layers in one launch
 _FUSED_OPERANDS = os.environ.get("MVK_FUSED_DEFORM_OPERANDS", "1") == "1"   # development switch: 0 = the tensor ops
+_ORDER_LOOKUP = os.environ.get("MVK_GATHER_ORDER", "1") != "0"   # gather work lists found by their points tensor (ops.work_order_for)
 
 
 def _bn_rows(x, module, use_bn=True):
@@ -130,9 +131,10 @@ class KPConv(nn.Module):
         kp = load_kernels(self.radius, self.K, dimension=self.p_dim, fixed=self.fixed_kernel_points)
         return Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)
 
-    def forward(self, q_pts, s_pts, neighb_inds, x, stats_n_valid=None):
+    def forward(self, q_pts, s_pts, neighb_inds, x, stats_n_valid=None, order=None):
         """stats_n_valid: DEVICE row count of the BatchNorm that follows this convolution (the contraction
-        then delivers its statistics, ops.bn_stats_of); not part of the reference signature."""
+        then delivers its statistics, ops.bn_stats_of); order: work list of the query points for the gather
+        (ops.kpconv). Neither is part of the reference signature."""
         if self.KP_influence not in ops.INFLUENCE:
             raise ValueError('Unknown influence function type (config.KP_influence)')
         if self.aggregation_mode not in ops.AGGREGATION:
@@ -140,7 +142,7 @@ class KPConv(nn.Module):
         offsets = modulations = None
         if self.deformable:
             # offsets from an inner rigid KPConv (blocks.py:243-266)
-            raw = self.offset_conv(q_pts, s_pts, neighb_inds, x)
+            raw = self.offset_conv(q_pts, s_pts, neighb_inds, x, order=order)
             if _FUSED_OPERANDS and raw.is_cuda:        # bias, scale, kernel points (and 2 sigmoid) in one launch
                 self.offset_features, offsets, self.deformed_KP, modulations = ops.deform_operands(
                     raw, self.offset_bias, self.kernel_points, self.KP_extent, self.modulated)
@@ -156,7 +158,7 @@ class KPConv(nn.Module):
                 self.deformed_KP = offsets + self.kernel_points          # blocks.py:287
         y, min_d2 = ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent,
                                self.KP_influence, self.aggregation_mode, offsets, modulations,
-                               stats_n_valid=stats_n_valid)
+                               stats_n_valid=stats_n_valid, order=order)
         if self.deformable:
             self.min_d2 = min_d2                                      # blocks.py:303
         return y
@@ -279,6 +281,16 @@ def _conv_inputs(block_name, layer_ind, batch):
     return batch.points[layer_ind], batch.points[layer_ind], batch.neighbors[layer_ind]
 
 
+def _work_order(block_name, layer_ind, batch):
+    """The cell-sorted work list of the block's query level when the batch carries one (datasets/common.py
+    `orders`, not a reference attribute): the gather then walks the points region by region."""
+    l = layer_ind + 1 if 'strided' in block_name else layer_ind
+    orders = getattr(batch, 'orders', None)
+    if orders:
+        return orders[l] if l < len(orders) else None
+    return ops.work_order_for(batch.points[l]) if _ORDER_LOOKUP else None
+
+
 class SimpleBlock(nn.Module):
 
     def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
@@ -300,7 +312,8 @@ class SimpleBlock(nn.Module):
     def forward(self, x, batch):
         q_pts, s_pts, inds = _conv_inputs(self.block_name, self.layer_ind, batch)
         nv = _bn_rows(q_pts, self, self.use_bn) if _GEMM_STATS else None
-        return self.batch_norm(self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv), 0.1)
+        return self.batch_norm(self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv,
+                                           order=_work_order(self.block_name, self.layer_ind, batch)), 0.1)
 
 
 class ResnetBottleneckBlock(nn.Module):
@@ -337,7 +350,8 @@ class ResnetBottleneckBlock(nn.Module):
         else:
             x = self.unary1(features)
         nv = _bn_rows(q_pts, self, self.use_bn) if _GEMM_STATS else None
-        x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv), 0.1)
+        x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv,
+                                             order=_work_order(self.block_name, self.layer_ind, batch)), 0.1)
         shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
         shortcut = self.unary_shortcut(shortcut)
         if _FUSE_ADD:       # x = unary2(x); return leaky_relu(x + shortcut)  (blocks.py:644-649), join fused

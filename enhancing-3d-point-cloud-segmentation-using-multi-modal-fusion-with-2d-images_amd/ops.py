@@ -337,9 +337,12 @@ def profile_collect(h_eff=None):
 
 
 def kpconv_gather(q, s, idx, x, kp, extent, influence="linear", aggregation="sum", offsets=None,
-                  want_min_d2=False):
-    """A[n,k,c] = sum_h w[n,h,k] x+[idx[n,h],c]; returns (A, min_d2 or None)."""
-    _dev(q, s, idx, x, kp, offsets)
+                  want_min_d2=False, order=None):
+    """A[n,k,c] = sum_h w[n,h,k] x+[idx[n,h],c]; returns (A, min_d2 or None). order [Nq] int32 (a permutation of the
+    query rows, e.g. sorted by grid cell): the order the points are WORKED on; the result does not depend on it."""
+    _dev(q, s, idx, x, kp, offsets, order)
+    if order is not None and (order.dtype != torch.int32 or order.shape != (q.shape[0],) or not order.is_contiguous()):
+        raise RuntimeError("kpconv_gather: order must be a contiguous int32 tensor of Nq entries")
     q, s, x, kp = _f32c(q), _f32c(s), _f32c(x), _f32c(kp)
     idx, i64 = _idx(idx)
     Nq, Ns, H, Cin, K = q.shape[0], s.shape[0], idx.shape[1] if idx.dim() == 2 else 0, x.shape[1], kp.shape[0]
@@ -355,9 +358,9 @@ def kpconv_gather(q, s, idx, x, kp, extent, influence="linear", aggregation="sum
             min_arg = torch.empty((Nq, K), device=q.device, dtype=torch.int32)
     if _PROF["on"]:
         e0, e1 = _timing_events()
-    check(lib().mvk_kpconv_gather_fwd(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, _p(x), Cin, _p(kp), K,
-                                      float(extent), INFLUENCE[influence], AGGREGATION[aggregation],
-                                      _p(offsets), _p(min_d2), _p(min_arg), _p(A), _stream()))
+    check(lib().mvk_kpconv_gather_fwd_ordered(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, _p(x), Cin, _p(kp), K,
+                                              float(extent), INFLUENCE[influence], AGGREGATION[aggregation],
+                                              _p(offsets), _p(min_d2), _p(min_arg), _p(A), _p(order), _stream()))
     if _PROF["on"]:
         e1.record()
         _PROF["rec"].append(((_gather_kernel_label(Nq, Ns, H, Cin, offsets is not None), Nq, Ns, H, Cin, K), e0, e1))
@@ -594,10 +597,12 @@ class _KPConvFn(torch.autograd.Function):
     (KPConv-PyTorch/models/blocks.py:277-374) and its autograd backward."""
 
     @staticmethod
-    def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation, stats_n_valid=None):
+    def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation, stats_n_valid=None,
+                order=None):
         K, Cin, Cout = W.shape
         deform = offsets is not None
-        A, min_d2 = kpconv_gather(q, s, idx, x, kp, extent, influence, aggregation, offsets, want_min_d2=deform)
+        A, min_d2 = kpconv_gather(q, s, idx, x, kp, extent, influence, aggregation, offsets, want_min_d2=deform,
+                                  order=order)
         Am = A * modulations.unsqueeze(2) if modulations is not None else A     # blocks.py:366-367
         if _PROF["on"]:
             e0, e1 = _timing_events()
@@ -647,7 +652,7 @@ class _KPConvFn(torch.autograd.Function):
             dx, d_off = kpconv_scatter(q, s, idx, dA, kp, extent, influence, aggregation, x=x,
                                        offsets=offsets,
                                        g_min_d2=g_min_d2 if offsets is not None else None, min_arg=ctx.min_arg)
-        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None
+        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None, None
 
 
 _LAST_STATS_ROWS = [0]       # rows per block of the statistics partials the last KPConv forward produced
@@ -697,7 +702,8 @@ class _KPConv16Fn(torch.autograd.Function):
     kernels on the fp16-rounded values. Gradients are those of y = A16 . W16 (straight-through rounding)."""
 
     @staticmethod
-    def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation, stats_n_valid=None):
+    def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation, stats_n_valid=None,
+                order=None):          # (the fp16 gather entry points take no work list)
         K, Cin, Cout = W.shape
         Kd = K * Cin
         x16 = x.to(torch.float16)
@@ -777,7 +783,7 @@ class _KPConv16Fn(torch.autograd.Function):
             dx, d_off = kpconv_scatter(q, s, idx, dA, kp, extent, influence, aggregation,
                                        x=x16.float() if offsets is not None else None, offsets=offsets,
                                        g_min_d2=g_min_d2 if offsets is not None else None, min_arg=ctx.min_arg)
-        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None
+        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None, None
 
 
 _STREAM16 = os.environ.get("MVK_GEMM16_STREAM", "1") == "1"      # development switch: 0 = the LDS-staged fp16 kernel everywhere
@@ -800,17 +806,19 @@ def bn_stats_of(t):
 
 
 def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", offsets=None, modulations=None,
-           feature_dtype=None, stats_n_valid=None):
+           feature_dtype=None, stats_n_valid=None, order=None):
     """Returns (y [Nq,Cout], min_d2 [Nq,K] or None). feature_dtype: None = the mode set by
     set_feature_dtype(). stats_n_valid (DEVICE int32 [1]): the contraction also produces the column statistics
-    of y over its first n_valid rows for the BatchNorm that follows (picked up by bn_lrelu via bn_stats_of)."""
+    of y over its first n_valid rows for the BatchNorm that follows (picked up by bn_lrelu via bn_stats_of).
+    order (int32 [Nq], a permutation, e.g. neighbors_cell_order of the query level): the order the f32 gather works
+    through the query points in (kpconv_gather); the layer's result does not depend on it."""
     if influence not in INFLUENCE:
         raise ValueError("Unknown influence function type (config.KP_influence)")
     if aggregation not in AGGREGATION:
         raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
     fn = _KPConv16Fn if (feature_dtype or _FEATURE_DTYPE["dtype"]) == torch.float16 else _KPConvFn
     y, min_d2, part = fn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation,
-                               stats_n_valid)
+                               stats_n_valid, order)
     if part is not None:        # rows per statistics block of the launch that just ran (set by the node's forward)
         rows = _LAST_STATS_ROWS[0]
         y._mvk_bn_stats = (part, rows)
@@ -1309,6 +1317,41 @@ def radius_neighbors_dev(queries, supports, q_lens_dev, s_lens_dev, radius, out,
                                          float(radius), _p(out), out.shape[1], int(shadow), _p(status),
                                          int(bool(reuse_grid)), _p(ws), ws.numel(), _stream()))
     _NB_GRID.pop(q.device.index, None)
+
+
+def neighbors_cell_order(Nq, Ns, B, out=None, s_lens_dev=None, device=None):
+    """Work list for kpconv(order=...) out of the cell grid the LAST neighbour search on this device built
+    (mvk_neighbors_cell_order; the search must have had these Nq / Ns / B -- the capacities for radius_neighbors_dev,
+    whose device lengths go in s_lens_dev): the support rows sorted by cloud, grid cell and row, int32 [Ns] (or written
+    into `out` [cap >= Ns], identity beyond the clouds' rows). One launch, no synchronisation."""
+    dev = out.device if out is not None else (s_lens_dev.device if s_lens_dev is not None else device)
+    if out is None:
+        out = torch.empty((Ns,), device=dev, dtype=torch.int32)
+    _dev(out, s_lens_dev)
+    if out.dtype != torch.int32 or not out.is_contiguous() or out.dim() != 1 or out.shape[0] < Ns:
+        raise RuntimeError("neighbors_cell_order: out must be a contiguous int32 vector of at least Ns entries")
+    ws = _workspace("nb", lib().mvk_radius_neighbors_workspace(Nq, Ns, B), dev)
+    check(lib().mvk_neighbors_cell_order(Ns, B, _p(s_lens_dev), _p(out), out.shape[0], _p(ws), ws.numel(), _stream()))
+    return out
+
+
+_WORK_ORDERS = collections.OrderedDict()      # (device index, address, rows) of a points tensor -> its work list
+_WORK_ORDERS_KEPT = 64
+
+
+def remember_work_order(points, order):
+    """Side channel for batch containers that cannot carry the lists (the reference's flat input_list): the work list
+    of a level, found again by the address and row count of its points tensor. A stale hit (another cloud of the same
+    size at a recycled address) is still a permutation of its rows, which is all the gather needs."""
+    key = (points.device.index, points.data_ptr(), points.shape[0])
+    _WORK_ORDERS[key] = order
+    _WORK_ORDERS.move_to_end(key)
+    while len(_WORK_ORDERS) > _WORK_ORDERS_KEPT:
+        _WORK_ORDERS.popitem(last=False)
+
+
+def work_order_for(points):
+    return _WORK_ORDERS.get((points.device.index, points.data_ptr(), points.shape[0])) if points.is_cuda else None
 
 
 def check_neighbor_status(status):

@@ -303,6 +303,10 @@ class StaticBatch:
         self.upsamples = [torch.full((caps[l], self.limits[l + 1]), caps[l + 1], dtype=it, device=dev) if l + 1 < L
                           else batch.upsamples[l] for l in range(L)]
         self.lengths = batch.lengths
+        # gather work lists (datasets/common.py `orders`): a permutation of ALL capacity rows, identity over the padding
+        self._iota = [torch.arange(caps[l], dtype=torch.int32, device=dev) for l in range(L)]
+        has = getattr(batch, 'orders', None)
+        self.orders = [self._iota[l].clone() if (has and has[l] is not None) else None for l in range(L)] if has else None
         self.valid = {caps[l]: torch.zeros(1, dtype=torch.int32, device=dev) for l in range(L)}
         self._counts = [self.valid[caps[l]] for l in range(L)]
         for name in self._DENSE:
@@ -322,6 +326,11 @@ class StaticBatch:
             raise RuntimeError("batch does not fit the captured capacities %s: %s" % (self.caps, n))
         for l in range(L):
             ops.pad_points(batch.points[l], self.points[l], 1e6, self._counts[l])
+            if self.orders and self.orders[l] is not None:
+                src = batch.orders[l] if getattr(batch, 'orders', None) else None
+                self.orders[l].copy_(self._iota[l])
+                if src is not None:
+                    self.orders[l][:n[l]].copy_(src)
             self._put(self.neighbors[l], batch.neighbors[l], n[l], self.caps[l])
             if l + 1 < L:
                 self._put(self.pools[l], batch.pools[l], n[l], self.caps[l])
@@ -402,6 +411,8 @@ class DeviceInputChain:
             e = plan[l]
             if e['conv_r'] is not None:
                 search(l, l, e['conv_r'], static.neighbors[l], l)
+                if static.orders and static.orders[l] is not None:     # the workspace holds this search's grid
+                    ops.neighbors_cell_order(caps[l], caps[l], self.B, static.orders[l], self.lens[l])
             if e['pool'] and l + 1 < L:
                 ops.grid_subsample_dev(static.points[l], self.lens[l], e['dl'], static.points[l + 1], self.lens[l + 1],
                                        self.status, rotations_dev=self.rot[l], total_out=static._counts[l + 1])

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVK_ABI_VERSION 4   /* 4: fp16 mode on gfx950 forms: padded fp16 aggregate rows, streaming contraction (v_mfma_f32_16x16x32_f16) with statistics epilogue, one-launch weight rounding; 3: gemm plan / BatchNorm-statistics epilogue, BatchNorm takes epilogue partials, fused clip + SGD, offset gradient + regulariser, segmentation loss, gather launch plan, strided gather-rows backward, channels-last fusion gather; 2: masked BatchNorm takes the batch counter and a residual addend; enqueue-only / device-lens pyramid entry points; fp16-feature mode; capacity padding */
+#define MVK_ABI_VERSION 5   /* 5: gather with a work list (mvk_kpconv_gather_fwd_ordered); 4: fp16 mode on gfx950 forms: padded fp16 aggregate rows, streaming contraction (v_mfma_f32_16x16x32_f16) with statistics epilogue, one-launch weight rounding; 3: gemm plan / BatchNorm-statistics epilogue, BatchNorm takes epilogue partials, fused clip + SGD, offset gradient + regulariser, segmentation loss, gather launch plan, strided gather-rows backward, channels-last fusion gather; 2: masked BatchNorm takes the batch counter and a residual addend; enqueue-only / device-lens pyramid entry points; fp16-feature mode; capacity padding */
 
 /* influence / aggregation codes (blocks.py:329-354) */
 #define MVK_INFL_CONSTANT 0
@@ -57,6 +57,17 @@ int mvk_kpconv_gather_fwd(const float* q, int64_t Nq, const float* s, int64_t Ns
                           const float* offsets, float* min_d2,
                           int32_t* min_arg /* [Nq,K] or NULL: neighbour column of the first entry attaining min_d2 */,
                           float* A_out, void* stream);
+
+/* The same with a work list: order [Nq] int32 = a permutation of 0 .. Nq-1 (NULL = row order). The vector kernels of
+ * rigid layers (5 <= Cin <= 512) process the points in that order -- consecutive entries share a wave, consecutive
+ * waves an XCD -- and write every result in the point's own row: A_out is what mvk_kpconv_gather_fwd writes, whatever
+ * the permutation (a spatially sorted one keeps the neighbour rows a workgroup pulls inside its XCD's L2). Entries
+ * outside [0, Nq) or repeated entries are the caller's error (rows written twice / not at all). */
+int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const float* s, int64_t Ns,
+                                  const void* idx, int idx64, int H, const float* x, int Cin,
+                                  const float* kp, int K, float extent, int influence, int aggregation,
+                                  const float* offsets, float* min_d2, int32_t* min_arg, float* A_out,
+                                  const int32_t* order, void* stream);
 
 /* fp16-feature mode of mvk_kpconv_gather_fwd (rigid KPConv, Cin <= 512): x [Ns,Cin] and A_out
  * [Nq,K,Cin] are fp16 in memory; geometry, correlation weights and the sums are f32. */
@@ -375,6 +386,15 @@ int mvk_radius_neighbors_enqueue(const float* q, int64_t Nq, const float* s, int
 int mvk_radius_neighbors_dev(const float* q, int64_t Nq_cap, const float* s, int64_t Ns_cap,
                              const int32_t* q_lens_dev, const int32_t* s_lens_dev, int B, float radius,
                              int32_t* out, int width, int32_t shadow, int32_t* status_dev, int reuse_grid,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+
+/* No reference counterpart. Work list for mvk_kpconv_gather_fwd_ordered out of the cell grid the workspace holds (built
+ * by the last search on it with the same Ns -- Ns_cap for the device-lens entry point --, B and lengths; the conv
+ * search of a level has supports = the level's points): order_out[0 .. total) = the stacked support rows sorted by
+ * cloud, grid cell (x fastest) and row, a permutation of 0 .. total-1 that is the same on every run;
+ * order_out[total .. order_cap) = identity (capacity-padded rows). s_lens_dev: the DEVICE lengths given to
+ * mvk_radius_neighbors_dev, NULL after the host-length entry points. One launch, never synchronises. */
+int mvk_neighbors_cell_order(int64_t Ns, int B, const int32_t* s_lens_dev, int32_t* order_out, int64_t order_cap,
                              void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ---------------- capacity padding (hipGraph replay over fixed shapes) ----- */

@@ -324,6 +324,75 @@ def test_kpconv_gather_launches_with_sharing_workgroups_vs_numpy_oracle(ops, Nq,
     assert rel_err(A[rows], want) < (2e-3 if f16 else FP_TOL)
 
 
+@pytest.mark.parametrize("Nq,cin,H", [(3001, 64, 30), (19000, 66, 40), (21000, 128, 30), (9000, 300, 20), (5000, 3, 20)])
+def test_kpconv_gather_with_a_work_list_writes_the_rows_of_the_plain_gather(ops, Nq, cin, H):
+    """mvk_kpconv_gather_fwd_ordered: the work list only changes which wave (and which XCD) works on a point. Launches
+    without a mix of independent waves and sharing workgroups (every point summed in the same way whatever its slot)
+    must give the same BITS as the row order; mixed launches (a point's slot decides whether one wave or four sum its
+    neighbours) within the rounding of that sum; the layer as a whole (ops.kpconv) likewise."""
+    rng = np.random.default_rng(Nq + cin)
+    Ns, K = Nq, 15
+    s = (rng.random((Ns, 3)) * 0.6).astype(np.float32)
+    q = s
+    idx = rng.integers(0, Ns + 1, (Nq, H)).astype(np.int32)
+    idx[:, H // 2:][rng.random((Nq, H - H // 2)) < 0.4] = Ns
+    x = T(rng.normal(size=(Ns, cin)).astype(np.float32))
+    kp = T((rng.normal(size=(K, 3)) * 0.05).astype(np.float32))
+    qt, st, it = T(q), T(s), T(idx)
+    plain = ops.kpconv_gather(qt, st, it, x, kp, 0.06)[0]
+    plan = ops.kpconv_gather_plan(Nq, Ns, H, cin)
+    mixed = 0 < plan["first_sharing_workgroup"] < plan["workgroups"]
+    cells = np.floor(s / 0.06).astype(np.int64)
+    orders = {"random": rng.permutation(Nq), "reversed": np.arange(Nq)[::-1].copy(),
+              "cells": np.lexsort((cells[:, 0], cells[:, 1], cells[:, 2]))}
+    for name, o in orders.items():
+        got = ops.kpconv_gather(qt, st, it, x, kp, 0.06, order=T(o.astype(np.int32)))[0]
+        if mixed:
+            err = float((got - plain).abs().max() / plain.abs().max())
+            check_err("gather with the %s work list vs the row order (Nq %d, Cin %d, mixed launch)" % (name, Nq, cin), err, 2e-6)
+        else:
+            assert torch.equal(got, plain), (name, plan)
+    with pytest.raises(RuntimeError):
+        ops.kpconv_gather(qt, st, it, x, kp, 0.06, order=T(np.arange(Nq - 1, dtype=np.int32)))
+    if cin == 66:
+        W = T((rng.normal(size=(K, cin, 32)) * 0.1).astype(np.float32))
+        y0 = ops.kpconv(qt, st, it, x, kp, W, 0.06)[0]
+        y1 = ops.kpconv(qt, st, it, x, kp, W, 0.06, order=T(orders["cells"].astype(np.int32)))[0]
+        check_err("KPConv layer with a work list vs without", float((y1 - y0).abs().max() / y0.abs().max()), 2e-6)
+
+
+def test_cell_order_of_the_neighbour_search_is_a_sorted_permutation(ops):
+    """mvk_neighbors_cell_order after a radius search over three stacked clouds: a permutation of the rows that stays
+    inside each cloud, ascending in the grid cell of the search (cell = 1.001 r from the cloud's minimum corner,
+    x fastest) and in the row inside a cell, identical on a second call, identity over the capacity padding."""
+    rng = np.random.default_rng(77)
+    lens = np.asarray([4000, 1, 2500], np.int32)
+    pts = np.concatenate([(rng.random((n, 3)) * (0.8 + 0.3 * i)).astype(np.float32) + 5.0 * i for i, n in enumerate(lens)])
+    r = 0.1
+    P = T(pts)
+    nb = ops.radius_neighbors_batch(P, P, lens, lens, r, limit=20)
+    assert nb.shape == (len(pts), 20)
+    cap = len(pts) + 100
+    out = torch.full((cap,), -7, dtype=torch.int32, device=P.device)
+    ops.neighbors_cell_order(len(pts), len(pts), 3, out)
+    again = ops.neighbors_cell_order(len(pts), len(pts), 3, device=P.device)
+    o = out.cpu().numpy()
+    assert np.array_equal(o[len(pts):], np.arange(len(pts), cap)) and np.array_equal(o[:len(pts)], again.cpu().numpy())
+    off = 0
+    for n in lens:
+        seg = o[off:off + n].astype(np.int64)
+        assert np.array_equal(np.sort(seg), np.arange(off, off + n))
+        p = pts[seg]
+        lo = pts[off:off + n].min(0)
+        cell = np.float32(r) * np.float32(1.001)
+        c = np.floor((p - lo) / cell).astype(np.int64)
+        d = np.floor((pts[off:off + n].max(0) - lo) / cell).astype(np.int64) + 1
+        lin = (c[:, 2] * d[1] + c[:, 1]) * d[0] + c[:, 0]
+        key = lin * (1 << 32) + seg
+        assert np.all(np.diff(key) > 0)
+        off += n
+
+
 @pytest.mark.parametrize("name,modulated", [("g4_kpconv_deform", False), ("g4_kpconv_deform_mod", True)])
 def test_kpconv_deformable_golden(ops, name, modulated):
     g = load_golden(name)

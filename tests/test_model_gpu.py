@@ -246,7 +246,7 @@ def test_device_input_chain_equals_eager_input_side(variant, deformable, nsphere
     batch, _ = syn.build_batch(cfg, staged, limits, torch.int32, rotations=rots)
     want = syn.StaticBatch(batch, limits)
     got = syn.StaticBatch(batch, limits, caps=want.caps)
-    for tl in (got.points[1:], got.neighbors, got.pools[:-1], got.upsamples[:-1]):
+    for tl in (got.points[1:], got.neighbors, got.pools[:-1], got.upsamples[:-1], [o for o in got.orders if o is not None]):
         for x in tl:
             x.fill_(-12345)                                           # everything must be rewritten
     chain = syn.DeviceInputChain(cfg, staged, limits, got)
@@ -261,6 +261,10 @@ def test_device_input_chain_equals_eager_input_side(variant, deformable, nsphere
         assert torch.equal(got.neighbors[l], want.neighbors[l]), l
         if l + 1 < L:
             assert torch.equal(got.pools[l], want.pools[l]) and torch.equal(got.upsamples[l], want.upsamples[l]), l
+        assert (got.orders[l] is None) == (want.orders[l] is None), l          # the gather's work lists
+        if want.orders[l] is not None:
+            assert torch.equal(got.orders[l], want.orders[l]), l
+            assert torch.equal(torch.sort(got.orders[l]).values, got._iota[l]), l
     for name in syn.StaticBatch._DENSE:
         a, b = getattr(got, name), getattr(want, name)
         assert (a is None) == (b is None) and (a is None or torch.equal(a, b)), name

@@ -116,6 +116,11 @@ def kpconv_gather_plan(Nq, Ns, H, Cin, elem_bytes=4, deformable=False):
     return dict(zip(keys, [int(v) for v in out]))
 
 
+# rows up to which a BatchNorm takes its statistics from the producing GEMM's epilogue: every workgroup of the
+# normalising launch merges ALL the epilogue's (sum, M2) partials of its channels, one per 64 rows -- beyond a few
+# hundred of them (FeatureAggregation's 58 392 rows: 913) the separate statistics launch is the cheaper way
+_STATS_EPILOGUE_ROWS = int(os.environ.get("MVK_GEMM_STATS_MAX_ROWS", "32768"))
+
 BN_SMALL_ROWS = 128      # csrc/bn.hip: up to this many rows one launch does statistics and normalisation (any D)
 
 
@@ -142,7 +147,8 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
     if M == 0 or N == 0 or Kd == 0:
         res = out.zero_() if out is not None else torch.zeros((M, N), device=A.device, dtype=torch.float32)
         return (res, None) if want else res
-    split, rows = gemm_plan(M, N, Kd, split_k, want and out is None and not accumulate and M > bn_single_launch_rows(N))
+    split, rows = gemm_plan(M, N, Kd, split_k, want and out is None and not accumulate and M > bn_single_launch_rows(N)
+                            and M <= _STATS_EPILOGUE_ROWS)
     if out is None:
         out = ((torch.zeros((M, N), device=A.device, dtype=torch.float32) if keep else _zeros((M, N), A.device))
                if split > 1 else torch.empty((M, N), device=A.device, dtype=torch.float32))

@@ -33,5 +33,10 @@ python3 $R/tools/gemm16_bench.py 2>/dev/null | cut -c1-400 > $O/${TAG}_gemm16_be
 MVK_GEMM32_STREAM=2 python3 $R/tools/gemm16_bench.py 2>/dev/null | grep "f32 stream" > $O/${TAG}_gemm_stream_bench.txt
 bash $R/tools/workloads_round.sh > $O/${TAG}_workloads.txt 2>&1
 bash $R/tools/config5.sh > $O/${TAG}_config5.txt 2>&1
+# 6. the gather's work list: launch time per order (1 and 8 spheres) and what each order fetches
+python3 $R/tools/gather_order_bench.py 66 2>/dev/null > $O/${TAG}_gather_order_bench.txt
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/po -- python3 $R/tools/gather_order_bench.py 66 pmc > /dev/null 2> $O/po.err
+python3 $R/tools/pmc_gather_orders.py $(ls $O/po/*/*_counter_collection.csv | head -1) > $O/${TAG}_pmc_gather_orders.txt 2>&1
+rm -rf $O/po
 cd $R && python3 bench.py > $O/${TAG}_bench_line.json 2> $O/bench_line.err; cp $R/gpurun_out/bench_detail.json $O/${TAG}_bench_detail.json; cd /tmp
 ls -la $O; cat $O/pmc_mfma.log; head -5 $O/pmc_traffic.log; head -3 $O/${TAG}_steady_state_per_step.txt

@@ -66,6 +66,36 @@ __global__ void gather_rows_fwd_k(const float* __restrict__ x, int64_t Ns, int C
   out[t] = j >= 0 ? x[(int64_t)j * C + c] : 0.f;
 }
 
+// out[n] = [x[idx[n,0]] | skip[n]]: nearest upsampling of the coarse features and the concatenation with the encoder's
+// skip features (KPFCNN decoder, architectures.py:334-335) in one launch; rows as float4 where the widths allow
+template <bool IDX64, int V>
+__global__ void gather_rows_cat_k(const float* __restrict__ x, int64_t Ns, int C1, const void* idx, int64_t Nq,
+                                  int64_t stride, const float* __restrict__ skip, int C2, float* __restrict__ out) {
+  const int W = (C1 + C2) / V;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Nq * W) return;
+  const int64_t n = t / W;
+  const int c = (int)(t % W) * V;
+  float v[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) v[e] = 0.f;
+  if (c < C1) {
+    const int j = load_idx<IDX64>(idx, n * stride, Ns);
+    if (j >= 0) {
+      const float* p = x + (int64_t)j * C1 + c;
+#pragma unroll
+      for (int e = 0; e < V; ++e) v[e] = p[e];
+    }
+  } else {
+    const float* p = skip + n * C2 + (c - C1);
+#pragma unroll
+    for (int e = 0; e < V; ++e) v[e] = p[e];
+  }
+  float* o = out + n * (int64_t)(C1 + C2) + c;
+#pragma unroll
+  for (int e = 0; e < V; ++e) o[e] = v[e];
+}
+
 template <bool IDX64>
 __global__ void gather_rows_bwd_k(const float* __restrict__ g, int64_t g_ld, const void* idx, int64_t Nq,
                                   int64_t stride, int64_t Ns, int C, float* __restrict__ dx) {
@@ -114,6 +144,25 @@ extern "C" int mvk_gather_rows_fwd(const float* x, int64_t Ns, int C, const void
   if (total == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   DISPATCH_IDX(gather_rows_fwd_k, x, Ns, C, idx, Nq, idx_stride, out);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_gather_rows_cat_fwd(const float* x, int64_t Ns, int C1, const void* idx, int idx64, int64_t Nq,
+                                       int64_t idx_stride, const float* skip, int C2, float* out, void* stream) {
+  MVK_REQUIRE(C1 > 0 && C2 > 0 && Nq >= 0 && Ns >= 0, "gather_rows_cat: bad sizes");
+  if (Nq == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  const bool v4 = C1 % 4 == 0 && C2 % 4 == 0 &&
+                  (((uintptr_t)x | (uintptr_t)skip | (uintptr_t)out) & 15) == 0;
+  const int64_t total = Nq * (int64_t)((C1 + C2) / (v4 ? 4 : 1));
+  if (v4) {
+    if (idx64) hipLaunchKernelGGL((gather_rows_cat_k<true, 4>), grid1d(total), dim3(256), 0, st, x, Ns, C1, idx, Nq, idx_stride, skip, C2, out);
+    else hipLaunchKernelGGL((gather_rows_cat_k<false, 4>), grid1d(total), dim3(256), 0, st, x, Ns, C1, idx, Nq, idx_stride, skip, C2, out);
+  } else {
+    if (idx64) hipLaunchKernelGGL((gather_rows_cat_k<true, 1>), grid1d(total), dim3(256), 0, st, x, Ns, C1, idx, Nq, idx_stride, skip, C2, out);
+    else hipLaunchKernelGGL((gather_rows_cat_k<false, 1>), grid1d(total), dim3(256), 0, st, x, Ns, C1, idx, Nq, idx_stride, skip, C2, out);
+  }
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -8,15 +8,16 @@ import torch
 import torch.nn as nn
 
 try:
-    from .blocks import KPConv, UnaryBlock, block_decider
+    from .blocks import KPConv, UnaryBlock, NearestUpsampleBlock, block_decider
     from .._native import ops as _ops
 except ImportError:
-    from models.blocks import KPConv, UnaryBlock, block_decider
+    from models.blocks import KPConv, UnaryBlock, NearestUpsampleBlock, block_decider
     from _native import ops as _ops
 
 
 _FUSED_REG = os.environ.get("MVK_FUSED_REGULARIZER", "1") == "1"   # development switch: 0 = the tensor-op form below
 _FUSED_LOSS = os.environ.get("MVK_FUSED_LOSS", "1") == "1"         # development switch: 0 = torch.nn.CrossEntropyLoss
+_FUSED_UPSAMPLE = os.environ.get("MVK_FUSED_UPSAMPLE", "1") == "1"  # development switch: 0 = closest_pool, then torch.cat
 
 
 def p2p_fitting_regularizer(net):
@@ -192,9 +193,17 @@ def run_encoder_decoder(net, x, batch, encoder=None):
         if block_i in net.encoder_skips:
             skip_x.append(x)
         x = block_op(x, batch)
+    joined = False
     for block_i, block_op in enumerate(net.decoder_blocks):
-        if block_i in net.decoder_concats:
+        if block_i in net.decoder_concats and not joined:
             x = torch.cat([x, skip_x.pop()], dim=1)
+        joined = False
+        if _FUSED_UPSAMPLE and isinstance(block_op, NearestUpsampleBlock) and (block_i + 1) in net.decoder_concats \
+                and x.is_cuda and block_i not in net.decoder_concats:
+            # nearest upsampling + the concatenation that follows it (:334-335) as one launch
+            x = _ops.upsample_cat(x, batch.upsamples[block_op.layer_ind - 1], skip_x.pop())
+            joined = True
+            continue
         x = block_op(x, batch)
     return x
 

@@ -1165,6 +1165,46 @@ class _GatherRowsFn(torch.autograd.Function):
         return dx, None
 
 
+class _UpsampleCatFn(torch.autograd.Function):
+    """[closest_pool(x, inds) | skip] in one launch (mvk_gather_rows_cat_fwd); the backward reads the upsampled half of
+    the gradient in place (as _GatherRowsFn does behind torch.cat) and hands the skip half on as a view."""
+
+    @staticmethod
+    def forward(ctx, x, inds2d, skip):
+        _dev(x, inds2d, skip)
+        x, skip = _f32c(x), _f32c(skip)
+        inds2d, i64 = _idx(inds2d)
+        Nq = inds2d.shape[0]
+        if skip.shape[0] != Nq:
+            raise RuntimeError("upsample_cat: the skip features and the upsampling indices differ in length")
+        stride = inds2d.shape[1] if inds2d.dim() == 2 else 1
+        C1, C2 = x.shape[1], skip.shape[1]
+        out = torch.empty((Nq, C1 + C2), device=x.device, dtype=torch.float32)
+        check(lib().mvk_gather_rows_cat_fwd(_p(x), x.shape[0], C1, _p(inds2d), i64, Nq, stride, _p(skip), C2, _p(out),
+                                            _stream()))
+        ctx.save_for_backward(inds2d)
+        ctx.ns, ctx.stride, ctx.c1 = x.shape[0], stride, C1
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (inds2d,) = ctx.saved_tensors
+        g = _f32c(g)
+        dx = d_skip = None
+        if ctx.needs_input_grad[0]:
+            dx = _zeros((ctx.ns, ctx.c1), g.device)
+            check(lib().mvk_gather_rows_bwd_ld(_p(g), g.shape[1], _p(inds2d), int(inds2d.dtype == torch.int64),
+                                               inds2d.shape[0], ctx.stride, ctx.ns, ctx.c1, _p(dx), _stream()))
+        if ctx.needs_input_grad[2]:
+            d_skip = g[:, ctx.c1:]
+        return dx, None, d_skip
+
+
+def upsample_cat(x, inds, skip):
+    """torch.cat([closest_pool(x, inds), skip], dim=1) of the KPFCNN decoder (blocks.py:79-91, architectures.py:334)."""
+    return _UpsampleCatFn.apply(x, inds, skip)
+
+
 def max_pool(x, inds):
     """blocks.py:94-110 (zero shadow row takes part in the max)."""
     return _MaxPoolFn.apply(x, inds)

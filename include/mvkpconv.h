@@ -311,6 +311,11 @@ int mvk_gather_rows_bwd(const float* g, const void* idx, int idx64, int64_t Nq, 
 int mvk_gather_rows_bwd_ld(const float* g, int64_t g_ld, const void* idx, int idx64, int64_t Nq,
                            int64_t idx_stride, int64_t Ns, int C, float* dx, void* stream);
 
+/* out [Nq, C1+C2] = [x[idx[n,0]] | skip[n]] : closest_pool of the coarse features (a row of zeros for the shadow index)
+ * and torch.cat with the encoder's skip features [Nq,C2] (KPFCNN decoder, architectures.py:334-335) in one launch. */
+int mvk_gather_rows_cat_fwd(const float* x, int64_t Ns, int C1, const void* idx, int idx64, int64_t Nq,
+                            int64_t idx_stride, const float* skip, int C2, float* out, void* stream);
+
 /* ---------------- input pyramid ------------------------------------------ */
 
 /* Scratch size in bytes needed by mvk_grid_subsample_batch for N points in B clouds. */

@@ -361,6 +361,27 @@ def test_kpconv_gather_with_a_work_list_writes_the_rows_of_the_plain_gather(ops,
         check_err("KPConv layer with a work list vs without", float((y1 - y0).abs().max() / y0.abs().max()), 2e-6)
 
 
+@pytest.mark.parametrize("C1,C2,idt", [(256, 128, torch.int32), (30, 7, torch.int64), (64, 64, torch.int32)])
+def test_upsample_cat_equals_closest_pool_then_cat(ops, C1, C2, idt):
+    """mvk_gather_rows_cat_fwd: [closest_pool(x, inds) | skip] (blocks.py:79-91 + architectures.py:334) in one launch --
+    the same bits as the two steps, shadow rows included, and the same gradients for both inputs."""
+    rng = np.random.default_rng(C1 + C2)
+    Ns, Nq, H = 700, 2900, 5
+    inds = T(rng.integers(0, Ns + 1, (Nq, H))).to(idt)
+    x = T(rng.normal(size=(Ns, C1)).astype(np.float32)).requires_grad_(True)
+    skip = T(rng.normal(size=(Nq, C2)).astype(np.float32)).requires_grad_(True)
+    x2, skip2 = x.detach().clone().requires_grad_(True), skip.detach().clone().requires_grad_(True)
+    g = T(rng.normal(size=(Nq, C1 + C2)).astype(np.float32))
+    got = ops.upsample_cat(x, inds, skip)
+    want = torch.cat([ops.closest_pool(x2, inds), skip2], dim=1)
+    assert torch.equal(got, want)
+    ops.step_begin()
+    (got * g).sum().backward()
+    (want * g).sum().backward()
+    assert torch.equal(skip.grad, skip2.grad)
+    assert rel_err(x.grad.cpu().numpy(), x2.grad.cpu().numpy()) < 1e-6       # float atomics: order of arrival
+
+
 def test_cell_order_of_the_neighbour_search_is_a_sorted_permutation(ops):
     """mvk_neighbors_cell_order after a radius search over three stacked clouds: a permutation of the rows that stays
     inside each cloud, ascending in the grid cell of the search (cell = 1.001 r from the cloud's minimum corner,

@@ -489,6 +489,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             graph_3.replay()
         return replay, loss
 
+    _SEED.setdefault(dev, torch.ones((), device=dev))      # (before the captures: see backward())
     replays = [capture(s) for s in statics]
     state = {"next": None, "k": 0, "free": [None, None]}
 
@@ -771,11 +772,17 @@ def backward_scope(ops):
     return ops.defer_weight_grads if os.environ.get("MVK_DEFER_DW", "1") == "1" else contextlib.nullcontext
 
 
+_SEED = {}
+
+
 def backward(ops, loss):
     """loss.backward() with the weight-gradient products on a side branch (ops.overlap_weight_grads): nothing reads
     a gradient before the optimiser (or the all-reduce), which run after the scope has joined."""
+    seed = _SEED.get(loss.device)
+    if seed is None:        # the seed of loss.backward() -- a tensor of ones, one fill launch per call -- made once
+        seed = _SEED[loss.device] = torch.ones((), device=loss.device, dtype=loss.dtype)
     with backward_scope(ops)():
-        loss.backward()
+        loss.backward(seed)
 
 
 def clip_and_step(params, opt, cfg):

@@ -65,6 +65,7 @@ _SIGNATURES = {
     "mvk_gather_rows_bwd": (C.c_int, [_vp, _vp, _i, _i64, _i64, _i64, _i, _vp, _vp]),
     "mvk_gather_rows_bwd_ld": (C.c_int, [_vp, _i64, _vp, _i, _i64, _i64, _i64, _i, _vp, _vp]),
     "mvk_gather_rows_cat_fwd": (C.c_int, [_vp, _i64, _i, _vp, _i, _i64, _i64, _vp, _i, _vp, _vp]),
+    "mvk_gather_rows_cat_bwd": (C.c_int, [_vp, _vp, _i, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp]),
     "mvk_grid_subsample_workspace": (C.c_int64, [_i64, _i, _i, _i]),
     "mvk_grid_subsample_batch": (C.c_int, [_vp, _i64, _vp, _i, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp,
                                            _vp, _vp, _i64, _vp]),

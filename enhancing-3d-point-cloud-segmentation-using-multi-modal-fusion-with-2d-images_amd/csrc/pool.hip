@@ -107,6 +107,25 @@ __global__ void gather_rows_bwd_k(const float* __restrict__ g, int64_t g_ld, con
   if (j >= 0) atomicAdd(dx + (int64_t)j * C + c, g[n * g_ld + c]);
 }
 
+// backward of gather_rows_cat_k: the upsampled half of g [Nq, C1+C2] scattered into dx [Ns,C1] (f32 atomics, dx zeroed
+// by the caller), the skip half copied out as a dense [Nq,C2] tensor (it becomes a gradient others accumulate onto)
+template <bool IDX64>
+__global__ void gather_rows_cat_bwd_k(const float* __restrict__ g, const void* idx, int64_t Nq, int64_t stride, int64_t Ns,
+                                      int C1, int C2, float* __restrict__ dx, float* __restrict__ d_skip) {
+  const int W = C1 + C2;
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= Nq * W) return;
+  const int64_t n = t / W;
+  const int c = (int)(t % W);
+  if (c < C1) {
+    if (dx == nullptr) return;
+    const int j = load_idx<IDX64>(idx, n * stride, Ns);
+    if (j >= 0) atomicAdd(dx + (int64_t)j * C1 + c, g[t]);
+  } else if (d_skip != nullptr) {
+    d_skip[n * C2 + (c - C1)] = g[t];
+  }
+}
+
 inline dim3 grid1d(int64_t total) { return dim3((unsigned)cdiv64(total, 256)); }
 
 }  // namespace
@@ -163,6 +182,17 @@ extern "C" int mvk_gather_rows_cat_fwd(const float* x, int64_t Ns, int C1, const
     if (idx64) hipLaunchKernelGGL((gather_rows_cat_k<true, 1>), grid1d(total), dim3(256), 0, st, x, Ns, C1, idx, Nq, idx_stride, skip, C2, out);
     else hipLaunchKernelGGL((gather_rows_cat_k<false, 1>), grid1d(total), dim3(256), 0, st, x, Ns, C1, idx, Nq, idx_stride, skip, C2, out);
   }
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_gather_rows_cat_bwd(const float* g, const void* idx, int idx64, int64_t Nq, int64_t idx_stride,
+                                       int64_t Ns, int C1, int C2, float* dx, float* d_skip, void* stream) {
+  MVK_REQUIRE(C1 > 0 && C2 > 0 && Nq >= 0 && Ns >= 0, "gather_rows_cat_bwd: bad sizes");
+  const int64_t total = Nq * (int64_t)(C1 + C2);
+  if (total == 0 || (dx == nullptr && d_skip == nullptr)) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  DISPATCH_IDX(gather_rows_cat_bwd_k, g, idx, Nq, idx_stride, Ns, C1, C2, dx, d_skip);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -166,6 +166,8 @@ class _SegmentationLossMixin:
             raise ValueError('point2plane fitting mode not implemented yet.')
         else:
             raise ValueError('Unknown fitting mode: ' + self.deform_fitting_mode)
+        if isinstance(self.reg_loss, (int, float)) and self.reg_loss == 0:
+            return self.output_loss            # rigid network: `+ 0` would be one more launch for the same value
         return self.output_loss + self.reg_loss
 
     def accuracy(self, outputs, labels):
@@ -193,6 +195,11 @@ def run_encoder_decoder(net, x, batch, encoder=None):
         if block_i in net.encoder_skips:
             skip_x.append(x)
         x = block_op(x, batch)
+        alias = getattr(block_op, 'skip_alias', None)
+        if alias is not None:
+            block_op.skip_alias = None
+            if block_i in net.encoder_skips and torch.is_grad_enabled():
+                skip_x[-1] = alias      # same values; its gradient reaches the block input through the block's own nodes
     joined = False
     for block_i, block_op in enumerate(net.decoder_blocks):
         if block_i in net.decoder_concats and not joined:

@@ -352,7 +352,13 @@ class ResnetBottleneckBlock(nn.Module):
         nv = _bn_rows(q_pts, self, self.use_bn) if _GEMM_STATS else None
         x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv,
                                              order=_work_order(self.block_name, self.layer_ind, batch)), 0.1)
-        shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
+        self.skip_alias = None
+        if 'strided' in self.block_name and _FUSE_FANOUT and features.is_cuda:
+            # the block's input is also the decoder's skip tensor (architectures.py:328-329): the alias handed out here
+            # lets the pooling's backward accumulate onto the decoder's gradient (run_encoder_decoder picks it up)
+            shortcut, self.skip_alias = ops.max_pool(features, inds, passthrough=True)
+        else:
+            shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
         shortcut = self.unary_shortcut(shortcut)
         if _FUSE_ADD:       # x = unary2(x); return leaky_relu(x + shortcut)  (blocks.py:644-649), join fused
             return self.unary2(x, join=(shortcut, 0.1))

@@ -1116,8 +1116,11 @@ def add_lrelu(a, b, slope=0.1):
 # --------------------------------------------------------------------------------------------
 
 class _MaxPoolFn(torch.autograd.Function):
+    """passthrough (see _LinearFn): a second, aliasing output of x for another consumer of x; the backward scatters onto
+    that consumer's gradient (the kernel accumulates with atomics anyway) instead of onto zeros + one more add."""
+
     @staticmethod
-    def forward(ctx, x, inds):
+    def forward(ctx, x, inds, passthrough=False):
         _dev(x, inds)
         x = _f32c(x)
         inds, i64 = _idx(inds)
@@ -1126,17 +1129,26 @@ class _MaxPoolFn(torch.autograd.Function):
         arg = torch.empty((Nq, x.shape[1]), device=x.device, dtype=torch.int32)
         check(lib().mvk_max_pool_fwd(_p(x), x.shape[0], x.shape[1], _p(inds), i64, Nq, H, _p(out), _p(arg), _stream()))
         ctx.save_for_backward(inds, arg)
-        ctx.ns = x.shape[0]
-        return out
+        ctx.ns, ctx.c = x.shape[0], x.shape[1]
+        ctx.set_materialize_grads(False)
+        return out, (x.view_as(x) if passthrough else None)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g_alias=None):
         inds, arg = ctx.saved_tensors
+        if g is None:
+            return g_alias, None, None
         g = _f32c(g)
-        dx = _zeros((ctx.ns, g.shape[1]), g.device)
+        if (g_alias is not None and g_alias.dtype == torch.float32 and g_alias.is_contiguous()
+                and g_alias.shape == (ctx.ns, ctx.c)):
+            dx = g_alias            # this node's own grad input: nobody else holds it
+        else:
+            dx = _zeros((ctx.ns, ctx.c), g.device)
         check(lib().mvk_max_pool_bwd(_p(g), _p(arg), _p(inds), int(inds.dtype == torch.int64), inds.shape[0],
                                      inds.shape[1], ctx.ns, g.shape[1], _p(dx), _stream()))
-        return dx, None
+        if g_alias is not None and dx is not g_alias:
+            dx = dx + g_alias
+        return dx, None, None
 
 
 class _GatherRowsFn(torch.autograd.Function):
@@ -1190,13 +1202,13 @@ class _UpsampleCatFn(torch.autograd.Function):
     def backward(ctx, g):
         (inds2d,) = ctx.saved_tensors
         g = _f32c(g)
-        dx = d_skip = None
-        if ctx.needs_input_grad[0]:
-            dx = _zeros((ctx.ns, ctx.c1), g.device)
-            check(lib().mvk_gather_rows_bwd_ld(_p(g), g.shape[1], _p(inds2d), int(inds2d.dtype == torch.int64),
-                                               inds2d.shape[0], ctx.stride, ctx.ns, ctx.c1, _p(dx), _stream()))
-        if ctx.needs_input_grad[2]:
-            d_skip = g[:, ctx.c1:]
+        c2 = g.shape[1] - ctx.c1
+        dx = _zeros((ctx.ns, ctx.c1), g.device) if ctx.needs_input_grad[0] else None
+        # the skip half leaves as a dense tensor of its own (same launch): the encoder block that produced the skip
+        # features accumulates its own gradient onto it (max_pool / linear passthrough) instead of a separate add
+        d_skip = torch.empty((g.shape[0], c2), device=g.device, dtype=torch.float32) if ctx.needs_input_grad[2] else None
+        check(lib().mvk_gather_rows_cat_bwd(_p(g), _p(inds2d), int(inds2d.dtype == torch.int64), inds2d.shape[0],
+                                            ctx.stride, ctx.ns, ctx.c1, c2, _p(dx), _p(d_skip), _stream()))
         return dx, None, d_skip
 
 
@@ -1205,9 +1217,11 @@ def upsample_cat(x, inds, skip):
     return _UpsampleCatFn.apply(x, inds, skip)
 
 
-def max_pool(x, inds):
-    """blocks.py:94-110 (zero shadow row takes part in the max)."""
-    return _MaxPoolFn.apply(x, inds)
+def max_pool(x, inds, passthrough=False):
+    """blocks.py:94-110 (zero shadow row takes part in the max). passthrough=True returns (pooled, x') with x' an alias
+    of x for another consumer of x, whose gradient the backward accumulates onto (see linear())."""
+    out, alias = _MaxPoolFn.apply(x, inds, passthrough)
+    return (out, alias) if passthrough else out
 
 
 def closest_pool(x, inds):

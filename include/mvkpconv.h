@@ -315,6 +315,10 @@ int mvk_gather_rows_bwd_ld(const float* g, int64_t g_ld, const void* idx, int id
  * and torch.cat with the encoder's skip features [Nq,C2] (KPFCNN decoder, architectures.py:334-335) in one launch. */
 int mvk_gather_rows_cat_fwd(const float* x, int64_t Ns, int C1, const void* idx, int idx64, int64_t Nq,
                             int64_t idx_stride, const float* skip, int C2, float* out, void* stream);
+/* Its backward: g [Nq, C1+C2] -> dx [Ns,C1] += the upsampled half (f32 atomics; zero-initialised by the caller; NULL =
+ * not needed) and d_skip [Nq,C2] = the skip half as a dense tensor (NULL = not needed). */
+int mvk_gather_rows_cat_bwd(const float* g, const void* idx, int idx64, int64_t Nq, int64_t idx_stride, int64_t Ns,
+                            int C1, int C2, float* dx, float* d_skip, void* stream);
 
 /* ---------------- input pyramid ------------------------------------------ */
 

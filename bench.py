@@ -328,6 +328,23 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     batch0, lens = syn.build_batch(cfg, staged, limits, torch.int32)
     if enc is not None:
         batch0.feature_2d = encode(enc_in)
+    # FeatureAggregation of batch k+1 beside step k as well, where the network detaches its output (early / middle
+    # fusion: no trainable state upstream of that point): 12 launches / 0.17 ms off the network's chain
+    fa_ahead = enc is not None and getattr(net, "fa_output_detached", False) and hasattr(syn, "DeviceInputChain") \
+        and os.environ.get("MVK_DEVICE_CHAIN", "1") == "1" and os.environ.get("MVK_FA_AHEAD", "1") == "1"
+    if fa_ahead:
+        lift = sys.modules[type(net).__module__].lift_2d_features
+
+        def aggregate(batch):
+            """FeatureAggregation on the batch's encoder features (BatchNorm in the module's own mode), no autograd."""
+            held, batch.feature_2d3d = getattr(batch, "feature_2d3d", None), None
+            try:
+                with torch.no_grad():
+                    return lift(net, batch)
+            finally:
+                batch.feature_2d3d = held
+
+        batch0.feature_2d3d = aggregate(batch0)
     # Row capacities of levels 1..: the level sizes move by about +-8 % with the random grid orientation, so one
     # batch is not a safe yardstick -- take the largest of a few draws, plus 10 %, rounded up to 64 rows
     # (distinct per level: the masked BatchNorm finds its row-count word by capacity).
@@ -414,6 +431,10 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             if use_chain:
                 with torch.cuda.stream(build_stream):
                     chains[1 - statics.index(static)].build(other)
+            if fa_ahead:        # needs both: the encoder's features and the chain's 3-NN pixels of batch k+1
+                enc_stream.wait_stream(build_stream)
+                with torch.cuda.stream(enc_stream):
+                    other.feature_2d3d.copy_(aggregate(other))
 
         def join_encoder():
             if enc is not None:
@@ -552,13 +573,16 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             print("DIAG graph replay (network + encoder + input chain branches) %.2f ms | input chain alone, eager "
                   "%.2f ms" % ((t1 - t0) * 50, (t2 - t1) * 100), file=sys.stderr)
         state_ref.append(state)
-        tag = "hipGraph[net|chain%s]%s" % ("|enc2d" if enc is not None else "",
+        tag = "hipGraph[net|chain%s]%s" % (("|enc2d+fa" if fa_ahead else "|enc2d") if enc is not None else "",
                                            "" if reducer is None else
                                            "+rccl-in-graph" if getattr(reducer, "capturable", False) else "+eager-rccl(3 graphs)")
         return step_chain, (tag, "hipGraph with %s branches per step: network fwd+loss+bwd+clip+SGD on static set k%%2 | "
                             "sync-free input chain (pyramid, unprojection, 3-NN; device-side counts) of batch k+1"
                             % ("three" if enc is not None else "two")
-                            + (" | frozen 2D encoder of batch k+1" if enc is not None else
+                            + ((" | frozen 2D encoder of batch k+1" + (", then its FeatureAggregation (the network "
+                                                                       "detaches that output: nothing trainable is "
+                                                                       "upstream of it)" if fa_ahead else ""))
+                               if enc is not None else
                                (" (2D encoder in line with the network)" if hasattr(net, "net_2d") else ""))
                             + ("" if reducer is None else
                                " | gradient all-reduce (RCCL, two buckets) captured as a branch of the same graph"

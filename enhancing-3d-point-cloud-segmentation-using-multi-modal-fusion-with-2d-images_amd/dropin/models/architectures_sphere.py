@@ -16,6 +16,7 @@ except ImportError:
 
 
 class KPFCNN_featureAggre(_SegmentationLossMixin, nn.Module):
+    fa_output_detached = True      # forward() detaches the lifted features (:295): see fusion_common.lift_2d_features
 
     def __init__(self, config, lbl_values, ign_lbls):
         super(KPFCNN_featureAggre, self).__init__()

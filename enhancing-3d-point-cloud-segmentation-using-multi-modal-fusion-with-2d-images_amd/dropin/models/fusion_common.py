@@ -43,6 +43,12 @@ def lift_2d_features(net, batch, fused=None):
     fused (default: one sphere per batch): FeatureAggregation.forward_fused -- a single HIP gather
     kernel + MFMA linear layers; with several spheres the BatchNorm statistics must span all of them,
     so the per-sphere inputs are gathered first (reference op sequence) and aggregated together."""
+    ahead = getattr(batch, 'feature_2d3d', None)
+    if ahead is not None and getattr(net, 'fa_output_detached', False):
+        # the lifted features of this batch were computed ahead of the step (bench.py: beside the previous step, like the
+        # frozen encoder's and the pyramid). Sound only where the network detaches them (early / middle fusion,
+        # architectures_sphere.py:295): nothing trainable is upstream of that point, FeatureAggregation included.
+        return ahead
     images = batch.images                                   # (b, nv, 3, h, w)
     b, nv, _, h, w = images.size()
     images = images.reshape([-1] + list(images.shape[2:]))

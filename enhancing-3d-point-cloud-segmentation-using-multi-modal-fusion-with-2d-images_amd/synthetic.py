@@ -316,7 +316,8 @@ class StaticBatch:
         self.load(batch)
 
     # feature_2d: output of the frozen 2D encoder when it was run ahead of the network step
-    _DENSE = ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images', 'feature_2d')
+    # feature_2d3d: FeatureAggregation's output when it, too, was computed ahead (networks that detach it)
+    _DENSE = ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images', 'feature_2d', 'feature_2d3d')
 
     def load(self, batch):
         """Copies one freshly built batch into the static buffers (raises if a level outgrew its capacity)."""

@@ -200,6 +200,11 @@ def run_encoder_decoder(net, x, batch, encoder=None):
             block_op.skip_alias = None
             if block_i in net.encoder_skips and torch.is_grad_enabled():
                 skip_x[-1] = alias      # same values; its gradient reaches the block input through the block's own nodes
+    return run_decoder(net, x, skip_x, batch)
+
+
+def run_decoder(net, x, skip_x, batch):
+    """Decoder walk (architectures.py:332-337): nearest upsampling, concatenation with the skip features, unary."""
     joined = False
     for block_i, block_op in enumerate(net.decoder_blocks):
         if block_i in net.decoder_concats and not joined:

@@ -5,11 +5,12 @@ import torch
 import torch.nn as nn
 
 try:
-    from .architectures import (p2p_fitting_regularizer, build_encoder, build_decoder, _SegmentationLossMixin)
+    from .architectures import (p2p_fitting_regularizer, build_encoder, build_decoder, run_decoder,
+                                _SegmentationLossMixin)
     from .blocks import UnaryBlock
     from .fusion_common import build_2d_branch, lift_2d_features
 except ImportError:
-    from models.architectures import (p2p_fitting_regularizer, build_encoder, build_decoder,
+    from models.architectures import (p2p_fitting_regularizer, build_encoder, build_decoder, run_decoder,
                                       _SegmentationLossMixin)
     from models.blocks import UnaryBlock
     from models.fusion_common import build_2d_branch, lift_2d_features
@@ -52,8 +53,5 @@ class KPFCNN_featureAggre(_SegmentationLossMixin, nn.Module):
                 index += 1
             x_2d = block_op(x_2d, batch)
         x = torch.mean(torch.stack([x_3d, x_2d]), 0)
-        for block_i, block_op in enumerate(self.decoder_blocks):
-            if block_i in self.decoder_concats:
-                x = torch.cat([x, skip_x.pop()], dim=1)
-            x = block_op(x, batch)
+        x = run_decoder(self, x, skip_x, batch)
         return self.head_softmax(self.head_mlp(x, batch), batch)

@@ -471,8 +471,8 @@ def test_default_multi_gpu_step_structure_trains_like_the_single_graph_step():
     one = run({})
     plain = run({"MVK_SPLIT_TAIL": "1"})           # opt-in: grouped dW + SGD of everything above the backward cut on a side branch
     dp = run({"MVK_BENCH_FORCE_DP": "1", "MASTER_PORT": "29531"})
-    assert one["config"]["execution"] == "hipGraph[net|chain|enc2d]" and one["config"]["backend"] is None
-    assert dp["config"]["execution"] == "hipGraph[net|chain|enc2d]+eager-rccl(3 graphs)", dp["config"]["execution"]
+    assert one["config"]["execution"] == "hipGraph[net|chain|enc2d+fa]" and one["config"]["backend"] is None
+    assert dp["config"]["execution"] == "hipGraph[net|chain|enc2d+fa]+eager-rccl(3 graphs)", dp["config"]["execution"]
     assert dp["config"]["backend"] == "rccl" and dp["config"]["ranks"] == 1
     assert not one["config"]["capacity_overflow"] and not dp["config"]["capacity_overflow"]
     a, b, c = one["config"]["final_loss"], dp["config"]["final_loss"], plain["config"]["final_loss"]

@@ -12,6 +12,23 @@ ABI_VERSION = 5
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
+
+
+class BnFwdProblem(C.Structure):
+    """mvk_bn_fwd_problem (include/mvkpconv.h): the arguments of mvk_bn_lrelu_fwd for one of two paired problems."""
+    _fields_ = [("x", _vp), ("n_valid", _vp), ("R", _i64), ("D", C.c_int32), ("gamma", _vp), ("beta", _vp), ("eps", _f),
+                ("momentum", _f), ("slope", _f), ("running_mean", _vp), ("running_var", _vp), ("mean", _vp), ("invstd", _vp),
+                ("scratch2D", _vp), ("y", _vp), ("num_batches_tracked", _vp), ("addend", _vp), ("ext_part", _vp),
+                ("ext_rows", C.c_int32)]
+
+
+class BnBwdProblem(C.Structure):
+    """mvk_bn_bwd_problem: the arguments of mvk_bn_lrelu_bwd."""
+    _fields_ = [("x", _vp), ("g", _vp), ("n_valid", _vp), ("R", _i64), ("D", C.c_int32), ("gamma", _vp), ("beta", _vp),
+                ("mean", _vp), ("invstd", _vp), ("slope", _f), ("scratch", _vp), ("dgamma_dbeta", _vp), ("dx", _vp),
+                ("y_out", _vp), ("d_addend", _vp)]
+
+
 _SIGNATURES = {
     "mvk_abi_version": (C.c_int, []),
     "mvk_last_error": (C.c_char_p, []),
@@ -55,6 +72,8 @@ _SIGNATURES = {
     "mvk_bn_lrelu_fwd": (C.c_int, [_vp, _vp, _i64, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                   _vp, _i, _vp]),
     "mvk_bn_lrelu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mvk_bn_lrelu_fwd_pair": (C.c_int, [C.POINTER(BnFwdProblem), C.POINTER(BnFwdProblem), _vp]),
+    "mvk_bn_lrelu_bwd_pair": (C.c_int, [C.POINTER(BnBwdProblem), C.POINTER(BnBwdProblem), _vp]),
     "mvk_bias_lrelu_fwd": (C.c_int, [_vp, _vp, _i64, _i, _f, _vp, _vp]),
     "mvk_bias_lrelu_bwd": (C.c_int, [_vp, _vp, _i64, _i, _f, _vp, _vp, _vp]),
     "mvk_add_lrelu_fwd": (C.c_int, [_vp, _vp, _i64, _f, _vp, _vp]),

@@ -213,7 +213,7 @@ __global__ void bn_apply(const float* __restrict__ x, const int* __restrict__ n_
 }
 
 // dbeta[c] = sum g', dgamma[c] = sum g' * xhat   (g' = g through the LeakyReLU)
-__global__ __launch_bounds__(BN_T) void bn_bwd_reduce(const float* __restrict__ x, const float* __restrict__ g,
+__device__ __forceinline__ void bn_bwd_reduce_body(const float* __restrict__ x, const float* __restrict__ g,
                                                       const int* __restrict__ n_valid, int R, int D,
                                                       const float* __restrict__ mean, const float* __restrict__ invstd,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -265,6 +265,36 @@ __global__ __launch_bounds__(BN_T) void bn_bwd_reduce(const float* __restrict__ 
   }
 }
 
+__global__ __launch_bounds__(BN_T) void bn_bwd_reduce(const float* __restrict__ x, const float* __restrict__ g,
+                                                      const int* __restrict__ n_valid, int R, int D,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float slope, const float* __restrict__ yout,
+                                                      float* __restrict__ part /* [nblk,2,D] */) {
+  bn_bwd_reduce_body(x, g, n_valid, R, D, mean, invstd, gamma, beta, slope, yout, part);
+}
+
+// two independent problems of the same row count in one launch (blockIdx.z): the BatchNorm of a bottleneck block's
+// convolution and the one of its shortcut (blocks.py:596-649) -- a launch of this chain costs more than its work
+struct bn_bwd_reduce_args {
+  const float* x;
+  const float* g;
+  const int* n_valid;
+  int R;
+  int D;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  float slope;
+  const float* yout;
+  float* part;
+};
+__global__ __launch_bounds__(BN_T) void bn_bwd_reduce_pair(bn_bwd_reduce_args a0, bn_bwd_reduce_args a1) {
+  const bn_bwd_reduce_args& a = blockIdx.z ? a1 : a0;
+  bn_bwd_reduce_body(a.x, a.g, a.n_valid, a.R, a.D, a.mean, a.invstd, a.gamma, a.beta, a.slope, a.yout, a.part);
+}
+
 __global__ __launch_bounds__(1024) void bn_bwd_finish(const float* __restrict__ part, int R, int D,
                                                       float* __restrict__ dgb /* [2,D] */) {
   float a, b;
@@ -314,7 +344,7 @@ int bn_fused_gy() {
   return v;
 }
 
-__global__ __launch_bounds__(1024) void bn_finish_apply(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
+__device__ __forceinline__ void bn_finish_apply_body(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
                                                         int D, const float* __restrict__ part, float eps, float momentum,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         float slope, float* __restrict__ mean, float* __restrict__ invstd,
@@ -392,7 +422,44 @@ __global__ __launch_bounds__(1024) void bn_finish_apply(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(1024) void bn_bwd_finish_apply(const float* __restrict__ x, const float* __restrict__ g,
+__global__ __launch_bounds__(1024) void bn_finish_apply(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
+                                                        int D, const float* __restrict__ part, float eps, float momentum,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        float slope, float* __restrict__ mean, float* __restrict__ invstd,
+                                                        float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                        long long* __restrict__ nbt, const float* __restrict__ addend,
+                                                        float* __restrict__ y, int ext_rows) {
+  bn_finish_apply_body(x, n_valid, R, D, part, eps, momentum, gamma, beta, slope, mean, invstd, running_mean, running_var, nbt, addend, y, ext_rows);
+}
+
+// two independent problems of the same row count in one launch (blockIdx.z): the BatchNorm of a bottleneck block's
+// convolution and the one of its shortcut (blocks.py:596-649) -- a launch of this chain costs more than its work
+struct bn_finish_apply_args {
+  const float* x;
+  const int* n_valid;
+  int R;
+  int D;
+  const float* part;
+  float eps;
+  float momentum;
+  const float* gamma;
+  const float* beta;
+  float slope;
+  float* mean;
+  float* invstd;
+  float* running_mean;
+  float* running_var;
+  long long* nbt;
+  const float* addend;
+  float* y;
+  int ext_rows;
+};
+__global__ __launch_bounds__(1024) void bn_finish_apply_pair(bn_finish_apply_args a0, bn_finish_apply_args a1) {
+  const bn_finish_apply_args& a = blockIdx.z ? a1 : a0;
+  bn_finish_apply_body(a.x, a.n_valid, a.R, a.D, a.part, a.eps, a.momentum, a.gamma, a.beta, a.slope, a.mean, a.invstd, a.running_mean, a.running_var, a.nbt, a.addend, a.y, a.ext_rows);
+}
+
+__device__ __forceinline__ void bn_bwd_finish_apply_body(const float* __restrict__ x, const float* __restrict__ g,
                                                             const int* __restrict__ n_valid, int R, int D,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -456,6 +523,40 @@ __global__ __launch_bounds__(1024) void bn_bwd_finish_apply(const float* __restr
   }
 }
 
+__global__ __launch_bounds__(1024) void bn_bwd_finish_apply(const float* __restrict__ x, const float* __restrict__ g,
+                                                            const int* __restrict__ n_valid, int R, int D,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float slope, const float* __restrict__ part,
+                                                            const float* __restrict__ yout, float* __restrict__ d_addend,
+                                                            float* __restrict__ dgb, float* __restrict__ dx) {
+  bn_bwd_finish_apply_body(x, g, n_valid, R, D, mean, invstd, gamma, beta, slope, part, yout, d_addend, dgb, dx);
+}
+
+// two independent problems of the same row count in one launch (blockIdx.z): the BatchNorm of a bottleneck block's
+// convolution and the one of its shortcut (blocks.py:596-649) -- a launch of this chain costs more than its work
+struct bn_bwd_finish_apply_args {
+  const float* x;
+  const float* g;
+  const int* n_valid;
+  int R;
+  int D;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  float slope;
+  const float* part;
+  const float* yout;
+  float* d_addend;
+  float* dgb;
+  float* dx;
+};
+__global__ __launch_bounds__(1024) void bn_bwd_finish_apply_pair(bn_bwd_finish_apply_args a0, bn_bwd_finish_apply_args a1) {
+  const bn_bwd_finish_apply_args& a = blockIdx.z ? a1 : a0;
+  bn_bwd_finish_apply_body(a.x, a.g, a.n_valid, a.R, a.D, a.mean, a.invstd, a.gamma, a.beta, a.slope, a.part, a.yout, a.d_addend, a.dgb, a.dx);
+}
+
 bool bn_fused_finish() {
   static int v = -1;
   if (v < 0) {
@@ -486,7 +587,7 @@ __device__ __forceinline__ void block_sum2(float& a, float& b, float (*r1)[64], 
 }
 
 // grid ceil(D/64), block 1024 = 64 channels x 16 row lanes
-__global__ __launch_bounds__(1024) void bn_small_fwd(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
+__device__ __forceinline__ void bn_small_fwd_body(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
                                                      int D, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, float momentum,
                                                      float slope, float* __restrict__ running_mean,
@@ -542,7 +643,42 @@ __global__ __launch_bounds__(1024) void bn_small_fwd(const float* __restrict__ x
   }
 }
 
-__global__ __launch_bounds__(1024) void bn_small_bwd(const float* __restrict__ x, const float* __restrict__ g,
+__global__ __launch_bounds__(1024) void bn_small_fwd(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
+                                                     int D, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, float momentum,
+                                                     float slope, float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var, float* __restrict__ mean,
+                                                     float* __restrict__ invstd, float* __restrict__ y,
+                                                     long long* __restrict__ nbt, const float* __restrict__ addend) {
+  bn_small_fwd_body(x, n_valid, R, D, gamma, beta, eps, momentum, slope, running_mean, running_var, mean, invstd, y, nbt, addend);
+}
+
+// two independent problems of the same row count in one launch (blockIdx.z): the BatchNorm of a bottleneck block's
+// convolution and the one of its shortcut (blocks.py:596-649) -- a launch of this chain costs more than its work
+struct bn_small_fwd_args {
+  const float* x;
+  const int* n_valid;
+  int R;
+  int D;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  float momentum;
+  float slope;
+  float* running_mean;
+  float* running_var;
+  float* mean;
+  float* invstd;
+  float* y;
+  long long* nbt;
+  const float* addend;
+};
+__global__ __launch_bounds__(1024) void bn_small_fwd_pair(bn_small_fwd_args a0, bn_small_fwd_args a1) {
+  const bn_small_fwd_args& a = blockIdx.z ? a1 : a0;
+  bn_small_fwd_body(a.x, a.n_valid, a.R, a.D, a.gamma, a.beta, a.eps, a.momentum, a.slope, a.running_mean, a.running_var, a.mean, a.invstd, a.y, a.nbt, a.addend);
+}
+
+__device__ __forceinline__ void bn_small_bwd_body(const float* __restrict__ x, const float* __restrict__ g,
                                                      const int* __restrict__ n_valid, int R, int D,
                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -586,6 +722,39 @@ __global__ __launch_bounds__(1024) void bn_small_bwd(const float* __restrict__ x
   }
 }
 
+__global__ __launch_bounds__(1024) void bn_small_bwd(const float* __restrict__ x, const float* __restrict__ g,
+                                                     const int* __restrict__ n_valid, int R, int D,
+                                                     const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float slope, const float* __restrict__ yout,
+                                                     float* __restrict__ d_addend, float* __restrict__ dgb,
+                                                     float* __restrict__ dx) {
+  bn_small_bwd_body(x, g, n_valid, R, D, mean, invstd, gamma, beta, slope, yout, d_addend, dgb, dx);
+}
+
+// two independent problems of the same row count in one launch (blockIdx.z): the BatchNorm of a bottleneck block's
+// convolution and the one of its shortcut (blocks.py:596-649) -- a launch of this chain costs more than its work
+struct bn_small_bwd_args {
+  const float* x;
+  const float* g;
+  const int* n_valid;
+  int R;
+  int D;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  float slope;
+  const float* yout;
+  float* d_addend;
+  float* dgb;
+  float* dx;
+};
+__global__ __launch_bounds__(1024) void bn_small_bwd_pair(bn_small_bwd_args a0, bn_small_bwd_args a1) {
+  const bn_small_bwd_args& a = blockIdx.z ? a1 : a0;
+  bn_small_bwd_body(a.x, a.g, a.n_valid, a.R, a.D, a.mean, a.invstd, a.gamma, a.beta, a.slope, a.yout, a.d_addend, a.dgb, a.dx);
+}
+
 // ---- the same single-launch BatchNorm for 129..1024 rows and D % 4 == 0, latency-shaped: a workgroup owns 16
 // channels (4 quads x 256 row lanes), a thread holds ALL its rows (at most 4) of x (and g, y) as float4 in
 // registers -- one round of loads, a reduction over the 256 row lanes (wave shuffles, then 16 partials through LDS),
@@ -627,7 +796,7 @@ __device__ __forceinline__ void mid_sum(float4& a, float4& b, float4 (*ra)[4], f
 }
 
 // grid ceil(D/16), block 1024 = 4 channel quads x 256 row lanes; R <= BN_MID_MAX
-__global__ __launch_bounds__(1024) void bn_mid_fwd(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
+__device__ __forceinline__ void bn_mid_fwd_body(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
                                                    int D, const float* __restrict__ gamma,
                                                    const float* __restrict__ beta, float eps, float momentum,
                                                    float slope, float* __restrict__ running_mean,
@@ -709,7 +878,42 @@ __global__ __launch_bounds__(1024) void bn_mid_fwd(const float* __restrict__ x, 
   }
 }
 
-__global__ __launch_bounds__(1024) void bn_mid_bwd(const float* __restrict__ x, const float* __restrict__ g,
+__global__ __launch_bounds__(1024) void bn_mid_fwd(const float* __restrict__ x, const int* __restrict__ n_valid, int R,
+                                                   int D, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps, float momentum,
+                                                   float slope, float* __restrict__ running_mean,
+                                                   float* __restrict__ running_var, float* __restrict__ mean,
+                                                   float* __restrict__ invstd, float* __restrict__ y,
+                                                   long long* __restrict__ nbt, const float* __restrict__ addend) {
+  bn_mid_fwd_body(x, n_valid, R, D, gamma, beta, eps, momentum, slope, running_mean, running_var, mean, invstd, y, nbt, addend);
+}
+
+// two independent problems of the same row count in one launch (blockIdx.z): the BatchNorm of a bottleneck block's
+// convolution and the one of its shortcut (blocks.py:596-649) -- a launch of this chain costs more than its work
+struct bn_mid_fwd_args {
+  const float* x;
+  const int* n_valid;
+  int R;
+  int D;
+  const float* gamma;
+  const float* beta;
+  float eps;
+  float momentum;
+  float slope;
+  float* running_mean;
+  float* running_var;
+  float* mean;
+  float* invstd;
+  float* y;
+  long long* nbt;
+  const float* addend;
+};
+__global__ __launch_bounds__(1024) void bn_mid_fwd_pair(bn_mid_fwd_args a0, bn_mid_fwd_args a1) {
+  const bn_mid_fwd_args& a = blockIdx.z ? a1 : a0;
+  bn_mid_fwd_body(a.x, a.n_valid, a.R, a.D, a.gamma, a.beta, a.eps, a.momentum, a.slope, a.running_mean, a.running_var, a.mean, a.invstd, a.y, a.nbt, a.addend);
+}
+
+__device__ __forceinline__ void bn_mid_bwd_body(const float* __restrict__ x, const float* __restrict__ g,
                                                    const int* __restrict__ n_valid, int R, int D,
                                                    const float* __restrict__ mean, const float* __restrict__ invstd,
                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -768,6 +972,39 @@ __global__ __launch_bounds__(1024) void bn_mid_bwd(const float* __restrict__ x, 
       if (d_addend) *reinterpret_cast<float4*>(d_addend + (int64_t)r * D + c) = go;
     }
   }
+}
+
+__global__ __launch_bounds__(1024) void bn_mid_bwd(const float* __restrict__ x, const float* __restrict__ g,
+                                                   const int* __restrict__ n_valid, int R, int D,
+                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                   float slope, const float* __restrict__ yout,
+                                                   float* __restrict__ d_addend, float* __restrict__ dgb,
+                                                   float* __restrict__ dx) {
+  bn_mid_bwd_body(x, g, n_valid, R, D, mean, invstd, gamma, beta, slope, yout, d_addend, dgb, dx);
+}
+
+// two independent problems of the same row count in one launch (blockIdx.z): the BatchNorm of a bottleneck block's
+// convolution and the one of its shortcut (blocks.py:596-649) -- a launch of this chain costs more than its work
+struct bn_mid_bwd_args {
+  const float* x;
+  const float* g;
+  const int* n_valid;
+  int R;
+  int D;
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  float slope;
+  const float* yout;
+  float* d_addend;
+  float* dgb;
+  float* dx;
+};
+__global__ __launch_bounds__(1024) void bn_mid_bwd_pair(bn_mid_bwd_args a0, bn_mid_bwd_args a1) {
+  const bn_mid_bwd_args& a = blockIdx.z ? a1 : a0;
+  bn_mid_bwd_body(a.x, a.g, a.n_valid, a.R, a.D, a.mean, a.invstd, a.gamma, a.beta, a.slope, a.yout, a.d_addend, a.dgb, a.dx);
 }
 
 // ---- y = LeakyReLU(a + b) (the residual join of ResnetBottleneckBlock, blocks.py:649) in one launch
@@ -909,6 +1146,128 @@ extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n
   hipLaunchKernelGGL(bn_bwd_finish, dim3((unsigned)cdiv64(D, 64)), dim3(1024), 0, st, scratch, (int)R, D, dgamma_dbeta);
   hipLaunchKernelGGL(bn_bwd_apply, dim3((unsigned)cdiv64(R * D, 256)), dim3(256), 0, st, x, g, n_valid, (int)R, D, mean,
                      invstd, gamma, beta, slope, dgamma_dbeta, y_out, d_addend, dx);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- two BatchNorm problems of the same row count per launch (include/mvkpconv.h: mvk_bn_fwd_problem / _bwd_problem).
+// A bottleneck block normalises its convolution output and its shortcut (blocks.py:596-649) independently; issued as a
+// pair they cost one launch each way instead of two (three instead of five... for the two-launch backward of the big
+// levels). Problems that fall into different kernel families (row count, alignment) run one after the other.
+namespace {
+
+int bn_family_fwd(const mvk_bn_fwd_problem& p) {
+  if (p.R <= bn_small_rows()) return 0;
+  if (p.R <= bn_mid_rows() && p.D % 4 == 0 &&
+      aligned16(p.x, p.y, p.addend, p.gamma, p.beta, p.mean, p.invstd, p.running_mean) &&
+      aligned16(p.running_var, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))
+    return 1;
+  return 2;
+}
+
+int bn_family_bwd(const mvk_bn_bwd_problem& p) {
+  if (p.R <= bn_small_rows()) return 0;
+  if (p.R <= bn_mid_rows() && p.D % 4 == 0 &&
+      aligned16(p.x, p.g, p.y_out, p.d_addend, p.dgamma_dbeta, p.dx, p.mean, p.invstd) &&
+      aligned16(p.gamma, p.beta, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr))
+    return 1;
+  return 2;
+}
+
+int bn_fwd_single(const mvk_bn_fwd_problem& p, void* stream) {
+  return mvk_bn_lrelu_fwd(p.x, p.n_valid, p.R, p.D, p.gamma, p.beta, p.eps, p.momentum, p.slope, p.running_mean,
+                          p.running_var, p.mean, p.invstd, p.scratch2D, p.y, p.num_batches_tracked, p.addend, p.ext_part,
+                          p.ext_rows, stream);
+}
+
+int bn_bwd_single(const mvk_bn_bwd_problem& p, void* stream) {
+  return mvk_bn_lrelu_bwd(p.x, p.g, p.n_valid, p.R, p.D, p.gamma, p.beta, p.mean, p.invstd, p.slope, p.scratch,
+                          p.dgamma_dbeta, p.dx, p.y_out, p.d_addend, stream);
+}
+
+}  // namespace
+
+extern "C" int mvk_bn_lrelu_fwd_pair(const mvk_bn_fwd_problem* pa, const mvk_bn_fwd_problem* pb, void* stream) {
+  MVK_REQUIRE(pa && pb, "bn pair: null problem");
+  const mvk_bn_fwd_problem &a = *pa, &b = *pb;
+  const int fam = bn_family_fwd(a);
+  if (a.R != b.R || a.R <= 0 || fam != bn_family_fwd(b) || (fam == 2 && !bn_fused_finish())) {
+    if (int e = bn_fwd_single(a, stream)) return e;
+    return bn_fwd_single(b, stream);
+  }
+  MVK_REQUIRE(a.D > 0 && b.D > 0 && a.R < (1ll << 31), "bn: bad sizes");
+  MVK_REQUIRE((a.ext_part == nullptr) == (a.ext_rows == 0) && (b.ext_part == nullptr) == (b.ext_rows == 0),
+              "bn: ext_part and ext_rows go together");
+  hipStream_t st = (hipStream_t)stream;
+  const int R = (int)a.R, Dm = a.D > b.D ? a.D : b.D;
+  if (fam == 0) {
+    bn_small_fwd_args k0{a.x, a.n_valid, R, a.D, a.gamma, a.beta, a.eps, a.momentum, a.slope, a.running_mean, a.running_var,
+                         a.mean, a.invstd, a.y, (long long*)a.num_batches_tracked, a.addend};
+    bn_small_fwd_args k1{b.x, b.n_valid, R, b.D, b.gamma, b.beta, b.eps, b.momentum, b.slope, b.running_mean, b.running_var,
+                         b.mean, b.invstd, b.y, (long long*)b.num_batches_tracked, b.addend};
+    hipLaunchKernelGGL(bn_small_fwd_pair, dim3((unsigned)cdiv64(Dm, 64), 1, 2), dim3(1024), 0, st, k0, k1);
+  } else if (fam == 1) {
+    bn_mid_fwd_args k0{a.x, a.n_valid, R, a.D, a.gamma, a.beta, a.eps, a.momentum, a.slope, a.running_mean, a.running_var,
+                       a.mean, a.invstd, a.y, (long long*)a.num_batches_tracked, a.addend};
+    bn_mid_fwd_args k1{b.x, b.n_valid, R, b.D, b.gamma, b.beta, b.eps, b.momentum, b.slope, b.running_mean, b.running_var,
+                       b.mean, b.invstd, b.y, (long long*)b.num_batches_tracked, b.addend};
+    hipLaunchKernelGGL(bn_mid_fwd_pair, dim3((unsigned)cdiv64(Dm, 16), 1, 2), dim3(1024), 0, st, k0, k1);
+  } else {
+    const unsigned gyr = (unsigned)cdiv64(R, BN_ROWS);
+    for (const mvk_bn_fwd_problem* p : {pa, pb})
+      if (p->ext_part == nullptr)       // no statistics from the producing GEMM (a split reduction): its own pass
+        hipLaunchKernelGGL(bn_stats_partial, dim3((unsigned)cdiv64(p->D, 64), gyr), dim3(BN_T), 0, st, p->x, p->n_valid, R,
+                           p->D, p->scratch2D);
+    const unsigned gy = gyr < (unsigned)bn_fused_gy() ? gyr : (unsigned)bn_fused_gy();
+    bn_finish_apply_args k0{a.x, a.n_valid, R, a.D, a.ext_part ? a.ext_part : a.scratch2D, a.eps, a.momentum, a.gamma, a.beta,
+                            a.slope, a.mean, a.invstd, a.running_mean, a.running_var, (long long*)a.num_batches_tracked,
+                            a.addend, a.y, a.ext_rows};
+    bn_finish_apply_args k1{b.x, b.n_valid, R, b.D, b.ext_part ? b.ext_part : b.scratch2D, b.eps, b.momentum, b.gamma, b.beta,
+                            b.slope, b.mean, b.invstd, b.running_mean, b.running_var, (long long*)b.num_batches_tracked,
+                            b.addend, b.y, b.ext_rows};
+    hipLaunchKernelGGL(bn_finish_apply_pair, dim3((unsigned)cdiv64(Dm, 64), gy, 2), dim3(1024), 0, st, k0, k1);
+  }
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mvk_bn_lrelu_bwd_pair(const mvk_bn_bwd_problem* pa, const mvk_bn_bwd_problem* pb, void* stream) {
+  MVK_REQUIRE(pa && pb, "bn pair: null problem");
+  const mvk_bn_bwd_problem &a = *pa, &b = *pb;
+  const int fam = bn_family_bwd(a);
+  if (a.R != b.R || a.R <= 0 || fam != bn_family_bwd(b) || (fam == 2 && !bn_fused_finish())) {
+    if (int e = bn_bwd_single(a, stream)) return e;
+    return bn_bwd_single(b, stream);
+  }
+  MVK_REQUIRE(a.D > 0 && b.D > 0 && a.R < (1ll << 31), "bn: bad sizes");
+  MVK_REQUIRE((a.y_out == nullptr) == (a.d_addend == nullptr) && (b.y_out == nullptr) == (b.d_addend == nullptr),
+              "bn: y_out and d_addend go together (residual-join mode)");
+  hipStream_t st = (hipStream_t)stream;
+  const int R = (int)a.R, Dm = a.D > b.D ? a.D : b.D;
+  if (fam == 0) {
+    bn_small_bwd_args k0{a.x, a.g, a.n_valid, R, a.D, a.mean, a.invstd, a.gamma, a.beta, a.slope, a.y_out, a.d_addend,
+                         a.dgamma_dbeta, a.dx};
+    bn_small_bwd_args k1{b.x, b.g, b.n_valid, R, b.D, b.mean, b.invstd, b.gamma, b.beta, b.slope, b.y_out, b.d_addend,
+                         b.dgamma_dbeta, b.dx};
+    hipLaunchKernelGGL(bn_small_bwd_pair, dim3((unsigned)cdiv64(Dm, 64), 1, 2), dim3(1024), 0, st, k0, k1);
+  } else if (fam == 1) {
+    bn_mid_bwd_args k0{a.x, a.g, a.n_valid, R, a.D, a.mean, a.invstd, a.gamma, a.beta, a.slope, a.y_out, a.d_addend,
+                       a.dgamma_dbeta, a.dx};
+    bn_mid_bwd_args k1{b.x, b.g, b.n_valid, R, b.D, b.mean, b.invstd, b.gamma, b.beta, b.slope, b.y_out, b.d_addend,
+                       b.dgamma_dbeta, b.dx};
+    hipLaunchKernelGGL(bn_mid_bwd_pair, dim3((unsigned)cdiv64(Dm, 16), 1, 2), dim3(1024), 0, st, k0, k1);
+  } else {
+    const unsigned gyr = (unsigned)cdiv64(R, BN_ROWS);
+    bn_bwd_reduce_args r0{a.x, a.g, a.n_valid, R, a.D, a.mean, a.invstd, a.gamma, a.beta, a.slope, a.y_out, a.scratch};
+    bn_bwd_reduce_args r1{b.x, b.g, b.n_valid, R, b.D, b.mean, b.invstd, b.gamma, b.beta, b.slope, b.y_out, b.scratch};
+    hipLaunchKernelGGL(bn_bwd_reduce_pair, dim3((unsigned)cdiv64(Dm, 64), gyr, 2), dim3(BN_T), 0, st, r0, r1);
+    const unsigned gy = gyr < (unsigned)bn_fused_gy() ? gyr : (unsigned)bn_fused_gy();
+    bn_bwd_finish_apply_args k0{a.x, a.g, a.n_valid, R, a.D, a.mean, a.invstd, a.gamma, a.beta, a.slope, a.scratch, a.y_out,
+                                a.d_addend, a.dgamma_dbeta, a.dx};
+    bn_bwd_finish_apply_args k1{b.x, b.g, b.n_valid, R, b.D, b.mean, b.invstd, b.gamma, b.beta, b.slope, b.scratch, b.y_out,
+                                b.d_addend, b.dgamma_dbeta, b.dx};
+    hipLaunchKernelGGL(bn_bwd_finish_apply_pair, dim3((unsigned)cdiv64(Dm, 64), gy, 2), dim3(1024), 0, st, k0, k1);
+  }
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -31,6 +31,7 @@ _GEMM_STATS = os.environ.get("MVK_GEMM_STATS", "1") == "1"  # BatchNorm statisti
 _FUSE_FANOUT = os.environ.get("MVK_FUSE_FANOUT", "1") == "1"    # the two gradients of a block's input summed inside unary1's backward GEMM
 _FUSED_BIAS = os.environ.get("MVK_FUSED_BIAS", "1") == "1"      # bias + LeakyReLU of the BatchNorm-less layers in one launch
 _FUSED_OPERANDS = os.environ.get("MVK_FUSED_DEFORM_OPERANDS", "1") == "1"   # development switch: 0 = the tensor ops
+_BN_PAIR = os.environ.get("MVK_BN_PAIR", "1") == "1"            # a block's two independent BatchNorms (convolution, shortcut) as one launch each way
 _ORDER_LOOKUP = os.environ.get("MVK_GATHER_ORDER", "1") != "0"   # gather work lists found by their points tensor (ops.work_order_for)
 
 
@@ -350,8 +351,7 @@ class ResnetBottleneckBlock(nn.Module):
         else:
             x = self.unary1(features)
         nv = _bn_rows(q_pts, self, self.use_bn) if _GEMM_STATS else None
-        x = self.batch_norm_conv(self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv,
-                                             order=_work_order(self.block_name, self.layer_ind, batch)), 0.1)
+        conv = self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv, order=_work_order(self.block_name, self.layer_ind, batch))
         self.skip_alias = None
         if 'strided' in self.block_name and _FUSE_FANOUT and features.is_cuda:
             # the block's input is also the decoder's skip tensor (architectures.py:328-329): the alias handed out here
@@ -359,7 +359,17 @@ class ResnetBottleneckBlock(nn.Module):
             shortcut, self.skip_alias = ops.max_pool(features, inds, passthrough=True)
         else:
             shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
-        shortcut = self.unary_shortcut(shortcut)
+        us = self.unary_shortcut
+        n_valid = _bn_rows(conv, self, self.use_bn) if (_BN_PAIR and _HIP_BN and _MFMA_LINEAR) else None
+        if n_valid is not None and isinstance(us, UnaryBlock) and us.use_bn:
+            # the BatchNorm of the convolution and the one of the shortcut are independent problems over the same rows:
+            # one launch each way for the pair (ops.bn_lrelu_pair)
+            ys = ops.linear(shortcut, us.mlp.weight, stats_n_valid=n_valid if _GEMM_STATS else None)
+            x, shortcut = ops.bn_lrelu_pair(conv, self.batch_norm_conv.batch_norm, 0.1, ys, us.batch_norm.batch_norm, 1.0,
+                                            n_valid)
+        else:
+            x = self.batch_norm_conv(conv, 0.1)
+            shortcut = us(shortcut)
         if _FUSE_ADD:       # x = unary2(x); return leaky_relu(x + shortcut)  (blocks.py:644-649), join fused
             return self.unary2(x, join=(shortcut, 0.1))
         return self.leaky_relu(self.unary2(x) + shortcut)

@@ -1053,6 +1053,80 @@ def bn_lrelu(x, n_valid, bn, slope=1.0, addend=None):
                             bn_stats_of(x))
 
 
+class _BNLReLUPairFn(torch.autograd.Function):
+    """Two masked BatchNorm (+ LeakyReLU) problems of the same row count, one launch each way (mvk_bn_lrelu_fwd_pair /
+    _bwd_pair): the convolution output and the shortcut of a bottleneck block. No residual addend in either."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, n_valid, ga, ba, rma, rva, gb, bb, rmb, rvb, cfg_a, cfg_b, nbt_a, nbt_b, ext_a, ext_b):
+        from ._lib import BnFwdProblem
+        _dev(xa, xb, n_valid, ga, ba, gb, bb)
+        xa, xb = _f32c(xa), _f32c(xb)
+        if xa.shape[0] != xb.shape[0]:
+            raise RuntimeError("bn_lrelu_pair: the two inputs differ in rows")
+        R = xa.shape[0]
+        probs, keep = [], []
+        for x, g, b, rm, rv, (eps, mom, slope), nbt, ext in ((xa, ga, ba, rma, rva, cfg_a, nbt_a, ext_a),
+                                                              (xb, gb, bb, rmb, rvb, cfg_b, nbt_b, ext_b)):
+            D = x.shape[1]
+            y = torch.empty_like(x)
+            mean = torch.empty(D, device=x.device, dtype=torch.float32)
+            invstd = torch.empty(D, device=x.device, dtype=torch.float32)
+            ext_part, ext_rows = ext if ext is not None else (None, 0)
+            if ext_part is not None and (ext_part.shape[2] != D or ext_part.shape[0] != (R + ext_rows - 1) // ext_rows):
+                raise RuntimeError("bn_lrelu_pair: the statistics partials do not belong to this tensor")
+            scratch = None if ext_part is not None else torch.empty(((R + 63) // 64) * 2 * D, device=x.device,
+                                                                    dtype=torch.float32)
+            probs.append(BnFwdProblem(_p(x), _p(n_valid), R, D, _p(g), _p(b), float(eps), float(mom), float(slope), _p(rm),
+                                      _p(rv), _p(mean), _p(invstd), _p(scratch), _p(y), _p(nbt), None, _p(ext_part),
+                                      int(ext_rows)))
+            keep.append((y, mean, invstd, scratch))
+        check(lib().mvk_bn_lrelu_fwd_pair(C.byref(probs[0]), C.byref(probs[1]), _stream()))
+        ctx.save_for_backward(xa, xb, n_valid, ga, ba, gb, bb, keep[0][1], keep[0][2], keep[1][1], keep[1][2])
+        ctx.slopes = (float(cfg_a[2]), float(cfg_b[2]))
+        ctx.set_materialize_grads(False)
+        return keep[0][0], keep[1][0]
+
+    @staticmethod
+    def backward(ctx, g_a, g_b):
+        from ._lib import BnBwdProblem
+        xa, xb, n_valid, ga, ba, gb, bb, mean_a, is_a, mean_b, is_b = ctx.saved_tensors
+        R = xa.shape[0]
+        sets = []
+        for x, g, gam, bet, mean, istd, slope in ((xa, g_a, ga, ba, mean_a, is_a, ctx.slopes[0]),
+                                                  (xb, g_b, gb, bb, mean_b, is_b, ctx.slopes[1])):
+            if g is None:
+                g = torch.zeros_like(x)
+            g = _f32c(g)
+            D = x.shape[1]
+            dgb = torch.empty(2 * D, device=x.device, dtype=torch.float32)
+            scratch = torch.empty(((R + 63) // 64) * 2 * D, device=x.device, dtype=torch.float32)
+            dx = torch.empty_like(x)
+            sets.append((BnBwdProblem(_p(x), _p(g), _p(n_valid), R, D, _p(gam), _p(bet), _p(mean), _p(istd), float(slope),
+                                      _p(scratch), _p(dgb), _p(dx), None, None), dgb, dx, g, scratch))
+        check(lib().mvk_bn_lrelu_bwd_pair(C.byref(sets[0][0]), C.byref(sets[1][0]), _stream()))
+        (_, dgb_a, dx_a, _, _), (_, dgb_b, dx_b, _, _) = sets
+        Da, Db = xa.shape[1], xb.shape[1]
+        return (dx_a, dx_b, None, dgb_a[Da:], dgb_a[:Da], None, None, dgb_b[Db:], dgb_b[:Db], None, None, None, None, None,
+                None, None, None)
+
+
+def bn_lrelu_pair(xa, bn_a, slope_a, xb, bn_b, slope_b, n_valid):
+    """(bn_lrelu(xa, n_valid, bn_a, slope_a), bn_lrelu(xb, n_valid, bn_b, slope_b)) as ONE launch each way: two inputs of
+    the same row count normalised independently (the convolution and the shortcut of a bottleneck block)."""
+    def unpack(bn):
+        nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None
+        return nbt, (bn.eps, bn.momentum if bn.momentum is not None else 0.0)
+    if not (bn_a.training and bn_b.training):
+        raise RuntimeError("masked BatchNorm is a training-mode op; use nn.BatchNorm1d in eval mode")
+    nbt_a, (eps_a, mom_a) = unpack(bn_a)
+    nbt_b, (eps_b, mom_b) = unpack(bn_b)
+    return _BNLReLUPairFn.apply(xa, xb, n_valid, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var,
+                                bn_b.weight, bn_b.bias, bn_b.running_mean, bn_b.running_var,
+                                (eps_a, mom_a, slope_a), (eps_b, mom_b, slope_b), nbt_a, nbt_b,
+                                bn_stats_of(xa), bn_stats_of(xb))
+
+
 class _AddLReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, slope):

@@ -280,6 +280,23 @@ int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n_valid, int
                      const float* y_out /* forward output, needed (with d_addend) when the forward had an addend */,
                      float* d_addend /* [R,D] gradient of the addend, or NULL */, void* stream);
 
+/* Two BatchNorm problems of the SAME row count in one launch each way (same kernels, the problem picked by blockIdx.z):
+ * a bottleneck block's convolution output and its shortcut (blocks.py:596-649) are normalised independently. The
+ * fields are the arguments of mvk_bn_lrelu_fwd / _bwd; problems that do not share a kernel family (row count,
+ * alignment) run one after the other. */
+typedef struct mvk_bn_fwd_problem {
+  const float* x; const int32_t* n_valid; int64_t R; int32_t D; const float* gamma; const float* beta;
+  float eps, momentum, slope; float* running_mean; float* running_var; float* mean; float* invstd; float* scratch2D;
+  float* y; int64_t* num_batches_tracked; const float* addend; const float* ext_part; int32_t ext_rows;
+} mvk_bn_fwd_problem;
+typedef struct mvk_bn_bwd_problem {
+  const float* x; const float* g; const int32_t* n_valid; int64_t R; int32_t D; const float* gamma; const float* beta;
+  const float* mean; const float* invstd; float slope; float* scratch; float* dgamma_dbeta; float* dx;
+  const float* y_out; float* d_addend;
+} mvk_bn_bwd_problem;
+int mvk_bn_lrelu_fwd_pair(const mvk_bn_fwd_problem* a, const mvk_bn_fwd_problem* b, void* stream);
+int mvk_bn_lrelu_bwd_pair(const mvk_bn_bwd_problem* a, const mvk_bn_bwd_problem* b, void* stream);
+
 /* y = LeakyReLU_slope(x + bias) over rows of C <= 256 channels: the BatchNorm-less form of BatchNormBlock
  * (models/blocks.py:462-463) fused with the LeakyReLU that follows it in UnaryBlock (:493-498) -- the two head layers.
  * _bwd: dx = g * (y > 0 ? 1 : slope) and dbias += column sums of dx (dbias zero-initialised by the caller; one float

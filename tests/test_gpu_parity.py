@@ -382,6 +382,55 @@ def test_upsample_cat_equals_closest_pool_then_cat(ops, C1, C2, idt):
     assert rel_err(x.grad.cpu().numpy(), x2.grad.cpu().numpy()) < 1e-6       # float atomics: order of arrival
 
 
+@pytest.mark.parametrize("R,Da,Db,from_gemm", [(85, 128, 512, False), (700, 64, 256, False), (700, 30, 64, False),
+                                               (5000, 32, 128, False), (5000, 64, 128, True), (19464, 32, 128, True)])
+def test_bn_lrelu_pair_equals_two_single_launches(ops, R, Da, Db, from_gemm):
+    """mvk_bn_lrelu_fwd_pair / _bwd_pair: the same kernels, two problems per launch (the convolution output and the
+    shortcut of a bottleneck block) -- outputs, running statistics, batch counters and all gradients bit-identical to
+    two calls of bn_lrelu, in every kernel family (one workgroup per channel group <= 128 rows, register-resident
+    <= 1024 rows, two-stage above; statistics from the producing GEMM's epilogue or from the extra pass), capacity
+    padding included."""
+    rng = np.random.default_rng(R + Da)
+    n_valid = T(np.asarray([R - 37 if R > 100 else R], np.int32))
+
+    def make():
+        torch.manual_seed(1)
+        bns = [torch.nn.BatchNorm1d(D, momentum=0.02).cuda().train() for D in (Da, Db)]
+        for bn in bns:
+            bn.weight.data.uniform_(0.5, 1.5)
+            bn.bias.data.uniform_(-0.3, 0.3)
+        return bns
+
+    if from_gemm:       # inputs that carry the epilogue statistics of the GEMM that made them
+        A = T(rng.normal(size=(R, 96)).astype(np.float32))
+        Wa, Wb = T(rng.normal(size=(Da, 96)).astype(np.float32)), T(rng.normal(size=(Db, 96)).astype(np.float32))
+        inputs = lambda: (ops.linear(A, Wa, stats_n_valid=n_valid), ops.linear(A, Wb, stats_n_valid=n_valid))
+    else:
+        Xa, Xb = T(rng.normal(size=(R, Da)).astype(np.float32)), T(rng.normal(size=(R, Db)).astype(np.float32) * 3 + 1)
+        inputs = lambda: (Xa.clone(), Xb.clone())
+    ga, gb = T(rng.normal(size=(R, Da)).astype(np.float32)), T(rng.normal(size=(R, Db)).astype(np.float32))
+
+    bn1 = make()
+    xa, xb = [t.detach().requires_grad_(True) for t in inputs()]
+    xa._mvk_bn_stats, xb._mvk_bn_stats = [getattr(t, "_mvk_bn_stats", None) for t in inputs()] if from_gemm else (None, None)
+    ya = ops.bn_lrelu(xa, n_valid, bn1[0], 0.1)
+    yb = ops.bn_lrelu(xb, n_valid, bn1[1], 1.0)
+    ((ya * ga).sum() + (yb * gb).sum()).backward()
+
+    bn2 = make()
+    pa, pb = [t.detach().requires_grad_(True) for t in inputs()]
+    pa._mvk_bn_stats, pb._mvk_bn_stats = [getattr(t, "_mvk_bn_stats", None) for t in inputs()] if from_gemm else (None, None)
+    za, zb = ops.bn_lrelu_pair(pa, bn2[0], 0.1, pb, bn2[1], 1.0, n_valid)
+    ((za * ga).sum() + (zb * gb).sum()).backward()
+
+    assert torch.equal(za, ya) and torch.equal(zb, yb)
+    assert torch.equal(pa.grad, xa.grad) and torch.equal(pb.grad, xb.grad)
+    for m1, m2 in zip(bn1, bn2):
+        assert torch.equal(m1.running_mean, m2.running_mean) and torch.equal(m1.running_var, m2.running_var)
+        assert int(m1.num_batches_tracked) == int(m2.num_batches_tracked) == 1
+        assert torch.equal(m1.weight.grad, m2.weight.grad) and torch.equal(m1.bias.grad, m2.bias.grad)
+
+
 def test_cell_order_of_the_neighbour_search_is_a_sorted_permutation(ops):
     """mvk_neighbors_cell_order after a radius search over three stacked clouds: a permutation of the rows that stays
     inside each cloud, ascending in the grid cell of the search (cell = 1.001 r from the cloud's minimum corner,

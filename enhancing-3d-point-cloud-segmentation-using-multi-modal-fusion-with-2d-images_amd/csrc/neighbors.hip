@@ -152,8 +152,8 @@ __global__ __launch_bounds__(TPB) void nb_build_kernel(const float* __restrict__
 
 // Work list for the KPConv gather out of a built grid: the stacked support rows sorted by (cloud, cell, row) -- the
 // record order of the counting sort with the rows of a cell put in ascending order (the scatter's atomics leave them in
-// arrival order; a cell holds a dozen rows), so the list is the same on every run. One workgroup per cloud, one
-// thread per cell; the last cloud's workgroup appends the identity for the rows up to order_cap (capacity padding).
+// arrival order; a cell holds a dozen rows), so the list is the same on every run. Up to 32 workgroups per cloud, one
+// thread per cell; the last cloud's first workgroup appends the identity for the rows up to order_cap (capacity padding).
 __global__ __launch_bounds__(TPB) void nb_cell_order_kernel(NbWs W, int B, int* __restrict__ order, int64_t order_cap) {
   const int b = blockIdx.x, tid = threadIdx.x;
   int off = 0, n;
@@ -167,19 +167,34 @@ __global__ __launch_bounds__(TPB) void nb_cell_order_kernel(NbWs W, int B, int* 
   const CloudGrid G = W.grids[b];
   const int ncell = G.dims[0] * G.dims[1] * G.dims[2];
   const int* cstart = W.cell_start + G.cell_base;
-  for (int c = tid; c < ncell; c += TPB) {
-    const int beg = cstart[c], end = cstart[c + 1];
-    for (int j = beg; j < end; ++j) {
-      const int v = __float_as_int(W.recs[off + j].w);
-      int k = j;
-      while (k > beg && order[off + k - 1] > v) {
-        order[off + k] = order[off + k - 1];
-        --k;
+  constexpr int CO_REG = 16;      // rows of a cell sorted in registers (a cell of the conv grid holds about a dozen)
+  for (int c = blockIdx.y * TPB + tid; c < ncell; c += gridDim.y * TPB) {      // (a cloud's cells over gridDim.y workgroups)
+    const int beg = cstart[c], end = cstart[c + 1], m = end - beg;
+    if (m <= CO_REG) {
+      // all loads, then the rank of every row among the cell's rows, then all stores: no dependent round trips
+      int v[CO_REG];
+#pragma unroll
+      for (int i = 0; i < CO_REG; ++i) v[i] = i < m ? __float_as_int(W.recs[off + beg + i].w) : 0x7fffffff;
+#pragma unroll
+      for (int i = 0; i < CO_REG; ++i) {
+        int rank = 0;
+#pragma unroll
+        for (int j = 0; j < CO_REG; ++j) rank += v[j] < v[i] ? 1 : 0;      // rows are distinct; the fillers are largest
+        if (i < m) order[off + beg + rank] = v[i];
       }
-      order[off + k] = v;
+    } else {
+      for (int j = beg; j < end; ++j) {
+        const int v = __float_as_int(W.recs[off + j].w);
+        int k = j;
+        while (k > beg && order[off + k - 1] > v) {
+          order[off + k] = order[off + k - 1];
+          --k;
+        }
+        order[off + k] = v;
+      }
     }
   }
-  if (b == B - 1)
+  if (b == B - 1 && blockIdx.y == 0)
     for (int64_t i = (int64_t)off + n + tid; i < order_cap; i += TPB) order[i] = (int)i;
 }
 
@@ -482,7 +497,11 @@ extern "C" int mvk_neighbors_cell_order(int64_t Ns, int B, const int32_t* s_lens
   int* hdr = cv.take<int>(4 + 2 * (B + 1));
   W.soffs = hdr + 4 + B + 1;
   W.s_lens = s_lens_dev;
-  hipLaunchKernelGGL(nb_cell_order_kernel, dim3(B), dim3(TPB), 0, (hipStream_t)stream, W, B, order_out, order_cap);
+  // a thread's cells are chains of dependent loads (cell range -> records -> stores): one workgroup per cloud took
+  // 150 us on the level-0 grid of a 19 464-point sphere (15 cells per thread, one after the other)
+  const unsigned chunks = (unsigned)((cell_cap(Ns) / B + TPB - 1) / TPB < 32 ? (cell_cap(Ns) / B + TPB - 1) / TPB : 32);
+  hipLaunchKernelGGL(nb_cell_order_kernel, dim3(B, chunks ? chunks : 1), dim3(TPB), 0, (hipStream_t)stream, W, B, order_out,
+                     order_cap);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -345,6 +345,10 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                 batch.feature_2d3d = held
 
         batch0.feature_2d3d = aggregate(batch0)
+        # early fusion's forward starts with cat(feature_3d, feature_2d3d) (:290-291): made on the branch as well
+        stack_ahead = cfg.variant == "early" and os.environ.get("MVK_STACK_AHEAD", "1") == "1"
+        if stack_ahead:
+            batch0.stacked_features = torch.cat((batch0.feature_3d, batch0.feature_2d3d), dim=1)
     # Row capacities of levels 1..: the level sizes move by about +-8 % with the random grid orientation, so one
     # batch is not a safe yardstick -- take the largest of a few draws, plus 10 %, rounded up to 64 rows
     # (distinct per level: the masked BatchNorm finds its row-count word by capacity).
@@ -434,7 +438,10 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             if fa_ahead:        # needs both: the encoder's features and the chain's 3-NN pixels of batch k+1
                 enc_stream.wait_stream(build_stream)
                 with torch.cuda.stream(enc_stream):
-                    other.feature_2d3d.copy_(aggregate(other))
+                    if stack_ahead:     # the network's input features in one go: [feature_3d | lifted features]
+                        torch.cat((other.feature_3d, aggregate(other)), dim=1, out=other.stacked_features)
+                    else:
+                        other.feature_2d3d.copy_(aggregate(other))
 
         def join_encoder():
             if enc is not None:

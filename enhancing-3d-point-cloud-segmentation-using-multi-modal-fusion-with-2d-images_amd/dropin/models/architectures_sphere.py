@@ -32,8 +32,10 @@ class KPFCNN_featureAggre(_SegmentationLossMixin, nn.Module):
         build_2d_branch(self, config)
 
     def forward(self, batch, config):
-        feature_2d3d = lift_2d_features(self, batch)                       # (np, 64)
-        stacked = torch.cat((batch.feature_3d, feature_2d3d), dim=1)       # e.g. 1 + z + 64 = 66 (:290-291)
+        stacked = getattr(batch, 'stacked_features', None)                  # built ahead with the lifted features (bench.py)
+        if stacked is None:
+            feature_2d3d = lift_2d_features(self, batch)                   # (np, 64)
+            stacked = torch.cat((batch.feature_3d, feature_2d3d), dim=1)   # e.g. 1 + z + 64 = 66 (:290-291)
         x = stacked.detach()               # :295 (`.clone().detach()`: no grad reaches the 2D branch; nothing below
                                            # writes x in place, so the copy itself is not needed)
         x = run_encoder_decoder(self, x, batch)

@@ -317,7 +317,9 @@ class StaticBatch:
 
     # feature_2d: output of the frozen 2D encoder when it was run ahead of the network step
     # feature_2d3d: FeatureAggregation's output when it, too, was computed ahead (networks that detach it)
-    _DENSE = ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images', 'feature_2d', 'feature_2d3d')
+    # stacked_features: early fusion's network input [feature_3d | feature_2d3d], built with the latter
+    _DENSE = ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images', 'feature_2d', 'feature_2d3d',
+              'stacked_features')
 
     def load(self, batch):
         """Copies one freshly built batch into the static buffers (raises if a level outgrew its capacity)."""

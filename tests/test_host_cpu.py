@@ -621,6 +621,34 @@ def _forked_child_calls_lib(q):
         q.put(str(e))
 
 
+def test_host_logic_of_the_gather_work_lists_and_the_features_computed_ahead():
+    """What does not need a GPU of round 3's host logic: the side channel that carries a level's work list from
+    segmentation_inputs_sphere to the blocks is bounded and keyed by (device, address, rows); a block prefers the batch's
+    own `orders`; lift_2d_features hands back features computed ahead only where the network declares that it detaches
+    them; the rigid loss does not add a python zero."""
+    import importlib
+    import types
+    ops = importlib.import_module(PKG + ".ops")
+    blocks = importlib.import_module(PKG + ".dropin.models.blocks")
+    fc = importlib.import_module(PKG + ".dropin.models.fusion_common")
+    ops._WORK_ORDERS.clear()
+    pts = [torch.zeros(5 + i, 3) for i in range(ops._WORK_ORDERS_KEPT + 6)]
+    for p in pts:
+        ops.remember_work_order(p, torch.arange(p.shape[0], dtype=torch.int32))
+    assert len(ops._WORK_ORDERS) == ops._WORK_ORDERS_KEPT
+    assert (None, pts[0].data_ptr(), 5) not in ops._WORK_ORDERS and (None, pts[-1].data_ptr(), pts[-1].shape[0]) in ops._WORK_ORDERS
+    assert ops.work_order_for(pts[-1]) is None                       # CPU tensors never reach a kernel
+    batch = types.SimpleNamespace(points=pts[:3], orders=["o0", "o1", None])
+    assert blocks._work_order("resnetb", 0, batch) == "o0" and blocks._work_order("resnetb_strided", 0, batch) == "o1"
+    assert blocks._work_order("resnetb", 2, batch) is None and blocks._work_order("resnetb_strided", 2, batch) is None
+    ahead = torch.ones(4, 64)
+    net = types.SimpleNamespace(fa_output_detached=True)
+    assert fc.lift_2d_features(net, types.SimpleNamespace(feature_2d3d=ahead)) is ahead
+    with pytest.raises(AttributeError):                               # a network that trains through the module recomputes
+        fc.lift_2d_features(types.SimpleNamespace(fa_output_detached=False), types.SimpleNamespace(feature_2d3d=ahead))
+    ops._WORK_ORDERS.clear()
+
+
 def test_forked_child_fails_loudly():
     """A forked child of the process that loaded the HIP library must get a RuntimeError with the
     INTEGRATION note (spawn / main-process pyramid), never a hang inside HIP."""

@@ -406,6 +406,20 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs a) {
   gemm_body<TA, TB, PM, QN, WM, WN>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
+// Two independent products of the same operand layout, tile shape and row count in one launch: their column tiles side
+// by side along blockIdx.x, each with its own split of the reduction (workgroups beyond a product's split leave at once).
+// unary1 and the shortcut layer of a bottleneck block read the same input (blocks.py:596-649).
+template <bool TA, bool TB, int PM, int QN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_pair(const GemmArgs a0, const GemmArgs a1, int gx0, int gz0, int gz1) {
+  if ((int)blockIdx.x < gx0) {
+    if ((int)blockIdx.z >= gz0) return;
+    gemm_body<TA, TB, PM, QN, WM, WN>(a0, blockIdx.x, blockIdx.y, blockIdx.z);
+  } else {
+    if ((int)blockIdx.z >= gz1) return;
+    gemm_body<TA, TB, PM, QN, WM, WN>(a1, blockIdx.x - gx0, blockIdx.y, blockIdx.z);
+  }
+}
+
 // Grouped launch: ONE grid walks a table of independent products of the same operand layout and tile shape (the
 // weight gradients of a whole backward pass: ~100 TN products dW = A^T g, each a latency-bound launch of ~10 us on
 // its own). Workgroup b finds its problem by a search over the prefix sums of the problems' workgroup counts.
@@ -516,7 +530,83 @@ bool launch_cfg(const Plan& p, dim3 grid, hipStream_t st, const GemmArgs& a) {
   return false;
 }
 
+template <bool TA, bool TB, int PM>
+void launch_pair_one(dim3 grid, hipStream_t st, const GemmArgs& a0, const GemmArgs& a1, int gx0, int gz0, int gz1) {
+  hipLaunchKernelGGL((gemm_f32_mfma_pair<TA, TB, PM, 1, 1, 4>), grid, dim3(256), 0, st, a0, a1, gx0, gz0, gz1);
+}
+
+template <bool TA, bool TB>
+bool launch_pair_cfg(const Plan& p, dim3 grid, hipStream_t st, const GemmArgs& a0, const GemmArgs& a1, int gx0, int gz0, int gz1) {
+  if (p.qn != 1) return false;
+  if (p.pm == 2) return launch_pair_one<TA, TB, 2>(grid, st, a0, a1, gx0, gz0, gz1), true;
+  if (p.pm == 4) return launch_pair_one<TA, TB, 4>(grid, st, a0, a1, gx0, gz0, gz1), true;
+  return false;
+}
+
+// fills the arguments of one product like mvk_gemm_f32_ex does; returns its split
+int fill_args(GemmArgs& a, const Plan& p, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd,
+              int transA, int transB, float* bn_part, const int32_t* n_valid) {
+  int split = p.split;
+  const int64_t ksteps = cdiv64(Kd, BK);
+  if (split > ksteps) split = (int)ksteps;
+  const int64_t k_per_split = cdiv64(ksteps, split) * BK;
+  split = (int)cdiv64(Kd, k_per_split);
+  a.A = A; a.B = B; a.C = C; a.M = M; a.N = N; a.Kd = Kd;
+  a.lda = transA ? M : Kd;
+  a.ldb = transB ? Kd : N;
+  a.k_per_split = k_per_split;
+  a.atomic_out = split > 1;
+  a.accumulate = 0;
+  a.vecA = ((a.lda % 4 == 0) && ((uintptr_t)A % 16 == 0)) ? 4 : ((a.lda % 2 == 0) && ((uintptr_t)A % 8 == 0)) ? 2 : 1;
+  a.vecB = ((a.ldb % 4 == 0) && ((uintptr_t)B % 16 == 0)) ? 4 : ((a.ldb % 2 == 0) && ((uintptr_t)B % 8 == 0)) ? 2 : 1;
+  a.bn_part = bn_part;
+  a.n_valid = n_valid;
+  return split;
+}
+
 }  // namespace
+
+// Plan of a pair (mvk_gemm_f32_pair): out[0] = 1 when C0 = A.op(B0), C1 = A.op(B1) can share one launch (both on the wide
+// tile class with the same row tile), out[1..2] = the splits of the two reductions (their outputs must be zero-initialised
+// when > 1), out[3..4] = the row-block sizes of their BatchNorm partials (0: none).
+extern "C" int mvk_gemm_f32_pair_plan(int64_t M, int64_t N0, int64_t N1, int64_t Kd, int want_stats, int* out /* [5] */) {
+  MVK_REQUIRE(M >= 0 && N0 >= 0 && N1 >= 0 && Kd >= 0 && out, "gemm pair plan: bad arguments");
+  for (int i = 0; i < 5; ++i) out[i] = 0;
+  if (M == 0 || N0 == 0 || N1 == 0 || Kd == 0) return 0;
+  const Plan p0 = plan_gemm(M, N0, Kd, 0, want_stats != 0), p1 = plan_gemm(M, N1, Kd, 0, want_stats != 0);
+  if (p0.narrow || p1.narrow || p0.pm != p1.pm || p0.qn != 1 || p1.qn != 1 || (p0.pm != 2 && p0.pm != 4)) return 0;
+  out[0] = 1;
+  out[1] = p0.split;
+  out[2] = p1.split;
+  out[3] = (want_stats && p0.split == 1) ? 16 * p0.pm : 0;
+  out[4] = (want_stats && p1.split == 1) ? 16 * p1.pm : 0;
+  return 0;
+}
+
+// C0 [M,N0] = A . op(B0) and C1 [M,N1] = A . op(B1) in ONE launch (A [M,Kd] row-major, not transposed; transB as in
+// mvk_gemm_f32_ex); plain stores (split reductions: atomics into zero-initialised outputs), statistics partials as in
+// mvk_gemm_f32_ex where the plan gives a row-block size. Fails when mvk_gemm_f32_pair_plan does not allow the pair.
+extern "C" int mvk_gemm_f32_pair(const float* A, const float* B0, const float* B1, float* C0, float* C1, int64_t M,
+                                 int64_t N0, int64_t N1, int64_t Kd, int transB, int want_stats, float* bn_part0,
+                                 float* bn_part1, const int32_t* n_valid, void* stream) {
+  MVK_REQUIRE(M > 0 && N0 > 0 && N1 > 0 && Kd > 0, "gemm pair: empty product");
+  const Plan p0 = plan_gemm(M, N0, Kd, 0, want_stats != 0), p1 = plan_gemm(M, N1, Kd, 0, want_stats != 0);
+  MVK_REQUIRE(!p0.narrow && !p1.narrow && p0.pm == p1.pm && p0.qn == 1 && p1.qn == 1 && (p0.pm == 2 || p0.pm == 4),
+              "gemm pair: the two products do not share a tile shape (ask mvk_gemm_f32_pair_plan first)");
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a0, a1;
+  const int s0 = fill_args(a0, p0, A, B0, C0, M, N0, Kd, 0, transB, (want_stats && p0.split == 1) ? bn_part0 : nullptr, n_valid);
+  const int s1 = fill_args(a1, p1, A, B1, C1, M, N1, Kd, 0, transB, (want_stats && p1.split == 1) ? bn_part1 : nullptr, n_valid);
+  const int64_t tm = 16 * p0.pm, tn = 64;
+  MVK_REQUIRE(cdiv64(M, tm) < 65536 && s0 < 65536 && s1 < 65536, "gemm: grid too large");
+  const int gx0 = (int)cdiv64(N0, tn), gx1 = (int)cdiv64(N1, tn);
+  dim3 grid((unsigned)(gx0 + gx1), (unsigned)cdiv64(M, tm), (unsigned)(s0 > s1 ? s0 : s1));
+  const bool ok = transB ? launch_pair_cfg<false, true>(p0, grid, st, a0, a1, gx0, s0, s1)
+                         : launch_pair_cfg<false, false>(p0, grid, st, a0, a1, gx0, s0, s1);
+  MVK_REQUIRE(ok, "gemm pair: no kernel for plan pm=%d", p0.pm);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 // Plan of mvk_gemm_f32_ex for a shape: the split of the reduction it will use (the caller zeroes C when > 1)
 // and the row-block size of the BatchNorm partials (0: no statistics are produced for this shape).

@@ -31,6 +31,7 @@ _GEMM_STATS = os.environ.get("MVK_GEMM_STATS", "1") == "1"  # BatchNorm statisti
 _FUSE_FANOUT = os.environ.get("MVK_FUSE_FANOUT", "1") == "1"    # the two gradients of a block's input summed inside unary1's backward GEMM
 _FUSED_BIAS = os.environ.get("MVK_FUSED_BIAS", "1") == "1"      # bias + LeakyReLU of the BatchNorm-less layers in one launch
 _FUSED_OPERANDS = os.environ.get("MVK_FUSED_DEFORM_OPERANDS", "1") == "1"   # development switch: 0 = the tensor ops
+_GEMM_PAIR = os.environ.get("MVK_GEMM_PAIR", "1") == "1"        # unary1 and the shortcut layer of a block (same input) as one GEMM launch
 _BN_PAIR = os.environ.get("MVK_BN_PAIR", "1") == "1"            # a block's two independent BatchNorms (convolution, shortcut) as one launch each way
 _ORDER_LOOKUP = os.environ.get("MVK_GATHER_ORDER", "1") != "0"   # gather work lists found by their points tensor (ops.work_order_for)
 
@@ -346,10 +347,20 @@ class ResnetBottleneckBlock(nn.Module):
 
     def forward(self, features, batch):
         q_pts, s_pts, inds = _conv_inputs(self.block_name, self.layer_ind, batch)
-        if isinstance(self.unary1, UnaryBlock):
-            x, features = self.unary1(features, passthrough=True)      # `features` from here on: the shortcut's input
-        else:
-            x = self.unary1(features)
+        us, ys = self.unary_shortcut, None
+        if (_GEMM_PAIR and _MFMA_LINEAR and features.is_cuda and 'strided' not in self.block_name
+                and isinstance(self.unary1, UnaryBlock) and isinstance(us, UnaryBlock)):
+            # unary1 and the shortcut layer read the same rows: their two products as one launch (ops.linear_pair)
+            nv_in = _bn_rows(features, self, self.use_bn) if _GEMM_STATS else None
+            pair = ops.linear_pair(features, self.unary1.mlp.weight, us.mlp.weight, nv_in)
+            if pair is not None:
+                ys = pair[1]
+                x = self.unary1.batch_norm(pair[0], 0.1)
+        if ys is None:
+            if isinstance(self.unary1, UnaryBlock):
+                x, features = self.unary1(features, passthrough=True)  # `features` from here on: the shortcut's input
+            else:
+                x = self.unary1(features)
         nv = _bn_rows(q_pts, self, self.use_bn) if _GEMM_STATS else None
         conv = self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv, order=_work_order(self.block_name, self.layer_ind, batch))
         self.skip_alias = None
@@ -359,17 +370,17 @@ class ResnetBottleneckBlock(nn.Module):
             shortcut, self.skip_alias = ops.max_pool(features, inds, passthrough=True)
         else:
             shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
-        us = self.unary_shortcut
         n_valid = _bn_rows(conv, self, self.use_bn) if (_BN_PAIR and _HIP_BN and _MFMA_LINEAR) else None
         if n_valid is not None and isinstance(us, UnaryBlock) and us.use_bn:
             # the BatchNorm of the convolution and the one of the shortcut are independent problems over the same rows:
             # one launch each way for the pair (ops.bn_lrelu_pair)
-            ys = ops.linear(shortcut, us.mlp.weight, stats_n_valid=n_valid if _GEMM_STATS else None)
+            if ys is None:
+                ys = ops.linear(shortcut, us.mlp.weight, stats_n_valid=n_valid if _GEMM_STATS else None)
             x, shortcut = ops.bn_lrelu_pair(conv, self.batch_norm_conv.batch_norm, 0.1, ys, us.batch_norm.batch_norm, 1.0,
                                             n_valid)
         else:
             x = self.batch_norm_conv(conv, 0.1)
-            shortcut = us(shortcut)
+            shortcut = us(shortcut) if ys is None else us.batch_norm(ys, None)
         if _FUSE_ADD:       # x = unary2(x); return leaky_relu(x + shortcut)  (blocks.py:644-649), join fused
             return self.unary2(x, join=(shortcut, 0.1))
         return self.leaky_relu(self.unary2(x) + shortcut)

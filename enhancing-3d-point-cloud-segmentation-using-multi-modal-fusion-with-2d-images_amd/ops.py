@@ -1661,6 +1661,71 @@ class _LinearFn(torch.autograd.Function):
         return dx, dW, None, None, None
 
 
+class _LinearPairFn(torch.autograd.Function):
+    """(x W0^T, x W1^T) in one launch (mvk_gemm_f32_pair): unary1 and the shortcut layer of a bottleneck block read the
+    same input. The backward is the two layers' own: dx = g0 W0 + g1 W1 (the second product accumulates onto the first),
+    the weight gradients go through _dw_gemm like every other layer's."""
+
+    @staticmethod
+    def forward(ctx, x, W0, W1, stats_n_valid, plan):
+        M, Kd = x.shape
+        N0, N1 = W0.shape[0], W1.shape[0]
+        _, s0, s1, r0, r1 = plan
+        want = r0 > 0 or r1 > 0
+        outs, parts = [], []
+        for N, sp, rows in ((N0, s0, r0), (N1, s1, r1)):
+            outs.append(_zeros((M, N), x.device) if sp > 1 else torch.empty((M, N), device=x.device, dtype=torch.float32))
+            parts.append(torch.empty(((M + rows - 1) // rows, 2, N), device=x.device, dtype=torch.float32) if rows > 0 else None)
+        check(lib().mvk_gemm_f32_pair(_p(x), _p(W0), _p(W1), _p(outs[0]), _p(outs[1]), M, N0, N1, Kd, 1, int(want),
+                                      _p(parts[0]), _p(parts[1]), _p(stats_n_valid) if want else None, _stream()))
+        ctx.save_for_backward(x, W0, W1)
+        ctx.set_materialize_grads(False)
+        for part in parts:
+            if part is not None:
+                ctx.mark_non_differentiable(part)
+        return outs[0], parts[0], outs[1], parts[1]
+
+    @staticmethod
+    def backward(ctx, g0, gp0, g1, gp1):
+        x, W0, W1 = ctx.saved_tensors
+        dx = dW0 = dW1 = None
+        g0 = _f32c(g0) if g0 is not None else None
+        g1 = _f32c(g1) if g1 is not None else None
+        if ctx.needs_input_grad[0]:
+            if g0 is not None:
+                dx = gemm(g0, W0)
+            if g1 is not None:
+                dx = gemm(g1, W1, out=dx, accumulate=True) if dx is not None else gemm(g1, W1)
+        if ctx.needs_input_grad[1] and g0 is not None:
+            dW0 = _dw_gemm(g0, x, target=W0)
+        if ctx.needs_input_grad[2] and g1 is not None:
+            dW1 = _dw_gemm(g1, x, target=W1)
+        return dx, dW0, dW1, None, None
+
+
+def linear_pair(x, W0, W1, stats_n_valid=None):
+    """(linear(x, W0), linear(x, W1)) in one launch, or None when the two products cannot share one (different tile
+    classes: the caller then runs them one after the other). Outputs carry their BatchNorm statistics like linear()'s."""
+    _dev(x, W0, W1, stats_n_valid)
+    if x.dtype != torch.float32 or not x.is_contiguous() or W0.dtype != torch.float32 or W1.dtype != torch.float32 \
+            or not W0.is_contiguous() or not W1.is_contiguous() or x.dim() != 2 or x.shape[0] == 0:
+        return None
+    M, Kd = x.shape
+    want = stats_n_valid is not None and M > bn_single_launch_rows(W0.shape[0]) and M > bn_single_launch_rows(W1.shape[0]) \
+        and M <= _STATS_EPILOGUE_ROWS
+    plan = (C.c_int * 5)()
+    check(lib().mvk_gemm_f32_pair_plan(M, W0.shape[0], W1.shape[0], Kd, int(want), plan))
+    if not plan[0]:
+        return None
+    plan = tuple(int(v) for v in plan)
+    y0, p0, y1, p1 = _LinearPairFn.apply(x, W0, W1, stats_n_valid if want else None, plan)
+    if p0 is not None:
+        y0._mvk_bn_stats = (p0, plan[3])
+    if p1 is not None:
+        y1._mvk_bn_stats = (p1, plan[4])
+    return y0, y1
+
+
 def linear(x, W, x_is_transposed=False, stats_n_valid=None, passthrough=False):
     """nn.Linear without bias / a 1x1 convolution over rows, on gemm_f32_mfma. stats_n_valid: see kpconv().
     passthrough=True returns (y, x') with x' an alias of x whose gradient is summed into x's inside the backward GEMM

@@ -125,6 +125,16 @@ int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, int want_st
 int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA,
                     int transB, int accumulate, int split_k, float* bn_part, const int32_t* n_valid, void* stream);
 
+/* Two products that share the left operand in ONE launch: C0 [M,N0] = A . op(B0), C1 [M,N1] = A . op(B1) (A [M,Kd]
+ * row-major; transB as above) -- unary1 and the shortcut layer of a bottleneck block read the same input
+ * (blocks.py:596-649). mvk_gemm_f32_pair_plan: out[0] = 1 when the pair can share a launch (both on the wide tile
+ * class with the same row tile), out[1..2] = the splits of the two reductions (zero-initialise an output whose split
+ * is > 1), out[3..4] = row-block sizes of the BatchNorm partials bn_part0 / bn_part1 (0: none produced). */
+int mvk_gemm_f32_pair_plan(int64_t M, int64_t N0, int64_t N1, int64_t Kd, int want_stats, int* out /* [5] */);
+int mvk_gemm_f32_pair(const float* A, const float* B0, const float* B1, float* C0, float* C1, int64_t M, int64_t N0,
+                      int64_t N1, int64_t Kd, int transB, int want_stats, float* bn_part0, float* bn_part1,
+                      const int32_t* n_valid, void* stream);
+
 /* Upper bound of the split of the reduction the grouped launch gives one product (the plan may choose fewer pieces for
  * a large group); the caller zero-initialises the outputs for which it is > 1. */
 int mvk_gemm_f32_tn_grouped_split(int64_t M, int64_t N, int64_t Kd);

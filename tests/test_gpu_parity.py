@@ -431,6 +431,38 @@ def test_bn_lrelu_pair_equals_two_single_launches(ops, R, Da, Db, from_gemm):
         assert torch.equal(m1.weight.grad, m2.weight.grad) and torch.equal(m1.bias.grad, m2.bias.grad)
 
 
+@pytest.mark.parametrize("M,Kd,N0,N1,stats", [(4288, 128, 64, 256, True), (332, 512, 256, 1024, False),
+                                              (85, 1024, 512, 2048, False), (19464, 64, 32, 128, True), (1300, 256, 128, 512, True)])
+def test_linear_pair_equals_two_linear_layers(ops, M, Kd, N0, N1, stats):
+    """mvk_gemm_f32_pair: unary1 and the shortcut layer of a bottleneck block (same input) as one launch -- outputs,
+    epilogue statistics and all three gradients against two ops.linear calls (unsplit products: the same bits; split
+    ones: the rounding of the atomics' order); None when the two products are not in the same tile class."""
+    rng = np.random.default_rng(M + N0)
+    x = T(rng.normal(size=(M, Kd)).astype(np.float32)).requires_grad_(True)
+    W0 = T((rng.normal(size=(N0, Kd)) * 0.1).astype(np.float32)).requires_grad_(True)
+    W1 = T((rng.normal(size=(N1, Kd)) * 0.1).astype(np.float32)).requires_grad_(True)
+    nv = T(np.asarray([M - 5], np.int32)) if stats else None
+    x2, V0, V1 = [t.detach().clone().requires_grad_(True) for t in (x, W0, W1)]
+    g0, g1 = T(rng.normal(size=(M, N0)).astype(np.float32)), T(rng.normal(size=(M, N1)).astype(np.float32))
+    pair = ops.linear_pair(x, W0, W1, nv)
+    if N0 <= 32:
+        assert pair is None            # a narrow and a wide tile class: no shared launch
+        return
+    y0, y1 = pair
+    r0, r1 = ops.linear(x2, V0, stats_n_valid=nv), ops.linear(x2, V1, stats_n_valid=nv)
+    for a, b_ in ((y0, r0), (y1, r1)):
+        assert rel_err(a.detach().cpu().numpy(), b_.detach().cpu().numpy()) < 2e-6
+        sa, sb = ops.bn_stats_of(a), ops.bn_stats_of(b_)
+        assert (sa is None) == (sb is None)
+        if sa is not None:
+            assert sa[1] == sb[1] and rel_err(sa[0].detach().cpu().numpy(), sb[0].detach().cpu().numpy()) < 2e-6
+    ((y0 * g0).sum() + (y1 * g1).sum()).backward()
+    ((r0 * g0).sum() + (r1 * g1).sum()).backward()
+    assert rel_err(x.grad.cpu().numpy(), x2.grad.cpu().numpy()) < 2e-6
+    assert rel_err(W0.grad.cpu().numpy(), V0.grad.cpu().numpy()) < 2e-6
+    assert rel_err(W1.grad.cpu().numpy(), V1.grad.cpu().numpy()) < 2e-6
+
+
 def test_cell_order_of_the_neighbour_search_is_a_sorted_permutation(ops):
     """mvk_neighbors_cell_order after a radius search over three stacked clouds: a permutation of the rows that stays
     inside each cloud, ascending in the grid cell of the search (cell = 1.001 r from the cloud's minimum corner,

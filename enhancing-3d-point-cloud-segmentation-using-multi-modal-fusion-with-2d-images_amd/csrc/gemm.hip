@@ -187,6 +187,8 @@ struct GemmArgs {
   int atomic_out, accumulate, vecA, vecB;
   float* bn_part;          // [ceil(M / TM), 2, N]: column sum and centred sum of squares per workgroup row block
   const int32_t* n_valid;  // device row count for the statistics (null: M)
+  const float* bias;       // [N] or null: C = LeakyReLU_slope(A.op(B) + bias) -- the BatchNorm-less layers (blocks.py:462-463);
+  float act_slope;         // plain stores only (no split, no accumulate)
 };
 
 template <bool TA, bool TB, int PM, int QN, int WM, int WN>
@@ -306,6 +308,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   for (int q = 0; q < QN; ++q) {
     const int64_t col = n0 + rb + 16 * q + ci;
     if (col < a.N) {
+      const float bq = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
       for (int p = 0; p < PM; ++p)
 #pragma unroll
@@ -317,7 +320,10 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
               atomicAdd(c, acc[p][q][r]);
             else if (a.accumulate)
               *c += acc[p][q][r];
-            else
+            else if (a.bias) {
+              const float v = acc[p][q][r] + bq;
+              *c = v > 0.f ? v : v * a.act_slope;
+            } else
               *c = acc[p][q][r];
           }
         }
@@ -561,6 +567,8 @@ int fill_args(GemmArgs& a, const Plan& p, const float* A, const float* B, float*
   a.vecB = ((a.ldb % 4 == 0) && ((uintptr_t)B % 16 == 0)) ? 4 : ((a.ldb % 2 == 0) && ((uintptr_t)B % 8 == 0)) ? 2 : 1;
   a.bn_part = bn_part;
   a.n_valid = n_valid;
+  a.bias = nullptr;
+  a.act_slope = 1.f;
   return split;
 }
 
@@ -624,9 +632,30 @@ extern "C" int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, 
   return 0;
 }
 
+namespace {
+int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA, int transB,
+             int accumulate, int split_k, float* bn_part, const int32_t* n_valid, const float* bias, float act_slope,
+             void* stream);
+}
+
 extern "C" int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd,
                                int transA, int transB, int accumulate, int split_k, float* bn_part,
                                const int32_t* n_valid, void* stream) {
+  return gemm_run(A, B, C, M, N, Kd, transA, transB, accumulate, split_k, bn_part, n_valid, nullptr, 1.f, stream);
+}
+
+// C = LeakyReLU_slope(A . op(B) + bias[col]) (slope 1: the bias alone): a BatchNorm-less layer (blocks.py:462-463, the two
+// head layers of every network) in one launch. The reduction is never split (a plain store is required).
+extern "C" int mvk_gemm_f32_bias_act(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transB,
+                                     const float* bias, float slope, void* stream) {
+  MVK_REQUIRE(bias != nullptr && slope > 0.f && Kd > 0, "gemm bias_act: bias, a positive slope and a non-empty product");
+  return gemm_run(A, B, C, M, N, Kd, 0, transB, 0, 1, nullptr, nullptr, bias, slope, stream);
+}
+
+namespace {
+int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA, int transB,
+             int accumulate, int split_k, float* bn_part, const int32_t* n_valid, const float* bias, float act_slope,
+             void* stream) {
   MVK_REQUIRE(M >= 0 && N >= 0 && Kd >= 0, "gemm: negative size");
   if (M == 0 || N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -653,6 +682,8 @@ extern "C" int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t
   a.vecB = ((a.ldb % 4 == 0) && ((uintptr_t)B % 16 == 0)) ? 4 : ((a.ldb % 2 == 0) && ((uintptr_t)B % 8 == 0)) ? 2 : 1;
   a.bn_part = bn_part;
   a.n_valid = n_valid;
+  a.bias = bias;
+  a.act_slope = act_slope;
   const int64_t tm = p.narrow ? 64 * p.pm : 16 * p.pm, tn = p.narrow ? 16 * p.qn : 64 * p.qn;
   MVK_REQUIRE(cdiv64(M, tm) < 65536 && split < 65536, "gemm: grid too large");
   dim3 grid((unsigned)cdiv64(N, tn), (unsigned)cdiv64(M, tm), (unsigned)split);
@@ -665,6 +696,7 @@ extern "C" int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }
+}  // namespace
 
 // One record of mvk_gemm_f32_tn_grouped (host side, 48 bytes): C [M,N] (+)= A^T B with A [Kd,M], B [Kd,N] row-major.
 struct MvkGemmProblem {
@@ -749,6 +781,8 @@ extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* t
     e.args.vecB = ((q.N % 4 == 0) && ((uintptr_t)q.B % 16 == 0)) ? 4 : ((q.N % 2 == 0) && ((uintptr_t)q.B % 8 == 0)) ? 2 : 1;
     e.args.bn_part = nullptr;
     e.args.n_valid = nullptr;
+    e.args.bias = nullptr;
+    e.args.act_slope = 1.f;
     const int64_t tm = narrow ? 64 : 16 * group_wide_pm(), tn = narrow ? 32 : 64;      // plan tiles: narrow (pm 1, qn 2), wide (pm 2, qn 1)
     e.gx = (int)cdiv64(q.N, tn);
     e.gy = (int)cdiv64(q.M, tm);

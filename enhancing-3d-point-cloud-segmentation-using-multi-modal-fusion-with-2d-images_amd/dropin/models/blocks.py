@@ -257,6 +257,10 @@ class UnaryBlock(nn.Module):
         # nn.Linear(bias=False) = x @ W^T: on the f32 MFMA GEMM (faster than the library GEMM on these
         # tall-skinny shapes, tools/gemm_bench.py); parameters stay those of self.mlp (state-dict compatible)
         alias = x
+        if (_MFMA_LINEAR and _FUSED_BIAS and x.is_cuda and not self.use_bn and join is None and not passthrough
+                and x.dim() == 2 and self.out_dim <= 256):
+            # BatchNorm-less layer: bias and activation leave with the GEMM's store (ops.linear_bias_lrelu)
+            return ops.linear_bias_lrelu(x, self.mlp.weight, self.batch_norm.bias, 1.0 if self.no_relu else 0.1)
         if _MFMA_LINEAR and x.is_cuda:
             nv = _bn_rows(x, self, self.use_bn) if _GEMM_STATS else None
             if passthrough and _FUSE_FANOUT and x.requires_grad:

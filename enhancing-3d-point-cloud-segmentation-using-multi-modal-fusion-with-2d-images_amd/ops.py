@@ -1178,6 +1178,44 @@ def bias_lrelu(x, bias, slope=0.1):
     return _BiasLReLUFn.apply(x, bias, slope)
 
 
+class _LinearBiasActFn(torch.autograd.Function):
+    """LeakyReLU_slope(x W^T + bias) with the bias and the activation in the GEMM's store (mvk_gemm_f32_bias_act); the
+    backward is bias_lrelu's (mask from the saved output, bias gradient in the same launch) followed by the layer's two
+    products."""
+
+    @staticmethod
+    def forward(ctx, x, W, bias, slope):
+        _dev(x, W, bias)
+        x, W, bias = _f32c(x), _f32c(W), _f32c(bias)
+        y = torch.empty((x.shape[0], W.shape[0]), device=x.device, dtype=torch.float32)
+        if x.shape[0] > 0:
+            check(lib().mvk_gemm_f32_bias_act(_p(x), _p(W), _p(y), x.shape[0], W.shape[0], x.shape[1], 1, _p(bias),
+                                              float(slope), _stream()))
+        ctx.save_for_backward(x, W, y)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W, y = ctx.saved_tensors
+        g = _f32c(g)
+        d = torch.empty_like(y)
+        db = _zeros((y.shape[1],), y.device)
+        check(lib().mvk_bias_lrelu_bwd(_p(y), _p(g), y.shape[0], y.shape[1], ctx.slope, _p(d), _p(db), _stream()))
+        dx = gemm(d, W) if ctx.needs_input_grad[0] else None
+        dW = _dw_gemm(d, x, target=W) if ctx.needs_input_grad[1] else None
+        return dx, dW, db, None
+
+
+def linear_bias_lrelu(x, W, bias, slope=0.1):
+    """bias_lrelu(linear(x, W), bias, slope) in one launch forward (a BatchNorm-less UnaryBlock: the head layers)."""
+    if x.dim() != 2 or bias.dim() != 1 or bias.shape[0] != W.shape[0] or W.shape[1] != x.shape[1]:
+        raise RuntimeError("linear_bias_lrelu: x [R,K], W [C,K] and bias [C] expected")
+    if not slope > 0:
+        raise ValueError("linear_bias_lrelu: slope must be positive")
+    return _LinearBiasActFn.apply(x, W, bias, slope)
+
+
 def add_lrelu(a, b, slope=0.1):
     """LeakyReLU(a + b) in one launch (residual join of ResnetBottleneckBlock, blocks.py:649)."""
     if a.shape != b.shape:

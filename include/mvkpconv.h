@@ -125,6 +125,12 @@ int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, int want_st
 int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA,
                     int transB, int accumulate, int split_k, float* bn_part, const int32_t* n_valid, void* stream);
 
+/* C [M,N] = LeakyReLU_slope(A . op(B) + bias[col]) (slope = 1: the bias alone; A [M,Kd] row-major): a BatchNorm-less
+ * layer -- `x W^T + self.bias` (blocks.py:462-463) and the block's activation, the two head layers of every network -- in
+ * one launch. The reduction is not split. */
+int mvk_gemm_f32_bias_act(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transB,
+                          const float* bias, float slope, void* stream);
+
 /* Two products that share the left operand in ONE launch: C0 [M,N0] = A . op(B0), C1 [M,N1] = A . op(B1) (A [M,Kd]
  * row-major; transB as above) -- unary1 and the shortcut layer of a bottleneck block read the same input
  * (blocks.py:596-649). mvk_gemm_f32_pair_plan: out[0] = 1 when the pair can share a launch (both on the wide tile

@@ -463,6 +463,26 @@ def test_linear_pair_equals_two_linear_layers(ops, M, Kd, N0, N1, stats):
     assert rel_err(W1.grad.cpu().numpy(), V1.grad.cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("M,Kd,N,slope", [(19464, 128, 128, 0.1), (19464, 128, 20, 1.0), (333, 64, 7, 0.1), (5, 256, 256, 0.2)])
+def test_linear_bias_lrelu_equals_linear_then_bias_lrelu(ops, M, Kd, N, slope):
+    """mvk_gemm_f32_bias_act: the BatchNorm-less head layers (x W^T + bias, LeakyReLU; blocks.py:462-463) with bias and
+    activation in the GEMM's store -- outputs and the three gradients against ops.linear + ops.bias_lrelu."""
+    rng = np.random.default_rng(M + N)
+    x = T(rng.normal(size=(M, Kd)).astype(np.float32)).requires_grad_(True)
+    W = T((rng.normal(size=(N, Kd)) * 0.1).astype(np.float32)).requires_grad_(True)
+    b = T(rng.normal(size=(N,)).astype(np.float32)).requires_grad_(True)
+    x2, W2, b2 = [t.detach().clone().requires_grad_(True) for t in (x, W, b)]
+    g = T(rng.normal(size=(M, N)).astype(np.float32))
+    y = ops.linear_bias_lrelu(x, W, b, slope)
+    r = ops.bias_lrelu(ops.linear(x2, W2), b2, slope)
+    assert rel_err(y.detach().cpu().numpy(), r.detach().cpu().numpy()) < 2e-6
+    ops.step_begin()
+    (y * g).sum().backward()
+    (r * g).sum().backward()
+    for a, c in ((x, x2), (W, W2), (b, b2)):
+        assert rel_err(a.grad.cpu().numpy(), c.grad.cpu().numpy()) < 5e-6
+
+
 def test_cell_order_of_the_neighbour_search_is_a_sorted_permutation(ops):
     """mvk_neighbors_cell_order after a radius search over three stacked clouds: a permutation of the rows that stays
     inside each cloud, ascending in the grid cell of the search (cell = 1.001 r from the cloud's minimum corner,

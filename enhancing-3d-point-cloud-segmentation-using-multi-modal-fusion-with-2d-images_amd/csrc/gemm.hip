@@ -189,9 +189,15 @@ struct GemmArgs {
   const int32_t* n_valid;  // device row count for the statistics (null: M)
   const float* bias;       // [N] or null: C = LeakyReLU_slope(A.op(B) + bias) -- the BatchNorm-less layers (blocks.py:462-463);
   float act_slope;         // plain stores only (no split, no accumulate)
+  // DUAL instantiations: C = A.op(B) + A2.op(B2), the second product's reduction appended to the first's (Kd a multiple
+  // of the k-tile): the gradient of a tensor that feeds two linear layers (unary1 and the shortcut of a bottleneck block)
+  const float* A2;
+  const float* B2;
+  int64_t Kd2, lda2, ldb2;
+  int vecA2, vecB2;
 };
 
-template <bool TA, bool TB, int PM, int QN, int WM, int WN>
+template <bool TA, bool TB, int PM, int QN, int WM, int WN, bool DUAL = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const int by, const int bz) {
   static_assert(WM * WN == 4, "four waves per workgroup");
   constexpr int TM = 16 * PM * WM, TN = 16 * QN * WN;
@@ -203,8 +209,9 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int64_t m0 = (int64_t)by * TM, n0 = (int64_t)bx * TN;
-  int64_t kbeg = (int64_t)bz * a.k_per_split;
-  const int64_t kend = kbeg + a.k_per_split < a.Kd ? kbeg + a.k_per_split : a.Kd;
+  const int64_t ktot = DUAL ? a.Kd + a.Kd2 : a.Kd;
+  const int64_t kbeg_all = (int64_t)bz * a.k_per_split;
+  const int64_t kend_all = kbeg_all + a.k_per_split < ktot ? kbeg_all + a.k_per_split : ktot;
 
   f32x4 acc[PM][QN];
 #pragma unroll
@@ -244,14 +251,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   // k-tiles; 0: the general loader, which also masks a ragged k-tail). Selected ONCE per workgroup below: a loader
   // chosen inside the loop would merge the loaded registers of its alternatives at every join, and each such
   // copy is a wait for the load it copies -- the loads would be synchronous again.
+  // one operand pair over its own k-range [kbeg, kend): the pipelined full tiles, then the ragged tail
+  auto run_range = [&](const float* __restrict__ pA, const int64_t lda, const int vecA, const float* __restrict__ pB,
+                       const int64_t ldb, const int vecB, int64_t kbeg, const int64_t kend) {
   auto pipeline = [&](auto va, auto vb, const int64_t klim) {
     constexpr int VA = decltype(va)::value, VB = decltype(vb)::value;
     if (kbeg >= klim) return;
-    la0.template fetch<VA>(a.A, a.lda, m0, a.M, kbeg, klim, a.vecA, tid);
-    lb0.template fetch<VB>(a.B, a.ldb, n0, a.N, kbeg, klim, a.vecB, tid);
+    la0.template fetch<VA>(pA, lda, m0, a.M, kbeg, klim, vecA, tid);
+    lb0.template fetch<VB>(pB, ldb, n0, a.N, kbeg, klim, vecB, tid);
     if (kbeg + BK < klim) {
-      la1.template fetch<VA>(a.A, a.lda, m0, a.M, kbeg + BK, klim, a.vecA, tid);
-      lb1.template fetch<VB>(a.B, a.ldb, n0, a.N, kbeg + BK, klim, a.vecB, tid);
+      la1.template fetch<VA>(pA, lda, m0, a.M, kbeg + BK, klim, vecA, tid);
+      lb1.template fetch<VB>(pB, ldb, n0, a.N, kbeg + BK, klim, vecB, tid);
     }
     la0.store(A0, tid);
     lb0.store(B0, tid);
@@ -259,8 +269,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
     for (int64_t k0 = kbeg; k0 < klim; k0 += 2 * BK) {
       // even k-tile (buffer 0): fetch tile +2 into set 0, multiply, publish tile +1 (set 1) in buffer 1
       if (k0 + 2 * BK < klim) {
-        la0.template fetch<VA>(a.A, a.lda, m0, a.M, k0 + 2 * BK, klim, a.vecA, tid);
-        lb0.template fetch<VB>(a.B, a.ldb, n0, a.N, k0 + 2 * BK, klim, a.vecB, tid);
+        la0.template fetch<VA>(pA, lda, m0, a.M, k0 + 2 * BK, klim, vecA, tid);
+        lb0.template fetch<VB>(pB, ldb, n0, a.N, k0 + 2 * BK, klim, vecB, tid);
       }
       compute(A0, B0);
       if (k0 + BK >= klim) break;
@@ -269,8 +279,8 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
       __syncthreads();
       // odd k-tile (buffer 1): fetch tile +3 into set 1, multiply, publish tile +2 (set 0) in buffer 0
       if (k0 + 3 * BK < klim) {
-        la1.template fetch<VA>(a.A, a.lda, m0, a.M, k0 + 3 * BK, klim, a.vecA, tid);
-        lb1.template fetch<VB>(a.B, a.ldb, n0, a.N, k0 + 3 * BK, klim, a.vecB, tid);
+        la1.template fetch<VA>(pA, lda, m0, a.M, k0 + 3 * BK, klim, vecA, tid);
+        lb1.template fetch<VB>(pB, ldb, n0, a.N, k0 + 3 * BK, klim, vecB, tid);
       }
       compute(A1, B1);
       if (k0 + 2 * BK >= klim) break;
@@ -279,14 +289,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
       __syncthreads();
     }
   };
-  const bool fastA = TileA::fast_ok(a.M, a.vecA), fastB = TileB::fast_ok(a.N, a.vecB);
+  const bool fastA = TileA::fast_ok(a.M, vecA), fastB = TileB::fast_ok(a.N, vecB);
   const int64_t kfull = kbeg + (kend - kbeg) / BK * BK;     // end of the full k-tiles of this split
   typedef std::integral_constant<int, 4> I4;
   typedef std::integral_constant<int, 2> I2;
   typedef std::integral_constant<int, 0> I0;
-  if (fastA && fastB && a.vecA == 4 && a.vecB == 4) {
+  if (fastA && fastB && vecA == 4 && vecB == 4) {
     pipeline(I4(), I4(), kfull);
-  } else if (fastA && fastB && a.vecA == 2 && a.vecB == 4) {      // K*Cin = 990: rows of A are only 8-byte aligned
+  } else if (fastA && fastB && vecA == 2 && vecB == 4) {      // K*Cin = 990: rows of A are only 8-byte aligned
     pipeline(I2(), I4(), kfull);
   } else {
     pipeline(I0(), I0(), kend);
@@ -294,12 +304,24 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   }
   if (kfull < kend && kbeg < kend) {     // ragged k-tail of a fast pipeline: one predicated tile, unpipelined
     __syncthreads();
-    la0.load(a.A, a.lda, m0, a.M, kfull, kend, a.vecA, tid);
-    lb0.load(a.B, a.ldb, n0, a.N, kfull, kend, a.vecB, tid);
+    la0.load(pA, lda, m0, a.M, kfull, kend, vecA, tid);
+    lb0.load(pB, ldb, n0, a.N, kfull, kend, vecB, tid);
     la0.store(A0, tid);
     lb0.store(B0, tid);
     __syncthreads();
     compute(A0, B0);
+  }
+  };
+  if (!DUAL) {
+    run_range(a.A, a.lda, a.vecA, a.B, a.ldb, a.vecB, kbeg_all, kend_all);
+  } else {
+    // this workgroup's share [kbeg_all, kend_all) of the concatenated reduction: its part in the first product, then its
+    // part in the second (a.Kd is a multiple of the k-tile, so is k_per_split: tiles never straddle the seam)
+    if (kbeg_all < a.Kd) run_range(a.A, a.lda, a.vecA, a.B, a.ldb, a.vecB, kbeg_all, kend_all < a.Kd ? kend_all : a.Kd);
+    if (kend_all > a.Kd) {
+      if (kbeg_all < a.Kd) __syncthreads();       // the first range's last tile is still being read from LDS
+      run_range(a.A2, a.lda2, a.vecA2, a.B2, a.ldb2, a.vecB2, kbeg_all > a.Kd ? kbeg_all - a.Kd : 0, kend_all - a.Kd);
+    }
   }
 
   // C/D map of the 16 x 16 MFMA: col = lane & 15, row = 4 (lane >> 4) + reg
@@ -424,6 +446,13 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_pair(const GemmArgs a0, con
     if ((int)blockIdx.z >= gz1) return;
     gemm_body<TA, TB, PM, QN, WM, WN>(a1, blockIdx.x - gx0, blockIdx.y, blockIdx.z);
   }
+}
+
+// C = A . op(B) + A2 . op(B2): two products of the same output shape with their reductions laid end to end (gemm_body's
+// DUAL form). dx of a tensor that feeds two linear layers.
+template <bool TA, bool TB, int PM, int QN, int WM, int WN>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_dual(const GemmArgs a) {
+  gemm_body<TA, TB, PM, QN, WM, WN, true>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Grouped launch: ONE grid walks a table of independent products of the same operand layout and tile shape (the
@@ -569,10 +598,50 @@ int fill_args(GemmArgs& a, const Plan& p, const float* A, const float* B, float*
   a.n_valid = n_valid;
   a.bias = nullptr;
   a.act_slope = 1.f;
+  a.A2 = nullptr; a.B2 = nullptr; a.Kd2 = 0; a.lda2 = 0; a.ldb2 = 0; a.vecA2 = 1; a.vecB2 = 1;
   return split;
 }
 
 }  // namespace
+
+// Split of mvk_gemm_f32_dual's concatenated reduction (the caller zeroes C when > 1); 0: the shape is not supported (the
+// first reduction must be a whole number of k-tiles, the output wider than 32 columns).
+extern "C" int mvk_gemm_f32_dual_plan(int64_t M, int64_t N, int64_t Kd, int64_t Kd2, int* out_split) {
+  MVK_REQUIRE(M >= 0 && N >= 0 && Kd >= 0 && Kd2 >= 0 && out_split, "gemm dual plan: bad arguments");
+  *out_split = 0;
+  if (M == 0 || N == 0 || Kd == 0 || Kd2 == 0 || Kd % BK != 0) return 0;
+  const Plan p = plan_gemm(M, N, Kd + Kd2, 0, false);
+  if (p.narrow || p.qn != 1 || p.pm != 2) return 0;
+  int split = p.split;
+  const int64_t ksteps = cdiv64(Kd + Kd2, BK);
+  if (split > ksteps) split = (int)ksteps;
+  const int64_t k_per_split = cdiv64(ksteps, split) * BK;
+  *out_split = (int)cdiv64(Kd + Kd2, k_per_split);
+  return 0;
+}
+
+// C [M,N] = A [M,Kd] . B [Kd,N] + A2 [M,Kd2] . B2 [Kd2,N] (all row-major, nothing transposed) in ONE launch: the two
+// reductions end to end, split as mvk_gemm_f32_dual_plan says (atomics into a zero-initialised C when > 1).
+extern "C" int mvk_gemm_f32_dual(const float* A, const float* B, const float* A2, const float* B2, float* C, int64_t M,
+                                 int64_t N, int64_t Kd, int64_t Kd2, void* stream) {
+  MVK_REQUIRE(M > 0 && N > 0 && Kd > 0 && Kd2 > 0 && Kd % BK == 0, "gemm dual: unsupported shape (ask mvk_gemm_f32_dual_plan)");
+  const Plan p = plan_gemm(M, N, Kd + Kd2, 0, false);
+  MVK_REQUIRE(!p.narrow && p.qn == 1 && p.pm == 2, "gemm dual: unsupported shape (ask mvk_gemm_f32_dual_plan)");
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs a;
+  const int split = fill_args(a, p, A, B, C, M, N, Kd + Kd2, 0, 0, nullptr, nullptr);
+  a.Kd = Kd;
+  a.lda = Kd;
+  a.vecA = ((a.lda % 4 == 0) && ((uintptr_t)A % 16 == 0)) ? 4 : ((a.lda % 2 == 0) && ((uintptr_t)A % 8 == 0)) ? 2 : 1;
+  a.A2 = A2; a.B2 = B2; a.Kd2 = Kd2; a.lda2 = Kd2; a.ldb2 = N;
+  a.vecA2 = ((a.lda2 % 4 == 0) && ((uintptr_t)A2 % 16 == 0)) ? 4 : ((a.lda2 % 2 == 0) && ((uintptr_t)A2 % 8 == 0)) ? 2 : 1;
+  a.vecB2 = ((a.ldb2 % 4 == 0) && ((uintptr_t)B2 % 16 == 0)) ? 4 : ((a.ldb2 % 2 == 0) && ((uintptr_t)B2 % 8 == 0)) ? 2 : 1;
+  MVK_REQUIRE(cdiv64(M, 32) < 65536 && split < 65536, "gemm: grid too large");
+  dim3 grid((unsigned)cdiv64(N, 64), (unsigned)cdiv64(M, 32), (unsigned)split);
+  hipLaunchKernelGGL((gemm_f32_mfma_dual<false, false, 2, 1, 1, 4>), grid, dim3(256), 0, st, a);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 // Plan of a pair (mvk_gemm_f32_pair): out[0] = 1 when C0 = A.op(B0), C1 = A.op(B1) can share one launch (both on the wide
 // tile class with the same row tile), out[1..2] = the splits of the two reductions (their outputs must be zero-initialised
@@ -684,6 +753,7 @@ int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int
   a.n_valid = n_valid;
   a.bias = bias;
   a.act_slope = act_slope;
+  a.A2 = nullptr; a.B2 = nullptr; a.Kd2 = 0; a.lda2 = 0; a.ldb2 = 0; a.vecA2 = 1; a.vecB2 = 1;
   const int64_t tm = p.narrow ? 64 * p.pm : 16 * p.pm, tn = p.narrow ? 16 * p.qn : 64 * p.qn;
   MVK_REQUIRE(cdiv64(M, tm) < 65536 && split < 65536, "gemm: grid too large");
   dim3 grid((unsigned)cdiv64(N, tn), (unsigned)cdiv64(M, tm), (unsigned)split);
@@ -783,6 +853,8 @@ extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* t
     e.args.n_valid = nullptr;
     e.args.bias = nullptr;
     e.args.act_slope = 1.f;
+    e.args.A2 = nullptr; e.args.B2 = nullptr; e.args.Kd2 = 0; e.args.lda2 = 0; e.args.ldb2 = 0;
+    e.args.vecA2 = 1; e.args.vecB2 = 1;
     const int64_t tm = narrow ? 64 : 16 * group_wide_pm(), tn = narrow ? 32 : 64;      // plan tiles: narrow (pm 1, qn 2), wide (pm 2, qn 1)
     e.gx = (int)cdiv64(q.N, tn);
     e.gy = (int)cdiv64(q.M, tm);

@@ -1699,6 +1699,27 @@ class _LinearFn(torch.autograd.Function):
         return dx, dW, None, None, None
 
 
+_GEMM_DUAL = os.environ.get("MVK_GEMM_DUAL", "1") == "1"
+
+
+def gemm_dual(A, B, A2, B2):
+    """A @ B + A2 @ B2 (all row-major, same output shape) in one launch with the two reductions laid end to end
+    (mvk_gemm_f32_dual), or None when the shape is not supported (the caller runs two products)."""
+    _dev(A, B, A2, B2)
+    A, B, A2, B2 = _f32c(A), _f32c(B), _f32c(A2), _f32c(B2)
+    M, Kd = A.shape
+    N, Kd2 = B.shape[1], A2.shape[1]
+    if A2.shape[0] != M or B.shape[0] != Kd or B2.shape != (Kd2, N):
+        raise RuntimeError("gemm_dual: shapes do not match")
+    split = C.c_int(0)
+    check(lib().mvk_gemm_f32_dual_plan(M, N, Kd, Kd2, C.byref(split)))
+    if split.value == 0:
+        return None
+    out = _zeros((M, N), A.device) if split.value > 1 else torch.empty((M, N), device=A.device, dtype=torch.float32)
+    check(lib().mvk_gemm_f32_dual(_p(A), _p(B), _p(A2), _p(B2), _p(out), M, N, Kd, Kd2, _stream()))
+    return out
+
+
 class _LinearPairFn(torch.autograd.Function):
     """(x W0^T, x W1^T) in one launch (mvk_gemm_f32_pair): unary1 and the shortcut layer of a bottleneck block read the
     same input. The backward is the two layers' own: dx = g0 W0 + g1 W1 (the second product accumulates onto the first),
@@ -1730,10 +1751,13 @@ class _LinearPairFn(torch.autograd.Function):
         g0 = _f32c(g0) if g0 is not None else None
         g1 = _f32c(g1) if g1 is not None else None
         if ctx.needs_input_grad[0]:
-            if g0 is not None:
-                dx = gemm(g0, W0)
-            if g1 is not None:
-                dx = gemm(g1, W1, out=dx, accumulate=True) if dx is not None else gemm(g1, W1)
+            if g0 is not None and g1 is not None and _GEMM_DUAL:
+                dx = gemm_dual(g0, W0, g1, W1)          # g0 W0 + g1 W1 as one launch, or None
+            if dx is None:
+                if g0 is not None:
+                    dx = gemm(g0, W0)
+                if g1 is not None:
+                    dx = gemm(g1, W1, out=dx, accumulate=True) if dx is not None else gemm(g1, W1)
         if ctx.needs_input_grad[1] and g0 is not None:
             dW0 = _dw_gemm(g0, x, target=W0)
         if ctx.needs_input_grad[2] and g1 is not None:

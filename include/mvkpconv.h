@@ -131,6 +131,14 @@ int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t
 int mvk_gemm_f32_bias_act(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transB,
                           const float* bias, float slope, void* stream);
 
+/* C [M,N] = A [M,Kd] . B [Kd,N] + A2 [M,Kd2] . B2 [Kd2,N] (row-major, nothing transposed) in ONE launch, the two
+ * reductions laid end to end: the gradient of a tensor that feeds two linear layers (dx = g0 W0 + g1 W1; unary1 and the
+ * shortcut of a bottleneck block, blocks.py:596-649). mvk_gemm_f32_dual_plan: the split of the concatenated reduction
+ * (zero-initialise C when > 1), or 0 when the shape is not supported (Kd must be a multiple of 32, N > 32). */
+int mvk_gemm_f32_dual_plan(int64_t M, int64_t N, int64_t Kd, int64_t Kd2, int* out_split);
+int mvk_gemm_f32_dual(const float* A, const float* B, const float* A2, const float* B2, float* C, int64_t M, int64_t N,
+                      int64_t Kd, int64_t Kd2, void* stream);
+
 /* Two products that share the left operand in ONE launch: C0 [M,N0] = A . op(B0), C1 [M,N1] = A . op(B1) (A [M,Kd]
  * row-major; transB as above) -- unary1 and the shortcut layer of a bottleneck block read the same input
  * (blocks.py:596-649). mvk_gemm_f32_pair_plan: out[0] = 1 when the pair can share a launch (both on the wide tile

@@ -483,6 +483,24 @@ def test_linear_bias_lrelu_equals_linear_then_bias_lrelu(ops, M, Kd, N, slope):
         assert rel_err(a.grad.cpu().numpy(), c.grad.cpu().numpy()) < 5e-6
 
 
+@pytest.mark.parametrize("M,N,Kd,Kd2", [(4288, 128, 64, 256), (85, 1024, 512, 2048), (332, 512, 256, 1024), (19464, 64, 32, 128),
+                                        (1300, 256, 128, 500), (700, 128, 48, 64), (700, 20, 64, 64)])
+def test_gemm_dual_equals_the_sum_of_two_products(ops, M, N, Kd, Kd2):
+    """mvk_gemm_f32_dual: A B + A2 B2 with the reductions laid end to end (every split of the concatenated reduction,
+    ragged second reduction included) against two float64 products; None for the shapes it does not take (a first
+    reduction that is not a whole number of k-tiles, outputs of <= 32 columns)."""
+    rng = np.random.default_rng(M + N + Kd2)
+    A, B = rng.normal(size=(M, Kd)).astype(np.float32), (rng.normal(size=(Kd, N)) * 0.1).astype(np.float32)
+    A2, B2 = rng.normal(size=(M, Kd2)).astype(np.float32), (rng.normal(size=(Kd2, N)) * 0.1).astype(np.float32)
+    ops.step_begin()
+    got = ops.gemm_dual(T(A), T(B), T(A2), T(B2))
+    if Kd % 32 != 0 or N <= 32:
+        assert got is None
+        return
+    want = A.astype(np.float64) @ B.astype(np.float64) + A2.astype(np.float64) @ B2.astype(np.float64)
+    assert rel_err(got.cpu().numpy(), want) < 2e-6
+
+
 def test_cell_order_of_the_neighbour_search_is_a_sorted_permutation(ops):
     """mvk_neighbors_cell_order after a radius search over three stacked clouds: a permutation of the rows that stays
     inside each cloud, ascending in the grid cell of the search (cell = 1.001 r from the cloud's minimum corner,

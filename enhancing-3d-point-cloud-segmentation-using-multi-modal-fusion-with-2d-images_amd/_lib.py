@@ -52,6 +52,7 @@ _SIGNATURES = {
     "mvk_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
     "mvk_gemm_f32_plan": (C.c_int, [_i64, _i64, _i64, _i, _i, _vp, _vp]),
     "mvk_gemm_f32_bias_act": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _vp, _f, _vp]),
+    "mvk_gemm_f32_scatter_cat": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i, _i64, _i64, _i, _vp, _vp, _vp]),
     "mvk_gemm_f32_dual_plan": (C.c_int, [_i64, _i64, _i64, _i64, _vp]),
     "mvk_gemm_f32_dual": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mvk_gemm_f32_pair_plan": (C.c_int, [_i64, _i64, _i64, _i64, _i, _vp]),

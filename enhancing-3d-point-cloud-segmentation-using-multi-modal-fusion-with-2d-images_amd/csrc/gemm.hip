@@ -195,6 +195,14 @@ struct GemmArgs {
   const float* B2;
   int64_t Kd2, lda2, ldb2;
   int vecA2, vecB2;
+  // scatter epilogue (null sc_idx: off): C is the gradient of [x[idx[m,0]] | skip[m]] (the decoder's upsampling +
+  // concatenation, architectures.py:334-335) and is never stored as such -- its first sc_c1 columns are added onto row
+  // idx[m,0] of sc_dst [sc_ns, sc_c1] (f32 atomics, zero-initialised by the caller), the rest goes to sc_rest [M, N - sc_c1]
+  const void* sc_idx;
+  int sc_idx64, sc_c1;
+  int64_t sc_stride, sc_ns;
+  float* sc_dst;
+  float* sc_rest;
 };
 
 template <bool TA, bool TB, int PM, int QN, int WM, int WN, bool DUAL = false>
@@ -337,6 +345,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
         for (int r = 0; r < 4; ++r) {
           const int64_t row = m0 + ra + 16 * p + g4 + r;
           if (row < a.M) {
+            if (a.sc_idx) {
+              const float v = acc[p][q][r];
+              if (col < a.sc_c1) {
+                const int j = a.sc_idx64 ? load_idx<true>(a.sc_idx, row * a.sc_stride, a.sc_ns)
+                                         : load_idx<false>(a.sc_idx, row * a.sc_stride, a.sc_ns);
+                if (j >= 0) atomicAdd(a.sc_dst + (int64_t)j * a.sc_c1 + col, v);
+              } else {
+                float* c2 = a.sc_rest + row * (a.N - a.sc_c1) + (col - a.sc_c1);
+                if (a.atomic_out) atomicAdd(c2, v);
+                else *c2 = v;
+              }
+              continue;
+            }
             float* c = a.C + row * a.N + col;
             if (a.atomic_out)
               atomicAdd(c, acc[p][q][r]);
@@ -599,6 +620,7 @@ int fill_args(GemmArgs& a, const Plan& p, const float* A, const float* B, float*
   a.bias = nullptr;
   a.act_slope = 1.f;
   a.A2 = nullptr; a.B2 = nullptr; a.Kd2 = 0; a.lda2 = 0; a.ldb2 = 0; a.vecA2 = 1; a.vecB2 = 1;
+  a.sc_idx = nullptr; a.sc_idx64 = 0; a.sc_c1 = 0; a.sc_stride = 0; a.sc_ns = 0; a.sc_dst = nullptr; a.sc_rest = nullptr;
   return split;
 }
 
@@ -702,9 +724,16 @@ extern "C" int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, 
 }
 
 namespace {
+struct ScatterOut {
+  const void* idx;
+  int idx64, c1;
+  int64_t stride, ns;
+  float* dst;
+  float* rest;
+};
 int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA, int transB,
              int accumulate, int split_k, float* bn_part, const int32_t* n_valid, const float* bias, float act_slope,
-             void* stream);
+             void* stream, const ScatterOut* scatter = nullptr);
 }
 
 extern "C" int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd,
@@ -721,10 +750,22 @@ extern "C" int mvk_gemm_f32_bias_act(const float* A, const float* B, float* C, i
   return gemm_run(A, B, C, M, N, Kd, 0, transB, 0, 1, nullptr, nullptr, bias, slope, stream);
 }
 
+// [d_x | d_skip] = A [M,Kd] . B [Kd,N] where the product is the gradient of cat([x[idx[m,0]], skip[m]]) (decoder:
+// closest_pool + torch.cat + nn.Linear, architectures.py:334-335): the first c1 columns are scattered onto d_x [Ns,c1]
+// (f32 atomics, zero-initialised by the caller), the others written to d_skip [M, N-c1] (atomics into a zero-initialised
+// d_skip when the plan of (M, N, Kd) splits the reduction: mvk_gemm_f32_plan). The product itself is never stored.
+extern "C" int mvk_gemm_f32_scatter_cat(const float* A, const float* B, int64_t M, int64_t N, int64_t Kd, const void* idx,
+                                        int idx64, int64_t idx_stride, int64_t Ns, int c1, float* d_x, float* d_skip,
+                                        void* stream) {
+  MVK_REQUIRE(idx && d_x && d_skip && c1 > 0 && c1 < N && Kd > 0 && Ns >= 0 && idx_stride >= 1, "gemm scatter_cat: bad arguments");
+  const ScatterOut sc{idx, idx64, c1, idx_stride, Ns, d_x, d_skip};
+  return gemm_run(A, B, d_skip /* unused */, M, N, Kd, 0, 0, 0, 0, nullptr, nullptr, nullptr, 1.f, stream, &sc);
+}
+
 namespace {
 int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA, int transB,
              int accumulate, int split_k, float* bn_part, const int32_t* n_valid, const float* bias, float act_slope,
-             void* stream) {
+             void* stream, const ScatterOut* scatter) {
   MVK_REQUIRE(M >= 0 && N >= 0 && Kd >= 0, "gemm: negative size");
   if (M == 0 || N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -754,6 +795,11 @@ int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int
   a.bias = bias;
   a.act_slope = act_slope;
   a.A2 = nullptr; a.B2 = nullptr; a.Kd2 = 0; a.lda2 = 0; a.ldb2 = 0; a.vecA2 = 1; a.vecB2 = 1;
+  a.sc_idx = nullptr; a.sc_idx64 = 0; a.sc_c1 = 0; a.sc_stride = 0; a.sc_ns = 0; a.sc_dst = nullptr; a.sc_rest = nullptr;
+  if (scatter) {
+    a.sc_idx = scatter->idx; a.sc_idx64 = scatter->idx64; a.sc_c1 = scatter->c1; a.sc_stride = scatter->stride;
+    a.sc_ns = scatter->ns; a.sc_dst = scatter->dst; a.sc_rest = scatter->rest;
+  }
   const int64_t tm = p.narrow ? 64 * p.pm : 16 * p.pm, tn = p.narrow ? 16 * p.qn : 64 * p.qn;
   MVK_REQUIRE(cdiv64(M, tm) < 65536 && split < 65536, "gemm: grid too large");
   dim3 grid((unsigned)cdiv64(N, tn), (unsigned)cdiv64(M, tm), (unsigned)split);
@@ -855,6 +901,8 @@ extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* t
     e.args.act_slope = 1.f;
     e.args.A2 = nullptr; e.args.B2 = nullptr; e.args.Kd2 = 0; e.args.lda2 = 0; e.args.ldb2 = 0;
     e.args.vecA2 = 1; e.args.vecB2 = 1;
+    e.args.sc_idx = nullptr; e.args.sc_idx64 = 0; e.args.sc_c1 = 0; e.args.sc_stride = 0; e.args.sc_ns = 0;
+    e.args.sc_dst = nullptr; e.args.sc_rest = nullptr;
     const int64_t tm = narrow ? 64 : 16 * group_wide_pm(), tn = narrow ? 32 : 64;      // plan tiles: narrow (pm 1, qn 2), wide (pm 2, qn 1)
     e.gx = (int)cdiv64(q.N, tn);
     e.gy = (int)cdiv64(q.M, tm);

@@ -18,6 +18,7 @@ except ImportError:
 _FUSED_REG = os.environ.get("MVK_FUSED_REGULARIZER", "1") == "1"   # development switch: 0 = the tensor-op form below
 _FUSED_LOSS = os.environ.get("MVK_FUSED_LOSS", "1") == "1"         # development switch: 0 = torch.nn.CrossEntropyLoss
 _FUSED_UPSAMPLE = os.environ.get("MVK_FUSED_UPSAMPLE", "1") == "1"  # development switch: 0 = closest_pool, then torch.cat
+_FUSED_UPSAMPLE_LINEAR = os.environ.get("MVK_FUSED_UPSAMPLE_LINEAR", "1") == "1"   # ... and the unary layer behind them: one backward product
 
 
 def p2p_fitting_regularizer(net):
@@ -205,15 +206,25 @@ def run_encoder_decoder(net, x, batch, encoder=None):
 
 def run_decoder(net, x, skip_x, batch):
     """Decoder walk (architectures.py:332-337): nearest upsampling, concatenation with the skip features, unary."""
-    joined = False
-    for block_i, block_op in enumerate(net.decoder_blocks):
+    joined, pending = False, None
+    blocks = list(net.decoder_blocks)
+    for block_i, block_op in enumerate(blocks):
+        if pending is not None:         # the unary layer behind a fused upsampling + concatenation takes all three
+            x = block_op.forward_upsampled(*pending)
+            pending = None
+            continue
         if block_i in net.decoder_concats and not joined:
             x = torch.cat([x, skip_x.pop()], dim=1)
         joined = False
         if _FUSED_UPSAMPLE and isinstance(block_op, NearestUpsampleBlock) and (block_i + 1) in net.decoder_concats \
                 and x.is_cuda and block_i not in net.decoder_concats:
+            inds, skip = batch.upsamples[block_op.layer_ind - 1], skip_x.pop()
+            nxt = blocks[block_i + 1] if block_i + 1 < len(blocks) else None
+            if _FUSED_UPSAMPLE_LINEAR and isinstance(nxt, UnaryBlock) and torch.is_grad_enabled() and net.training:
+                pending = (x, inds, skip)
+                continue
             # nearest upsampling + the concatenation that follows it (:334-335) as one launch
-            x = _ops.upsample_cat(x, batch.upsamples[block_op.layer_ind - 1], skip_x.pop())
+            x = _ops.upsample_cat(x, inds, skip)
             joined = True
             continue
         x = block_op(x, batch)

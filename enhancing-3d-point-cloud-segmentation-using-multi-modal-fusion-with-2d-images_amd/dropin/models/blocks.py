@@ -275,6 +275,13 @@ class UnaryBlock(nn.Module):
             out = self.batch_norm(y, None if self.no_relu else 0.1)
         return (out, alias) if passthrough else out
 
+    def forward_upsampled(self, x, inds, skip):
+        """forward(cat([closest_pool(x, inds), skip], 1)): the decoder's upsampling + concatenation + this layer
+        (architectures.py:334-337) with the backward of all three as one product (ops.upsample_cat_linear)."""
+        nv = _bn_rows(skip, self, self.use_bn) if _GEMM_STATS else None
+        y = ops.upsample_cat_linear(x, inds, skip, self.mlp.weight, stats_n_valid=nv)
+        return self.batch_norm(y, None if self.no_relu else 0.1)
+
     def __repr__(self):
         return 'UnaryBlock(in_feat: {:d}, out_feat: {:d}, BN: {:s}, ReLU: {:s})'.format(
             self.in_dim, self.out_dim, str(self.use_bn), str(not self.no_relu))

@@ -1324,6 +1324,60 @@ class _UpsampleCatFn(torch.autograd.Function):
         return dx, None, d_skip
 
 
+class _UpsampleCatLinearFn(torch.autograd.Function):
+    """linear(cat([closest_pool(x, inds), skip], 1), W): the decoder's upsampling, concatenation and unary layer. Forward:
+    the fused gather + concatenation, then the GEMM (statistics epilogue as in linear()). Backward: ONE product for both
+    inputs -- g W is never stored, the GEMM's epilogue scatters its upsampled columns onto dx and writes the skip columns
+    (mvk_gemm_f32_scatter_cat) -- and the weight gradient from the saved concatenation."""
+
+    @staticmethod
+    def forward(ctx, x, inds2d, skip, W, stats_n_valid):
+        _dev(x, inds2d, skip, W)
+        x, skip = _f32c(x), _f32c(skip)
+        inds2d, i64 = _idx(inds2d)
+        Nq = inds2d.shape[0]
+        if skip.shape[0] != Nq:
+            raise RuntimeError("upsample_cat_linear: the skip features and the upsampling indices differ in length")
+        stride = inds2d.shape[1] if inds2d.dim() == 2 else 1
+        C1, C2 = x.shape[1], skip.shape[1]
+        cat = torch.empty((Nq, C1 + C2), device=x.device, dtype=torch.float32)
+        check(lib().mvk_gather_rows_cat_fwd(_p(x), x.shape[0], C1, _p(inds2d), i64, Nq, stride, _p(skip), C2, _p(cat),
+                                            _stream()))
+        ctx.set_materialize_grads(False)
+        ctx.save_for_backward(cat, W, inds2d)
+        ctx.dims = (x.shape[0], C1, C2, stride, i64)
+        if stats_n_valid is None:
+            return gemm(cat, W, transB=True), None
+        y, st = gemm(cat, W, transB=True, stats_n_valid=stats_n_valid)
+        part = st[0] if st is not None else None
+        if part is not None:
+            ctx.mark_non_differentiable(part)
+        return y, part
+
+    @staticmethod
+    def backward(ctx, g, g_part=None):
+        cat, W, inds2d = ctx.saved_tensors
+        ns, C1, C2, stride, i64 = ctx.dims
+        g = _f32c(g)
+        M, N, Kd = cat.shape[0], C1 + C2, W.shape[0]
+        dx = _zeros((ns, C1), g.device)
+        split = gemm_plan(M, N, Kd, None, False)[0] if M > 0 else 1
+        d_skip = _zeros((M, C2), g.device) if split > 1 else torch.empty((M, C2), device=g.device, dtype=torch.float32)
+        if M > 0:
+            check(lib().mvk_gemm_f32_scatter_cat(_p(g), _p(W), M, N, Kd, _p(inds2d), i64, stride, ns, C1, _p(dx),
+                                                 _p(d_skip), _stream()))
+        dW = _dw_gemm(g, cat, target=W) if ctx.needs_input_grad[3] else None
+        return (dx if ctx.needs_input_grad[0] else None), None, (d_skip if ctx.needs_input_grad[2] else None), dW, None
+
+
+def upsample_cat_linear(x, inds, skip, W, stats_n_valid=None):
+    """linear(upsample_cat(x, inds, skip), W, stats_n_valid=...) with a one-launch backward for x and skip."""
+    y, part = _UpsampleCatLinearFn.apply(x, inds, skip, W, stats_n_valid)
+    if part is not None:
+        y._mvk_bn_stats = (part, gemm_plan(y.shape[0], y.shape[1], W.shape[1], None, True)[1])
+    return y
+
+
 def upsample_cat(x, inds, skip):
     """torch.cat([closest_pool(x, inds), skip], dim=1) of the KPFCNN decoder (blocks.py:79-91, architectures.py:334)."""
     return _UpsampleCatFn.apply(x, inds, skip)

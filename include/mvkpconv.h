@@ -131,6 +131,14 @@ int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t
 int mvk_gemm_f32_bias_act(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transB,
                           const float* bias, float slope, void* stream);
 
+/* Backward of closest_pool + torch.cat + nn.Linear (KPFCNN decoder, architectures.py:334-335 + the unary block behind):
+ * the product A [M,Kd] . B [Kd,N] is the gradient of cat([x[idx[m,0]], skip[m]]) and is never stored -- its first c1
+ * columns are added onto row idx[m,0] of d_x [Ns,c1] (f32 atomics; zero-initialised by the caller; shadow indices
+ * dropped), the other N - c1 columns are written to d_skip [M, N-c1] (atomics into a zero-initialised d_skip when
+ * mvk_gemm_f32_plan(M, N, Kd) splits the reduction). */
+int mvk_gemm_f32_scatter_cat(const float* A, const float* B, int64_t M, int64_t N, int64_t Kd, const void* idx, int idx64,
+                             int64_t idx_stride, int64_t Ns, int c1, float* d_x, float* d_skip, void* stream);
+
 /* C [M,N] = A [M,Kd] . B [Kd,N] + A2 [M,Kd2] . B2 [Kd2,N] (row-major, nothing transposed) in ONE launch, the two
  * reductions laid end to end: the gradient of a tensor that feeds two linear layers (dx = g0 W0 + g1 W1; unary1 and the
  * shortcut of a bottleneck block, blocks.py:596-649). mvk_gemm_f32_dual_plan: the split of the concatenated reduction

@@ -501,6 +501,29 @@ def test_gemm_dual_equals_the_sum_of_two_products(ops, M, N, Kd, Kd2):
     assert rel_err(got.cpu().numpy(), want) < 2e-6
 
 
+@pytest.mark.parametrize("Ns,Nq,C1,C2,Cout,idt", [(1300, 4288, 512, 256, 256, torch.int32), (85, 332, 2048, 1024, 1024, torch.int32),
+                                                   (4288, 19464, 256, 128, 128, torch.int64), (300, 1000, 30, 7, 16, torch.int32)])
+def test_upsample_cat_linear_equals_the_three_steps(ops, Ns, Nq, C1, C2, Cout, idt):
+    """closest_pool + torch.cat + nn.Linear of the decoder as one autograd node whose backward is ONE product with a
+    scatter epilogue (mvk_gemm_f32_scatter_cat): output and the gradients of the coarse features, the skip features and
+    the weight against the three separate steps (split and unsplit plans, shadow indices, both index widths)."""
+    rng = np.random.default_rng(Ns + C1)
+    inds = T(rng.integers(0, Ns + 1, (Nq, 4))).to(idt)
+    x = T(rng.normal(size=(Ns, C1)).astype(np.float32)).requires_grad_(True)
+    skip = T(rng.normal(size=(Nq, C2)).astype(np.float32)).requires_grad_(True)
+    W = T((rng.normal(size=(Cout, C1 + C2)) * 0.05).astype(np.float32)).requires_grad_(True)
+    x2, skip2, W2 = [t.detach().clone().requires_grad_(True) for t in (x, skip, W)]
+    g = T(rng.normal(size=(Nq, Cout)).astype(np.float32))
+    ops.step_begin()
+    y = ops.upsample_cat_linear(x, inds, skip, W)
+    r = ops.linear(torch.cat([ops.closest_pool(x2, inds), skip2], dim=1), W2)
+    assert rel_err(y.detach().cpu().numpy(), r.detach().cpu().numpy()) < 2e-6
+    (y * g).sum().backward()
+    (r * g).sum().backward()
+    for a, c in ((x, x2), (skip, skip2), (W, W2)):
+        assert rel_err(a.grad.cpu().numpy(), c.grad.cpu().numpy()) < 5e-6
+
+
 def test_cell_order_of_the_neighbour_search_is_a_sorted_permutation(ops):
     """mvk_neighbors_cell_order after a radius search over three stacked clouds: a permutation of the rows that stays
     inside each cloud, ascending in the grid cell of the search (cell = 1.001 r from the cloud's minimum corner,

@@ -599,6 +599,17 @@ bool launch_pair_cfg(const Plan& p, dim3 grid, hipStream_t st, const GemmArgs& a
   return false;
 }
 
+// a product of <= 32 columns (the narrow tile class) beside a wide one with a short reduction: it rides on the wide
+// tiles of its partner, half of its one column tile empty -- level 0's unary1 (64 -> 32) beside its shortcut (64 -> 128)
+void pair_widen(Plan& a, const Plan& b, int64_t Kd) {
+  if (a.narrow && !b.narrow && Kd <= 512) {
+    a.narrow = 0;
+    a.pm = b.pm;
+    a.qn = 1;
+    a.split = 1;
+  }
+}
+
 // fills the arguments of one product like mvk_gemm_f32_ex does; returns its split
 int fill_args(GemmArgs& a, const Plan& p, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd,
               int transA, int transB, float* bn_part, const int32_t* n_valid) {
@@ -672,7 +683,8 @@ extern "C" int mvk_gemm_f32_pair_plan(int64_t M, int64_t N0, int64_t N1, int64_t
   MVK_REQUIRE(M >= 0 && N0 >= 0 && N1 >= 0 && Kd >= 0 && out, "gemm pair plan: bad arguments");
   for (int i = 0; i < 5; ++i) out[i] = 0;
   if (M == 0 || N0 == 0 || N1 == 0 || Kd == 0) return 0;
-  const Plan p0 = plan_gemm(M, N0, Kd, 0, want_stats != 0), p1 = plan_gemm(M, N1, Kd, 0, want_stats != 0);
+  Plan p0 = plan_gemm(M, N0, Kd, 0, want_stats != 0), p1 = plan_gemm(M, N1, Kd, 0, want_stats != 0);
+  pair_widen(p0, p1, Kd);
   if (p0.narrow || p1.narrow || p0.pm != p1.pm || p0.qn != 1 || p1.qn != 1 || (p0.pm != 2 && p0.pm != 4)) return 0;
   out[0] = 1;
   out[1] = p0.split;
@@ -689,7 +701,8 @@ extern "C" int mvk_gemm_f32_pair(const float* A, const float* B0, const float* B
                                  int64_t N0, int64_t N1, int64_t Kd, int transB, int want_stats, float* bn_part0,
                                  float* bn_part1, const int32_t* n_valid, void* stream) {
   MVK_REQUIRE(M > 0 && N0 > 0 && N1 > 0 && Kd > 0, "gemm pair: empty product");
-  const Plan p0 = plan_gemm(M, N0, Kd, 0, want_stats != 0), p1 = plan_gemm(M, N1, Kd, 0, want_stats != 0);
+  Plan p0 = plan_gemm(M, N0, Kd, 0, want_stats != 0), p1 = plan_gemm(M, N1, Kd, 0, want_stats != 0);
+  pair_widen(p0, p1, Kd);
   MVK_REQUIRE(!p0.narrow && !p1.narrow && p0.pm == p1.pm && p0.qn == 1 && p1.qn == 1 && (p0.pm == 2 || p0.pm == 4),
               "gemm pair: the two products do not share a tile shape (ask mvk_gemm_f32_pair_plan first)");
   hipStream_t st = (hipStream_t)stream;

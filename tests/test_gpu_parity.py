@@ -436,7 +436,7 @@ def test_bn_lrelu_pair_equals_two_single_launches(ops, R, Da, Db, from_gemm):
 def test_linear_pair_equals_two_linear_layers(ops, M, Kd, N0, N1, stats):
     """mvk_gemm_f32_pair: unary1 and the shortcut layer of a bottleneck block (same input) as one launch -- outputs,
     epilogue statistics and all three gradients against two ops.linear calls (unsplit products: the same bits; split
-    ones: the rounding of the atomics' order); None when the two products are not in the same tile class."""
+    ones: the rounding of the atomics' order)."""
     rng = np.random.default_rng(M + N0)
     x = T(rng.normal(size=(M, Kd)).astype(np.float32)).requires_grad_(True)
     W0 = T((rng.normal(size=(N0, Kd)) * 0.1).astype(np.float32)).requires_grad_(True)
@@ -444,10 +444,7 @@ def test_linear_pair_equals_two_linear_layers(ops, M, Kd, N0, N1, stats):
     nv = T(np.asarray([M - 5], np.int32)) if stats else None
     x2, V0, V1 = [t.detach().clone().requires_grad_(True) for t in (x, W0, W1)]
     g0, g1 = T(rng.normal(size=(M, N0)).astype(np.float32)), T(rng.normal(size=(M, N1)).astype(np.float32))
-    pair = ops.linear_pair(x, W0, W1, nv)
-    if N0 <= 32:
-        assert pair is None            # a narrow and a wide tile class: no shared launch
-        return
+    pair = ops.linear_pair(x, W0, W1, nv)       # (N0 = 32: the narrow product rides on its partner's wide tiles)
     y0, y1 = pair
     r0, r1 = ops.linear(x2, V0, stats_n_valid=nv), ops.linear(x2, V1, stats_n_valid=nv)
     for a, b_ in ((y0, r0), (y1, r1)):

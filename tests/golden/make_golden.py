@@ -670,7 +670,207 @@ def g11_unproject_select():
     save("g11_unproject_select", **arrs)
 
 
-GROUPS = {"g11": g11_unproject_select, "g9": g9_ply, "g8": g8_metrics, "g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn, "g5b": g5b_kpfcnn_deformable, "g10": g10_reprojection,
+def _reference_network_class(rel_path, substitutes):
+    """The classes and functions of a reference MODEL file that cannot be imported here (the three fusion networks need
+    torchvision through `mvpnet.models.unet_resnet34` and the compiled `group_points_cuda` through `mvpnet.ops.group_points`
+    at import time): ast.parse the file where it lies, drop its `from mvpnet... import` lines, execute every other top-level
+    node (`from models.blocks import *` -- the reference's own importable blocks --, `import numpy as np`,
+    `p2p_fitting_regularizer`, `KPFCNN_featureAggre`) in a namespace that holds `substitutes` under the names the dropped
+    imports would have bound. The reference's own text runs; none of it is written anywhere."""
+    import ast
+    path = os.path.join(REFROOT, rel_path)
+    tree = ast.parse(open(path).read(), filename=path)
+    body, dropped = [], []
+    for n in tree.body:
+        if isinstance(n, ast.ImportFrom) and n.module and n.module.startswith("mvpnet"):
+            dropped += [a.name for a in n.names]
+            continue
+        body.append(n)
+    assert sorted(dropped) == sorted(substitutes), (dropped, list(substitutes))
+    ns = dict(substitutes)
+    ns["__name__"] = "g12_reference_text"
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), ns)
+    cls = ns["KPFCNN_featureAggre"]
+    fwd = cls.forward.__code__
+    return cls, (fwd.co_firstlineno, max(l for _, _, l in fwd.co_lines() if l))
+
+
+def g12_fusion_wirings():
+    """a16 pinned: the `KPFCNN_featureAggre` class of each fusion variant -- `__init__`, `forward`
+    (architectures_sphere.py:242-316, architectures_sphere_middle_fusion.py:231-320, architectures_sphere_late_fusion.py:
+    235-306) and `loss` -- EXECUTED from the reference files (see _reference_network_class) over the reference's own
+    importable modules: `models.blocks` (block_decider, UnaryBlock, KPConv ...), `utils.config.Config`, and the
+    `FeatureAggregation` class of mvpnet/FeatureAggregation_dummy_test.py:7-65 (the reference's byte-identical copy of
+    mvpnet/models/mvpnet_3d.py:12-70, whose own module needs the CUDA extension). Exactly THREE names are substituted:
+      * `UNetResNet34` (torchvision is absent): a module without parameters whose forward returns the fixed feature map
+        util.g12_feature_map -- the frozen 2D encoder is a PyTorch-ROCm library network outside the wiring under test;
+      * `group_points` (CUDA extension): `group_points_torch`, the reference test's own torch.gather restatement,
+        executed from mvpnet/ops/tests/test_group_points.py:6-12 by the same ast route;
+      * `torch.Tensor.cuda` is a no-op while the forward runs (`torch.from_numpy(knn_list[i]).long().cuda()`, :266 /
+        :255 / :259): this container has no GPU.
+    Weights: util.seeded_state (a formula over the parameter names and shapes, shared with the tests) loaded into the
+    reference network with load_state_dict(strict=True) -- the 24.4 M parameters never enter the fixture. Batch: two
+    ragged spheres, 3 views of 24 x 32 pixels, k = 3, pyramid through the compiled reference core."""
+    import ast
+    import tempfile
+    import types
+    import torch
+    from sklearn.neighbors import NearestNeighbors
+    from oracle import npref, pyramid
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import util
+    _ref_blocks()                                                # cwd on sys.path: models.*, utils.*, kernels.*
+    from utils.config import Config
+    sys.path.insert(0, REFROOT)
+    cwd = os.getcwd()
+    os.chdir(REFROOT)
+    from mvpnet.FeatureAggregation_dummy_test import FeatureAggregation
+    os.chdir(cwd)
+    tpath = os.path.join(REFROOT, "mvpnet/ops/tests/test_group_points.py")
+    ttree = ast.parse(open(tpath).read(), filename=tpath)
+    gdef = [n for n in ttree.body if isinstance(n, ast.FunctionDef) and n.name == "group_points_torch"]
+    gns = {"torch": torch}
+    exec(compile(ast.Module(body=gdef, type_ignores=[]), tpath, "exec"), gns)
+    group_points_torch = gns["group_points_torch"]
+
+    rng = np.random.default_rng(1212)
+    clouds = [room_cloud(rng, 60000, 0.9), room_cloud(rng, 40000, 0.75)]
+    subs = [cport.subsample_batch(c, [c.shape[0]], dl=0.04, impl="ref")[0] for c in clouds]
+    p0 = np.concatenate(subs, 0)
+    l0 = np.array([s.shape[0] for s in subs], np.int32)
+    np.random.seed(1212)
+    rots = [pyramid.draw_rotations(2) for _ in range(4)]
+    limits = [30, 32, 32, 30, 20]
+    pyr = pyramid.segmentation_inputs(_Cfg, p0, l0, limits, rots, impl="ref")
+    nv, h, w, k = 3, 24, 32, 3
+    cam = np.array([[28.9, 0, 15.9], [0, 28.9, 11.9], [0, 0, 1]], np.float32)
+    image_xyz, knn_list, i0 = [], [], 0
+    for bi, n in enumerate(l0):
+        depth = rng.integers(400, 2500, (nv, h, w)).astype(np.uint16)
+        depth[rng.random((nv, h, w)) < 0.1] = 0
+        poses = np.stack([np.eye(4, dtype=np.float32) for _ in range(nv)])
+        for i in range(nv):
+            a = 0.5 * i + 0.3 * bi
+            poses[i, :3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]], np.float32)
+            poses[i, :3, 3] = [0.1 * i - 0.4, -0.3, -1.2 + 0.05 * bi]
+        xyz, mask = npref.unproject_frames(cam, depth, poses)
+        valid_xyz = xyz.reshape(-1, 3)[mask.reshape(-1)]
+        ind_all = np.nonzero(mask.reshape(-1))[0]
+        pts = p0[i0:i0 + n]
+        nbrs = NearestNeighbors(n_neighbors=k, algorithm='ball_tree').fit(valid_xyz)       # ScanNet_sphere_color.py:448-451
+        dist, knn = nbrs.kneighbors(pts)
+        assert np.all(np.diff(dist, axis=1) > 0), "k-NN fixture must be tie-free"
+        knn_list.append(ind_all[knn].astype(np.int64)[None])                                 # (1, s_np, k)
+        image_xyz.append(xyz.astype(np.float32))
+        i0 += n
+    image_xyz = np.stack(image_xyz)                                                          # (b, nv, h, w, 3)
+    fmap = util.g12_feature_map(len(l0) * nv, 64, h, w)
+    labels = rng.integers(0, 20, p0.shape[0]).astype(np.int64)
+    ones = np.ones((p0.shape[0], 1), np.float32)
+    feature_3d = {"early": np.concatenate([ones, p0[:, 2:3]], 1), "middle": np.concatenate([ones, p0], 1),
+                  "late": np.concatenate([ones, p0], 1)}
+
+    class UNetResNet34(torch.nn.Module):
+        def __init__(self, num_classes, p=0.0, pretrained=True):
+            super().__init__()
+
+        def forward(self, data_batch):
+            assert tuple(data_batch['image'].shape) == (len(l0) * nv, 3, h, w)
+            return {'feature': torch.from_numpy(fmap)}
+
+    ckpt = os.path.join(tempfile.mkdtemp(), "net2d.pth")
+    torch.save({'model': {}}, ckpt)
+    arrs = dict(points0=p0, lens0=l0, limits=np.array(limits, np.int32), rotations=np.stack(rots, 0), labels=labels,
+                image_xyz=image_xyz, knn0=knn_list[0], knn1=knn_list[1], views=np.array([nv, h, w, k], np.int32))
+    for l in range(5):
+        arrs["points%d" % l] = pyr['points'][l]
+        arrs["lengths%d" % l] = pyr['lengths'][l]
+        arrs["neighbors%d" % l] = pyr['neighbors'][l].astype(np.int32)
+        arrs["pools%d" % l] = pyr['pools'][l].astype(np.int32)
+        arrs["upsamples%d" % l] = pyr['upsamples'][l].astype(np.int32)
+    files = {"early": "KPConv-PyTorch/models/architectures_sphere.py",
+             "middle": "KPConv-PyTorch/models/architectures_sphere_middle_fusion.py",
+             "late": "KPConv-PyTorch/models/architectures_sphere_late_fusion.py"}
+    for variant, rel in files.items():
+        cls, lines = _reference_network_class(rel, {"FeatureAggregation": FeatureAggregation, "UNetResNet34": UNetResNet34,
+                                                    "group_points": group_points_torch})
+        print("executed from the reference:", rel, "forward at lines", lines)
+
+        class C(Config):
+            dataset = 'ScanNet'
+            dataset_task = 'cloud_segmentation'
+            num_classes = 20
+            architecture = ARCH
+            num_kernel_points = 15
+            first_subsampling_dl = 0.04
+            conv_radius = 2.5
+            deform_radius = 6.0
+            KP_extent = 1.2
+            KP_influence = 'linear'
+            aggregation_mode = 'sum'
+            first_features_dim = 128
+            in_points_dim = 3
+            modulated = False
+            use_batch_norm = True
+            batch_norm_momentum = 0.02
+            deform_fitting_mode = 'point2point'
+            deform_fitting_power = 1.0
+            deform_lr_factor = 0.1
+            repulse_extent = 1.2
+            class_w = []
+            path_2D = ckpt
+        if variant == "early":
+            C.in_features_dim = 66
+        elif variant == "middle":
+            C.in_features_dim_3d, C.in_features_dim_2d, C.in_features_dim = 4, 65, 4
+        else:
+            C.in_features_dim = 4
+        cfg = C()
+        torch.manual_seed(12)
+        np.random.seed(12)
+        net = cls(cfg, list(range(20)), [])
+        shapes = {n: tuple(t.shape) for n, t in net.state_dict().items()}
+        kp = {n: t.detach().numpy() for n, t in net.state_dict().items() if n.endswith("kernel_points")}
+        sd = util.seeded_state(shapes, 1200 + len(variant), fixed=kp)
+        net.load_state_dict({n: torch.from_numpy(v) for n, v in sd.items()}, strict=True)
+        net.train()
+        batch = types.SimpleNamespace(
+            points=[torch.from_numpy(a) for a in pyr['points']], neighbors=[torch.from_numpy(a) for a in pyr['neighbors']],
+            pools=[torch.from_numpy(a) for a in pyr['pools']], upsamples=[torch.from_numpy(a) for a in pyr['upsamples']],
+            lengths=[torch.from_numpy(a) for a in pyr['lengths']], labels=torch.from_numpy(labels),
+            images=torch.zeros((len(l0), nv, 3, h, w)), image_xyz=torch.from_numpy(image_xyz), knn_list=knn_list,
+            feat_aggre_points=torch.from_numpy(p0).unsqueeze(0), feature_3d=torch.from_numpy(feature_3d[variant]))
+        real_cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **kw: self
+        try:
+            out = net(batch, cfg)
+        finally:
+            torch.Tensor.cuda = real_cuda
+        loss = net.loss(out, batch.labels)
+        loss.backward()
+        named = dict(net.named_parameters())
+        fa_grads = [named[n].grad for n in named if n.startswith("feat_aggreg.")]
+        if variant == "late":
+            assert all(g is not None and float(g.abs().max()) > 0 for g in fa_grads)
+        else:
+            assert all(g is None for g in fa_grads)                # `.clone().detach()`: nothing reaches the 2D branch
+        arrs[variant + "/logits"] = out.detach().numpy()
+        arrs[variant + "/loss"] = np.float32(loss.item())
+        arrs[variant + "/forward_lines"] = np.array(lines, np.int32)
+        arrs[variant + "/param_names"] = np.array(sorted(shapes))
+        arrs[variant + "/param_shapes"] = np.array([",".join(map(str, shapes[n])) for n in sorted(shapes)])
+        for n, idx, vals, norm in util.gradient_digest({n: p.grad.numpy() for n, p in named.items() if p.grad is not None}):
+            arrs["%s/gnorm/%s" % (variant, n)] = np.float64(norm)
+            arrs["%s/gidx/%s" % (variant, n)] = idx
+            arrs["%s/gval/%s" % (variant, n)] = vals
+        for n in kp:
+            assert np.array_equal(kp[n], sd[n])
+        for n in sorted(kp):               # drawn by load_kernels (random rotation + noise): data of this network instance
+            arrs["%s/kp/%s" % (variant, n)] = kp[n]
+    save("g12_fusion_wirings", **arrs)
+
+
+GROUPS = {"g12": g12_fusion_wirings, "g11": g11_unproject_select, "g9": g9_ply, "g8": g8_metrics, "g7": g7_sphere_picking, "g1": g1_subsample, "g2": g2_neighbors, "g3": g3_pyramid, "g4": g4_kpconv, "g5": g5_kpfcnn, "g5b": g5b_kpfcnn_deformable, "g10": g10_reprojection,
           "g6": g6_fusion}
 
 if __name__ == "__main__":

@@ -9,7 +9,7 @@ import torch
 
 from conftest import load_golden
 from util import bits_equal, rel_err, check_err
-from test_oracle_vs_golden import check_pyramid, g5_config, g5b_config, g5_batch, _Cfg
+from test_oracle_vs_golden import check_pyramid, g5_config, g5b_config, g5_batch, _Cfg, g12_inputs, g12_check_gradients
 
 pytestmark = pytest.mark.gpu
 G5_GRAD_TOL = 1e-3      # round 3: ~3x the measured worst case (2.9e-4 on G5, 5.6e-5 on G5b; profiles/r03_parity_errors.txt); was 2e-3
@@ -97,6 +97,44 @@ def test_reference_deformable_kpfcnn_state_dict_runs_on_the_hip_path(name):
         # kink (make_golden.py seed loop): on such inputs the two float32 paths take different slopes and the END-TO-END
         # gradient is discontinuous -- what is bounded here is rounding, not that discontinuity
         check_err("G5b %s worst parameter gradient (%s)" % (tag, worst[1][5:]), worst[0], G5_GRAD_TOL)
+
+
+@pytest.mark.parametrize("variant", ["early", "middle", "late"])
+def test_fusion_networks_vs_reference_forward_texts(variant):
+    """a16 on the HIP path: the drop-in early / middle / late fusion networks against fixture G12 = the reference's own
+    `KPFCNN_featureAggre.forward` texts executed over the reference's blocks (see make_golden.g12_fusion_wirings for the
+    three substituted names). Two ragged spheres, so the per-sphere group_points loop and the BatchNorm over the stacked
+    batch are exercised; the fixed feature map enters as `batch.feature_2d` (the frozen encoder's output)."""
+    syn = importlib.import_module(PKG + ".synthetic")
+    common = importlib.import_module(PKG + ".dropin.datasets.common")
+    g = load_golden("g12_fusion_wirings")
+    cfg, sd, b = g12_inputs(g, variant)
+    np.random.seed(0)
+    net = syn.build_model(cfg, torch.device("cuda:0"))
+    res = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("net_2d.") for k in res.missing_keys), res
+    net.train()
+    for m in net.net_2d._modules.values():
+        m.train(False)
+    for dt in (torch.int64, torch.int32):
+        net.zero_grad(set_to_none=True)
+        net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+        pyr = dict(points=[t.cuda() for t in b["points"]], neighbors=[t.cuda().to(dt) for t in b["neighbors"]],
+                   pools=[t.cuda().to(dt) for t in b["pools"]], upsamples=[t.cuda().to(dt) for t in b["upsamples"]],
+                   lengths=[torch.from_numpy(l) for l in b["lengths"]])
+        batch = common.SphereBatch(pyr, b["labels"].cuda(), feature_3d=b["feature_3d"].cuda(),
+                                   feat_aggre_points=b["feat_aggre_points"].cuda(), image_xyz=b["image_xyz"].cuda(),
+                                   images=b["images"].cuda(), knn_list=[k.numpy() for k in b["knn_list"]])
+        batch.feature_2d = b["feature_2d"].cuda()
+        out = net(batch, cfg)
+        loss = net.loss(out, batch.labels)
+        loss.backward()
+        tag = "%s %s" % (variant, "i64" if dt == torch.int64 else "i32")
+        check_err("G12 %s logits vs the reference's forward" % tag, rel_err(out.detach().cpu().numpy(), g[variant + "/logits"]), 1e-4)
+        check_err("G12 %s loss (abs)" % tag, abs(loss.item() - float(g[variant + "/loss"])), 1e-5)
+        grads = {n: p.grad.cpu().numpy() for n, p in net.named_parameters() if p.grad is not None}
+        assert any(k.startswith("feat_aggreg.") for k in grads) == (variant == "late")
+        g12_check_gradients(g, variant, grads, tag, 5e-3, 5e-2)
 
 
 def test_fusion_chain_vs_golden():

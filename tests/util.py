@@ -67,3 +67,53 @@ def check_err(label, err, bound):
     except OSError:
         pass
     assert err < bound, line
+
+
+def seeded_state(shapes, seed, fixed=None):
+    """A state dict as a FORMULA over parameter names and shapes (fixtures G12 / G13 hold the seed, not 24 M weights):
+    entries in sorted-name order from one np.random.default_rng(seed) stream; weights ~ N(0, 1/fan_in) (KPConv
+    `weights` [K,Cin,Cout]: fan_in = K*Cin; `mlp.weight` / conv weights [out,in,...]: fan_in = in), BatchNorm weight
+    1 + 0.1 n, every bias 0.1 n, running_mean 0.1 n, running_var 1 + 0.1 |n|, num_batches_tracked 0. `fixed`: entries
+    taken as given (the kernel points a network instance drew)."""
+    rng = np.random.default_rng(int(seed))
+    fixed = fixed or {}
+    out = {}
+    for name in sorted(shapes):
+        shape = tuple(int(v) for v in shapes[name])
+        if name in fixed:
+            out[name] = np.ascontiguousarray(fixed[name], np.float32)
+            continue
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "num_batches_tracked":
+            out[name] = np.zeros(shape, np.int64)
+            continue
+        n = rng.standard_normal(shape).astype(np.float32)
+        if leaf == "weights":
+            v = n * np.float32(1.0 / np.sqrt(shape[0] * shape[1]))
+        elif leaf == "weight" and len(shape) >= 2:
+            v = n * np.float32(1.0 / np.sqrt(shape[1]))
+        elif leaf == "weight":
+            v = np.float32(1.0) + np.float32(0.1) * n
+        elif leaf == "running_var":
+            v = np.float32(1.0) + np.float32(0.1) * np.abs(n)
+        else:                                   # bias, running_mean, offset_bias
+            v = np.float32(0.1) * n
+        out[name] = np.ascontiguousarray(v, np.float32)
+    return out
+
+
+def g12_feature_map(n, c, h, w, seed=1234):
+    """The fixed output of the stand-in 2D encoder of fixture G12: (n, c, h, w) float32."""
+    return np.random.default_rng(seed).standard_normal((n, c, h, w)).astype(np.float32)
+
+
+def gradient_digest(grads, n_elements=64, seed=77):
+    """[(name, flat indices int64 [<= 64], values float32, float64 norm)] per gradient tensor, sorted by name: what a
+    fixture keeps of a full set of parameter gradients (G12 / G13)."""
+    out = []
+    for name in sorted(grads):
+        g = np.asarray(grads[name], np.float32).reshape(-1)
+        rng = np.random.default_rng(seed + len(name) + g.size % 9973)
+        idx = np.sort(rng.choice(g.size, size=min(n_elements, g.size), replace=False)).astype(np.int64)
+        out.append((name, idx, g[idx].copy(), float(np.linalg.norm(g.astype(np.float64)))))
+    return out

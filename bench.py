@@ -52,6 +52,30 @@ def parse():
     return ap.parse_args()
 
 
+def visible_gpu_count():
+    """GPUs of this node as the kernel driver lists them (/sys/class/kfd topology nodes with SIMDs; CPUs are nodes
+    without), cut to HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES when set; None when sysfs cannot tell (the ranks then
+    find out themselves and fail loudly). No HIP or torch.cuda call: the launcher parent never touches the GPU runtime."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for path in nodes:
+        try:
+            with open(path) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process
     (python -m torch.distributed.run, one rank per GPU) before this process has touched the GPU, relay
@@ -60,8 +84,8 @@ def launch_ranks(args):
     import socket
     import subprocess
     one_gpu = os.environ.get("MVK_BENCH_ONE_GPU") == "1" or os.environ.get("MVK_BENCH_DRY") == "1"
-    have = torch.cuda.device_count()            # counting devices does not initialise the GPU
-    if not one_gpu and have < args.gpus:
+    have = visible_gpu_count()                  # from sysfs: the parent makes no GPU-runtime call at all
+    if not one_gpu and have is not None and have < args.gpus:
         print("bench.py: --gpus %d but only %d GPU(s) visible" % (args.gpus, have), file=sys.stderr)
         return 2
     with socket.socket() as sk:

@@ -55,12 +55,25 @@ def worker_start_method():
     after the model has initialised the GPU in the parent. A HIP context does not survive ``fork`` (the library
     refuses such a call, ``_lib.FORK_MESSAGE``), so the drop-in makes ``spawn`` the default start method before the
     script creates its loaders: every worker is then a fresh interpreter with its own HIP context, the script stays
-    unmodified. ``MVK_DATALOADER_START=keep`` leaves the start method alone (``fork`` / ``forkserver`` / ``spawn``
-    select one explicitly)."""
+    unmodified. Only a start method nobody has chosen yet is set: one the host script picked explicitly
+    (``multiprocessing.set_start_method`` before importing ``datasets``) is left alone, with a warning when it is
+    ``fork``. ``MVK_DATALOADER_START=keep`` never touches the start method; ``fork`` / ``forkserver`` / ``spawn`` in that
+    variable select one explicitly (and then override an earlier choice: the variable is the operator's word)."""
     import multiprocessing as mp
-    want = os.environ.get("MVK_DATALOADER_START", "spawn")
+    import warnings
+    want = os.environ.get("MVK_DATALOADER_START")
+    current = mp.get_start_method(allow_none=True)
     if want == "keep":
-        return mp.get_start_method(allow_none=True)
-    if mp.get_start_method(allow_none=True) != want:
+        return current
+    if want is None:
+        if current is None:
+            mp.set_start_method("spawn")
+            return "spawn"
+        if current == "fork":
+            warnings.warn("the multiprocessing start method was set to 'fork' before the MV-KPConv drop-in was imported: "
+                          "DataLoader workers that call into the HIP library will fail (a HIP context does not survive "
+                          "fork); use 'spawn' or 'forkserver', or pass multiprocessing_context to the loaders")
+        return current
+    if current != want:
         mp.set_start_method(want, force=True)
     return want

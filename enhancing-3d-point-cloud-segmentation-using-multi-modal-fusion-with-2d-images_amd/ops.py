@@ -512,6 +512,15 @@ def flush_deferred(items, stream=None):
         _flush_deferred(items)
 
 
+_HAS_USE_COUNT = hasattr(torch._C, "_storage_Use_Count")
+
+
+def _storage_use_count(storage):
+    """Owners of an untyped storage (private torch API, present in the torch 2.x builds this was written against,
+    INTEGRATION.md). Without it the deferred mode is not offered at all (_dw_gemm runs every product in line)."""
+    return torch._C._storage_Use_Count(storage._cdata)
+
+
 def _flush_deferred(items=None):
     if items is None:
         items = _DEFER["items"]
@@ -522,7 +531,7 @@ def _flush_deferred(items=None):
     n = len(items)
     prob = np.zeros(n, dtype=np.dtype([("A", "<u8"), ("B", "<u8"), ("C", "<u8"), ("M", "<i8"), ("N", "<i8"), ("Kd", "<i8")]))
     for i, (A, B, out_ptr, _, storage) in enumerate(items):
-        if torch._C._storage_Use_Count(storage._cdata) < 2:
+        if _storage_use_count(storage) < 2:
             # nothing but this list still owns the result: autograd did not adopt it as a .grad (it added the not yet
             # computed tensor to an existing gradient, or dropped it) -- the product would be lost silently
             raise RuntimeError("defer_weight_grads: a deferred weight-gradient result (%d x %d) was consumed before the "
@@ -557,6 +566,22 @@ def _flush_deferred(items=None):
         slot["event"] = ev
 
 
+def _accumulate_in_place_ok(t):
+    """Whether a backward node may ADD onto its incoming gradient `t` in place (the fan-out sums of _LinearFn /
+    _MaxPoolFn). Autograd hands the SAME tensor to every consumer of an addition's gradient (AddBackward, and
+    _AddLReLUFn before it returned copies), so `t` may also be an operand of a weight-gradient product that has only
+    been RECORDED (defer_weight_grads) or enqueued on a side stream (overlap_weight_grads): mutating it first would
+    corrupt that product silently. Not provably exclusive -> the caller computes `product + t` instead."""
+    if _OVERLAP["on"]:
+        return False
+    if _DEFER["on"] and _DEFER["items"]:
+        st = t.untyped_storage().data_ptr()
+        for it in _DEFER["items"]:
+            if it[0].untyped_storage().data_ptr() == st or it[1].untyped_storage().data_ptr() == st:
+                return False
+    return True
+
+
 def _dw_gemm(A, B, transB=False, target=None):
     """A^T @ B for a weight gradient: deferred into the grouped launch inside defer_weight_grads(), on a side stream
     inside overlap_weight_grads(), a plain product otherwise. `target`: the tensor the gradient is FOR (the Function's
@@ -572,7 +597,7 @@ def _dw_gemm(A, B, transB=False, target=None):
                                "(shared weights): run this backward without the scope (MVK_DEFER_DW=0)")
         if leaf.grad is not None:
             return _gemm_off_chain(A, B, transA=True, transB=transB)
-    if _DEFER["on"] and not transB and A.is_cuda and B.shape[1] > 16 and len(_DEFER["items"]) < _DW_MAX \
+    if _DEFER["on"] and _HAS_USE_COUNT and not transB and A.is_cuda and B.shape[1] > 16 and len(_DEFER["items"]) < _DW_MAX \
             and A.shape[0] > 0 and A.shape[1] > 0:
         A, B = _f32c(A), _f32c(B)
         # a split reduction accumulates into a zero-initialised output (arena slice); an unsplit one (the big
@@ -970,34 +995,42 @@ def row_count_for(rows):
     return _ROW_COUNTS.get(int(rows))
 
 
-_FULL_COUNTS = collections.OrderedDict()       # eager entries: bounded LRU
-_FULL_COUNTS_KEPT = {}                          # entries a captured graph may point at: never evicted
-_FULL_COUNTS_MAX = 256
+_COUNT_TABLE = {}                    # device index -> int32 [0, 1, 2, ...]: word r of it holds the value r, for good
+_COUNT_TABLE_ROWS = 1 << 22
+_BIG_COUNTS = {}                     # (rows, device index) beyond the table: one word each, never freed
 
 
 def full_count(rows, device):
-    """Device int32 [1] holding `rows`: the n_valid of a tensor without padded rows. Produced by an asynchronous
-    fill launch (no host-to-device copy, no synchronisation) and kept in a bounded LRU table: in ordinary training
-    the row count of every pyramid level changes with each batch. Words handed out while a stream is capturing are
-    kept for good (the graph's kernel nodes hold their addresses)."""
-    key = (int(rows), device.index)
-    t = _FULL_COUNTS_KEPT.get(key)
-    if t is not None:
-        return t
-    capturing = torch.cuda.is_current_stream_capturing()
-    t = _FULL_COUNTS.get(key)
+    """Device int32 [1] holding `rows`: the n_valid of a tensor without padded rows. A view of word `rows` of a constant
+    table [0, 1, 2, ...] (16 MB per device, written ONCE by an eager launch): no fill launch per call, no
+    host-to-device copy, nothing to evict, and the same word is valid in eager code and in every captured graph -- the
+    row count of every pyramid level changes with each batch in ordinary training. The table cannot be created while a
+    stream is capturing (its fill would become a node of that graph and the words would be undefined for everyone
+    else until that graph has replayed): any eager step before the capture creates it, or full_count_prepare()."""
+    rows = int(rows)
+    t = _COUNT_TABLE.get(device.index)
     if t is None:
-        t = torch.full((1,), int(rows), dtype=torch.int32, device=device)
-        if not capturing:
-            _FULL_COUNTS[key] = t
-            if len(_FULL_COUNTS) > _FULL_COUNTS_MAX:
-                _FULL_COUNTS.popitem(last=False)
-    else:
-        _FULL_COUNTS.move_to_end(key)
-    if capturing:
-        _FULL_COUNTS_KEPT[key] = t
-        _FULL_COUNTS.pop(key, None)
-    return t
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ops.full_count: the constant row-count table does not exist yet and cannot be created "
+                               "inside a graph capture; run one eager step first or call ops.full_count_prepare(device)")
+        t = torch.arange(_COUNT_TABLE_ROWS, dtype=torch.int32, device=device)
+        _COUNT_TABLE[device.index] = t
+    if 0 <= rows < _COUNT_TABLE_ROWS:
+        return t[rows:rows + 1]
+    key = (rows, device.index)
+    w = _BIG_COUNTS.get(key)
+    if w is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ops.full_count: %d rows lie beyond the constant table; request this count once outside "
+                               "the capture" % rows)
+        w = torch.full((1,), rows, dtype=torch.int32, device=device)
+        _BIG_COUNTS[key] = w
+    return w
+
+
+def full_count_prepare(device):
+    """Creates the constant table of full_count() (call before capturing a graph that was never run eagerly)."""
+    full_count(0, torch.device(device))
 
 
 class _BNLReLUFn(torch.autograd.Function):
@@ -1144,7 +1177,9 @@ class _AddLReLUFn(torch.autograd.Function):
         g = _f32c(g)
         d = torch.empty_like(y)
         check(lib().mvk_add_lrelu_bwd(_p(y), _p(g), y.numel(), ctx.slope, _p(d), _stream()))
-        return d, d, None
+        # two DISTINCT tensors: downstream nodes accumulate onto their incoming gradient in place (_LinearFn, _MaxPoolFn)
+        # or record it as the operand of a deferred product -- one buffer for both branches would alias them
+        return d, d.clone(), None
 
 
 class _BiasLReLUFn(torch.autograd.Function):
@@ -1252,8 +1287,8 @@ class _MaxPoolFn(torch.autograd.Function):
             return g_alias, None, None
         g = _f32c(g)
         if (g_alias is not None and g_alias.dtype == torch.float32 and g_alias.is_contiguous()
-                and g_alias.shape == (ctx.ns, ctx.c)):
-            dx = g_alias            # this node's own grad input: nobody else holds it
+                and g_alias.shape == (ctx.ns, ctx.c) and _accumulate_in_place_ok(g_alias)):
+            dx = g_alias            # this node's own grad input, not an operand of a pending product
         else:
             dx = _zeros((ctx.ns, ctx.c), g.device)
         check(lib().mvk_max_pool_bwd(_p(g), _p(arg), _p(inds), int(inds.dtype == torch.int64), inds.shape[0],
@@ -1740,8 +1775,8 @@ class _LinearFn(torch.autograd.Function):
                 if g_alias is not None:
                     dx = dx + g_alias
             elif (g_alias is not None and g_alias.dtype == torch.float32 and g_alias.is_contiguous()
-                  and g_alias.shape == (g.shape[0], W.shape[1])):
-                # nobody else holds the parallel consumer's gradient (it is this node's own grad input): add onto it
+                  and g_alias.shape == (g.shape[0], W.shape[1]) and _accumulate_in_place_ok(g_alias)):
+                # the parallel consumer's gradient is this node's own grad input and no pending product reads it: add onto it
                 dx = gemm(g, W, out=g_alias, accumulate=True)
             else:
                 dx = gemm(g, W)                                              # [M,Kd]

@@ -137,6 +137,64 @@ def test_fusion_networks_vs_reference_forward_texts(variant):
         g12_check_gradients(g, variant, grads, tag, 5e-3, 5e-2)
 
 
+@pytest.mark.parametrize("name,variant,deformable,radius", [("g13_early_19k", "early", False, 1.2),
+                                                            ("g13_late_deform_mod_55k", "late", True, 1.7)])
+def test_full_size_gradients_vs_cpu_port_digest(name, variant, deformable, radius):
+    """Gradients at BASELINE's own sizes (configs[2]: 19 464 points, early fusion; configs[4]'s geometry: 55 070 points,
+    late fusion, deformable + modulated): the product rebuilds the fixture's batch from the synthetic sphere (HIP
+    subsampling, pyramid with the captured rotations and limits, unprojection, 3-NN), runs forward + backward on the
+    fixture's weight formula and is held to the CPU port's digest (make_golden.g13_full_size_gradients): loss, 256
+    logit rows, and per parameter tensor the gradient norm, the cosine over 256 fixed elements and their error."""
+    from util import g13_state, g12_feature_map
+    syn = importlib.import_module(PKG + ".synthetic")
+    g = load_golden(name)
+    dev = torch.device("cuda:0")
+    cfg = syn.make_config(variant, deformable=deformable, modulated=deformable)
+    sph = syn.raw_sphere(seed=0, radius=radius)
+    views = syn.sphere_views(sph, nv=3, h=120, w=160)
+    staged = syn.stage_spheres([sph], dev, [views])
+    batch, lens = syn.build_batch(cfg, staged, [int(v) for v in g["limits"]], torch.int32, rotations=list(g["rotations"]))
+    assert lens[0] == int(g["n_points"])
+    batch.feature_2d = torch.from_numpy(g12_feature_map(3, 64, 120, 160, seed=1313)).to(dev)
+    np.random.seed(0)
+    net = syn.build_model(cfg, dev)
+    shapes = {str(n): tuple(int(v) for v in str(s).split(",") if v) for n, s in zip(g["param_names"], g["param_shapes"])}
+    kp = {k[3:]: g[k] for k in g if k.startswith("kp/")}
+    sd = g13_state(shapes, variant, deformable, kp)
+    res = net.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("net_2d.") for k in res.missing_keys), res
+    net.train()
+    for m in net.net_2d._modules.values():
+        m.train(False)
+    out = net(batch, cfg)
+    loss = net.loss(out, batch.labels)
+    loss.backward()
+    rows = torch.from_numpy(g["logit_rows"]).to(dev)
+    err = np.abs(out.detach()[rows].cpu().numpy().astype(np.float64) - g["logits"]).max() / float(g["logits_absmax"])
+    check_err("G13 %s: 256 logit rows vs the CPU port" % name, err, 1e-4)
+    check_err("G13 %s: loss (rel)" % name, abs(loss.item() - float(g["loss"])) / max(1.0, abs(float(g["loss"]))), 1e-5)
+    names = sorted(k[6:] for k in g if k.startswith("gnorm/"))
+    grads = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    assert set(names) == set(grads), set(names) ^ set(grads)
+    scale = max(float(g["gnorm/" + n]) for n in names)
+    worst = {"norm": 0.0, "cos": 0.0, "elem": 0.0}
+    for n in names:
+        want_norm = float(g["gnorm/" + n])
+        got = grads[n].reshape(-1)
+        got_norm = got.double().norm().item()
+        if want_norm < 1e-3 * scale:                    # analytically ~0 (a bias in front of a BatchNorm): rounding only
+            assert got_norm < 2e-3 * scale, n
+            continue
+        a = got[torch.from_numpy(g["gidx/" + n]).to(dev)].double().cpu().numpy()
+        b = g["gval/" + n].astype(np.float64)
+        worst["norm"] = max(worst["norm"], abs(got_norm / want_norm - 1.0))
+        worst["cos"] = max(worst["cos"], 1.0 - float(a @ b) / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+        worst["elem"] = max(worst["elem"], np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+    check_err("G13 %s: worst per-parameter |gradient norm ratio - 1|" % name, worst["norm"], 1e-2)
+    check_err("G13 %s: worst per-parameter 1 - cosine over 256 fixed elements" % name, worst["cos"], 1e-3)
+    check_err("G13 %s: worst digest element error" % name, worst["elem"], 5e-2)
+
+
 def test_fusion_chain_vs_golden():
     ops = importlib.import_module(PKG + ".ops")
     fa_mod = importlib.import_module(PKG + ".dropin.mvpnet.models.mvpnet_3d")

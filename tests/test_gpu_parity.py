@@ -259,6 +259,48 @@ def test_kpconv_fwd_bwd_golden(ops, name, influence, agg, idt):
     assert rel_err(W.grad.cpu().numpy(), g["weights_grad"]) < FP_TOL
 
 
+@pytest.mark.parametrize("idt", [torch.int32, torch.int64])
+def test_kpconv_config1_literal_radius_degenerate_rows(ops, idt):
+    """BASELINE configs[0] read LITERALLY: conv radius r = 0.04 on the 4 096-point lattice of pitch
+    0.04 (U(-0.015, 0.015) jitter, 2 cm sine ripple, seed 0), Cin = Cout = 64, K = 15 -- a degenerate neighbourhood of
+    1-6 real neighbours per row, 2.7 on average (the point itself, plus the lattice neighbours the jitter pulled inside r), kernel
+    extent 0.04 * 1.2 / 2.5 so that most kernel points reach nothing; plus rows emptied completely (all shadow).
+    Neighbour rows from the HIP search equal the C oracle's, y / dx / dW equal the float64 NumPy restatement to 1e-4."""
+    from oracle import npref, cport
+    rng = np.random.default_rng(0)
+    ii, jj = np.meshgrid(np.arange(64), np.arange(64), indexing="ij")
+    p = np.stack([ii * 0.04, jj * 0.04, 0.02 * np.sin(ii * 0.3)], -1).reshape(-1, 3)
+    p = (p + rng.uniform(-0.015, 0.015, p.shape)).astype(np.float32)
+    r = 0.04
+    lens = np.array([p.shape[0]], np.int32)
+    nb = ops.radius_neighbors_batch(T(p), T(p), lens, lens, r)
+    want = cport.radius_neighbors_batch(p, p, lens, lens, r)
+    assert_neighbors_equal_mod_ties(nb.cpu().numpy(), want, p, p, lens, lens)
+    counts = (want < p.shape[0]).sum(1)
+    assert counts.min() >= 1 and counts.max() <= 6 and 1.0 < counts.mean() < 4.0, (counts.min(), counts.max(), counts.mean())
+    idx = want.copy()
+    idx[rng.choice(p.shape[0], 37, replace=False)] = p.shape[0]          # empty rows: all shadow
+    K, cin, cout = 15, 64, 64
+    extent = r * 1.2 / 2.5
+    kp = (rng.normal(size=(K, 3)) * (0.66 * r / 2)).astype(np.float32)
+    kp[0] = 0.0
+    x = rng.normal(size=(p.shape[0], cin)).astype(np.float32)
+    W = (rng.normal(size=(K, cin, cout)) * 0.05).astype(np.float32)
+    g = rng.normal(size=(p.shape[0], cout)).astype(np.float32)
+    xt, Wt = T(x).requires_grad_(True), T(W).requires_grad_(True)
+    y, _ = ops.kpconv(T(p), T(p), T(idx).to(idt), xt, T(kp), Wt, extent)
+    (y * T(g)).sum().backward()
+    a64 = [p.astype(np.float64), p.astype(np.float64), idx.astype(np.int64), x.astype(np.float64), kp.astype(np.float64),
+           W.astype(np.float64), extent]
+    yr = npref.kpconv_forward(*a64)
+    assert np.abs(yr[(idx >= p.shape[0]).all(1)]).max() == 0.0                    # empty rows convolve to exactly zero
+    assert np.array_equal(y.detach().cpu().numpy()[(idx >= p.shape[0]).all(1)], yr[(idx >= p.shape[0]).all(1)].astype(np.float32))
+    check_err("config 1 literal r=0.04: y", rel_err(y.detach().cpu().numpy(), yr), FP_TOL)
+    dx, dW = npref.kpconv_backward(*a64, g.astype(np.float64))
+    check_err("config 1 literal r=0.04: dx", rel_err(xt.grad.cpu().numpy(), dx), FP_TOL)
+    check_err("config 1 literal r=0.04: dW", rel_err(Wt.grad.cpu().numpy(), dW), FP_TOL)
+
+
 @pytest.mark.parametrize("cin,cout,H", [(1, 5, 9), (4, 32, 17), (8, 8, 70), (20, 12, 33), (68, 64, 40),
                                         (128, 16, 25), (256, 8, 64), (512, 4, 10), (516, 4, 6), (1040, 3, 5),
                                         (2, 6, 130), (130, 16, 150), (600, 4, 130), (30, 5, 260),

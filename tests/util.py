@@ -117,3 +117,14 @@ def gradient_digest(grads, n_elements=64, seed=77):
         idx = np.sort(rng.choice(g.size, size=min(n_elements, g.size), replace=False)).astype(np.int64)
         out.append((name, idx, g[idx].copy(), float(np.linalg.norm(g.astype(np.float64)))))
     return out
+
+
+def g13_state(shapes, variant, deformable, kernel_points):
+    """The weights of fixture G13 (shared by make_golden.g13_full_size_gradients and the GPU test): seeded_state with the
+    network instance's kernel points, the offset convolutions scaled to offsets of a fraction of the kernel extent."""
+    sd = seeded_state(shapes, 1300 + len(variant), fixed=kernel_points)
+    if deformable:
+        for n in sd:
+            if n.endswith("offset_conv.weights"):
+                sd[n] = (sd[n] * np.float32(0.2)).astype(np.float32)
+    return sd

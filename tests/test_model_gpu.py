@@ -129,6 +129,65 @@ def test_full_size_late_fusion_deformable_40k_forward_vs_cpu_port():
     _run("late", deformable=True, modulated=True, radius=1.7, density=None, hw=(120, 160), gradients=False)
 
 
+def test_network_without_batch_norm_deferred_weight_gradients_equal_inline_ones():
+    """config.use_batch_norm = False (BatchNormBlock = a learned bias, models/blocks.py:462-463): the residual join then
+    runs through ops.add_lrelu, and plain additions hand the SAME gradient tensor to both branches of a block. The
+    fan-out sum inside unary1's backward GEMM must not add onto such a tensor in place while it is the operand of a
+    recorded weight-gradient product: the gradients of a backward inside ops.defer_weight_grads() equal
+    those of a plain backward, and both follow the CPU port."""
+    import mvkpconv
+    from oracle import torch_port
+    from util import check_err
+    syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    cfg = syn.make_config("baseline")
+    cfg.use_batch_norm = False
+    sph = [syn.raw_sphere(seed=1, radius=0.6, density=2500.0)]
+    staged = syn.stage_spheres(sph, dev, None)
+    limits = syn.calibrate_limits(cfg, staged)
+    batch, lens = syn.build_batch(cfg, staged, limits, torch.int32)
+    net = syn.build_model(cfg, dev)
+    net.train()
+    with torch.no_grad():                      # without normalisation the default initialisation blows the activations up
+        for n, p in net.named_parameters():
+            if n.endswith("weights") or n.endswith("mlp.weight"):
+                p.mul_(0.5)
+            if n.endswith(".bias"):
+                p.normal_(0, 0.05)
+
+    def grads(deferred):
+        net.zero_grad(set_to_none=True)
+        out = net(batch, cfg)
+        loss = net.loss(out, batch.labels)
+        if deferred:
+            with ops.defer_weight_grads():
+                loss.backward()
+        else:
+            loss.backward()
+        return out.detach(), loss.item(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+    out_a, loss_a, ga = grads(False)
+    out_b, loss_b, gb = grads(True)
+    assert set(ga) == set(gb) and len(ga) > 40
+    scale = max(v.norm().item() for v in ga.values())
+    worst = max(((ga[n] - gb[n]).norm().item() / max(ga[n].norm().item(), 1e-3 * scale), n) for n in ga)
+    check_err("no-BN network: deferred vs in-line weight gradients (%s)" % worst[1], worst[0], 1e-4)
+    sd = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+    leaf = {k: sd[k].clone().requires_grad_(True) for k, p in net.named_parameters() if p.requires_grad}
+    sdl = dict(sd)
+    sdl.update(leaf)
+    ref, reg = torch_port.forward(sdl, cfg, torch_port.batch_to_cpu(batch), None, True)
+    ref_loss = torch_port.loss_fn(ref, batch.labels.cpu(), reg, cfg)
+    ref_loss.backward()
+    rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+    check_err("no-BN network: logits vs CPU port", rel(out_a.cpu(), ref.detach()), 1e-4)
+    A = torch.cat([gb[n].cpu().reshape(-1).double() for n in sorted(gb)])
+    B = torch.cat([leaf[n].grad.reshape(-1).double() for n in sorted(gb)])
+    check_err("no-BN network: 1 - cosine of the whole (deferred) gradient vs CPU port", 1.0 - (A @ B).item() / (A.norm().item() * B.norm().item()), 5e-4)
+
+
 def test_state_dict_keys_follow_the_reference_names():
     net = _run("baseline")
     keys = set(net.state_dict().keys())

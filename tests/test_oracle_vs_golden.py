@@ -222,14 +222,18 @@ def g12_inputs(g, variant):
     return cfg, sd, batch
 
 
-def g12_check_gradients(g, variant, grads, label, norm_tol, elem_tol):
-    """grads {name: numpy gradient} against the fixture's digest: per tensor the float64 norm and 64 fixed elements
-    (error of an element relative to the tensor's largest digest element). Returns the two worst figures."""
+def g12_check_gradients(g, variant, grads, label, norm_tol, cos_tol):
+    """grads {name: numpy gradient} against the fixture's digest: per tensor the float64 norm and the cosine over its 64
+    fixed elements, plus the cosine over ALL digest elements (every tensor's elements scaled by 1 / its norm). Single
+    elements are not bounded: through ~36 layers with train-mode BatchNorm a LeakyReLU input within rounding of zero
+    takes the other slope in another float32 evaluation order and moves individual elements by percents (the CPU port
+    ALONE moves by 3e-2 between float32 and float64) while norms and directions stay put."""
     from util import check_err
     names = sorted(k[len(variant) + 7:] for k in g if k.startswith(variant + "/gnorm/"))
     assert names and set(names) == set(grads), (set(names) ^ set(grads))
     scale = max(float(g["%s/gnorm/%s" % (variant, n)]) for n in names)
-    worst_n = worst_e = 0.0
+    worst_n = worst_c = 0.0
+    all_a, all_b = [], []
     for n in names:
         want_norm = float(g["%s/gnorm/%s" % (variant, n)])
         got = np.asarray(grads[n], np.float64).reshape(-1)
@@ -237,10 +241,16 @@ def g12_check_gradients(g, variant, grads, label, norm_tol, elem_tol):
         if want_norm < 1e-3 * scale:        # analytically ~0 (a bias in front of a BatchNorm): rounding noise, absolute bound
             assert np.linalg.norm(got) < 2e-3 * scale, n
             continue
+        a = got[idx]
         worst_n = max(worst_n, abs(np.linalg.norm(got) / want_norm - 1.0))
-        worst_e = max(worst_e, np.abs(got[idx] - val).max() / max(np.abs(val).max(), 1e-30))
+        worst_c = max(worst_c, 1.0 - float(a @ val) / max(np.linalg.norm(a) * np.linalg.norm(val), 1e-300))
+        all_a.append(a / want_norm)
+        all_b.append(val / want_norm)
+    A, B = np.concatenate(all_a), np.concatenate(all_b)
     check_err("G12 %s %s: worst |gradient norm ratio - 1|" % (variant, label), worst_n, norm_tol)
-    check_err("G12 %s %s: worst digest element error" % (variant, label), worst_e, elem_tol)
+    check_err("G12 %s %s: worst per-parameter 1 - cosine over 64 fixed elements" % (variant, label), worst_c, cos_tol)
+    check_err("G12 %s %s: 1 - cosine over all digest elements" % (variant, label),
+              1.0 - float(A @ B) / (np.linalg.norm(A) * np.linalg.norm(B)), cos_tol / 10)
 
 
 @pytest.mark.parametrize("variant", ["early", "middle", "late"])
@@ -268,9 +278,7 @@ def test_torch_port_fusion_wirings_vs_reference_forward_texts(variant):
     check_err("G12 %s CPU port: loss (abs)" % variant, abs(loss.item() - float(g[variant + "/loss"])), 1e-5)
     grads = {k: v.grad.numpy() for k, v in leaf.items() if v.grad is not None}
     assert any(k.startswith("feat_aggreg.") for k in grads) == (variant == "late")
-    # measured (f32 port): norms <= 2e-3, elements <= 3.4e-2 -- level 4 holds ~30 points, train-mode BatchNorm over them is
-    # ill-conditioned in float32; the SAME port in float64 is within 4.8e-3 / 1.4e-4 of the reference's float32 fixture
-    g12_check_gradients(g, variant, grads, "CPU port", 5e-3, 5e-2)
+    g12_check_gradients(g, variant, grads, "CPU port", 5e-3, 2e-3)
 
 
 def test_fusion_oracle_vs_golden():

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvkpconv.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -51,6 +51,8 @@ _SIGNATURES = {
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvk_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
     "mvk_gemm_f32_plan": (C.c_int, [_i64, _i64, _i64, _i, _i, _vp, _vp]),
+    "mvk_gemm_split_arena": (C.c_int, [_vp, _i64, _vp, _i64]),
+    "mvk_gemm_split_ordered": (C.c_int, []),
     "mvk_gemm_f32_bias_act": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _vp, _f, _vp]),
     "mvk_gemm_f32_scatter_cat": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i, _i64, _i64, _i, _vp, _vp, _vp]),
     "mvk_gemm_f32_dual_plan": (C.c_int, [_i64, _i64, _i64, _i64, _vp]),

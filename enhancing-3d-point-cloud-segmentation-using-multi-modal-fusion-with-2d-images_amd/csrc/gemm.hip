@@ -203,6 +203,14 @@ struct GemmArgs {
   int64_t sc_stride, sc_ns;
   float* sc_dst;
   float* sc_rest;
+  // ordered split reduction (null det_ws: a split adds its partial sums with f32 atomics): every workgroup of a split
+  // product parks its accumulators in its slot of det_ws [tile][split][TM * TN]; the workgroup that arrives LAST at the
+  // tile's counter det_cnt[tile] adds the slots in the order 0 .. nsplit-1 and runs the ordinary epilogue (plain store,
+  // accumulate, bias, scatter, BatchNorm statistics) -- the sum no longer depends on the order the workgroups ran in,
+  // and C needs no zero fill. The counter is back at zero when the launch ends.
+  float* det_ws;
+  int* det_cnt;
+  int det_gx, det_nsplit;
 };
 
 template <bool TA, bool TB, int PM, int QN, int WM, int WN, bool DUAL = false>
@@ -329,6 +337,52 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
     if (kend_all > a.Kd) {
       if (kbeg_all < a.Kd) __syncthreads();       // the first range's last tile is still being read from LDS
       run_range(a.A2, a.lda2, a.vecA2, a.B2, a.ldb2, a.vecB2, kbeg_all > a.Kd ? kbeg_all - a.Kd : 0, kend_all - a.Kd);
+    }
+  }
+
+  if (a.det_ws) {
+    // Slots and counters are read and written with RELAXED AGENT-SCOPE atomics (gfx950: sc1 loads / stores, served at
+    // the memory side, past the XCD-private L2s) instead of plain accesses fenced by __threadfence(): an agent-scope
+    // release / acquire fence writes back and invalidates the whole L2 of the XCD for every workgroup of the launch.
+    // Order: the slot stores are complete (s_waitcnt via the workgroup-scope release + barrier) before thread 0 bumps the
+    // counter; the last arriver reads the slots only after its own bump returned the full count.
+    constexpr int SLOT = PM * QN * 4 * 256;
+    const int64_t tile = (int64_t)by * a.det_gx + bx;
+    float* const mine = a.det_ws + (tile * a.det_nsplit + bz) * SLOT + tid;
+#pragma unroll
+    for (int p = 0; p < PM; ++p)
+#pragma unroll
+      for (int q = 0; q < QN; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          __hip_atomic_store(mine + ((p * QN + q) * 4 + r) * 256, acc[p][q][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();              // every thread's stores have left; the operand tiles in LDS are dead
+    int* const flag = reinterpret_cast<int*>(lds);
+    if (tid == 0) {
+      const int old = __hip_atomic_fetch_add(a.det_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = old == a.det_nsplit - 1;
+      if (last) __hip_atomic_store(a.det_cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      *flag = last;
+    }
+    __syncthreads();
+    const int last = *flag;
+    __syncthreads();              // (the statistics epilogue reuses lds)
+    if (!last) return;
+    const float* const all = a.det_ws + tile * a.det_nsplit * SLOT + tid;
+#pragma unroll
+    for (int p = 0; p < PM; ++p)
+#pragma unroll
+      for (int q = 0; q < QN; ++q) acc[p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int z = 0; z < a.det_nsplit; ++z) {
+      const float* const sl = all + (int64_t)z * SLOT;
+#pragma unroll
+      for (int p = 0; p < PM; ++p)
+#pragma unroll
+        for (int q = 0; q < QN; ++q)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[p][q][r] += __hip_atomic_load(sl + ((p * QN + q) * 4 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 
@@ -507,6 +561,8 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_grouped(const GroupEntry* _
   a.C = load_global_ptr(&e.args.C);
   a.bn_part = load_global_ptr(&e.args.bn_part);
   a.n_valid = load_global_ptr(&e.args.n_valid);
+  a.det_ws = load_global_ptr(&e.args.det_ws);
+  a.det_cnt = load_global_ptr(&e.args.det_cnt);
   gemm_body<TA, TB, PM, QN, WM, WN>(a, bx, by, bz);
 }
 
@@ -515,6 +571,42 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma_grouped(const GroupEntry* _
 struct Plan {
   int pm, qn, narrow, split;
 };
+
+// Arena of the ordered split reductions (mvk_gemm_split_arena): the host layer hands over one large slot buffer and one
+// zero-initialised counter buffer; every split product takes the next slice of both (bump allocation, wrapping around at
+// the end). A slice is in use only while its launch runs, the counters return to zero by themselves, so nothing is ever
+// cleared; two launches could only collide if a whole arena's worth of later split products were enqueued while the
+// first was still running. A captured graph keeps the slices its nodes were given.
+struct SplitArena {
+  float* ws = nullptr;
+  int* cnt = nullptr;
+  int64_t ws_floats = 0, n_cnt = 0, ws_off = 0, cnt_off = 0;
+};
+SplitArena g_arena;
+
+bool ordered_splits() { return g_arena.ws != nullptr; }
+
+// slices for `tiles` output tiles of `slot` floats each, split `split` ways; false: the request does not fit the arena
+bool arena_take(int64_t tiles, int split, int64_t slot, float** ws, int** cnt) {
+  const int64_t need = tiles * split * slot;
+  if (need > g_arena.ws_floats || tiles > g_arena.n_cnt) return false;
+  if (g_arena.ws_off + need > g_arena.ws_floats) g_arena.ws_off = 0;
+  if (g_arena.cnt_off + tiles > g_arena.n_cnt) g_arena.cnt_off = 0;
+  *ws = g_arena.ws + g_arena.ws_off;
+  *cnt = g_arena.cnt + g_arena.cnt_off;
+  g_arena.ws_off += (need + 63) / 64 * 64;
+  g_arena.cnt_off += tiles;
+  return true;
+}
+
+// gives a split product its slices (or leaves it on the atomic path when no arena is set); false: arena too small
+bool make_ordered(GemmArgs& a, int split, int gx, int64_t gy, int64_t tm, int64_t tn) {
+  a.det_ws = nullptr; a.det_cnt = nullptr; a.det_gx = gx; a.det_nsplit = split;
+  if (split <= 1 || !ordered_splits()) return true;
+  if (!arena_take((int64_t)gx * gy, split, tm * tn, &a.det_ws, &a.det_cnt)) return false;
+  a.atomic_out = 0;
+  return true;
+}
 
 // Measured on MI355X (tools/gemm_bench.py --sweep, device time of graph-captured launches): for every product
 // shape of the networks the fastest tiles are the SMALL ones -- 32 rows per workgroup for wide outputs (PM = 2),
@@ -551,7 +643,7 @@ Plan plan_gemm(int64_t M, int64_t N, int64_t Kd, int split_req, bool want_stats)
     const char* eb = getenv("MVK_GEMM_STATS_BONUS");
     bonus = eb ? atof(eb) : 14000.0;
   }
-  if (want_stats && t1 <= best_t + bonus) best.split = 1;
+  if (want_stats && !ordered_splits() && t1 <= best_t + bonus) best.split = 1;   // (an ordered split keeps its statistics)
   const char* e = getenv("MVK_GEMM_FORCE");       // development override: "pm,qn,split"
   if (e) {
     int pm = 0, qn = 0, sp = 0;
@@ -632,10 +724,31 @@ int fill_args(GemmArgs& a, const Plan& p, const float* A, const float* B, float*
   a.act_slope = 1.f;
   a.A2 = nullptr; a.B2 = nullptr; a.Kd2 = 0; a.lda2 = 0; a.ldb2 = 0; a.vecA2 = 1; a.vecB2 = 1;
   a.sc_idx = nullptr; a.sc_idx64 = 0; a.sc_c1 = 0; a.sc_stride = 0; a.sc_ns = 0; a.sc_dst = nullptr; a.sc_rest = nullptr;
+  a.det_ws = nullptr; a.det_cnt = nullptr; a.det_gx = 0; a.det_nsplit = split;
   return split;
 }
 
 }  // namespace
+
+// Hands the library the arena of its ordered split reductions: `ws` (bytes, HBM) for the parked partial tiles, `counters`
+// (n_counters int32, HBM, ZERO on entry and never touched by the caller again). ws == null: back to f32 atomics onto a
+// zero-initialised output. With an arena set, a split product writes every element of C itself (no zero fill needed),
+// sums its partial tiles in a fixed order (run-to-run bit-identical) and may carry the BatchNorm statistics epilogue.
+extern "C" int mvk_gemm_split_arena(void* ws, int64_t ws_bytes, void* counters, int64_t n_counters) {
+  MVK_REQUIRE((ws == nullptr) == (counters == nullptr) && ws_bytes >= 0 && n_counters >= 0, "gemm arena: bad arguments");
+  MVK_REQUIRE(ws == nullptr || (ws_bytes >= (1 << 20) && n_counters >= 4096 && (uintptr_t)ws % 256 == 0),
+              "gemm arena: at least 1 MB of 256-byte aligned slots and 4096 counters");
+  g_arena.ws = (float*)ws;
+  g_arena.cnt = (int*)counters;
+  g_arena.ws_floats = ws ? ws_bytes / 4 : 0;
+  g_arena.n_cnt = ws ? n_counters : 0;
+  g_arena.ws_off = 0;
+  g_arena.cnt_off = 0;
+  return 0;
+}
+
+// 1 when split reductions are ordered (an arena is set), 0 when they use atomics (outputs must then be zero-initialised)
+extern "C" int mvk_gemm_split_ordered(void) { return ordered_splits() ? 1 : 0; }
 
 // Split of mvk_gemm_f32_dual's concatenated reduction (the caller zeroes C when > 1); 0: the shape is not supported (the
 // first reduction must be a whole number of k-tiles, the output wider than 32 columns).
@@ -671,6 +784,7 @@ extern "C" int mvk_gemm_f32_dual(const float* A, const float* B, const float* A2
   a.vecB2 = ((a.ldb2 % 4 == 0) && ((uintptr_t)B2 % 16 == 0)) ? 4 : ((a.ldb2 % 2 == 0) && ((uintptr_t)B2 % 8 == 0)) ? 2 : 1;
   MVK_REQUIRE(cdiv64(M, 32) < 65536 && split < 65536, "gemm: grid too large");
   dim3 grid((unsigned)cdiv64(N, 64), (unsigned)cdiv64(M, 32), (unsigned)split);
+  MVK_REQUIRE(make_ordered(a, split, (int)grid.x, grid.y, 32, 64), "gemm: the split-reduction arena is too small");
   hipLaunchKernelGGL((gemm_f32_mfma_dual<false, false, 2, 1, 1, 4>), grid, dim3(256), 0, st, a);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
@@ -689,8 +803,8 @@ extern "C" int mvk_gemm_f32_pair_plan(int64_t M, int64_t N0, int64_t N1, int64_t
   out[0] = 1;
   out[1] = p0.split;
   out[2] = p1.split;
-  out[3] = (want_stats && p0.split == 1) ? 16 * p0.pm : 0;
-  out[4] = (want_stats && p1.split == 1) ? 16 * p1.pm : 0;
+  out[3] = (want_stats && (p0.split == 1 || ordered_splits())) ? 16 * p0.pm : 0;
+  out[4] = (want_stats && (p1.split == 1 || ordered_splits())) ? 16 * p1.pm : 0;
   return 0;
 }
 
@@ -707,11 +821,15 @@ extern "C" int mvk_gemm_f32_pair(const float* A, const float* B0, const float* B
               "gemm pair: the two products do not share a tile shape (ask mvk_gemm_f32_pair_plan first)");
   hipStream_t st = (hipStream_t)stream;
   GemmArgs a0, a1;
-  const int s0 = fill_args(a0, p0, A, B0, C0, M, N0, Kd, 0, transB, (want_stats && p0.split == 1) ? bn_part0 : nullptr, n_valid);
-  const int s1 = fill_args(a1, p1, A, B1, C1, M, N1, Kd, 0, transB, (want_stats && p1.split == 1) ? bn_part1 : nullptr, n_valid);
+  const bool ord = ordered_splits();
+  const int s0 = fill_args(a0, p0, A, B0, C0, M, N0, Kd, 0, transB, (want_stats && (p0.split == 1 || ord)) ? bn_part0 : nullptr, n_valid);
+  const int s1 = fill_args(a1, p1, A, B1, C1, M, N1, Kd, 0, transB, (want_stats && (p1.split == 1 || ord)) ? bn_part1 : nullptr, n_valid);
   const int64_t tm = 16 * p0.pm, tn = 64;
   MVK_REQUIRE(cdiv64(M, tm) < 65536 && s0 < 65536 && s1 < 65536, "gemm: grid too large");
   const int gx0 = (int)cdiv64(N0, tn), gx1 = (int)cdiv64(N1, tn);
+  MVK_REQUIRE(make_ordered(a0, s0, gx0, cdiv64(M, tm), tm, tn) && make_ordered(a1, s1, gx1, cdiv64(M, tm), tm, tn),
+              "gemm: the split-reduction arena is too small");
+  MVK_REQUIRE(ord || ((s0 == 1 || !a0.bn_part) && (s1 == 1 || !a1.bn_part)), "gemm pair: statistics of a split product");
   dim3 grid((unsigned)(gx0 + gx1), (unsigned)cdiv64(M, tm), (unsigned)(s0 > s1 ? s0 : s1));
   const bool ok = transB ? launch_pair_cfg<false, true>(p0, grid, st, a0, a1, gx0, s0, s1)
                          : launch_pair_cfg<false, false>(p0, grid, st, a0, a1, gx0, s0, s1);
@@ -732,7 +850,7 @@ extern "C" int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, 
   }
   const Plan p = plan_gemm(M, N, Kd, split_k > 0 ? split_k : 0, want_stats != 0);
   *out_split = p.split;
-  *out_stat_rows = (want_stats && p.split == 1) ? (p.narrow ? 64 * p.pm : 16 * p.pm) : 0;
+  *out_stat_rows = (want_stats && (p.split == 1 || ordered_splits())) ? (p.narrow ? 64 * p.pm : 16 * p.pm) : 0;
   return 0;
 }
 
@@ -787,8 +905,8 @@ int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int
     if (!accumulate && split_k <= 1) MVK_CHECK_HIP(hipMemsetAsync(C, 0, sizeof(float) * M * N, st));
     return 0;
   }
-  MVK_REQUIRE(!(bn_part && split_k > 1), "gemm: BatchNorm statistics need an unsplit reduction");
-  Plan p = plan_gemm(M, N, Kd, bn_part ? 1 : (split_k > 0 ? split_k : 0), bn_part != nullptr);
+  MVK_REQUIRE(!(bn_part && split_k > 1 && !ordered_splits()), "gemm: BatchNorm statistics need an unsplit (or ordered) reduction");
+  Plan p = plan_gemm(M, N, Kd, (bn_part && !ordered_splits()) ? 1 : (split_k > 0 ? split_k : 0), bn_part != nullptr);
   int split = p.split;
   const int64_t ksteps = cdiv64(Kd, BK);
   if (split > ksteps) split = (int)ksteps;
@@ -816,6 +934,8 @@ int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int
   const int64_t tm = p.narrow ? 64 * p.pm : 16 * p.pm, tn = p.narrow ? 16 * p.qn : 64 * p.qn;
   MVK_REQUIRE(cdiv64(M, tm) < 65536 && split < 65536, "gemm: grid too large");
   dim3 grid((unsigned)cdiv64(N, tn), (unsigned)cdiv64(M, tm), (unsigned)split);
+  MVK_REQUIRE(make_ordered(a, split, (int)grid.x, grid.y, tm, tn), "gemm: the split-reduction arena is too small");
+  MVK_REQUIRE(!(bn_part && split > 1 && !a.det_ws), "gemm: BatchNorm statistics of a split product need the ordered reduction");
   bool ok;
   if (!transA && !transB) ok = launch_cfg<false, false>(p, grid, st, a);
   else if (!transA && transB) ok = launch_cfg<false, true>(p, grid, st, a);
@@ -920,6 +1040,7 @@ extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* t
     e.gx = (int)cdiv64(q.N, tn);
     e.gy = (int)cdiv64(q.M, tm);
     e.gz = split;
+    MVK_REQUIRE(make_ordered(e.args, split, e.gx, e.gy, tm, tn), "grouped gemm: the split-reduction arena is too small");
     const int64_t wgs = (int64_t)e.gx * e.gy * e.gz;
     if (narrow) {
       e.wg_begin = (int)wn;

@@ -96,6 +96,58 @@ def _zeros(shape, device, dtype=torch.float32):
 # raw kernels
 # --------------------------------------------------------------------------------------------
 
+# --------------------------------------------------------------------------------------------
+# ordered split reductions (run-to-run bit-identical products, no zero-initialised outputs)
+# --------------------------------------------------------------------------------------------
+# mvk_gemm_split_arena: with an arena set, every split product parks its partial tiles in HBM and the last-arriving
+# workgroup of a tile adds them in a fixed order (csrc/gemm.hip) instead of f32 atomics onto a zero-filled output.
+# Default on (MVK_GEMM_ORDERED=0: the atomic path). The arena is created by the first product on a device, outside any
+# graph capture (a capture must not allocate 1 GB in its private pool, and the counters' one zero fill must not become a
+# node of the graph).
+_ORDERED = os.environ.get("MVK_GEMM_ORDERED", "1") == "1"
+_SPLIT_ARENA = {}
+_SPLIT_ARENA_BYTES = int(os.environ.get("MVK_GEMM_ARENA_MB", "1024")) << 20
+_SPLIT_COUNTERS = 1 << 20
+
+
+def split_arena_prepare(device):
+    """Creates the arena of the ordered split reductions on `device` (no-op when it exists or MVK_GEMM_ORDERED=0).
+    Called by the first gemm(); call it yourself before capturing a graph that was never run eagerly."""
+    if not _ORDERED:
+        return False
+    device = torch.device(device)
+    if device.index in _SPLIT_ARENA:
+        return True
+    if _SPLIT_ARENA:
+        raise RuntimeError("the ordered split reductions use ONE arena per process (one GPU per process); it lives on "
+                           "cuda:%d" % next(iter(_SPLIT_ARENA)))
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("ops.gemm: the split-reduction arena does not exist yet and cannot be created inside a graph "
+                           "capture; run one eager step first or call ops.split_arena_prepare(device)")
+    ws = torch.empty(_SPLIT_ARENA_BYTES, dtype=torch.uint8, device=device)
+    cnt = torch.zeros(_SPLIT_COUNTERS, dtype=torch.int32, device=device)
+    torch.cuda.current_stream(device).synchronize()          # the counters are zero before any stream uses them
+    check(lib().mvk_gemm_split_arena(_p(ws), ws.numel(), _p(cnt), cnt.numel()))
+    _SPLIT_ARENA[device.index] = (ws, cnt)
+    return True
+
+
+def split_arena_release():
+    """Back to the atomic split reductions (tests); frees the arena."""
+    if _SPLIT_ARENA:
+        torch.cuda.synchronize()
+        check(lib().mvk_gemm_split_arena(None, 0, None, 0))
+        _SPLIT_ARENA.clear()
+
+
+def _split_out(shape, device, split, keep=False):
+    """Output buffer of a product whose reduction is split `split` ways: the ordered reduction writes every element
+    (empty); the atomic one accumulates onto zeros (arena slice, or a tensor of its own when it outlives the step)."""
+    if split <= 1 or (_ORDERED and device.index in _SPLIT_ARENA):
+        return torch.empty(shape, device=device, dtype=torch.float32)
+    return torch.zeros(shape, device=device, dtype=torch.float32) if keep else _zeros(shape, device)
+
+
 def gemm_plan(M, N, Kd, split_k=None, want_stats=False):
     """(split, stat_rows) mvk_gemm_f32_ex will use for this shape: the split of the reduction (the output must
     be zero-initialised when > 1) and the row-block size of the BatchNorm partials (0 = none produced)."""
@@ -147,11 +199,11 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
     if M == 0 or N == 0 or Kd == 0:
         res = out.zero_() if out is not None else torch.zeros((M, N), device=A.device, dtype=torch.float32)
         return (res, None) if want else res
+    split_arena_prepare(A.device)
     split, rows = gemm_plan(M, N, Kd, split_k, want and out is None and not accumulate and M > bn_single_launch_rows(N)
                             and M <= _STATS_EPILOGUE_ROWS)
     if out is None:
-        out = ((torch.zeros((M, N), device=A.device, dtype=torch.float32) if keep else _zeros((M, N), A.device))
-               if split > 1 else torch.empty((M, N), device=A.device, dtype=torch.float32))
+        out = _split_out((M, N), A.device, split, keep)
     part = torch.empty(((M + rows - 1) // rows, 2, N), device=A.device, dtype=torch.float32) if rows > 0 else None
     check(lib().mvk_gemm_f32_ex(_p(A), _p(B), _p(out), M, N, Kd, int(transA), int(transB), int(accumulate),
                                 int(split), _p(part), _p(stats_n_valid) if part is not None else None, _stream()))
@@ -555,7 +607,7 @@ def _flush_deferred(items=None):
     check(lib().mvk_gemm_f32_tn_grouped_plan(prob.ctypes.data_as(C.c_void_p), n, C.c_void_p(slot["host"].data_ptr()),
                                              C.byref(nn), C.byref(wn), C.byref(ww), splits.ctypes.data_as(C.c_void_p)))
     for i, item in enumerate(items):
-        if splits[i] > 1 and not item[3]:
+        if splits[i] > 1 and not item[3] and not lib().mvk_gemm_split_ordered():
             raise RuntimeError("defer_weight_grads: the grouped plan splits a product whose output was not zero-initialised")
     nb = n * int(lib().mvk_gemm_group_entry_bytes())
     slot["dev"][:nb].copy_(slot["host"][:nb], non_blocking=True)
@@ -602,7 +654,9 @@ def _dw_gemm(A, B, transB=False, target=None):
         A, B = _f32c(A), _f32c(B)
         # a split reduction accumulates into a zero-initialised output (arena slice); an unsplit one (the big
         # coarse-level weights: few rows to reduce over, 2/3 of all weight-gradient bytes) writes every element
-        zeroed = lib().mvk_gemm_f32_tn_grouped_split(A.shape[1], B.shape[1], A.shape[0]) > 1
+        split_arena_prepare(A.device)
+        zeroed = lib().mvk_gemm_f32_tn_grouped_split(A.shape[1], B.shape[1], A.shape[0]) > 1 \
+            and not lib().mvk_gemm_split_ordered()
         out = (_zeros((A.shape[1], B.shape[1]), A.device) if zeroed
                else torch.empty((A.shape[1], B.shape[1]), device=A.device, dtype=torch.float32))
         # only the ADDRESS is recorded: a second reference to the tensor would make autograd's AccumulateGrad clone the
@@ -1395,9 +1449,10 @@ class _UpsampleCatLinearFn(torch.autograd.Function):
         ns, C1, C2, stride, i64 = ctx.dims
         g = _f32c(g)
         M, N, Kd = cat.shape[0], C1 + C2, W.shape[0]
+        split_arena_prepare(g.device)
         dx = _zeros((ns, C1), g.device)
         split = gemm_plan(M, N, Kd, None, False)[0] if M > 0 else 1
-        d_skip = _zeros((M, C2), g.device) if split > 1 else torch.empty((M, C2), device=g.device, dtype=torch.float32)
+        d_skip = _split_out((M, C2), g.device, split)
         if M > 0:
             check(lib().mvk_gemm_f32_scatter_cat(_p(g), _p(W), M, N, Kd, _p(inds2d), i64, stride, ns, C1, _p(dx),
                                                  _p(d_skip), _stream()))
@@ -1800,11 +1855,12 @@ def gemm_dual(A, B, A2, B2):
     N, Kd2 = B.shape[1], A2.shape[1]
     if A2.shape[0] != M or B.shape[0] != Kd or B2.shape != (Kd2, N):
         raise RuntimeError("gemm_dual: shapes do not match")
+    split_arena_prepare(A.device)
     split = C.c_int(0)
     check(lib().mvk_gemm_f32_dual_plan(M, N, Kd, Kd2, C.byref(split)))
     if split.value == 0:
         return None
-    out = _zeros((M, N), A.device) if split.value > 1 else torch.empty((M, N), device=A.device, dtype=torch.float32)
+    out = _split_out((M, N), A.device, split.value)
     check(lib().mvk_gemm_f32_dual(_p(A), _p(B), _p(A2), _p(B2), _p(out), M, N, Kd, Kd2, _stream()))
     return out
 
@@ -1822,7 +1878,7 @@ class _LinearPairFn(torch.autograd.Function):
         want = r0 > 0 or r1 > 0
         outs, parts = [], []
         for N, sp, rows in ((N0, s0, r0), (N1, s1, r1)):
-            outs.append(_zeros((M, N), x.device) if sp > 1 else torch.empty((M, N), device=x.device, dtype=torch.float32))
+            outs.append(_split_out((M, N), x.device, sp))
             parts.append(torch.empty(((M + rows - 1) // rows, 2, N), device=x.device, dtype=torch.float32) if rows > 0 else None)
         check(lib().mvk_gemm_f32_pair(_p(x), _p(W0), _p(W1), _p(outs[0]), _p(outs[1]), M, N0, N1, Kd, 1, int(want),
                                       _p(parts[0]), _p(parts[1]), _p(stats_n_valid) if want else None, _stream()))
@@ -1862,6 +1918,7 @@ def linear_pair(x, W0, W1, stats_n_valid=None):
             or not W0.is_contiguous() or not W1.is_contiguous() or x.dim() != 2 or x.shape[0] == 0:
         return None
     M, Kd = x.shape
+    split_arena_prepare(x.device)
     want = stats_n_valid is not None and M > bn_single_launch_rows(W0.shape[0]) and M > bn_single_launch_rows(W1.shape[0]) \
         and M <= _STATS_EPILOGUE_ROWS
     plan = (C.c_int * 5)()

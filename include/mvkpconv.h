@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVK_ABI_VERSION 5   /* 5: gather with a work list (mvk_kpconv_gather_fwd_ordered); 4: fp16 mode on gfx950 forms: padded fp16 aggregate rows, streaming contraction (v_mfma_f32_16x16x32_f16) with statistics epilogue, one-launch weight rounding; 3: gemm plan / BatchNorm-statistics epilogue, BatchNorm takes epilogue partials, fused clip + SGD, offset gradient + regulariser, segmentation loss, gather launch plan, strided gather-rows backward, channels-last fusion gather; 2: masked BatchNorm takes the batch counter and a residual addend; enqueue-only / device-lens pyramid entry points; fp16-feature mode; capacity padding */
+#define MVK_ABI_VERSION 6   /* 6: ordered split reductions (mvk_gemm_split_arena), reverse neighbour lists; 5: gather with a work list (mvk_kpconv_gather_fwd_ordered); 4: fp16 mode on gfx950 forms: padded fp16 aggregate rows, streaming contraction (v_mfma_f32_16x16x32_f16) with statistics epilogue, one-launch weight rounding; 3: gemm plan / BatchNorm-statistics epilogue, BatchNorm takes epilogue partials, fused clip + SGD, offset gradient + regulariser, segmentation loss, gather launch plan, strided gather-rows backward, channels-last fusion gather; 2: masked BatchNorm takes the batch counter and a residual addend; enqueue-only / device-lens pyramid entry points; fp16-feature mode; capacity padding */
 
 /* influence / aggregation codes (blocks.py:329-354) */
 #define MVK_INFL_CONSTANT 0
@@ -124,6 +124,21 @@ int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, int want_st
                       int* out_stat_rows);
 int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA,
                     int transB, int accumulate, int split_k, float* bn_part, const int32_t* n_valid, void* stream);
+
+/* Ordered split reductions (round 4). By default a split product adds its partial sums with f32 atomics onto a
+ * zero-initialised C: the value depends on the order the workgroups ran in (rounding only, but a LeakyReLU input within
+ * an ulp of zero then flips, and two runs of the same network differ). mvk_gemm_split_arena hands the library `ws`
+ * (ws_bytes of HBM, 256-byte aligned, >= 1 MB) and `counters` (n_counters >= 4096 int32 in HBM, ZERO on entry; the
+ * library returns every counter to zero itself, the caller never touches the buffer again): from then on EVERY split
+ * product of this library (mvk_gemm_f32 / _ex / _pair / _dual / _scatter_cat's dense half / _tn_grouped) parks its
+ * partial tiles in a slice of `ws` and the workgroup that arrives last at a tile adds them in the fixed order of the
+ * splits -- bit-identical from run to run, C needs no zero fill (every element is written), `accumulate` adds onto C
+ * once, and the BatchNorm-statistics epilogue works on split plans too (mvk_gemm_f32_plan then reports rows > 0 with
+ * split > 1). Slices are handed out in call order and wrap around at the end of the arena; a product larger than the
+ * whole arena fails with an error. ws == NULL restores the atomic path. mvk_gemm_split_ordered() = 1 while an arena
+ * is set. (The reference's products are single ATen matmuls: deterministic. This makes ours so.) */
+int mvk_gemm_split_arena(void* ws, int64_t ws_bytes, void* counters, int64_t n_counters);
+int mvk_gemm_split_ordered(void);
 
 /* C [M,N] = LeakyReLU_slope(A . op(B) + bias[col]) (slope = 1: the bias alone; A [M,Kd] row-major): a BatchNorm-less
  * layer -- `x W^T + self.bias` (blocks.py:462-463) and the block's activation, the two head layers of every network -- in

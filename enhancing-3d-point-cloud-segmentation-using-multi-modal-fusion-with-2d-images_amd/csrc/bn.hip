@@ -1289,9 +1289,14 @@ __global__ __launch_bounds__(256) void bias_lrelu_fwd_k(const float* __restrict_
   }
 }
 
+// ordered form (park != null): every workgroup parks its column sums in park [workgroup][C] (agent-scope relaxed stores,
+// see the split reduction of csrc/gemm.hip); the one that arrives last at *counter adds them in workgroup order and
+// writes dbias with plain stores -- bit-identical from run to run, no zero-initialised dbias, *counter back at zero.
 __global__ __launch_bounds__(256) void bias_lrelu_bwd_k(const float* __restrict__ y, const float* __restrict__ g, int64_t R, int C,
-                                                       int CP, float slope, float* __restrict__ dx, float* __restrict__ dbias) {
+                                                       int CP, float slope, float* __restrict__ dx, float* __restrict__ dbias,
+                                                       float* __restrict__ park, int* __restrict__ counter) {
   __shared__ float part[256];
+  __shared__ int last_flag;
   const int col = threadIdx.x % CP, rl = threadIdx.x / CP, RL = 256 / CP;
   float s = 0.f;
   if (col < C) {
@@ -1307,7 +1312,48 @@ __global__ __launch_bounds__(256) void bias_lrelu_bwd_k(const float* __restrict_
   __syncthreads();
   if (rl == 0 && col < C) {
     for (int i = 1; i < RL; ++i) s += part[i * CP + col];
-    atomicAdd(dbias + col, s);
+    if (park)
+      park_store1(park + (int64_t)blockIdx.x * C + col, s);
+    else
+      atomicAdd(dbias + col, s);
+  }
+  if (!park) return;
+  park_wait();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    last_flag = old == (int)gridDim.x - 1;
+    if (last_flag) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (!last_flag) return;
+  // the last workgroup: row lane rl adds the parked sums of workgroups rl, rl + RL, ... in that order, sixteen loads per
+  // round trip; the RL partial results meet in LDS and are added in lane order -- a fixed order throughout
+  float t = 0.f;
+  if (col < C) {
+    const int nb = (int)gridDim.x;
+    for (int b0 = rl; b0 < nb; b0 += 16 * RL) {
+      float v[16];
+      // (no branch around the loads, see the split reduction of csrc/gemm.hip: blocks past the end are clamped, then skipped)
+#pragma unroll
+      for (int u = 0; u < 16; ++u) {
+        const int b = b0 + u * RL < nb ? b0 + u * RL : nb - 1;
+        park_load1(v[u], park + (int64_t)b * C + col);
+      }
+      park_wait();
+#pragma unroll
+      for (int u = 0; u < 16; ++u) park_pin(v[u]);
+#pragma unroll
+      for (int u = 0; u < 16; ++u)
+        if (b0 + u * RL < nb) t += v[u];
+    }
+  }
+  __syncthreads();
+  part[threadIdx.x] = t;
+  __syncthreads();
+  if (rl == 0 && col < C) {
+    for (int i = 1; i < RL; ++i) t += part[i * CP + col];
+    dbias[col] = t;
   }
 }
 
@@ -1340,13 +1386,23 @@ extern "C" int mvk_bias_lrelu_fwd(const float* x, const float* bias, int64_t R, 
   return 0;
 }
 
-/* dbias [C] must be zero-initialised (one atomic per 64-row block and column is added to it) */
+/* dbias [C]: with the arena of ordered reductions set (mvk_gemm_split_ordered() == 1) it is WRITTEN (the workgroups'
+ * column sums are added in workgroup order: bit-identical from run to run); otherwise it must be zero-initialised (one
+ * atomic per 64-row block and column is added to it) */
 extern "C" int mvk_bias_lrelu_bwd(const float* y, const float* g, int64_t R, int C, float slope, float* dx, float* dbias,
                                   void* stream) {
   MVK_REQUIRE(R >= 0 && C >= 1 && C <= 256, "bias_lrelu: C=%d unsupported (1..256)", C);
-  if (R == 0) return 0;
-  hipLaunchKernelGGL(bias_lrelu_bwd_k, dim3((unsigned)cdiv64(R, 64)), dim3(256), 0, (hipStream_t)stream, y, g, R, C,
-                     pow2_ge(C), slope, dx, dbias);
+  if (R == 0) {
+    if (mvk_gemm_split_ordered()) MVK_CHECK_HIP(hipMemsetAsync(dbias, 0, sizeof(float) * C, (hipStream_t)stream));
+    return 0;
+  }
+  float* park = nullptr;
+  int* counter = nullptr;
+  const int64_t blocks = cdiv64(R, 64);
+  if (mvk_gemm_split_ordered())
+    MVK_REQUIRE(mvk_internal_arena_take(blocks * C, 1, &park, &counter), "bias_lrelu: the arena of ordered reductions is too small");
+  hipLaunchKernelGGL(bias_lrelu_bwd_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, g, R, C,
+                     pow2_ge(C), slope, dx, dbias, park, counter);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }

@@ -341,23 +341,19 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   }
 
   if (a.det_ws) {
-    // Slots and counters are read and written with RELAXED AGENT-SCOPE atomics (gfx950: sc1 loads / stores, served at
-    // the memory side, past the XCD-private L2s) instead of plain accesses fenced by __threadfence(): an agent-scope
-    // release / acquire fence writes back and invalidates the whole L2 of the XCD for every workgroup of the launch.
-    // Order: the slot stores are complete (s_waitcnt via the workgroup-scope release + barrier) before thread 0 bumps the
-    // counter; the last arriver reads the slots only after its own bump returned the full count.
-    constexpr int SLOT = PM * QN * 4 * 256;
+    // Slots are written and read with agent-scope (sc1) accesses (park_* of common.h), the counter with a relaxed
+    // agent-scope atomic: no fence, no L2 write-back. Order: a workgroup's slot stores are complete (park_wait + barrier)
+    // before thread 0 bumps the tile's counter; the last arriver reads the slots only after its own bump returned the
+    // full count. Slot layout [accumulator block][thread][4]: one 16-byte access per lane.
+    constexpr int NB = PM * QN, SLOT = NB * 4 * 256;
     const int64_t tile = (int64_t)by * a.det_gx + bx;
-    float* const mine = a.det_ws + (tile * a.det_nsplit + bz) * SLOT + tid;
+    float* const mine = a.det_ws + (tile * a.det_nsplit + bz) * SLOT + tid * 4;
 #pragma unroll
     for (int p = 0; p < PM; ++p)
 #pragma unroll
-      for (int q = 0; q < QN; ++q)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          __hip_atomic_store(mine + ((p * QN + q) * 4 + r) * 256, acc[p][q][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __syncthreads();              // every thread's stores have left; the operand tiles in LDS are dead
+      for (int q = 0; q < QN; ++q) park_store4(mine + (p * QN + q) * 1024, acc[p][q]);
+    park_wait();
+    __syncthreads();              // every thread's stores have arrived; the operand tiles in LDS are dead
     int* const flag = reinterpret_cast<int*>(lds);
     if (tid == 0) {
       const int old = __hip_atomic_fetch_add(a.det_cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -369,20 +365,36 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
     const int last = *flag;
     __syncthreads();              // (the statistics epilogue reuses lds)
     if (!last) return;
-    const float* const all = a.det_ws + tile * a.det_nsplit * SLOT + tid;
+    const float* const all = a.det_ws + tile * a.det_nsplit * SLOT + tid * 4;
 #pragma unroll
     for (int p = 0; p < PM; ++p)
 #pragma unroll
       for (int q = 0; q < QN; ++q) acc[p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int z = 0; z < a.det_nsplit; ++z) {
-      const float* const sl = all + (int64_t)z * SLOT;
+    constexpr int ZC = NB >= 8 ? 2 : 4;      // slots in flight: up to 16 loads per thread and round trip
+    for (int z0 = 0; z0 < a.det_nsplit; z0 += ZC) {
+      f32x4 t[ZC][NB];
+      // no branch around the loads: a register written by an untracked load must not pass through a join before the
+      // wait (the compiler would copy it there, before the data has arrived); slots beyond the split are clamped to
+      // the last one and skipped when adding
 #pragma unroll
-      for (int p = 0; p < PM; ++p)
+      for (int zz = 0; zz < ZC; ++zz) {
+        const int z = z0 + zz < a.det_nsplit ? z0 + zz : a.det_nsplit - 1;
 #pragma unroll
-        for (int q = 0; q < QN; ++q)
+        for (int b = 0; b < NB; ++b) park_load4(t[zz][b], all + (int64_t)z * SLOT + b * 1024);
+      }
+      park_wait();
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc[p][q][r] += __hip_atomic_load(sl + ((p * QN + q) * 4 + r) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      for (int zz = 0; zz < ZC; ++zz)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) park_pin(t[zz][b]);
+#pragma unroll
+      for (int zz = 0; zz < ZC; ++zz)
+        if (z0 + zz < a.det_nsplit) {
+#pragma unroll
+          for (int p = 0; p < PM; ++p)
+#pragma unroll
+            for (int q = 0; q < QN; ++q) acc[p][q] += t[zz][p * QN + q];          // split order 0, 1, 2, ...: fixed
+        }
     }
   }
 
@@ -729,6 +741,11 @@ int fill_args(GemmArgs& a, const Plan& p, const float* A, const float* B, float*
 }
 
 }  // namespace
+
+bool mvk_internal_arena_take(int64_t floats, int64_t counters, float** ws, int** cnt) {
+  if (!ordered_splits() || floats < 0 || counters < 0) return false;
+  return arena_take(counters > 0 ? counters : 1, 1, cdiv64(floats, counters > 0 ? counters : 1), ws, cnt);
+}
 
 // Hands the library the arena of its ordered split reductions: `ws` (bytes, HBM) for the parked partial tiles, `counters`
 // (n_counters int32, HBM, ZERO on entry and never touched by the caller again). ws == null: back to f32 atomics onto a

@@ -97,33 +97,51 @@ def _zeros(shape, device, dtype=torch.float32):
 # --------------------------------------------------------------------------------------------
 
 # --------------------------------------------------------------------------------------------
-# ordered split reductions (run-to-run bit-identical products, no zero-initialised outputs)
+# deterministic mode: ordered reductions (run-to-run bit-identical products, no zero-initialised outputs)
 # --------------------------------------------------------------------------------------------
-# mvk_gemm_split_arena: with an arena set, every split product parks its partial tiles in HBM and the last-arriving
-# workgroup of a tile adds them in a fixed order (csrc/gemm.hip) instead of f32 atomics onto a zero-filled output.
-# Default on (MVK_GEMM_ORDERED=0: the atomic path). The arena is created by the first product on a device, outside any
-# graph capture (a capture must not allocate 1 GB in its private pool, and the counters' one zero fill must not become a
-# node of the graph).
-_ORDERED = os.environ.get("MVK_GEMM_ORDERED", "1") == "1"
+# By default a product whose reduction is split over workgroups adds its partial sums with f32 atomics: the fastest way
+# (fire and forget), but the sum depends on the order the workgroups ran in -- rounding only, yet a LeakyReLU input within
+# an ulp of zero then takes the other slope and two runs of one network differ visibly. set_deterministic(True) (or
+# MVK_DETERMINISTIC=1) hands the library an arena (mvk_gemm_split_arena): every split product then parks its partial
+# tiles in HBM and the last-arriving workgroup of a tile adds them in split order (csrc/gemm.hip), the bias gradient of
+# the BatchNorm-less layers is summed in workgroup order, outputs need no zero fill and split plans keep their
+# BatchNorm-statistics epilogue. The price is three memory-side round trips at the tail of every split launch (~4 us
+# each, +0.2 ms on the 4.1 ms early-fusion step): opt-in, like torch.use_deterministic_algorithms.
+_DET = {"on": os.environ.get("MVK_DETERMINISTIC", os.environ.get("MVK_GEMM_ORDERED", "0")) == "1"}
 _SPLIT_ARENA = {}
 _SPLIT_ARENA_BYTES = int(os.environ.get("MVK_GEMM_ARENA_MB", "1024")) << 20
 _SPLIT_COUNTERS = 1 << 20
 
 
+def set_deterministic(flag, device=None):
+    """Turns the ordered reductions on or off (see above). Turning them on creates the arena on `device` (default: the
+    current one) at once: do it outside any graph capture."""
+    _DET["on"] = bool(flag)
+    if flag:
+        split_arena_prepare(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
+    else:
+        split_arena_release()
+
+
+def is_deterministic():
+    return bool(_DET["on"] and _SPLIT_ARENA)
+
+
 def split_arena_prepare(device):
-    """Creates the arena of the ordered split reductions on `device` (no-op when it exists or MVK_GEMM_ORDERED=0).
-    Called by the first gemm(); call it yourself before capturing a graph that was never run eagerly."""
-    if not _ORDERED:
+    """Creates the arena of the ordered reductions on `device` in deterministic mode (no-op otherwise, or when it exists).
+    Called by the first product; call it (or set_deterministic) yourself before capturing a graph that was never run
+    eagerly."""
+    if not _DET["on"]:
         return False
     device = torch.device(device)
     if device.index in _SPLIT_ARENA:
         return True
     if _SPLIT_ARENA:
-        raise RuntimeError("the ordered split reductions use ONE arena per process (one GPU per process); it lives on "
+        raise RuntimeError("the ordered reductions use ONE arena per process (one GPU per process); it lives on "
                            "cuda:%d" % next(iter(_SPLIT_ARENA)))
     if torch.cuda.is_current_stream_capturing():
-        raise RuntimeError("ops.gemm: the split-reduction arena does not exist yet and cannot be created inside a graph "
-                           "capture; run one eager step first or call ops.split_arena_prepare(device)")
+        raise RuntimeError("ops: the arena of the ordered reductions does not exist yet and cannot be created inside a "
+                           "graph capture; run one eager step first or call ops.set_deterministic(True) before")
     ws = torch.empty(_SPLIT_ARENA_BYTES, dtype=torch.uint8, device=device)
     cnt = torch.zeros(_SPLIT_COUNTERS, dtype=torch.int32, device=device)
     torch.cuda.current_stream(device).synchronize()          # the counters are zero before any stream uses them
@@ -133,7 +151,7 @@ def split_arena_prepare(device):
 
 
 def split_arena_release():
-    """Back to the atomic split reductions (tests); frees the arena."""
+    """Back to the atomic split reductions; frees the arena."""
     if _SPLIT_ARENA:
         torch.cuda.synchronize()
         check(lib().mvk_gemm_split_arena(None, 0, None, 0))
@@ -143,7 +161,7 @@ def split_arena_release():
 def _split_out(shape, device, split, keep=False):
     """Output buffer of a product whose reduction is split `split` ways: the ordered reduction writes every element
     (empty); the atomic one accumulates onto zeros (arena slice, or a tensor of its own when it outlives the step)."""
-    if split <= 1 or (_ORDERED and device.index in _SPLIT_ARENA):
+    if split <= 1 or device.index in _SPLIT_ARENA:
         return torch.empty(shape, device=device, dtype=torch.float32)
     return torch.zeros(shape, device=device, dtype=torch.float32) if keep else _zeros(shape, device)
 
@@ -1236,6 +1254,15 @@ class _AddLReLUFn(torch.autograd.Function):
         return d, d.clone(), None
 
 
+def _bias_grad(y):
+    """Buffer for the bias gradient of mvk_bias_lrelu_bwd: it becomes the .grad of a leaf parameter, so it is never a
+    slice of the per-step zero arena; written whole by the ordered reduction, zero-initialised otherwise."""
+    split_arena_prepare(y.device)
+    if lib().mvk_gemm_split_ordered():
+        return torch.empty((y.shape[1],), device=y.device, dtype=torch.float32)
+    return torch.zeros((y.shape[1],), device=y.device, dtype=torch.float32)
+
+
 class _BiasLReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, bias, slope):
@@ -1252,7 +1279,7 @@ class _BiasLReLUFn(torch.autograd.Function):
         (y,) = ctx.saved_tensors
         g = _f32c(g)
         dx = torch.empty_like(y)
-        db = _zeros((y.shape[1],), y.device)
+        db = _bias_grad(y)
         check(lib().mvk_bias_lrelu_bwd(_p(y), _p(g), y.shape[0], y.shape[1], ctx.slope, _p(dx), _p(db), _stream()))
         return dx, db, None
 
@@ -1289,7 +1316,7 @@ class _LinearBiasActFn(torch.autograd.Function):
         x, W, y = ctx.saved_tensors
         g = _f32c(g)
         d = torch.empty_like(y)
-        db = _zeros((y.shape[1],), y.device)
+        db = _bias_grad(y)
         check(lib().mvk_bias_lrelu_bwd(_p(y), _p(g), y.shape[0], y.shape[1], ctx.slope, _p(d), _p(db), _stream()))
         dx = gemm(d, W) if ctx.needs_input_grad[0] else None
         dW = _dw_gemm(d, x, target=W) if ctx.needs_input_grad[1] else None

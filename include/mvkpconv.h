@@ -346,8 +346,9 @@ int mvk_bn_lrelu_bwd_pair(const mvk_bn_bwd_problem* a, const mvk_bn_bwd_problem*
 
 /* y = LeakyReLU_slope(x + bias) over rows of C <= 256 channels: the BatchNorm-less form of BatchNormBlock
  * (models/blocks.py:462-463) fused with the LeakyReLU that follows it in UnaryBlock (:493-498) -- the two head layers.
- * _bwd: dx = g * (y > 0 ? 1 : slope) and dbias += column sums of dx (dbias zero-initialised by the caller; one float
- * atomic per 64-row block and column). */
+ * _bwd: dx = g * (y > 0 ? 1 : slope) and dbias = column sums of dx: WRITTEN, the 64-row blocks' sums added in block
+ * order, while mvk_gemm_split_ordered() == 1 (the arena of ordered reductions); otherwise ADDED with one float atomic
+ * per block and column onto a dbias the caller zero-initialised. */
 int mvk_bias_lrelu_fwd(const float* x, const float* bias, int64_t R, int C, float slope, float* y, void* stream);
 int mvk_bias_lrelu_bwd(const float* y, const float* g, int64_t R, int C, float slope, float* dx, float* dbias, void* stream);
 

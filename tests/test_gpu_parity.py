@@ -848,6 +848,92 @@ def test_gemm_batchnorm_statistics_epilogue(ops, M, N, K, n):
     assert rel_err(bn.running_var.cpu().numpy(), ref.running_var.cpu().numpy()) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K,split,n", [(19464, 64, 990, 4, 19000), (1300, 128, 1920, 6, 1300), (85, 512, 7680, 20, 85),
+                                           (4096, 32, 480, 3, 4096), (333, 2048, 512, 2, 300), (19464, 32, 256, 2, 19464)])
+def test_split_products_are_ordered_bit_reproducible_and_carry_statistics(ops, M, N, K, split, n):
+    """The ordered split reduction (mvk_gemm_split_arena, csrc/gemm.hip): a product whose reduction is split over
+    workgroups gives the SAME BITS on every run (the partial tiles are added in split order by the last-arriving
+    workgroup, not with f32 atomics), needs no zero-initialised output (the output buffer is filled with NaN first),
+    honours `accumulate`, and delivers the BatchNorm statistics of the complete sums. The counters it uses are back at
+    zero afterwards (a second product on the same slices works)."""
+    ops.set_deterministic(True)
+    try:
+        _split_products_ordered(ops, M, N, K, split, n)
+    finally:
+        ops.set_deterministic(False)
+
+
+def _split_products_ordered(ops, M, N, K, split, n):
+    assert ops.is_deterministic() and ops.lib().mvk_gemm_split_ordered() == 1
+    torch.manual_seed(M + K)
+    A = torch.randn(M, K, device="cuda")
+    A[:, 0] = 7.0
+    B = torch.randn(K, N, device="cuda")
+    ref = (A.double() @ B.double())
+    nv = torch.tensor([n], dtype=torch.int32, device="cuda")
+    outs = []
+    for _ in range(6):
+        y, st = ops.gemm(A, B, split_k=split, stats_n_valid=nv)
+        outs.append((y.clone(), None if st is None else st[0].clone()))
+    assert rel_err(outs[0][0].cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    for y, part in outs[1:]:
+        assert torch.equal(y, outs[0][0])
+        assert (part is None) == (outs[0][1] is None) and (part is None or torch.equal(part, outs[0][1]))
+    sp, rows = ops.gemm_plan(M, N, K, split, True)
+    assert sp == split
+    if M > ops.bn_single_launch_rows(N):
+        assert rows > 0 and outs[0][1] is not None          # statistics although the reduction is split
+        part = outs[0][1]
+        yv = outs[0][0][:n].double()
+        nb = (n + rows - 1) // rows
+        pad = torch.zeros(nb * rows - n, N, device="cuda", dtype=torch.float64)
+        blocks = torch.cat([yv, pad]).view(nb, rows, N)
+        assert rel_err(part[:nb, 0].cpu().numpy(), blocks.sum(1).cpu().numpy()) < 1e-5
+    # a NaN-filled output is overwritten completely; accumulate adds the whole product once
+    out = torch.full((M, N), float("nan"), device="cuda")
+    ops.gemm(A, B, out=out, split_k=split)
+    assert torch.equal(out, outs[0][0])
+    base = torch.randn(M, N, device="cuda")
+    acc = base.clone()
+    ops.gemm(A, B, out=acc, accumulate=True, split_k=split)
+    assert rel_err(acc.cpu().numpy(), (ref + base.double()).cpu().numpy()) < 1e-5
+    # transposed operand layouts through the same epilogue
+    yt = ops.gemm(A.t().contiguous(), B.t().contiguous(), transA=True, transB=True, split_k=split)
+    assert rel_err(yt.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    assert torch.equal(yt, ops.gemm(A.t().contiguous(), B.t().contiguous(), transA=True, transB=True, split_k=split))
+
+
+def test_weight_gradients_of_a_backward_pass_are_bit_reproducible(ops):
+    """The grouped weight-gradient launch (long reductions over the points, split many ways) with ordered splits: two
+    backward passes over the same tensors give identical bits in every dW, in-line and deferred."""
+    ops.set_deterministic(True)
+    try:
+        _weight_gradients_reproducible(ops)
+    finally:
+        ops.set_deterministic(False)
+
+
+def _weight_gradients_reproducible(ops):
+    torch.manual_seed(3)
+    xs = [torch.randn(m, k, device="cuda") for m, k in ((19464, 64), (19464, 32), (4000, 128), (700, 990), (90, 1920))]
+    gs = [torch.randn(x.shape[0], n, device="cuda") for x, n in zip(xs, (128, 64, 256, 64, 512))]
+    runs = []
+    for deferred in (False, True, True, False):
+        Ws = [torch.nn.Parameter(torch.randn(g.shape[1], x.shape[1], device="cuda") * 0.05) for x, g in zip(xs, gs)]
+        loss = sum((ops.linear(x, W) * g).sum() for x, W, g in zip(xs, Ws, gs))
+        if deferred:
+            with ops.defer_weight_grads():
+                loss.backward()
+        else:
+            loss.backward()
+        runs.append([W.grad.clone() for W in Ws])
+    for i, (x, g) in enumerate(zip(xs, gs)):
+        want = (g.double().t() @ x.double()).cpu().numpy()
+        assert rel_err(runs[0][i].cpu().numpy(), want) < 1e-5 and rel_err(runs[1][i].cpu().numpy(), want) < 1e-5
+        assert torch.equal(runs[0][i], runs[3][i]), i          # in-line twice
+        assert torch.equal(runs[1][i], runs[2][i]), i          # grouped twice
+
+
 def test_deferred_weight_gradients_run_as_one_grouped_launch(ops):
     """ops.defer_weight_grads(): the dW products recorded during a backward pass (TN, wide and narrow outputs, ragged
     sizes, split and unsplit reductions) come out of the grouped launch equal to the individual products; under

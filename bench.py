@@ -553,12 +553,13 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             while pending and (block or pending[0][0].query()):
                 ev, host = pending.pop(0)
                 ev.synchronize()
-                if int(host[1]) and not state.get("overflow"):
+                if (int(host[1]) or int(host[3])) and not state.get("overflow"):
                     # never silent: the step ran on a level cut at its capacity (or a neighbour row cut at the
                     # list size); reported on stderr and in the JSON line, the run goes on
                     state["overflow"] = True
-                    print("WARNING input chain: a level outgrew its captured capacity or a query its neighbour "
-                          "list (status %s, capacities %s)" % (host.tolist(), statics[0].caps), file=sys.stderr)
+                    print("WARNING input chain: a level outgrew its captured capacity, a query its neighbour list or a "
+                          "support its reverse-list width (status %s, capacities %s)" % (host.tolist(), statics[0].caps),
+                          file=sys.stderr)
 
         chains[0].draw_rotations()
         chains[0].build(statics[0])             # batch 0; every later batch is built by the graph before it
@@ -576,9 +577,9 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                 enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
             ta = time.perf_counter()
             replays[slot][0]()
-            host = torch.empty(2, dtype=torch.int32).pin_memory() if len(pending) < 4 else None
+            host = torch.empty(4, dtype=torch.int32).pin_memory() if len(pending) < 4 else None
             if host is not None:
-                host.copy_(chains[slot ^ 1].status, non_blocking=True)
+                host.copy_(chains[slot ^ 1].status4, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
                 pending.append((ev, host))
@@ -627,11 +628,14 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         if free is not None:                       # (the searches of the batch this set held are long done)
             with torch.cuda.stream(build_stream):
                 ops.check_neighbor_status(status[slot])
+                if state.get("rev_status", [None, None])[slot] is not None:
+                    ops.check_reverse_status(state["rev_status"][slot])
         if free is not None:                       # the replay that last read this set has finished
             build_stream.wait_event(free)
         with torch.cuda.stream(build_stream):
             status[slot].zero_()
             batch, lens = syn.build_batch(cfg, staged, limits, torch.int32, status=status[slot])
+            state.setdefault("rev_status", [None, None])[slot] = getattr(batch, "rev_status", None)
             fits = True
             try:
                 statics[slot].load(batch)

@@ -51,6 +51,11 @@ _SIGNATURES = {
                                          _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvk_gemm_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp]),
     "mvk_gemm_f32_plan": (C.c_int, [_i64, _i64, _i64, _i, _i, _vp, _vp]),
+    "mvk_gemm_f32_kp_transposed": (C.c_int, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "mvk_reverse_neighbors": (C.c_int, [_vp, _i, _i64, _i, _i64, _i64, _vp, _i, C.c_int32, _i, _vp, _vp, _vp]),
+    "mvk_gather_sum_rows": (C.c_int, [_vp, _i64, _i64, _vp, _i, _i64, _i, _vp, _vp, _vp]),
+    "mvk_max_pool_bwd_gather": (C.c_int, [_vp, _vp, _vp, _i, _i, _i64, _vp, _i, _i64, _i, _vp, _vp, _vp]),
+    "mvk_gemm_f32_ldb": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp]),
     "mvk_gemm_split_arena": (C.c_int, [_vp, _i64, _vp, _i64]),
     "mvk_gemm_split_ordered": (C.c_int, []),
     "mvk_gemm_f32_bias_act": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _vp, _f, _vp]),

@@ -26,6 +26,7 @@ SOURCES = [
     ("deform.hip", []),
     ("loss.hip", []),
     ("batchpad.hip", []),
+    ("revlist.hip", []),
     ("subsample.hip", ["-ffp-contract=off"]),
     ("neighbors.hip", ["-ffp-contract=off"]),
     ("fusion.hip", ["-ffp-contract=off"]),

@@ -211,6 +211,13 @@ struct GemmArgs {
   float* det_ws;
   int* det_cnt;
   int det_gx, det_nsplit;
+  // segmented B (seg_shift < 0: off; NT products only): the reduction is a sequence of segments of 2^seg_shift elements
+  // (a multiple of the k-tile) and B's row pointer advances by seg_extra extra floats from one segment to the next --
+  // B[(k, o), c] = W[k, c, o] read in place from a KPConv weight tensor [K, Cin, Cout] (segment = one kernel point:
+  // 2^seg_shift = Cout, ldb = Cout, seg_extra = Cin * Cout - Cout): the per-kernel-point transposed weights of the
+  // gather-form feature gradient, without a transposed copy of the weights.
+  int seg_shift;
+  int64_t seg_extra;
 };
 
 template <bool TA, bool TB, int PM, int QN, int WM, int WN, bool DUAL = false>
@@ -270,14 +277,18 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   // one operand pair over its own k-range [kbeg, kend): the pipelined full tiles, then the ragged tail
   auto run_range = [&](const float* __restrict__ pA, const int64_t lda, const int vecA, const float* __restrict__ pB,
                        const int64_t ldb, const int vecB, int64_t kbeg, const int64_t kend) {
+  // B's base for the k-tile at k (segmented B: every segment starts seg_extra floats further than its position implies)
+  auto Bat = [&](const int64_t k) -> const float* {
+    return (TB && !DUAL && a.seg_shift >= 0) ? pB + (k >> a.seg_shift) * a.seg_extra : pB;
+  };
   auto pipeline = [&](auto va, auto vb, const int64_t klim) {
     constexpr int VA = decltype(va)::value, VB = decltype(vb)::value;
     if (kbeg >= klim) return;
     la0.template fetch<VA>(pA, lda, m0, a.M, kbeg, klim, vecA, tid);
-    lb0.template fetch<VB>(pB, ldb, n0, a.N, kbeg, klim, vecB, tid);
+    lb0.template fetch<VB>(Bat(kbeg), ldb, n0, a.N, kbeg, klim, vecB, tid);
     if (kbeg + BK < klim) {
       la1.template fetch<VA>(pA, lda, m0, a.M, kbeg + BK, klim, vecA, tid);
-      lb1.template fetch<VB>(pB, ldb, n0, a.N, kbeg + BK, klim, vecB, tid);
+      lb1.template fetch<VB>(Bat(kbeg + BK), ldb, n0, a.N, kbeg + BK, klim, vecB, tid);
     }
     la0.store(A0, tid);
     lb0.store(B0, tid);
@@ -286,7 +297,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
       // even k-tile (buffer 0): fetch tile +2 into set 0, multiply, publish tile +1 (set 1) in buffer 1
       if (k0 + 2 * BK < klim) {
         la0.template fetch<VA>(pA, lda, m0, a.M, k0 + 2 * BK, klim, vecA, tid);
-        lb0.template fetch<VB>(pB, ldb, n0, a.N, k0 + 2 * BK, klim, vecB, tid);
+        lb0.template fetch<VB>(Bat(k0 + 2 * BK), ldb, n0, a.N, k0 + 2 * BK, klim, vecB, tid);
       }
       compute(A0, B0);
       if (k0 + BK >= klim) break;
@@ -296,7 +307,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
       // odd k-tile (buffer 1): fetch tile +3 into set 1, multiply, publish tile +2 (set 0) in buffer 0
       if (k0 + 3 * BK < klim) {
         la1.template fetch<VA>(pA, lda, m0, a.M, k0 + 3 * BK, klim, vecA, tid);
-        lb1.template fetch<VB>(pB, ldb, n0, a.N, k0 + 3 * BK, klim, vecB, tid);
+        lb1.template fetch<VB>(Bat(k0 + 3 * BK), ldb, n0, a.N, k0 + 3 * BK, klim, vecB, tid);
       }
       compute(A1, B1);
       if (k0 + 2 * BK >= klim) break;
@@ -321,7 +332,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   if (kfull < kend && kbeg < kend) {     // ragged k-tail of a fast pipeline: one predicated tile, unpipelined
     __syncthreads();
     la0.load(pA, lda, m0, a.M, kfull, kend, vecA, tid);
-    lb0.load(pB, ldb, n0, a.N, kfull, kend, vecB, tid);
+    lb0.load(Bat(kfull), ldb, n0, a.N, kfull, kend, vecB, tid);
     la0.store(A0, tid);
     lb0.store(B0, tid);
     __syncthreads();
@@ -737,6 +748,7 @@ int fill_args(GemmArgs& a, const Plan& p, const float* A, const float* B, float*
   a.A2 = nullptr; a.B2 = nullptr; a.Kd2 = 0; a.lda2 = 0; a.ldb2 = 0; a.vecA2 = 1; a.vecB2 = 1;
   a.sc_idx = nullptr; a.sc_idx64 = 0; a.sc_c1 = 0; a.sc_stride = 0; a.sc_ns = 0; a.sc_dst = nullptr; a.sc_rest = nullptr;
   a.det_ws = nullptr; a.det_cnt = nullptr; a.det_gx = 0; a.det_nsplit = split;
+  a.seg_shift = -1; a.seg_extra = 0;
   return split;
 }
 
@@ -881,7 +893,7 @@ struct ScatterOut {
 };
 int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA, int transB,
              int accumulate, int split_k, float* bn_part, const int32_t* n_valid, const float* bias, float act_slope,
-             void* stream, const ScatterOut* scatter = nullptr);
+             void* stream, const ScatterOut* scatter = nullptr, int seg_shift = -1, int64_t seg_extra = 0, int64_t ldb = 0);
 }
 
 extern "C" int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd,
@@ -896,6 +908,25 @@ extern "C" int mvk_gemm_f32_bias_act(const float* A, const float* B, float* C, i
                                      const float* bias, float slope, void* stream) {
   MVK_REQUIRE(bias != nullptr && slope > 0.f && Kd > 0, "gemm bias_act: bias, a positive slope and a non-empty product");
   return gemm_run(A, B, C, M, N, Kd, 0, transB, 0, 1, nullptr, nullptr, bias, slope, stream);
+}
+
+// dx [M, Cin] = sum_k A[:, k, :] [M, Cout] . W[k]^T [Cout, Cin] with A [M, K, Cout] row-major and W [K, Cin, Cout] the
+// KPConv weight tensor read in place (segmented B, see GemmArgs): the contraction of the gather-form feature gradient
+// (csrc/revlist.hip). Cout a power of two >= 32.
+extern "C" int mvk_gemm_f32_kp_transposed(const float* A, const float* W, float* dx, int64_t M, int K, int Cin, int Cout,
+                                          void* stream) {
+  MVK_REQUIRE(K >= 1 && Cin >= 1 && Cout >= BK && (Cout & (Cout - 1)) == 0, "gemm kp_transposed: Cout must be a power of two >= 32");
+  int shift = 0;
+  while ((1 << shift) < Cout) ++shift;
+  return gemm_run(A, W, dx, M, Cin, (int64_t)K * Cout, 0, 1, 0, 0, nullptr, nullptr, nullptr, 1.f, stream, nullptr, shift,
+                  (int64_t)Cin * Cout - Cout);
+}
+
+// C [M,N] = A [M,Kd] . B with B [Kd, N] a column block of a wider row-major matrix (rows ldb >= N floats apart)
+extern "C" int mvk_gemm_f32_ldb(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int64_t ldb,
+                                void* stream) {
+  MVK_REQUIRE(ldb >= N, "gemm ldb: ldb < N");
+  return gemm_run(A, B, C, M, N, Kd, 0, 0, 0, 0, nullptr, nullptr, nullptr, 1.f, stream, nullptr, -1, 0, ldb);
 }
 
 // [d_x | d_skip] = A [M,Kd] . B [Kd,N] where the product is the gradient of cat([x[idx[m,0]], skip[m]]) (decoder:
@@ -913,7 +944,7 @@ extern "C" int mvk_gemm_f32_scatter_cat(const float* A, const float* B, int64_t 
 namespace {
 int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA, int transB,
              int accumulate, int split_k, float* bn_part, const int32_t* n_valid, const float* bias, float act_slope,
-             void* stream, const ScatterOut* scatter) {
+             void* stream, const ScatterOut* scatter, int seg_shift, int64_t seg_extra, int64_t ldb) {
   MVK_REQUIRE(M >= 0 && N >= 0 && Kd >= 0, "gemm: negative size");
   if (M == 0 || N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -938,12 +969,22 @@ int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int
   a.accumulate = accumulate;
   a.vecA = ((a.lda % 4 == 0) && ((uintptr_t)A % 16 == 0)) ? 4 : ((a.lda % 2 == 0) && ((uintptr_t)A % 8 == 0)) ? 2 : 1;
   a.vecB = ((a.ldb % 4 == 0) && ((uintptr_t)B % 16 == 0)) ? 4 : ((a.ldb % 2 == 0) && ((uintptr_t)B % 8 == 0)) ? 2 : 1;
+  if (ldb > 0) {                              // B = a column block of a wider matrix
+    a.ldb = ldb;
+    a.vecB = ((a.ldb % 4 == 0) && ((uintptr_t)B % 16 == 0)) ? 4 : ((a.ldb % 2 == 0) && ((uintptr_t)B % 8 == 0)) ? 2 : 1;
+  }
+  if (seg_shift >= 0) {
+    a.ldb = (int64_t)1 << seg_shift;          // rows of W[k]: Cout floats
+    a.vecB = ((uintptr_t)B % 16 == 0 && seg_extra % 4 == 0) ? 4 : 1;
+  }
   a.bn_part = bn_part;
   a.n_valid = n_valid;
   a.bias = bias;
   a.act_slope = act_slope;
   a.A2 = nullptr; a.B2 = nullptr; a.Kd2 = 0; a.lda2 = 0; a.ldb2 = 0; a.vecA2 = 1; a.vecB2 = 1;
   a.sc_idx = nullptr; a.sc_idx64 = 0; a.sc_c1 = 0; a.sc_stride = 0; a.sc_ns = 0; a.sc_dst = nullptr; a.sc_rest = nullptr;
+  a.seg_shift = seg_shift;
+  a.seg_extra = seg_extra;
   if (scatter) {
     a.sc_idx = scatter->idx; a.sc_idx64 = scatter->idx64; a.sc_c1 = scatter->c1; a.sc_stride = scatter->stride;
     a.sc_ns = scatter->ns; a.sc_dst = scatter->dst; a.sc_rest = scatter->rest;
@@ -1053,6 +1094,7 @@ extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* t
     e.args.vecA2 = 1; e.args.vecB2 = 1;
     e.args.sc_idx = nullptr; e.args.sc_idx64 = 0; e.args.sc_c1 = 0; e.args.sc_stride = 0; e.args.sc_ns = 0;
     e.args.sc_dst = nullptr; e.args.sc_rest = nullptr;
+    e.args.seg_shift = -1; e.args.seg_extra = 0;
     const int64_t tm = narrow ? 64 : 16 * group_wide_pm(), tn = narrow ? 32 : 64;      // plan tiles: narrow (pm 1, qn 2), wide (pm 2, qn 1)
     e.gx = (int)cdiv64(q.N, tn);
     e.gy = (int)cdiv64(q.M, tm);

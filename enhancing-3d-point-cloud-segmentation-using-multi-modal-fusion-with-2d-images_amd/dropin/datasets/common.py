@@ -131,7 +131,11 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
     (ops.neighbors_cell_order; None for a layer without conv blocks), the work list the KPConv gather walks
     (MVK_GATHER_ORDER=0: no lists). The reference's flat batch list has no slot for them: each list is also
     remembered under its points tensor (ops.remember_work_order), where the blocks find it as long as that tensor
-    reaches the network as it is (device-resident batches in the process that built them)."""
+    reaches the network as it is (device-resident batches in the process that built them).
+    ``rev_neighbors`` / ``rev_pools`` -- per layer the transposed conv / pool neighbour matrix of the rigid layers
+    (ops.reverse_neighbors; None elsewhere): the feature gradient of those convolutions then runs as a gather in a fixed
+    summation order instead of an atomic scatter (MVK_REVERSE_DX=0: none). With ``status`` they are built at a fixed width
+    and ``rev_status`` collects their overflow word (ops.check_reverse_status)."""
     r_normal = config.first_subsampling_dl * config.conv_radius
     want_orders = os.environ.get("MVK_GATHER_ORDER", "1") != "0"
     grid_of = [None, None]          # supports tensor and radius of the grid the neighbour workspace holds
@@ -146,7 +150,9 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
     pts = _t(stacked_points, np.float32)
     lens = np.ascontiguousarray(stack_lengths.cpu().numpy() if isinstance(stack_lengths, torch.Tensor)
                                 else stack_lengths, dtype=np.int32)
-    out = dict(points=[], neighbors=[], pools=[], upsamples=[], lengths=[], deform_layers=[], orders=[])
+    out = dict(points=[], neighbors=[], pools=[], upsamples=[], lengths=[], deform_layers=[], orders=[],
+               rev_neighbors=[], rev_pools=[])
+    want_rev = ops.REVERSE_DX
     layer_blocks = []
     level = 0
     dev = pts.device
@@ -195,6 +201,33 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
             pool_i, up_i = empty_idx(), empty_idx()
             pool_p = torch.zeros((0, 3), dtype=torch.float32, device=dev)
             pool_b = np.zeros((0,), dtype=np.int32)
+        # transposed relations for the gather-form feature gradient of the RIGID convolutions (ops.reverse_neighbors);
+        # the deformable layers (searched at the wide deform radius) keep the scatter
+        rigid = want_rev and not deform_layer and pts.is_cuda
+
+        def reverse(m):
+            if not rigid or m.shape[0] == 0 or m.shape[1] == 0:
+                return None
+            if status is None:
+                return ops.reverse_neighbors(m, pts.shape[0])               # exact width (one read-back)
+            if 'rev_status' not in out:                                     # sync-free pyramid: fixed width, one status word
+                out['rev_status'] = torch.zeros(2, dtype=torch.int32, device=dev)
+            return ops.reverse_neighbors(m, pts.shape[0], width=min(512, 2 * m.shape[1] + 16), status=out['rev_status'])
+
+        out['rev_neighbors'].append(reverse(conv_i))
+        out['rev_pools'].append(reverse(pool_i))
+        if out['rev_pools'][-1] is not None:
+            ops.remember_reverse(pool_i, out['rev_pools'][-1])              # max_pool's backward finds it by the matrix
+        if ops.is_deterministic() and want_rev and pts.is_cuda and up_i.shape[0] > 0 and up_i.shape[1] > 0:
+            # deterministic mode: the nearest-upsampling scatter of the decoder as a gather too
+            if status is None:
+                rev_up = ops.reverse_neighbors(up_i, pool_p.shape[0], first_column=True)
+            else:
+                if 'rev_status' not in out:
+                    out['rev_status'] = torch.zeros(2, dtype=torch.int32, device=dev)
+                rev_up = ops.reverse_neighbors(up_i, pool_p.shape[0], width=64, status=out['rev_status'], first_column=True)
+            ops.remember_reverse(up_i, rev_up, first_column=True)
+            out.setdefault('rev_ups', {})[layer] = rev_up
         out['points'].append(pts)
         out['neighbors'].append(conv_i)
         out['pools'].append(pool_i)
@@ -224,6 +257,10 @@ class SphereBatch:
         self.upsamples = pyramid['upsamples']
         self.lengths = pyramid['lengths']
         self.orders = pyramid.get('orders')          # work lists of the KPConv gather (None: row order)
+        self.rev_neighbors = pyramid.get('rev_neighbors')    # transposed neighbour matrices (gather-form feature gradient)
+        self.rev_pools = pyramid.get('rev_pools')
+        self.rev_status = pyramid.get('rev_status')      # sync-free pyramids: ops.check_reverse_status(batch.rev_status)
+        self.rev_ups = pyramid.get('rev_ups')            # deterministic mode: {layer: transposed first column of upsamples[layer]}
         self.labels = labels
         self.features = features
         self.feature_3d = feature_3d
@@ -237,6 +274,9 @@ class SphereBatch:
             setattr(self, name, [t.to(device) for t in getattr(self, name)])
         if self.orders:
             self.orders = [None if t is None else t.to(device) for t in self.orders]
+        for name in ('rev_neighbors', 'rev_pools'):
+            if getattr(self, name):
+                setattr(self, name, [None if t is None else t.to(device) for t in getattr(self, name)])
         for name in ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images'):
             t = getattr(self, name)
             if t is not None:

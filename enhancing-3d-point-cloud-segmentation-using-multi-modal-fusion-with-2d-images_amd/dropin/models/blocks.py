@@ -133,10 +133,11 @@ class KPConv(nn.Module):
         kp = load_kernels(self.radius, self.K, dimension=self.p_dim, fixed=self.fixed_kernel_points)
         return Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)
 
-    def forward(self, q_pts, s_pts, neighb_inds, x, stats_n_valid=None, order=None):
+    def forward(self, q_pts, s_pts, neighb_inds, x, stats_n_valid=None, order=None, rev=None, rev_order=None):
         """stats_n_valid: DEVICE row count of the BatchNorm that follows this convolution (the contraction
         then delivers its statistics, ops.bn_stats_of); order: work list of the query points for the gather
-        (ops.kpconv). Neither is part of the reference signature."""
+        (ops.kpconv); rev / rev_order: the transposed neighbour matrix and the support level's work list for the
+        gather-form feature gradient (ops.reverse_neighbors). None of them is part of the reference signature."""
         if self.KP_influence not in ops.INFLUENCE:
             raise ValueError('Unknown influence function type (config.KP_influence)')
         if self.aggregation_mode not in ops.AGGREGATION:
@@ -160,7 +161,8 @@ class KPConv(nn.Module):
                 self.deformed_KP = offsets + self.kernel_points          # blocks.py:287
         y, min_d2 = ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent,
                                self.KP_influence, self.aggregation_mode, offsets, modulations,
-                               stats_n_valid=stats_n_valid, order=order)
+                               stats_n_valid=stats_n_valid, order=order, rev=None if self.deformable else rev,
+                               rev_order=rev_order)
         if self.deformable:
             self.min_d2 = min_d2                                      # blocks.py:303
         return y
@@ -304,6 +306,17 @@ def _work_order(block_name, layer_ind, batch):
     return ops.work_order_for(batch.points[l]) if _ORDER_LOOKUP else None
 
 
+def _reverse_list(block_name, layer_ind, batch):
+    """(transposed neighbour matrix, work list of the support level) of the block's convolution when the batch carries
+    them (datasets/common.py `rev_neighbors` / `rev_pools`, not reference attributes), else (None, None): the feature
+    gradient then runs as the atomic scatter."""
+    revs = getattr(batch, 'rev_pools' if 'strided' in block_name else 'rev_neighbors', None)
+    if not revs or layer_ind >= len(revs) or revs[layer_ind] is None:
+        return None, None
+    orders = getattr(batch, 'orders', None)
+    return revs[layer_ind], (orders[layer_ind] if orders and layer_ind < len(orders) else None)
+
+
 class SimpleBlock(nn.Module):
 
     def __init__(self, block_name, in_dim, out_dim, radius, layer_ind, config):
@@ -325,8 +338,10 @@ class SimpleBlock(nn.Module):
     def forward(self, x, batch):
         q_pts, s_pts, inds = _conv_inputs(self.block_name, self.layer_ind, batch)
         nv = _bn_rows(q_pts, self, self.use_bn) if _GEMM_STATS else None
+        rev, rev_order = _reverse_list(self.block_name, self.layer_ind, batch) if x.requires_grad else (None, None)
         return self.batch_norm(self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv,
-                                           order=_work_order(self.block_name, self.layer_ind, batch)), 0.1)
+                                           order=_work_order(self.block_name, self.layer_ind, batch), rev=rev,
+                                           rev_order=rev_order), 0.1)
 
 
 class ResnetBottleneckBlock(nn.Module):
@@ -373,7 +388,9 @@ class ResnetBottleneckBlock(nn.Module):
             else:
                 x = self.unary1(features)
         nv = _bn_rows(q_pts, self, self.use_bn) if _GEMM_STATS else None
-        conv = self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv, order=_work_order(self.block_name, self.layer_ind, batch))
+        rev, rev_order = _reverse_list(self.block_name, self.layer_ind, batch)
+        conv = self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv, order=_work_order(self.block_name, self.layer_ind, batch),
+                           rev=rev, rev_order=rev_order)
         self.skip_alias = None
         if 'strided' in self.block_name and _FUSE_FANOUT and features.is_cuda:
             # the block's input is also the decoder's skip tensor (architectures.py:328-329): the alias handed out here

@@ -117,6 +117,7 @@ def set_deterministic(flag, device=None):
     """Turns the ordered reductions on or off (see above). Turning them on creates the arena on `device` (default: the
     current one) at once: do it outside any graph capture."""
     _DET["on"] = bool(flag)
+    torch.backends.cudnn.deterministic = bool(flag)      # MIOpen: no split-reduction solvers in the frozen 2D encoder
     if flag:
         split_arena_prepare(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
     else:
@@ -701,11 +702,12 @@ class _KPConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation, stats_n_valid=None,
-                order=None):
+                order=None, rev=None, rev_order=None):
         K, Cin, Cout = W.shape
         deform = offsets is not None
         A, min_d2 = kpconv_gather(q, s, idx, x, kp, extent, influence, aggregation, offsets, want_min_d2=deform,
                                   order=order)
+        ctx.rev = (rev, rev_order)
         Am = A * modulations.unsqueeze(2) if modulations is not None else A     # blocks.py:366-367
         if _PROF["on"]:
             e0, e1 = _timing_events()
@@ -744,7 +746,16 @@ class _KPConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[5]:
             dW = _dw_gemm(Am.view(Nq, K * Cin), gy, target=W).view(K, Cin, Cout)
         need_dA = ctx.needs_input_grad[3] or (offsets is not None)
-        if need_dA:
+        rev, rev_order = ctx.rev
+        if (need_dA and rev is not None and offsets is None and modulations is None and REVERSE_DX
+                and Cout >= 32 and (Cout & (Cout - 1)) == 0 and rev.shape[0] >= s.shape[0]):
+            # gather form (csrc/revlist.hip): the forward kernel over the transposed neighbourhood relation with the
+            # kernel points negated, then the per-kernel-point transposed contraction -- no atomics, fixed summation order
+            if rev.shape[0] != s.shape[0]:
+                rev = rev[:s.shape[0]]
+            A2, _ = kpconv_gather(s, q, rev, gy, _neg_kernel_points(kp), extent, influence, aggregation, order=rev_order)
+            dx = kp_transposed_contraction(A2, W)
+        elif need_dA:
             dAm = gemm(gy, W.reshape(K * Cin, Cout), transB=True).view(Nq, K, Cin)
             if modulations is not None:
                 if ctx.needs_input_grad[7]:
@@ -755,7 +766,7 @@ class _KPConvFn(torch.autograd.Function):
             dx, d_off = kpconv_scatter(q, s, idx, dA, kp, extent, influence, aggregation, x=x,
                                        offsets=offsets,
                                        g_min_d2=g_min_d2 if offsets is not None else None, min_arg=ctx.min_arg)
-        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None, None
+        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None, None, None, None
 
 
 _LAST_STATS_ROWS = [0]       # rows per block of the statistics partials the last KPConv forward produced
@@ -806,7 +817,7 @@ class _KPConv16Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation, stats_n_valid=None,
-                order=None):          # (the fp16 gather entry points take no work list)
+                order=None, rev=None, rev_order=None):          # (the fp16 gather entry points take no work list / reverse list)
         K, Cin, Cout = W.shape
         Kd = K * Cin
         x16 = x.to(torch.float16)
@@ -886,7 +897,7 @@ class _KPConv16Fn(torch.autograd.Function):
             dx, d_off = kpconv_scatter(q, s, idx, dA, kp, extent, influence, aggregation,
                                        x=x16.float() if offsets is not None else None, offsets=offsets,
                                        g_min_d2=g_min_d2 if offsets is not None else None, min_arg=ctx.min_arg)
-        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None, None
+        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None, None, None, None
 
 
 _STREAM16 = os.environ.get("MVK_GEMM16_STREAM", "1") == "1"      # development switch: 0 = the LDS-staged fp16 kernel everywhere
@@ -909,19 +920,24 @@ def bn_stats_of(t):
 
 
 def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", offsets=None, modulations=None,
-           feature_dtype=None, stats_n_valid=None, order=None):
+           feature_dtype=None, stats_n_valid=None, order=None, rev=None, rev_order=None):
     """Returns (y [Nq,Cout], min_d2 [Nq,K] or None). feature_dtype: None = the mode set by
     set_feature_dtype(). stats_n_valid (DEVICE int32 [1]): the contraction also produces the column statistics
     of y over its first n_valid rows for the BatchNorm that follows (picked up by bn_lrelu via bn_stats_of).
     order (int32 [Nq], a permutation, e.g. neighbors_cell_order of the query level): the order the f32 gather works
-    through the query points in (kpconv_gather); the layer's result does not depend on it."""
+    through the query points in (kpconv_gather); the layer's result does not depend on it.
+    rev (int32 [Ns, Hr], reverse_neighbors(idx, Ns)) and rev_order (a work list of the SUPPORT level): rigid f32 layers
+    with a power-of-two Cout >= 32 then compute the feature gradient as a gather over the transposed relation (fixed
+    summation order, no atomics) instead of the atomic scatter."""
+    if rev is not None and (rev.dtype != torch.int32 or rev.dim() != 2 or not rev.is_contiguous()):
+        raise RuntimeError("kpconv: rev must be a contiguous int32 [Ns, Hr] matrix (ops.reverse_neighbors)")
     if influence not in INFLUENCE:
         raise ValueError("Unknown influence function type (config.KP_influence)")
     if aggregation not in AGGREGATION:
         raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
     fn = _KPConv16Fn if (feature_dtype or _FEATURE_DTYPE["dtype"]) == torch.float16 else _KPConvFn
     y, min_d2, part = fn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation,
-                               stats_n_valid, order)
+                               stats_n_valid, order, rev, rev_order)
     if part is not None:        # rows per statistics block of the launch that just ran (set by the node's forward)
         rows = _LAST_STATS_ROWS[0]
         y._mvk_bn_stats = (part, rows)
@@ -1367,6 +1383,18 @@ class _MaxPoolFn(torch.autograd.Function):
         if g is None:
             return g_alias, None, None
         g = _f32c(g)
+        if is_deterministic():
+            rev = reverse_for(inds)
+            if rev is not None and rev.shape[0] >= ctx.ns:
+                base = g_alias if (g_alias is not None and g_alias.shape == (ctx.ns, ctx.c)) else None
+                dx = torch.empty((ctx.ns, ctx.c), device=g.device, dtype=torch.float32)
+                check(lib().mvk_max_pool_bwd_gather(_p(g), _p(arg), _p(inds), int(inds.dtype == torch.int64), inds.shape[1],
+                                                    inds.shape[0], _p(rev), rev.shape[1], ctx.ns, ctx.c,
+                                                    _p(_f32c(base)) if base is not None else None, _p(dx), _stream()))
+                if g_alias is not None and base is None:
+                    dx = dx + g_alias
+                return dx, None, None
+            _no_reverse_list("a max_pool matrix")
         if (g_alias is not None and g_alias.dtype == torch.float32 and g_alias.is_contiguous()
                 and g_alias.shape == (ctx.ns, ctx.c) and _accumulate_in_place_ok(g_alias)):
             dx = g_alias            # this node's own grad input, not an operand of a pending product
@@ -1399,6 +1427,11 @@ class _GatherRowsFn(torch.autograd.Function):
         # a column slice of a wider gradient (one half of the decoder's concatenation) is read in place
         if not (g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1 and g.stride(0) >= g.shape[1]):
             g = _f32c(g)
+        if is_deterministic():
+            rev = reverse_for(inds2d, first_column=True)
+            if rev is not None and rev.shape[0] >= ctx.ns:
+                return gather_sum_rows(g, rev[:ctx.ns]), None
+            _no_reverse_list("a closest_pool / upsampling matrix")
         dx = _zeros((ctx.ns, g.shape[1]), g.device)
         check(lib().mvk_gather_rows_bwd_ld(_p(g), g.stride(0), _p(inds2d), int(inds2d.dtype == torch.int64),
                                            inds2d.shape[0], ctx.stride, ctx.ns, g.shape[1], _p(dx), _stream()))
@@ -1431,6 +1464,12 @@ class _UpsampleCatFn(torch.autograd.Function):
         (inds2d,) = ctx.saved_tensors
         g = _f32c(g)
         c2 = g.shape[1] - ctx.c1
+        if is_deterministic():
+            rev = reverse_for(inds2d, first_column=True)
+            if rev is not None and rev.shape[0] >= ctx.ns:
+                dx = gather_sum_rows(g[:, :ctx.c1], rev[:ctx.ns]) if ctx.needs_input_grad[0] else None
+                return dx, None, (g[:, ctx.c1:].contiguous() if ctx.needs_input_grad[2] else None)
+            _no_reverse_list("a closest_pool / upsampling matrix")
         dx = _zeros((ctx.ns, ctx.c1), g.device) if ctx.needs_input_grad[0] else None
         # the skip half leaves as a dense tensor of its own (same launch): the encoder block that produced the skip
         # features accumulates its own gradient onto it (max_pool / linear passthrough) instead of a separate add
@@ -1477,6 +1516,16 @@ class _UpsampleCatLinearFn(torch.autograd.Function):
         g = _f32c(g)
         M, N, Kd = cat.shape[0], C1 + C2, W.shape[0]
         split_arena_prepare(g.device)
+        if is_deterministic() and M > 0:
+            rev = reverse_for(inds2d, first_column=True)
+            if rev is not None and rev.shape[0] >= ns:
+                # (sum of the gradient rows of every coarse point's fine points) . W[:, :C1]: the scatter as a gather, then
+                # the two halves of g W as two products -- fixed summation order throughout
+                dx = gemm_ldb(gather_sum_rows(g, rev[:ns]), W, 0, C1, N) if ctx.needs_input_grad[0] else None
+                d_skip = gemm_ldb(g, W, C1, C2, N) if ctx.needs_input_grad[2] else None
+                dW = _dw_gemm(g, cat, target=W) if ctx.needs_input_grad[3] else None
+                return dx, None, d_skip, dW, None
+            _no_reverse_list("a closest_pool / upsampling matrix")
         dx = _zeros((ns, C1), g.device)
         split = gemm_plan(M, N, Kd, None, False)[0] if M > 0 else 1
         d_skip = _split_out((M, C2), g.device, split)
@@ -1676,6 +1725,168 @@ def neighbors_cell_order(Nq, Ns, B, out=None, s_lens_dev=None, device=None):
     ws = _workspace("nb", lib().mvk_radius_neighbors_workspace(Nq, Ns, B), dev)
     check(lib().mvk_neighbors_cell_order(Ns, B, _p(s_lens_dev), _p(out), out.shape[0], _p(ws), ws.numel(), _stream()))
     return out
+
+
+_REV_COUNTS = {}      # device index -> persistent zero int32 buffer of mvk_reverse_neighbors (self-cleaning)
+REVERSE_DX = os.environ.get("MVK_REVERSE_DX", "1") == "1"      # development switch: 0 = the scatter backward everywhere
+
+
+def _rev_counts(n, device):
+    # one buffer per device: reverse lists are built by ONE stream at a time (the input side of a step); two builds
+    # running concurrently on different streams would share the counters
+    key = device.index
+    buf = _REV_COUNTS.get(key)
+    if buf is None or buf.numel() < n:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ops.reverse_neighbors: the counter buffer of this device does not exist yet (or is too "
+                               "small) and cannot be created inside a graph capture; build one batch eagerly first")
+        buf = torch.zeros(max(int(n), 1 << 16), dtype=torch.int32, device=device)
+        _REV_COUNTS[key] = buf
+    return buf
+
+
+def reverse_neighbors(idx, Ns, width=None, out=None, status=None, shadow=None, sort=None, first_column=False):
+    """The transposed neighbourhood relation of idx [Nq, H] (int32 / int64, entries outside [0, Ns) = shadow): rev
+    [Ns, width] int32, row j = the rows n of idx that contain j, padded with `shadow` (default Nq)
+    (mvk_reverse_neighbors). It turns the feature gradient of a rigid KPConv into a gather (kpconv(..., rev=...)).
+    sort: rows ascending (what run-to-run identical sums need; default: in deterministic mode) or in order of arrival
+    (saves the ranking pass). first_column: the relation of idx[:, 0] alone (nearest upsampling).
+    width None: the exact longest row (one read-back: eager use); with a width, `status` (int32 [2] HBM) accumulates
+    [longest row, overflow] without any synchronisation -- check it with check_reverse_status. out: write into this
+    int32 [>= Ns, width] matrix instead of allocating (capacity-padded batches)."""
+    _dev(idx, out, status)
+    idx, i64 = _idx(idx)
+    Nq, H = idx.shape[0], idx.shape[1] if idx.dim() == 2 else 0
+    stride = H
+    if first_column:
+        H = min(H, 1)
+    Ns = int(Ns)
+    shadow = Nq if shadow is None else int(shadow)
+    dev = idx.device
+    counts = _rev_counts(Ns, dev)
+    do_sort = int(is_deterministic() if sort is None else bool(sort))
+
+    def run(dst, w, st):
+        check(lib().mvk_reverse_neighbors(_p(idx), i64, Nq, H, max(stride, H), Ns, _p(dst), int(w), shadow, do_sort,
+                                          _p(counts), _p(st), _stream()))
+
+    if out is not None:
+        if out.dtype != torch.int32 or not out.is_contiguous() or out.dim() != 2 or out.shape[0] < Ns:
+            raise RuntimeError("reverse_neighbors: out must be a contiguous int32 [>= Ns, width] matrix")
+        run(out, out.shape[1], status)
+        return out
+    if width is not None:
+        rev = torch.empty((Ns, max(int(width), 1)), device=dev, dtype=torch.int32)
+        run(rev, rev.shape[1], status)
+        return rev
+    st = torch.zeros(2, dtype=torch.int32, device=dev)
+    w = max(8, min(512, 2 * H + 8))
+    rev = torch.empty((Ns, w), device=dev, dtype=torch.int32)
+    run(rev, w, st)
+    longest, ovf = (int(v) for v in st.cpu())
+    if ovf:
+        if longest > 512:
+            raise RuntimeError("reverse_neighbors: a support has %d reverse neighbours (> 512)" % longest)
+        rev = torch.empty((Ns, longest), device=dev, dtype=torch.int32)
+        run(rev, longest, None)
+        return rev
+    return rev[:, :max(longest, 1)].contiguous()
+
+
+# reverse lists of pooling / upsampling matrices, found again by the matrix itself (the blocks hand max_pool and
+# closest_pool nothing but `batch.pools[l]` / `batch.upsamples[l]`): deterministic mode's gather-form backwards
+_REVERSES = collections.OrderedDict()
+_REVERSES_KEPT = 256
+
+
+def _rev_key(inds, first):
+    return (inds.device.index, inds.data_ptr(), tuple(inds.shape), inds.dtype, bool(first))
+
+
+def remember_reverse(inds, rev, first_column=False):
+    """Registers rev = reverse_neighbors(inds, ...) (first_column: of inds[:, 0]) under the index matrix itself."""
+    key = _rev_key(inds, first_column)
+    _REVERSES[key] = rev
+    _REVERSES.move_to_end(key)
+    while len(_REVERSES) > _REVERSES_KEPT:
+        _REVERSES.popitem(last=False)
+
+
+def reverse_for(inds, first_column=False):
+    return _REVERSES.get(_rev_key(inds, first_column)) if inds.is_cuda else None
+
+
+_DET_WARNED = set()
+
+
+def _no_reverse_list(what):
+    """Deterministic mode met a scatter without a reverse list (a deformable block's pooling, a batch that was moved
+    or rebuilt outside datasets.common): the atomic path runs, the result is correct but not bit-reproducible."""
+    if what not in _DET_WARNED:
+        _DET_WARNED.add(what)
+        import warnings
+        warnings.warn("deterministic mode: no reverse list for %s; its backward uses float atomics (not bit-reproducible)" % what)
+
+
+def gather_sum_rows(g, rev, base=None):
+    """out[j] = (base[j] or 0) + sum of g[n] over the entries n of rev[j] (mvk_gather_sum_rows); g [Nq, C] may be a column
+    block of a wider tensor (row stride >= C)."""
+    _dev(g, rev, base)
+    if not (g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1 and g.stride(0) >= g.shape[1]):
+        g = _f32c(g)
+    Ns, Hr = rev.shape
+    out = torch.empty((Ns, g.shape[1]), device=g.device, dtype=torch.float32)
+    if base is not None:
+        base = _f32c(base)
+    check(lib().mvk_gather_sum_rows(_p(g), g.stride(0), g.shape[0], _p(rev), Hr, Ns, g.shape[1], _p(base), _p(out), _stream()))
+    return out
+
+
+def gemm_ldb(A, B_base, col0, N, ldb):
+    """A [M,Kd] @ B[:, col0:col0+N] for a row-major B [Kd, ldb] read in place (mvk_gemm_f32_ldb)."""
+    _dev(A, B_base)
+    A, B_base = _f32c(A), _f32c(B_base)
+    M, Kd = A.shape
+    split_arena_prepare(A.device)
+    out = _split_out((M, N), A.device, gemm_plan(M, N, Kd)[0] if M > 0 and N > 0 else 1)
+    if M > 0 and N > 0:
+        check(lib().mvk_gemm_f32_ldb(_p(A), C.c_void_p(B_base.data_ptr() + 4 * int(col0)), _p(out), M, int(N), Kd, int(ldb),
+                                     _stream()))
+    return out
+
+
+def check_reverse_status(status):
+    """Reads a reverse-list status word back (synchronises): raises when a row did not fit its width."""
+    longest, ovf = (int(v) for v in status.cpu())
+    if ovf:
+        raise RuntimeError("reverse neighbours: a support row has %d entries, more than the width it was built with"
+                           % longest)
+    return longest
+
+
+def _neg_kernel_points(kp):
+    """-kp, cached on the tensor (kernel points are frozen parameters; the cache follows in-place updates)."""
+    c = getattr(kp, "_mvk_neg", None)
+    if c is None or c[0] != kp._version:
+        c = (kp._version, (-kp.detach()).contiguous())
+        kp._mvk_neg = c
+    return c[1]
+
+
+def kp_transposed_contraction(A2, W):
+    """dx [M, Cin] = sum_k A2[:, k, :] . W[k]^T for A2 [M, K, Cout], W [K, Cin, Cout] (mvk_gemm_f32_kp_transposed)."""
+    _dev(A2, W)
+    A2, W = _f32c(A2), _f32c(W)
+    M, K, Cout = A2.shape
+    Cin = W.shape[1]
+    if W.shape[0] != K or W.shape[2] != Cout:
+        raise RuntimeError("kp_transposed_contraction: A2 [M,K,Cout] and W [K,Cin,Cout] expected")
+    split_arena_prepare(A2.device)
+    split = gemm_plan(M, Cin, K * Cout)[0] if M > 0 else 1
+    dx = _split_out((M, Cin), A2.device, split)
+    if M > 0:
+        check(lib().mvk_gemm_f32_kp_transposed(_p(A2), _p(W), _p(dx), M, K, Cin, Cout, _stream()))
+    return dx
 
 
 _WORK_ORDERS = collections.OrderedDict()      # (device index, address, rows) of a points tensor -> its work list

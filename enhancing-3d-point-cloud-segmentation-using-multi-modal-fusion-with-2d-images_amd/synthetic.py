@@ -307,6 +307,30 @@ class StaticBatch:
         self._iota = [torch.arange(caps[l], dtype=torch.int32, device=dev) for l in range(L)]
         has = getattr(batch, 'orders', None)
         self.orders = [self._iota[l].clone() if (has and has[l] is not None) else None for l in range(L)] if has else None
+        # transposed neighbour matrices of the rigid layers (datasets/common.py `rev_neighbors` / `rev_pools`): capacity
+        # rows, width = the first batch's longest row + a third (rows longer than that raise the chain's overflow word)
+        def rev_static(name, shadow_of):
+            src = getattr(batch, name, None)
+            if not src:
+                return None
+            mats = []
+            for l in range(L):
+                if l >= len(src) or src[l] is None:
+                    mats.append(None)
+                    continue
+                w = min(512, -(-int(src[l].shape[1] * 1.35 + 8) // 8) * 8)
+                mats.append(torch.full((caps[l], w), caps[shadow_of(l)], dtype=torch.int32, device=dev))
+            return mats
+        self.rev_neighbors = rev_static('rev_neighbors', lambda l: l)
+        self.rev_pools = rev_static('rev_pools', lambda l: min(l + 1, L - 1))
+        # the blocks' max_pool / closest_pool find their reverse lists by the index matrix itself (ops.remember_reverse)
+        for l in range(L):
+            if self.rev_pools and self.rev_pools[l] is not None:
+                ops.remember_reverse(self.pools[l], self.rev_pools[l])
+        self.rev_ups = {}
+        for l, src in (getattr(batch, 'rev_ups', None) or {}).items():        # deterministic mode only
+            self.rev_ups[l] = torch.full((caps[l + 1], 64), caps[l], dtype=torch.int32, device=dev)
+            ops.remember_reverse(self.upsamples[l], self.rev_ups[l], first_column=True)
         self.valid = {caps[l]: torch.zeros(1, dtype=torch.int32, device=dev) for l in range(L)}
         self._counts = [self.valid[caps[l]] for l in range(L)]
         for name in self._DENSE:
@@ -338,6 +362,17 @@ class StaticBatch:
             if l + 1 < L:
                 self._put(self.pools[l], batch.pools[l], n[l], self.caps[l])
                 self._put(self.upsamples[l], batch.upsamples[l], n[l + 1], self.caps[l + 1])
+            for dst, src, ql in ((self.rev_neighbors, getattr(batch, 'rev_neighbors', None), l),
+                                 (self.rev_pools, getattr(batch, 'rev_pools', None), min(l + 1, L - 1))):
+                if dst and dst[l] is not None:
+                    if not src or src[l] is None:
+                        raise RuntimeError("batch carries no reverse neighbour list for layer %d" % l)
+                    self._put(dst[l], src[l], n[ql], self.caps[ql])
+            if l in self.rev_ups:
+                src = (getattr(batch, 'rev_ups', None) or {}).get(l)
+                if src is None:
+                    raise RuntimeError("batch carries no reverse upsampling list for layer %d" % l)
+                self._put(self.rev_ups[l], src, n[l], self.caps[l])
         for name in self._DENSE:
             v = getattr(batch, name, None)
             if v is not None:
@@ -374,7 +409,9 @@ class DeviceInputChain:
                     [torch.zeros(self.B, dtype=torch.int32, device=dev) for _ in range(L - 1)]
         self.rot = torch.zeros((max(L - 1, 1), self.B, 3, 3), dtype=torch.float32, device=dev)
         self.rot_host = torch.zeros((max(L - 1, 1), self.B, 3, 3), dtype=torch.float32).pin_memory()
-        self.status = torch.zeros(2, dtype=torch.int32, device=dev)
+        self.status4 = torch.zeros(4, dtype=torch.int32, device=dev)      # [max neighbours, overflow | longest reverse row, overflow]
+        self.status = self.status4[:2]
+        self.rev_status = self.status4[2:]
         self.limits = [int(x) for x in limits]
         if static.neighbors[0].dtype != torch.int32:
             raise RuntimeError("DeviceInputChain writes int32 neighbour matrices")
@@ -416,11 +453,20 @@ class DeviceInputChain:
                 search(l, l, e['conv_r'], static.neighbors[l], l)
                 if static.orders and static.orders[l] is not None:     # the workspace holds this search's grid
                     ops.neighbors_cell_order(caps[l], caps[l], self.B, static.orders[l], self.lens[l])
+                if static.rev_neighbors and static.rev_neighbors[l] is not None:
+                    ops.reverse_neighbors(static.neighbors[l], caps[l], out=static.rev_neighbors[l], status=self.rev_status,
+                                          shadow=caps[l])
             if e['pool'] and l + 1 < L:
                 ops.grid_subsample_dev(static.points[l], self.lens[l], e['dl'], static.points[l + 1], self.lens[l + 1],
                                        self.status, rotations_dev=self.rot[l], total_out=static._counts[l + 1])
                 search(l + 1, l, e['pool_r'], static.pools[l], l)
+                if static.rev_pools and static.rev_pools[l] is not None:
+                    ops.reverse_neighbors(static.pools[l], caps[l], out=static.rev_pools[l], status=self.rev_status,
+                                          shadow=caps[l + 1])
                 search(l, l + 1, e['up_r'], static.upsamples[l], l + 1)
+                if l in static.rev_ups:
+                    ops.reverse_neighbors(static.upsamples[l], caps[l + 1], out=static.rev_ups[l], status=self.rev_status,
+                                          shadow=caps[l], first_column=True)
         torch.cat(st['labels'], 0, out=static.labels)
         ones = torch.ones_like(stacked_world[:, :1])
         z = stacked_world[:, 2:3]

@@ -140,6 +140,38 @@ int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t
 int mvk_gemm_split_arena(void* ws, int64_t ws_bytes, void* counters, int64_t n_counters);
 int mvk_gemm_split_ordered(void);
 
+/* Gather form of KPConv's feature gradient (round 4). The reference's backward of `gather` (models/blocks.py:52-64, used
+ * at :360) is an index-add dx[idx[n,h]] += sum_k w[n,h,k] dA[n,k,:]; mvk_kpconv_scatter_bwd runs it with float atomics
+ * (sums in order of arrival). With the TRANSPOSED neighbourhood relation the same sums are a gather:
+ *   dx[j, :] = sum_k ( sum_{n in rev[j]} w_k(q_n - s_j) g[n, :] ) . W[k]^T
+ * = mvk_kpconv_gather_fwd over (queries = the layer's supports, supports = its queries, idx = rev, features = g,
+ * kernel points NEGATED) followed by mvk_gemm_f32_kp_transposed -- fixed summation order, no atomics.
+ *
+ * mvk_reverse_neighbors: rev [Ns, Hr] int32 <- idx [Nq, H] (int32 / int64; entries outside [0, Ns) are shadow entries):
+ *   row j = the rows n of idx that contain j (ascending with sort != 0), padded with `shadow` (normally Nq). counts [Ns] int32: ZERO on
+ *   entry, zero again afterwards (keep one persistent buffer). status (int32 [2] or NULL): [0] = running maximum of the
+ *   row lengths, [1] |= 1 when a row is longer than Hr (entries dropped: treat as an error). Hr <= 512. Two launches.
+ * mvk_gemm_f32_kp_transposed: dx [M, Cin] = sum_k A[:, k, :] . W[k]^T, A [M, K, Cout], W [K, Cin, Cout] (the layer's
+ *   weights, read in place), Cout a power of two >= 32. */
+int mvk_reverse_neighbors(const void* idx, int idx64, int64_t Nq, int H, int64_t idx_stride, int64_t Ns, int32_t* rev, int Hr,
+                          int32_t shadow, int sort, int32_t* counts, int32_t* status, void* stream);
+int mvk_gemm_f32_kp_transposed(const float* A, const float* W, float* dx, int64_t M, int K, int Cin, int Cout, void* stream);
+
+/* The other scatter backwards of the network as gathers over a reverse list (deterministic mode; every output element is
+ * written, `base` [Ns, C] or NULL is added): mvk_gather_sum_rows -- out[j, :] = base[j, :] + sum_{n in rev[j]} g[n, 0:C]
+ * (g rows ldg floats apart): backward of closest_pool / nearest upsampling (models/blocks.py:79-91), rev = the transposed
+ * FIRST column of the upsampling matrix (mvk_reverse_neighbors with H = 1, idx_stride = its width);
+ * mvk_max_pool_bwd_gather -- backward of max_pool (blocks.py:94-110) over the transposed pooling matrix, arg [Nq, C] the
+ * winning columns recorded by mvk_max_pool_fwd. mvk_gemm_f32_ldb: C [M,N] = A [M,Kd] . B where B is a column block of a
+ * wider row-major matrix (rows ldb floats apart) -- the two halves of the decoder's concatenated gradient as two
+ * products. (In mvk_reverse_neighbors: idx row n starts at idx + n * idx_stride; sort != 0: rows ascending -- what a
+ * fixed summation order needs --, 0: in order of arrival, which saves the ranking pass.) */
+int mvk_gather_sum_rows(const float* g, int64_t ldg, int64_t Nq, const int32_t* rev, int Hr, int64_t Ns, int C,
+                        const float* base, float* out, void* stream);
+int mvk_max_pool_bwd_gather(const float* g, const int32_t* arg, const void* idx, int idx64, int H, int64_t Nq,
+                            const int32_t* rev, int Hr, int64_t Ns, int C, const float* base, float* dx, void* stream);
+int mvk_gemm_f32_ldb(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int64_t ldb, void* stream);
+
 /* C [M,N] = LeakyReLU_slope(A . op(B) + bias[col]) (slope = 1: the bias alone; A [M,Kd] row-major): a BatchNorm-less
  * layer -- `x W^T + self.bias` (blocks.py:462-463) and the block's activation, the two head layers of every network -- in
  * one launch. The reduction is not split. */

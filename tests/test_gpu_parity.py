@@ -934,6 +934,115 @@ def _weight_gradients_reproducible(ops):
         assert torch.equal(runs[1][i], runs[2][i]), i          # grouped twice
 
 
+@pytest.mark.parametrize("Nq,Ns,H,idt", [(3000, 3000, 40, torch.int32), (700, 2900, 33, torch.int64), (19464, 19464, 58, torch.int32),
+                                         (50, 4000, 300, torch.int32)])
+def test_reverse_neighbors_is_the_sorted_transposed_relation(ops, Nq, Ns, H, idt):
+    """mvk_reverse_neighbors: row j of the result = the rows n of idx that contain j, ascending, padded with the shadow
+    value -- against a NumPy transposition; the persistent counters are back at zero; a width that is too small raises the
+    overflow word instead of passing silently; the sync-free form writes into a given matrix."""
+    rng = np.random.default_rng(Nq + H)
+    idx = np.stack([rng.choice(Ns + Ns // 3, size=H, replace=False) for _ in range(Nq)]).astype(np.int64)
+    idx[idx >= Ns] = Ns                                  # a third of the entries are shadow entries
+    idx[7] = Ns                                          # an all-shadow row
+    want = [[] for _ in range(Ns)]
+    for n in range(Nq):
+        for j in idx[n]:
+            if j < Ns:
+                want[j].append(n)
+    longest = max(len(r) for r in want)
+    rev = ops.reverse_neighbors(T(idx).to(idt), Ns, sort=True)
+    assert rev.dtype == torch.int32 and rev.shape == (Ns, max(longest, 1))
+    unsorted = ops.reverse_neighbors(T(idx).to(idt), Ns, sort=False).cpu().numpy()        # order of arrival: same sets
+    for j in range(0, Ns, max(1, Ns // 200)):
+        assert sorted(unsorted[j, :len(want[j])]) == want[j] and (unsorted[j, len(want[j]):] == Nq).all(), j
+    first = ops.reverse_neighbors(T(idx).to(idt), Ns, sort=True, first_column=True).cpu().numpy()   # idx[:, 0] alone
+    col0 = idx[:, 0]
+    for j in range(0, Ns, max(1, Ns // 200)):
+        w = [n for n in np.nonzero(col0 == j)[0]]
+        assert list(first[j, :len(w)]) == w and (first[j, len(w):] == Nq).all(), j
+    got = rev.cpu().numpy()
+    for j in range(0, Ns, max(1, Ns // 500)):
+        assert list(got[j, :len(want[j])]) == want[j] and (got[j, len(want[j]):] == Nq).all(), j
+    assert int(ops._rev_counts(Ns, torch.device("cuda:0"))[:Ns].abs().sum()) == 0
+    # fixed width + status word, another shadow value, into a wider capacity matrix
+    out = torch.full((Ns + 64, longest + 5), -7, dtype=torch.int32, device="cuda")
+    st = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ops.reverse_neighbors(T(idx).to(idt), Ns, out=out, status=st, shadow=123456, sort=True)
+    assert ops.check_reverse_status(st) == longest
+    o = out.cpu().numpy()
+    assert (o[Ns:] == -7).all()
+    for j in range(0, Ns, max(1, Ns // 300)):
+        assert list(o[j, :len(want[j])]) == want[j] and (o[j, len(want[j]):] == 123456).all(), j
+    if longest > 2:
+        st.zero_()
+        ops.reverse_neighbors(T(idx).to(idt), Ns, width=longest - 1, status=st)
+        with pytest.raises(RuntimeError, match="reverse neighbours"):
+            ops.check_reverse_status(st)
+        assert int(ops._rev_counts(Ns, torch.device("cuda:0"))[:Ns].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,K,Cin,Cout", [(19464, 15, 32, 32), (1300, 15, 128, 128), (85, 15, 512, 512), (700, 15, 66, 64), (33, 3, 5, 32)])
+def test_kp_transposed_contraction_vs_float64(ops, M, K, Cin, Cout):
+    """mvk_gemm_f32_kp_transposed: dx = sum_k A[:, k, :] . W[k]^T with the KPConv weights read in place (segmented B)."""
+    torch.manual_seed(M)
+    A = torch.randn(M, K, Cout, device="cuda")
+    W = torch.randn(K, Cin, Cout, device="cuda") * 0.1
+    want = torch.einsum("mko,kco->mc", A.double(), W.double()).cpu().numpy()
+    assert rel_err(ops.kp_transposed_contraction(A, W).cpu().numpy(), want) < 1e-5
+
+
+@pytest.mark.parametrize("Nq,Ns,H,C,strided", [(2500, 2500, 30, 32, False), (600, 2500, 28, 64, True), (19464, 19464, 45, 32, False),
+                                               (90, 350, 20, 256, True)])
+def test_kpconv_gather_form_feature_gradient(ops, Nq, Ns, H, C, strided):
+    """The feature gradient of a rigid KPConv as a GATHER over the transposed neighbourhood relation (kpconv(..., rev=)):
+    equal to the atomic scatter (same sums, another order: 1e-5) and to the float64 NumPy restatement (1e-4), and the
+    same bits on every run; the weight gradient and the output are untouched."""
+    from oracle import npref
+    rng = np.random.default_rng(Nq + C)
+    s = (rng.random((Ns, 3)) * 0.5).astype(np.float32)
+    q = s.copy() if not strided else s[rng.choice(Ns, Nq, replace=False)] + rng.normal(0, 0.01, (Nq, 3)).astype(np.float32)
+    d2 = ((q[:, None, :] - s[None, :, :]) ** 2).sum(-1) if Nq * Ns < 4e7 else None
+    if d2 is not None:
+        idx = np.argsort(d2, axis=1)[:, :H].astype(np.int32)
+        idx[np.take_along_axis(d2, idx.astype(np.int64), 1) > 0.05 ** 2] = Ns           # radius crop -> shadow entries
+    else:
+        # (distinct entries per row, like every real neighbour matrix: a start plus increasing steps, modulo the range)
+        idx = ((rng.integers(0, Ns + Ns // 4, (Nq, 1)) + np.cumsum(rng.integers(1, 7, (Nq, H)), 1)) % (Ns + Ns // 4)).astype(np.int32)
+        idx[idx >= Ns] = Ns
+    K = 15
+    kp = (rng.normal(size=(K, 3)) * 0.02).astype(np.float32)
+    x = rng.normal(size=(Ns, C)).astype(np.float32)
+    W = (rng.normal(size=(K, C, C)) * 0.05).astype(np.float32)
+    g = rng.normal(size=(Nq, C)).astype(np.float32)
+    ops.set_deterministic(True)
+    try:
+        _gather_form_gradient(ops, q, s, idx, x, W, g, kp, Nq, Ns, H, C)
+    finally:
+        ops.set_deterministic(False)
+
+
+def _gather_form_gradient(ops, q, s, idx, x, W, g, kp, Nq, Ns, H, C):
+    from oracle import npref
+    rev = ops.reverse_neighbors(T(idx), Ns)
+    order = torch.randperm(Ns, device="cuda").to(torch.int32)
+    res = []
+    for use_rev in (False, True, True):
+        xt, Wt = T(x).requires_grad_(True), T(W).requires_grad_(True)
+        y, _ = ops.kpconv(T(q), T(s), T(idx), xt, T(kp), Wt, 0.03, rev=rev if use_rev else None,
+                          rev_order=order if use_rev else None)
+        (y * T(g)).sum().backward()
+        res.append((y.detach(), xt.grad.clone(), Wt.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0])
+    check_err("gather-form dx vs atomic scatter (Nq %d, C %d)" % (Nq, C), rel_err(res[1][1].cpu().numpy(), res[0][1].cpu().numpy()), 1e-5)
+    assert torch.equal(res[1][1], res[2][1]), "gather-form dx differs between two runs"
+    if Nq * H * C < 3e7:
+        a64 = [q.astype(np.float64), s.astype(np.float64), idx.astype(np.int64), x.astype(np.float64), kp.astype(np.float64),
+               W.astype(np.float64), 0.03]
+        dx, dW = npref.kpconv_backward(*a64, g.astype(np.float64))
+        check_err("gather-form dx vs float64 oracle (Nq %d, C %d)" % (Nq, C), rel_err(res[1][1].cpu().numpy(), dx), FP_TOL)
+        assert rel_err(res[1][2].cpu().numpy(), dW) < FP_TOL
+
+
 def test_deferred_weight_gradients_run_as_one_grouped_launch(ops):
     """ops.defer_weight_grads(): the dW products recorded during a backward pass (TN, wide and narrow outputs, ragged
     sizes, split and unsplit reductions) come out of the grouped launch equal to the individual products; under

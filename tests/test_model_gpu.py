@@ -188,6 +188,63 @@ def test_network_without_batch_norm_deferred_weight_gradients_equal_inline_ones(
     check_err("no-BN network: 1 - cosine of the whole (deferred) gradient vs CPU port", 1.0 - (A @ B).item() / (A.norm().item() * B.norm().item()), 5e-4)
 
 
+@pytest.mark.parametrize("variant,spheres", [("early", 1), ("baseline", 2), ("late", 1)])
+def test_deterministic_mode_step_is_bit_reproducible(variant, spheres):
+    """ops.set_deterministic(True): ordered split reductions (csrc/gemm.hip), the feature gradients of the rigid
+    convolutions, of max_pool and of the nearest upsampling as gathers over sorted reverse lists (csrc/revlist.hip), the
+    bias gradients in workgroup order -- two runs of the same step on the same batch give the same BITS in the logits,
+    the loss and every parameter gradient (the reference's CPU path is deterministic; the default mode here trades that
+    for ~5 % of the step). The frozen 2D encoder's output enters as a fixed map (MIOpen is outside this
+    library); the pyramid is built once per run from the same rotations."""
+    import mvkpconv
+    syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
+    dev = torch.device("cuda:0")
+    ops.set_deterministic(True)
+    try:
+        torch.manual_seed(0)
+        np.random.seed(0)
+        cfg = syn.make_config(variant)
+        sph = [syn.raw_sphere(seed=i, radius=0.7, density=3000.0) for i in range(spheres)]
+        views = [syn.sphere_views(s, nv=3, h=60, w=80) for s in sph] if variant != "baseline" else None
+        staged = syn.stage_spheres(sph, dev, views)
+        limits = syn.calibrate_limits(cfg, staged)
+        common = mvkpconv.sub("dropin.datasets.common")
+        rots = [common.random_grid_rotations(spheres) for _ in range(4)]
+        net = syn.build_model(cfg, dev)
+        net.train()
+        if hasattr(net, "net_2d"):
+            for m in net.net_2d._modules.values():
+                m.train(False)
+        sd0 = {k: v.clone() for k, v in net.state_dict().items()}
+        fmap = torch.randn(spheres * 3, 64, 60, 80, device=dev) if variant != "baseline" else None
+
+        def run():
+            net.load_state_dict(sd0)
+            net.zero_grad(set_to_none=True)
+            batch, _ = syn.build_batch(cfg, staged, limits, torch.int32, rotations=rots)
+            assert batch.rev_neighbors[0] is not None and batch.rev_pools[0] is not None and batch.rev_ups
+            if fmap is not None:
+                batch.feature_2d = fmap
+            out = net(batch, cfg)
+            loss = net.loss(out, batch.labels)
+            with ops.defer_weight_grads():
+                loss.backward()
+            return out.detach().clone(), loss.detach().clone(), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")                      # a scatter without its reverse list would warn
+            o1, l1, g1 = run()
+            o2, l2, g2 = run()
+        assert torch.equal(o1, o2), "logits differ between two runs: %g" % (o1 - o2).abs().max().item()
+        assert torch.equal(l1, l2)
+        assert set(g1) == set(g2) and len(g1) > 50
+        bad = [n for n in g1 if not torch.equal(g1[n], g2[n])]
+        assert not bad, "gradients differ between two runs: %s" % bad[:5]
+    finally:
+        ops.set_deterministic(False)
+
+
 def test_state_dict_keys_follow_the_reference_names():
     net = _run("baseline")
     keys = set(net.state_dict().keys())

@@ -156,6 +156,8 @@ def main():
         os.environ.setdefault("MIOPEN_CUSTOM_CACHE_DIR", "/tmp/mvk_miopen_cache_rank%d" % local)
         for k in ("MIOPEN_USER_DB_PATH", "MIOPEN_CUSTOM_CACHE_DIR"):
             os.makedirs(os.environ[k], exist_ok=True)
+    if os.environ.get("MVK_MIOPEN_DETERMINISTIC") == "1":      # development: only solvers without atomic split reductions
+        torch.backends.cudnn.deterministic = True
     if os.environ.get("MVK_MIOPEN_BENCHMARK", "1") == "1":
         # MIOpen picks its fastest solver per convolution shape of the frozen 2D encoder, as the reference's own 2D
         # training scripts do (mvpnet/train_2d.py:17, train_mvpnet_3d.py:16: torch.backends.cudnn.benchmark = True);
@@ -459,6 +461,8 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             if use_chain:
                 with torch.cuda.stream(build_stream):
                     chains[1 - statics.index(static)].build(other)
+                    for _ in range(int(os.environ.get("MVK_BENCH_DUMMY_LAUNCHES", "0"))):   # development: what is one more
+                        _DUMMY.setdefault(dev, torch.zeros(64, device=dev)).add_(1.0)        # tiny launch on a side branch worth?
             if fa_ahead:        # needs both: the encoder's features and the chain's 3-NN pixels of batch k+1
                 enc_stream.wait_stream(build_stream)
                 with torch.cuda.stream(enc_stream):
@@ -542,6 +546,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         return replay, loss
 
     _SEED.setdefault(dev, torch.ones((), device=dev))      # (before the captures: see backward())
+    _DUMMY.setdefault(dev, torch.zeros(64, device=dev))
     replays = [capture(s) for s in statics]
     state = {"next": None, "k": 0, "free": [None, None]}
 
@@ -832,6 +837,7 @@ def backward_scope(ops):
 
 
 _SEED = {}
+_DUMMY = {}
 
 
 def backward(ops, loss):

@@ -117,7 +117,8 @@ def set_deterministic(flag, device=None):
     """Turns the ordered reductions on or off (see above). Turning them on creates the arena on `device` (default: the
     current one) at once: do it outside any graph capture."""
     _DET["on"] = bool(flag)
-    torch.backends.cudnn.deterministic = bool(flag)      # MIOpen: no split-reduction solvers in the frozen 2D encoder
+    # (torch.backends.cudnn.deterministic is NOT touched: on this image it drops MIOpen to naive convolution kernels, 4 ms
+    # -> 226 ms per step; the frozen 2D encoder is a library network outside this mode)
     if flag:
         split_arena_prepare(torch.device("cuda", torch.cuda.current_device()) if device is None else device)
     else:

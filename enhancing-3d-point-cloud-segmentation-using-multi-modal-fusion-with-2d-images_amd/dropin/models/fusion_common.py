@@ -40,9 +40,9 @@ def lift_2d_features(net, batch, fused=None):
     """images -> UNet features -> k nearest pixels of every point -> FeatureAggregation.
     Returns feature_2d3d (np, 64).
 
-    fused (default: one sphere per batch): FeatureAggregation.forward_fused -- a single HIP gather
-    kernel + MFMA linear layers; with several spheres the BatchNorm statistics must span all of them,
-    so the per-sphere inputs are gathered first (reference op sequence) and aggregated together."""
+    fused (default on the GPU): FeatureAggregation.forward_fused -- a single HIP gather kernel over the stacked points of
+    ALL spheres + MFMA linear layers, BatchNorm statistics over all of them like the reference; fused=False: the
+    reference's op sequence (per-sphere group_points, concatenation, the module's tensor-op forward)."""
     ahead = getattr(batch, 'feature_2d3d', None)
     if ahead is not None and getattr(net, 'fa_output_detached', False):
         # the lifted features of this batch were computed ahead of the step (bench.py: beside the previous step, like the
@@ -63,11 +63,21 @@ def lift_2d_features(net, batch, fused=None):
         return knn.long().to(feature_2d.device)
 
     if fused is None:
-        fused = b == 1
-    if fused and b == 1:
-        knn = knn_of(0)
-        knn = knn[0] if knn.dim() == 3 else knn              # (s_np, k)
-        return net.feat_aggreg.forward_fused(feature_2d, batch.image_xyz[0], knn, batch.feat_aggre_points[0])
+        fused = feature_2d.is_cuda
+    if fused:
+        # The (b*nv, c, h, w) feature map is ONE stack of views: the pixel indices of sphere i (flat over ITS nv views,
+        # ScanNet_sphere_color.py:436-451) shift by i*nv*h*w and the per-sphere group_points loop of the reference
+        # (:262-279) becomes one gather over the stacked points; BatchNorm then spans all sum(np)*k rows, as it does in
+        # the reference, where the grouped tensors are concatenated before FeatureAggregation (:278-283).
+        knn_all = getattr(batch, 'knn_stacked', None)        # built with the offsets by the input side when present
+        if knn_all is None:
+            per = []
+            for i in range(b):
+                knn = knn_of(i)
+                per.append((knn[0] if knn.dim() == 3 else knn) + i * nv * h * w)
+            knn_all = per[0] if b == 1 else torch.cat(per, dim=0)
+        return net.feat_aggreg.forward_fused(feature_2d, batch.image_xyz.reshape(b * nv, h, w, 3), knn_all,
+                                             batch.feat_aggre_points[0])
 
     feature_2d = feature_2d.reshape(b, nv, -1, h, w).transpose(1, 2).contiguous().reshape(b, -1, nv * h * w)
     image_xyz = batch.image_xyz.permute(0, 4, 1, 2, 3).reshape(b, 3, nv * h * w)

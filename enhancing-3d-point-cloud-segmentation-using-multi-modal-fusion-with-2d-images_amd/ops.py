@@ -1164,11 +1164,58 @@ class _BNLReLUFn(torch.autograd.Function):
         return dx, None, dgb[D:], dgb[:D], None, None, None, None, None, None, None, d_add, None
 
 
+# ---- synchronised BatchNorm (opt-in; SURVEY.md 8e, models/blocks.py:453-460) --------------------------------------
+# The reference normalises over the stacked point axis of the WHOLE batch. Sharding the spheres over ranks leaves every
+# rank the statistics of its own spheres (the default, a documented deviation); with set_sync_batchnorm(group) the
+# statistics of every BatchNorm -- blocks and FeatureAggregation alike -- are those of all ranks' rows: N ranks x S
+# spheres then compute what one rank x N*S spheres computes (tests/test_model_gpu.py, two ranks). Written with
+# differentiable tensor ops and torch.distributed.nn's differentiable all-reduce (two all-reduces of C floats forward,
+# their mirror images backward): an option for runs that must match a single-GPU run, not a tuned path.
+_SYNC_BN = {"group": None}
+
+
+def set_sync_batchnorm(group):
+    """group: a torch.distributed process group, True (the default group) or None (per-rank statistics: the default)."""
+    if group is True:
+        import torch.distributed as dist
+        group = dist.group.WORLD
+    _SYNC_BN["group"] = group
+
+
+def _sync_bn_lrelu(x, n_valid, bn, slope, addend):
+    import torch.distributed as dist
+    from torch.distributed.nn.functional import all_reduce
+    group = _SYNC_BN["group"]
+    if not bn.training:
+        raise RuntimeError("synchronised BatchNorm is a training-mode op; use nn.BatchNorm1d in eval mode")
+    x = _f32c(x)
+    R, D = x.shape
+    mask = (torch.arange(R, device=x.device) < n_valid.to(torch.int64)).to(x.dtype).unsqueeze(1)     # valid rows
+    n = all_reduce(n_valid.to(x.dtype).reshape(1), op=dist.ReduceOp.SUM, group=group)
+    mean = all_reduce((x * mask).sum(0), op=dist.ReduceOp.SUM, group=group) / n
+    d = (x - mean) * mask
+    var = all_reduce((d * d).sum(0), op=dist.ReduceOp.SUM, group=group) / n                          # biased, about the GLOBAL mean
+    y = d * torch.rsqrt(var + bn.eps) * bn.weight + bn.bias
+    if addend is not None:
+        y = y + addend
+    y = torch.nn.functional.leaky_relu(y, slope) if slope != 1.0 else y
+    y = y * mask
+    if bn.track_running_stats:
+        with torch.no_grad():
+            m = bn.momentum if bn.momentum is not None else 0.0
+            bn.running_mean.mul_(1 - m).add_(m * mean.detach())
+            bn.running_var.mul_(1 - m).add_(m * var.detach() * (n / (n - 1).clamp(min=1)))
+            bn.num_batches_tracked += 1
+    return y
+
+
 def bn_lrelu(x, n_valid, bn, slope=1.0, addend=None):
     """y = LeakyReLU_slope(BatchNorm1d(x[:n_valid]) [+ addend]) with rows >= n_valid zeroed; `bn` is an
     nn.BatchNorm1d whose parameters / running statistics are used and updated; n_valid is a DEVICE
     int32 tensor of one element. addend [R,D]: the shortcut of a residual block, joined before the
     activation (blocks.py:649) inside the same launch; it receives its own gradient."""
+    if _SYNC_BN["group"] is not None:
+        return _sync_bn_lrelu(x, n_valid, bn, slope, addend)
     nbt = bn.num_batches_tracked if (bn.training and bn.track_running_stats) else None   # += 1 inside the kernel
     return _BNLReLUFn.apply(x, n_valid, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps,
                             bn.momentum if bn.momentum is not None else 0.0, slope, bn.training, nbt, addend,
@@ -1241,6 +1288,8 @@ def bn_lrelu_pair(xa, bn_a, slope_a, xb, bn_b, slope_b, n_valid):
         return nbt, (bn.eps, bn.momentum if bn.momentum is not None else 0.0)
     if not (bn_a.training and bn_b.training):
         raise RuntimeError("masked BatchNorm is a training-mode op; use nn.BatchNorm1d in eval mode")
+    if _SYNC_BN["group"] is not None:
+        return _sync_bn_lrelu(xa, n_valid, bn_a, slope_a, None), _sync_bn_lrelu(xb, n_valid, bn_b, slope_b, None)
     nbt_a, (eps_a, mom_a) = unpack(bn_a)
     nbt_b, (eps_b, mom_b) = unpack(bn_b)
     return _BNLReLUPairFn.apply(xa, xb, n_valid, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var,

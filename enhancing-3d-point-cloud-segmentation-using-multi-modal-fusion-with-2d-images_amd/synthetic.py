@@ -248,6 +248,9 @@ def build_batch(config, staged, limits=None, index_dtype=torch.int32, rotations=
     batch = SphereBatch(pyr, labels, feature_3d=feat3d, feat_aggre_points=stacked_world.unsqueeze(0),
                         image_xyz=torch.stack(image_xyz, 0), images=torch.stack(staged['images'], 0),
                         knn_list=knn)
+    # pixel indices into the stacked (b*nv) views for the one-gather FeatureAggregation (fusion_common.lift_2d_features)
+    per_sphere = int(np.prod(staged['depth'][0].shape))
+    batch.knn_stacked = torch.cat([k[0] + i * per_sphere for i, k in enumerate(knn)], 0) if len(knn) > 1 else knn[0][0]
     return batch, lens
 
 
@@ -343,7 +346,7 @@ class StaticBatch:
     # feature_2d3d: FeatureAggregation's output when it, too, was computed ahead (networks that detach it)
     # stacked_features: early fusion's network input [feature_3d | feature_2d3d], built with the latter
     _DENSE = ('labels', 'features', 'feature_3d', 'feat_aggre_points', 'image_xyz', 'images', 'feature_2d', 'feature_2d3d',
-              'stacked_features')
+              'stacked_features', 'knn_stacked')
 
     def load(self, batch):
         """Copies one freshly built batch into the static buffers (raises if a level outgrew its capacity)."""
@@ -477,7 +480,12 @@ class DeviceInputChain:
         torch.cat([ones, z] if v == "early" else [ones] + [torch.cat(st['colors'], 0)], 1, out=static.feature_3d)
         static.feat_aggre_points.copy_(stacked_world.unsqueeze(0))
         torch.stack(st['images'], 0, out=static.images)
+        row0 = 0
         for i, pw in enumerate(world):
             xyz, valid = ops.unproject_depth(st['depth'][i], st['cam'][i], st['poses'][i])
-            static.knn_list[i].copy_(ops.knn_pixels(pw, xyz, valid, k=3).unsqueeze(0))
+            knn = ops.knn_pixels(pw, xyz, valid, k=3)
+            static.knn_list[i].copy_(knn.unsqueeze(0))
+            if getattr(static, 'knn_stacked', None) is not None:      # + the sphere's first view in the stacked feature map
+                torch.add(knn, i * int(np.prod(st['depth'][i].shape)), out=static.knn_stacked[row0:row0 + pw.shape[0]])
+            row0 += pw.shape[0]
             static.image_xyz[i].copy_(xyz.to(torch.float32))

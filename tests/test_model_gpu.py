@@ -101,6 +101,15 @@ def test_two_spheres_stacked_batch():
     _run("early", spheres=2)
 
 
+def test_three_spheres_one_gather_feature_aggregation_vs_cpu_port():
+    """The reference's batch shape (several spheres stacked, train_ScanNet_sphere.py:232 batch_num = 5): FeatureAggregation
+    as ONE gather over the stacked points of all spheres (fusion_common.lift_2d_features), BatchNorm statistics over all
+    sum(np) * k rows like mvpnet_3d.py:54-61 over the concatenated grouped tensors (architectures_sphere.py:278-283) --
+    three ragged spheres, late fusion (the variant that trains through the module), against the CPU port, which runs the
+    reference's per-sphere group_points loop."""
+    _run("late", spheres=3)
+
+
 def test_deformable_middle_fusion_vs_cpu_port():
     _run("middle", deformable=True)
 
@@ -243,6 +252,74 @@ def test_deterministic_mode_step_is_bit_reproducible(variant, spheres):
         assert not bad, "gradients differ between two runs: %s" % bad[:5]
     finally:
         ops.set_deterministic(False)
+
+
+def test_sync_batchnorm_two_ranks_equal_one_rank_with_two_spheres(tmp_path):
+    """SURVEY.md 8e / models/blocks.py:453-460: BatchNorm spans the stacked batch. With ops.set_sync_batchnorm the
+    statistics of every BatchNorm (blocks and FeatureAggregation) are all-reduced, so TWO ranks with ONE sphere each
+    (gloo, both on this card, tests/_syncbn_worker.py) compute what ONE rank computes on the two spheres stacked:
+    logits 1e-4, loss 1e-5, parameter gradients (summed over the ranks, each rank's mean loss weighted by its share of
+    the points) by the cosine / norm criteria of the stacked-batch tests, BatchNorm running statistics 1e-5. The default
+    stays per-rank statistics."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import mvkpconv
+    from util import check_err
+    syn = mvkpconv.sub("synthetic")
+    common = mvkpconv.sub("dropin.datasets.common")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    variant, seeds, radius, density = "early", [0, 1], 0.6, 2500.0
+    cfg = syn.make_config(variant)
+    sph = [syn.raw_sphere(seed=s, radius=radius, density=density) for s in seeds]
+    views = [syn.sphere_views(s, nv=3, h=60, w=80) for s in sph]
+    staged = syn.stage_spheres(sph, dev, views)
+    limits = syn.calibrate_limits(cfg, staged)
+    rots = [common.random_grid_rotations(2) for _ in range(4)]
+    batch, lens = syn.build_batch(cfg, staged, limits, torch.int64, rotations=rots)
+    net = syn.build_model(cfg, dev)
+    net.train()
+    for m in net.net_2d._modules.values():
+        m.train(False)
+    state = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    torch.save({"variant": variant, "seeds": seeds, "radius": radius, "density": density, "limits": limits,
+                "rotations": rots, "state": state}, str(tmp_path / "meta.pt"))
+    out = net(batch, cfg)
+    loss = net.loss(out, batch.labels)
+    loss.backward()
+    ref_rm = net.encoder_blocks[3].batch_norm_conv.batch_norm.running_mean.cpu()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "_syncbn_worker.py"), str(r), "2", str(port), str(tmp_path)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    logs = [p.communicate(timeout=600)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(l[-1500:] for l in logs)
+    r0, r1 = (torch.load(str(tmp_path / ("rank%d.pt" % r)), weights_only=False) for r in range(2))
+    assert [r0["n"], r1["n"]] == lens
+    rel = lambda a, b: (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+    got = torch.cat([r0["logits"], r1["logits"]], 0)
+    check_err("SyncBN 2 ranks x 1 sphere vs 1 rank x 2 spheres: logits", rel(got, out.detach().cpu()), 1e-4)
+    check_err("SyncBN: loss (abs)", abs(r0["loss"].item() - loss.item()), 1e-5)
+    check_err("SyncBN: BatchNorm running mean", rel(r0["running_mean"], ref_rm), 1e-5)
+    worst_cos = worst_ratio = 0.0
+    pairs = [(n, r0["grads"][n].reshape(-1).double(), p.grad.cpu().reshape(-1).double())
+             for n, p in net.named_parameters() if p.grad is not None]
+    assert len(pairs) > 50 and set(n for n, _, _ in pairs) == set(r0["grads"])
+    scale = max(b.norm().item() for _, _, b in pairs)
+    for n, a, b in pairs:
+        if b.norm().item() < 1e-3 * scale:
+            assert (a - b).norm().item() < 1e-3 * scale, n
+            continue
+        worst_cos = max(worst_cos, 1 - (a @ b).item() / (a.norm().item() * b.norm().item()))
+        worst_ratio = max(worst_ratio, abs(a.norm().item() / b.norm().item() - 1))
+    check_err("SyncBN: worst per-parameter 1 - cosine", worst_cos, 1e-3)
+    check_err("SyncBN: worst per-parameter |norm ratio - 1|", worst_ratio, 3e-2)
 
 
 def test_state_dict_keys_follow_the_reference_names():

@@ -931,12 +931,16 @@ def gather_by_level(prof):
     for a in sorted(agg.values(), key=lambda a: -a["total_ms"]):
         a["avg_us"] = a["total_ms"] / a["launches"] * 1e3
         a["GBps"] = a.pop("bytes") / (a["total_ms"] * 1e-3) / 1e9
+        a["frac_of_hbm_peak"] = a["GBps"] / HBM_PEAK_GBS          # every class, not only the one `roofline` reports
         out.append(a)
     return out
 
 
 def _dominant(prof):
-    return max(prof.values(), key=lambda r: r["total_ms"]) if prof else None
+    """The FORWARD gather class with the largest total time (the gather-form feature gradient runs on the same kernel
+    over the reverse lists: listed per level in bench_detail.json, tagged [dx], not a candidate for `roofline`)."""
+    fwd = [r for r in prof.values() if not r["kernel"].endswith("[dx]")]
+    return max(fwd, key=lambda r: r["total_ms"]) if fwd else None
 
 
 def roofline(prof):

@@ -341,6 +341,7 @@ def profile_reset(enabled):
     _PROF["on"] = bool(enabled)
     _PROF["rec"] = []
     _PROF["gemm"] = []
+    _PROF["h_eff"] = {}
 
 
 def _timing_events():
@@ -404,10 +405,12 @@ def profile_collect(h_eff=None):
         r["each_ms"].append(t)
     for key, r in out.items():
         name, Nq, Ns, H, Cin, K = key
-        he = (h_eff or {}).get((Nq, Ns, H), H)
+        he = _PROF.get("h_eff", {}).get((Nq, Ns, H)) if name.endswith("[dx]") else None
+        if he is None:
+            he = (h_eff or {}).get((Nq, Ns, H), H)
         # algorithmic bytes: feature row + xyz + int32 index per real neighbour,
         # query xyz, and the [Nq,K,Cin] aggregate written by the gather kernel (s_x = 2 in the fp16 mode)
-        sx = 2 if name.endswith("[f16]") else 4
+        sx = 2 if "[f16]" in name else 4
         r["bytes_per_launch"] = Nq * he * (Cin * sx + 12 + 4) + Nq * 12 + Nq * K * Cin * sx
         r["kernel"] = name
         r["shape"] = {"Nq": Nq, "Ns": Ns, "H": H, "H_eff": he, "Cin": Cin, "K": K}
@@ -415,7 +418,7 @@ def profile_collect(h_eff=None):
 
 
 def kpconv_gather(q, s, idx, x, kp, extent, influence="linear", aggregation="sum", offsets=None,
-                  want_min_d2=False, order=None):
+                  want_min_d2=False, order=None, tag=None):
     """A[n,k,c] = sum_h w[n,h,k] x+[idx[n,h],c]; returns (A, min_d2 or None). order [Nq] int32 (a permutation of the
     query rows, e.g. sorted by grid cell): the order the points are WORKED on; the result does not depend on it."""
     _dev(q, s, idx, x, kp, offsets, order)
@@ -441,7 +444,11 @@ def kpconv_gather(q, s, idx, x, kp, extent, influence="linear", aggregation="sum
                                               _p(offsets), _p(min_d2), _p(min_arg), _p(A), _p(order), _stream()))
     if _PROF["on"]:
         e1.record()
-        _PROF["rec"].append(((_gather_kernel_label(Nq, Ns, H, Cin, offsets is not None), Nq, Ns, H, Cin, K), e0, e1))
+        name = _gather_kernel_label(Nq, Ns, H, Cin, offsets is not None)
+        if tag:         # the gather-form feature gradient: its own class, with the mean length of ITS (reverse) rows
+            name += tag
+            _PROF.setdefault("h_eff", {})[(Nq, Ns, H)] = float((idx < Ns).sum().item()) / max(Nq, 1)
+        _PROF["rec"].append(((name, Nq, Ns, H, Cin, K), e0, e1))
     if min_d2 is not None:
         min_d2._mvk_min_arg = min_arg          # neighbour column of each minimum: the backward's min_d2 path starts there
     return A, min_d2
@@ -754,7 +761,8 @@ class _KPConvFn(torch.autograd.Function):
             # kernel points negated, then the per-kernel-point transposed contraction -- no atomics, fixed summation order
             if rev.shape[0] != s.shape[0]:
                 rev = rev[:s.shape[0]]
-            A2, _ = kpconv_gather(s, q, rev, gy, _neg_kernel_points(kp), extent, influence, aggregation, order=rev_order)
+            A2, _ = kpconv_gather(s, q, rev, gy, _neg_kernel_points(kp), extent, influence, aggregation, order=rev_order,
+                                  tag="[dx]")
             dx = kp_transposed_contraction(A2, W)
         elif need_dA:
             dAm = gemm(gy, W.reshape(K * Cin, Cout), transB=True).view(Nq, K, Cin)

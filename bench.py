@@ -430,6 +430,10 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             print("DIAG %3d %-18s %s" % (n, name, st), file=sys.stderr)
         opt.zero_grad(set_to_none=True)
 
+    # the per-step inputs (views, grid orientations) as nodes of the side branches (MVK_INPUTS_IN_GRAPH=0: eager launches
+    # on the network's stream between two replays, as up to round 3: ~45 us in front of every step's first kernel)
+    in_graph_inputs = use_chain and os.environ.get("MVK_INPUTS_IN_GRAPH", "1") == "1"
+
     def capture(static):
         ops.set_row_counts(static.valid)
         opt.zero_grad(set_to_none=True)         # every graph instance produces its own .grad tensors
@@ -457,9 +461,13 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
         def side_work():
             if enc is not None:
                 with torch.cuda.stream(enc_stream):
+                    if in_graph_inputs:       # the views of batch k+1 enter on this branch, not by eager launches on the network's queue
+                        enc_in.copy_(torch.stack(staged['images'], 0))
                     other.feature_2d.copy_(encode(enc_in))
             if use_chain:
                 with torch.cuda.stream(build_stream):
+                    if in_graph_inputs:       # this step's grid orientations: a copy node reading the pinned draw of the host
+                        chains[1 - statics.index(static)].upload_rotations()
                     chains[1 - statics.index(static)].build(other)
                     for _ in range(int(os.environ.get("MVK_BENCH_DUMMY_LAUNCHES", "0"))):   # development: what is one more
                         _DUMMY.setdefault(dev, torch.zeros(64, device=dev)).add_(1.0)        # tiny launch on a side branch worth?
@@ -577,8 +585,10 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             check_status()
             if replayed[slot ^ 1] is not None:  # bound the host's run-ahead to two steps: the pinned staging
                 replayed[slot ^ 1].synchronize()   # buffer of this chain must not be rewritten before its copy ran
-            chains[slot ^ 1].draw_rotations()   # host draw + one small async copy: the orientations of batch k+1
-            if enc is not None:
+            # host draw of batch k+1's grid orientations into pinned memory (the replay's copy node reads it: the previous
+            # replay of this chain is two steps back and has long read its own) + the views of batch k+1
+            chains[slot ^ 1].draw_rotations(upload=not in_graph_inputs)
+            if enc is not None and not in_graph_inputs:
                 enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
             ta = time.perf_counter()
             replays[slot][0]()

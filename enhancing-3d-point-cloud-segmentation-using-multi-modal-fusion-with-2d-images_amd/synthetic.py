@@ -424,13 +424,18 @@ class DeviceInputChain:
                                  for a in range(L) for b in range(L) if abs(a - b) <= 1), dev)
         ops._workspace("sub", ops.lib().mvk_grid_subsample_workspace(caps[0], self.B, 0, 0), dev)
 
-    def draw_rotations(self, rotations=None):
+    def draw_rotations(self, rotations=None, upload=True):
         """Host side of a step: one random rotation per cloud and level (or the given ones), staged in
-        pinned memory and copied to the device asynchronously on the current stream."""
+        pinned memory and (upload) copied to the device asynchronously on the current stream. upload=False: the copy is
+        a node of a captured graph (upload_rotations() under capture) that reads the pinned bytes at every replay."""
         L1 = self.rot.shape[0]
         for l in range(L1):
             R = random_grid_rotations(self.B) if rotations is None else rotations[l]
             self.rot_host[l].copy_(torch.from_numpy(np.ascontiguousarray(R, dtype=np.float32)))
+        if upload:
+            self.upload_rotations()
+
+    def upload_rotations(self):
         self.rot.copy_(self.rot_host, non_blocking=True)
 
     def build(self, static):

@@ -488,8 +488,8 @@ def test_graph_replay_trains_like_eager(device_chain):
                                  build_batch=lambda c, st, lim, dt, **kw: syn.build_batch(c, st, lim, dt, rotations=rots, **kw))
     if device_chain:        # the input side as a captured branch of the graph (device-side counts)
         class PinnedChain(syn.DeviceInputChain):
-            def draw_rotations(self, rotations=None):
-                super().draw_rotations(rots)
+            def draw_rotations(self, rotations=None, upload=True):
+                super().draw_rotations(rots, upload=upload)
         shim.DeviceInputChain = PinnedChain
 
     def make():

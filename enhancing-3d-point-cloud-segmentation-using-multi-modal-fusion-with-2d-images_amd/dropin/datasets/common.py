@@ -216,6 +216,8 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
 
         out['rev_neighbors'].append(reverse(conv_i))
         out['rev_pools'].append(reverse(pool_i))
+        if out['rev_neighbors'][-1] is not None:
+            ops.remember_reverse(conv_i, out['rev_neighbors'][-1])          # for batch containers without the attribute
         if out['rev_pools'][-1] is not None:
             ops.remember_reverse(pool_i, out['rev_pools'][-1])              # max_pool's backward finds it by the matrix
         if ops.is_deterministic() and want_rev and pts.is_cuda and up_i.shape[0] > 0 and up_i.shape[1] > 0:

@@ -310,11 +310,21 @@ def _reverse_list(block_name, layer_ind, batch):
     """(transposed neighbour matrix, work list of the support level) of the block's convolution when the batch carries
     them (datasets/common.py `rev_neighbors` / `rev_pools`, not reference attributes), else (None, None): the feature
     gradient then runs as the atomic scatter."""
-    revs = getattr(batch, 'rev_pools' if 'strided' in block_name else 'rev_neighbors', None)
-    if not revs or layer_ind >= len(revs) or revs[layer_ind] is None:
-        return None, None
+    strided = 'strided' in block_name
+    revs = getattr(batch, 'rev_pools' if strided else 'rev_neighbors', None)
+    if revs and layer_ind < len(revs) and revs[layer_ind] is not None:
+        rev = revs[layer_ind]
+    else:
+        # batch containers without these attributes (the reference's flat input_list): the list registered under the
+        # neighbour matrix itself when the pyramid was built in this process (ops.remember_reverse), like the work lists
+        inds = (batch.pools if strided else batch.neighbors)[layer_ind]
+        rev = ops.reverse_for(inds) if (_ORDER_LOOKUP and ops.REVERSE_DX and torch.is_tensor(inds)) else None
+        if rev is None:
+            return None, None
     orders = getattr(batch, 'orders', None)
-    return revs[layer_ind], (orders[layer_ind] if orders and layer_ind < len(orders) else None)
+    order = orders[layer_ind] if orders and layer_ind < len(orders) else \
+        (ops.work_order_for(batch.points[layer_ind]) if _ORDER_LOOKUP else None)
+    return rev, order
 
 
 class SimpleBlock(nn.Module):

@@ -1425,6 +1425,7 @@ class _MaxPoolFn(torch.autograd.Function):
     def forward(ctx, x, inds, passthrough=False):
         _dev(x, inds)
         x = _f32c(x)
+        ctx.rev = reverse_for(inds) if is_deterministic() else None       # (by the batch's own tensor object)
         inds, i64 = _idx(inds)
         Nq, H = inds.shape
         out = torch.empty((Nq, x.shape[1]), device=x.device, dtype=torch.float32)
@@ -1442,7 +1443,7 @@ class _MaxPoolFn(torch.autograd.Function):
             return g_alias, None, None
         g = _f32c(g)
         if is_deterministic():
-            rev = reverse_for(inds)
+            rev = ctx.rev
             if rev is not None and rev.shape[0] >= ctx.ns:
                 base = g_alias if (g_alias is not None and g_alias.shape == (ctx.ns, ctx.c)) else None
                 dx = torch.empty((ctx.ns, ctx.c), device=g.device, dtype=torch.float32)
@@ -1470,6 +1471,7 @@ class _GatherRowsFn(torch.autograd.Function):
     def forward(ctx, x, inds2d):
         _dev(x, inds2d)
         x = _f32c(x)
+        ctx.rev = reverse_for(inds2d, first_column=True) if is_deterministic() else None
         inds2d, i64 = _idx(inds2d)
         Nq = inds2d.shape[0]
         stride = inds2d.shape[1] if inds2d.dim() == 2 else 1
@@ -1486,7 +1488,7 @@ class _GatherRowsFn(torch.autograd.Function):
         if not (g.dtype == torch.float32 and g.dim() == 2 and g.stride(1) == 1 and g.stride(0) >= g.shape[1]):
             g = _f32c(g)
         if is_deterministic():
-            rev = reverse_for(inds2d, first_column=True)
+            rev = ctx.rev
             if rev is not None and rev.shape[0] >= ctx.ns:
                 return gather_sum_rows(g, rev[:ctx.ns]), None
             _no_reverse_list("a closest_pool / upsampling matrix")
@@ -1504,6 +1506,7 @@ class _UpsampleCatFn(torch.autograd.Function):
     def forward(ctx, x, inds2d, skip):
         _dev(x, inds2d, skip)
         x, skip = _f32c(x), _f32c(skip)
+        ctx.rev = reverse_for(inds2d, first_column=True) if is_deterministic() else None
         inds2d, i64 = _idx(inds2d)
         Nq = inds2d.shape[0]
         if skip.shape[0] != Nq:
@@ -1523,7 +1526,7 @@ class _UpsampleCatFn(torch.autograd.Function):
         g = _f32c(g)
         c2 = g.shape[1] - ctx.c1
         if is_deterministic():
-            rev = reverse_for(inds2d, first_column=True)
+            rev = ctx.rev
             if rev is not None and rev.shape[0] >= ctx.ns:
                 dx = gather_sum_rows(g[:, :ctx.c1], rev[:ctx.ns]) if ctx.needs_input_grad[0] else None
                 return dx, None, (g[:, ctx.c1:].contiguous() if ctx.needs_input_grad[2] else None)
@@ -1547,6 +1550,7 @@ class _UpsampleCatLinearFn(torch.autograd.Function):
     def forward(ctx, x, inds2d, skip, W, stats_n_valid):
         _dev(x, inds2d, skip, W)
         x, skip = _f32c(x), _f32c(skip)
+        ctx.rev = reverse_for(inds2d, first_column=True) if is_deterministic() else None
         inds2d, i64 = _idx(inds2d)
         Nq = inds2d.shape[0]
         if skip.shape[0] != Nq:
@@ -1575,7 +1579,7 @@ class _UpsampleCatLinearFn(torch.autograd.Function):
         M, N, Kd = cat.shape[0], C1 + C2, W.shape[0]
         split_arena_prepare(g.device)
         if is_deterministic() and M > 0:
-            rev = reverse_for(inds2d, first_column=True)
+            rev = ctx.rev
             if rev is not None and rev.shape[0] >= ns:
                 # (sum of the gradient rows of every coarse point's fine points) . W[:, :C1]: the scatter as a gather, then
                 # the two halves of g W as two products -- fixed summation order throughout
@@ -1862,16 +1866,23 @@ def _rev_key(inds, first):
 
 
 def remember_reverse(inds, rev, first_column=False):
-    """Registers rev = reverse_neighbors(inds, ...) (first_column: of inds[:, 0]) under the index matrix itself."""
+    """Registers rev = reverse_neighbors(inds, ...) (first_column: of inds[:, 0]) under the index matrix itself. The
+    entry holds a weak reference to THAT tensor object: another matrix of the same shape at a recycled address never
+    matches (a wrong reverse list would be a silently wrong gradient, unlike a stale work list)."""
     key = _rev_key(inds, first_column)
-    _REVERSES[key] = rev
+    _REVERSES[key] = (weakref.ref(inds), rev)
     _REVERSES.move_to_end(key)
     while len(_REVERSES) > _REVERSES_KEPT:
         _REVERSES.popitem(last=False)
 
 
 def reverse_for(inds, first_column=False):
-    return _REVERSES.get(_rev_key(inds, first_column)) if inds.is_cuda else None
+    """The reverse list registered for this very tensor object (call it where the matrix is still the object the batch
+    holds: in the forward), or None."""
+    if not (torch.is_tensor(inds) and inds.is_cuda):
+        return None
+    e = _REVERSES.get(_rev_key(inds, first_column))
+    return e[1] if (e is not None and e[0]() is inds) else None
 
 
 _DET_WARNED = set()

@@ -973,6 +973,10 @@ def test_reverse_neighbors_is_the_sorted_transposed_relation(ops, Nq, Ns, H, idt
     assert (o[Ns:] == -7).all()
     for j in range(0, Ns, max(1, Ns // 300)):
         assert list(o[j, :len(want[j])]) == want[j] and (o[j, len(want[j]):] == 123456).all(), j
+    # the registry matches the tensor OBJECT, never a look-alike at another (or the same, recycled) address
+    mat = T(idx).to(idt)
+    ops.remember_reverse(mat, rev)
+    assert ops.reverse_for(mat) is rev and ops.reverse_for(mat.clone()) is None and ops.reverse_for(mat, first_column=True) is None
     if longest > 2:
         st.zero_()
         ops.reverse_neighbors(T(idx).to(idt), Ns, width=longest - 1, status=st)

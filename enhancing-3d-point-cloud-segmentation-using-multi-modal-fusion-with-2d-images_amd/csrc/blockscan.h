@@ -12,6 +12,28 @@ __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long*
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The same loads for GLOBAL memory with N of them in flight. The compiler waits for every relaxed ATOMIC load before it
+// issues the next (one L2 round trip per element: the one-workgroup-per-cloud kernels are chains of such trips); these are
+// plain `global_load ... sc1` instructions written as inline assembly, one wait behind the last, every register pinned after
+// the wait so that no use is scheduled above it. Callers clamp out-of-range addresses instead of branching around the
+// call (a register written by an untracked load must not pass through a join before the wait). NOT for LDS pointers.
+template <int N>
+__device__ __forceinline__ void ldg_agent(int (&v)[N], const int* const (&p)[N]) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[u]) : "v"(p[u]) : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < N; ++u) asm volatile("" : "+v"(v[u]));
+}
+template <int N>
+__device__ __forceinline__ void ldg_agent(unsigned long long (&v)[N], const unsigned long long* const (&p)[N]) {
+#pragma unroll
+  for (int u = 0; u < N; ++u) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[u]) : "v"(p[u]) : "memory");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int u = 0; u < N; ++u) asm volatile("" : "+v"(v[u]));
+}
+
 __device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* sh /* TPB/64 + 1 */) {
   // wave scan + cross-wave
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -69,3 +91,63 @@ __device__ int block_scan_array(int* arr, int n, int* sh, bool suffix) {
   return total;
 }
 
+
+
+// block_scan_array for an array in GLOBAL memory: the same result, the loads of a thread's chunk eight at a time.
+__device__ int block_scan_array_g(int* arr, int n, int* sh, bool suffix) {
+  const int per = (n + TPB - 1) / TPB;
+  const int beg = min(n, (int)threadIdx.x * per), end = min(n, beg + per);
+  int s = 0;
+  for (int i0 = beg; i0 < end; i0 += 8) {
+    const int* ap[8];
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u < end ? i0 + u : end - 1;
+      ap[u] = arr + (suffix ? n - 1 - i : i);
+    }
+    ldg_agent<8>(v, ap);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += i0 + u < end ? v[u] : 0;
+  }
+  int total;
+  int base = block_exclusive_scan(s, &total, sh);
+  for (int i0 = beg; i0 < end; i0 += 8) {
+    const int* ap[8];
+    int v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u < end ? i0 + u : end - 1;
+      ap[u] = arr + (suffix ? n - 1 - i : i);
+    }
+    ldg_agent<8>(v, ap);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < end) {
+        arr[suffix ? n - 1 - (i0 + u) : i0 + u] = base;
+        base += v[u];
+      }
+  }
+  __syncthreads();
+  return total;
+}
+
+
+// block_scan_array for an array in LDS (the workgroup's own memory: plain loads are coherent after a barrier, and the
+// compiler may keep several in flight).
+__device__ int block_scan_array_lds(int* arr, int n, int* sh, bool suffix) {
+  const int per = (n + TPB - 1) / TPB;
+  const int beg = min(n, (int)threadIdx.x * per), end = min(n, beg + per);
+  int s = 0;
+  for (int i = beg; i < end; ++i) s += arr[suffix ? n - 1 - i : i];
+  int total;
+  int base = block_exclusive_scan(s, &total, sh);
+  for (int i = beg; i < end; ++i) {
+    const int j = suffix ? n - 1 - i : i;
+    const int t = arr[j];
+    arr[j] = base;
+    base += t;
+  }
+  __syncthreads();
+  return total;
+}

@@ -70,7 +70,14 @@ struct SubWs {
   float* stage_pts;
   float* stage_feat;
   int* stage_lab;
+  // development (MVK_SUB_TIMING=1): [cloud][16] wall-clock stamps (100 MHz) at the phase boundaries, or null
+  long long* dbg;
 };
+
+#define SUB_STAMP(k)                                                         \
+  do {                                                                       \
+    if (W.dbg && threadIdx.x == 0) W.dbg[blockIdx.x * 16 + (k)] = wall_clock64(); \
+  } while (0)
 
 // Bucket-count schedule of libstdc++'s unordered_map (13, 29, 59, 127, ...): nb[e+1] =
 // next_bkt(2 * nb[e]); identical for every cloud, computed once on the host.
@@ -169,6 +176,7 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
     P = Q;
   }
 
+  SUB_STAMP(0);
   // ---- P1: min / max
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
   for (int i = tid; i < n; i += TPB)
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   const float ox = corner[0], oy = corner[1], oz = corner[2];
   const unsigned long long NX = dims[0], NY = dims[1];
 
+  SUB_STAMP(1);
   // ---- P2: hash insert
   unsigned int T = 2;
   while (T < 2u * (unsigned)n) T <<= 1;
@@ -221,16 +230,16 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   }
   __syncthreads();
   int* slot = W.slot + off;
-  // Four points of a thread at a time: their first compare-and-swap attempts (and then their atomicMin) are issued
+  // Eight points of a thread at a time (four until round 4): their first compare-and-swap attempts (and then their atomicMin) are issued
   // together, so a thread's chain of dependent L2 round trips is a quarter as long (the kernel is one workgroup per
   // cloud: 19 points per thread at 19 k points, every atomic a ~1.5 us round trip; 151 -> see DESIGN 4.3). The table
   // ends up with the same keys and the same minima whatever the order of the attempts.
-  for (int i0 = tid; i0 < n; i0 += 4 * TPB) {
-    unsigned long long key[4], prev[4];
-    unsigned int h[4];
-    bool live[4];
+  for (int i0 = tid; i0 < n; i0 += 8 * TPB) {
+    unsigned long long key[8], prev[8];
+    unsigned int h[8];
+    bool live[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       const int i = i0 + u * TPB;
       live[u] = i < n;
       const int ii = live[u] ? i : i0;
@@ -241,9 +250,9 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
       h[u] = hash64(key[u]) & (T - 1);
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u) prev[u] = live[u] ? atomicCAS(&hkey[h[u]], EMPTY_KEY, key[u]) : key[u];
+    for (int u = 0; u < 8; ++u) prev[u] = live[u] ? atomicCAS(&hkey[h[u]], EMPTY_KEY, key[u]) : key[u];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
+    for (int u = 0; u < 8; ++u) {
       if (!live[u]) continue;
       unsigned long long p = prev[u];
       while (!(p == EMPTY_KEY || p == key[u])) {       // occupied by another voxel: linear probing
@@ -253,25 +262,51 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
       slot[i0 + u * TPB] = (int)h[u];
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 8; ++u)
       if (live[u]) atomicMin(&hfirst[h[u]], i0 + u * TPB);
   }
   __syncthreads();
 
+  SUB_STAMP(2);
   // ---- P3: first-occurrence flags -> voxel ids in insertion order
   int* scan = W.scan + off;
-  for (int i = tid; i < n; i += TPB) scan[i] = (ld_agent(&hfirst[slot[i]]) == i) ? 1 : 0;
+  for (int i0 = tid; i0 < n; i0 += 8 * TPB) {          // eight dependent slot -> first chains of a thread in flight together
+    const int* ap[8];
+    int f[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ap[u] = hfirst + slot[i0 + u * TPB < n ? i0 + u * TPB : i0];
+    ldg_agent<8>(f, ap);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * TPB < n) scan[i0 + u * TPB] = (f[u] == i0 + u * TPB) ? 1 : 0;
+  }
   __syncthreads();
-  const int M = block_scan_array(scan, n, sh, false);
+  const int M = block_scan_array_g(scan, n, sh, false);
   unsigned long long* vkey = W.vkey + off;
   int* vcount = W.vcount + off;
   int* vseg = W.vseg + off;
   int* vcursor = W.vcursor + off;
-  for (int i = tid; i < n; i += TPB) {
-    const int s = slot[i];
-    if (ld_agent(&hfirst[s]) == i) {
-      hvox[s] = scan[i];
-      vkey[scan[i]] = ld_agent(&hkey[s]);
+  for (int i0 = tid; i0 < n; i0 += 4 * TPB) {
+    const int* ap[4];
+    const unsigned long long* kp[4];
+    int f[4], sl[4];
+    unsigned long long kv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      sl[u] = slot[i0 + u * TPB < n ? i0 + u * TPB : i0];
+      ap[u] = hfirst + sl[u];
+      kp[u] = hkey + sl[u];
+    }
+    ldg_agent<4>(f, ap);
+    ldg_agent<4>(kv, kp);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + u * TPB;
+      if (i < n && f[u] == i) {
+        const int vid = scan[i];
+        hvox[sl[u]] = vid;
+        vkey[vid] = kv[u];
+      }
     }
   }
   for (int v = tid; v < M; v += TPB) {
@@ -279,26 +314,52 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
     vcursor[v] = 0;
   }
   __syncthreads();
+  SUB_STAMP(3);
   // ---- P4: counts
-  for (int i = tid; i < n; i += TPB) atomicAdd(&vcount[hvox[slot[i]]], 1);
-  __syncthreads();
-  // ---- P5: segment offsets
-  for (int v = tid; v < M; v += TPB) vseg[v] = ld_agent(&vcount[v]);
-  __syncthreads();
-  block_scan_array(vseg, M, sh, false);
-  // ---- P6: scatter members
-  int* member = W.member + off;
-  for (int i0 = tid; i0 < n; i0 += 4 * TPB) {       // four cursor increments of a thread in flight together (see P2)
-    int v[4], pos[4];
+  for (int i0 = tid; i0 < n; i0 += 8 * TPB) {          // slot -> voxel id chains eight at a time, then the atomics
+    int sl[8], vv[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) v[u] = i0 + u * TPB < n ? hvox[slot[i0 + u * TPB]] : -1;
+    for (int u = 0; u < 8; ++u) sl[u] = slot[i0 + u * TPB < n ? i0 + u * TPB : i0];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) pos[u] = v[u] >= 0 ? atomicAdd(&vcursor[v[u]], 1) : 0;
+    for (int u = 0; u < 8; ++u) vv[u] = hvox[sl[u]];
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (v[u] >= 0) member[vseg[v[u]] + pos[u]] = i0 + u * TPB;
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * TPB < n) atomicAdd(&vcount[vv[u]], 1);
   }
   __syncthreads();
+  SUB_STAMP(4);
+  // ---- P5: segment offsets
+  for (int v0 = tid; v0 < M; v0 += 8 * TPB) {
+    const int* ap[8];
+    int c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) ap[u] = vcount + (v0 + u * TPB < M ? v0 + u * TPB : v0);
+    ldg_agent<8>(c, ap);
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (v0 + u * TPB < M) vseg[v0 + u * TPB] = c[u];
+  }
+  __syncthreads();
+  block_scan_array_g(vseg, M, sh, false);
+  SUB_STAMP(5);
+  // ---- P6: scatter members
+  int* member = W.member + off;
+  for (int i0 = tid; i0 < n; i0 += 8 * TPB) {       // eight cursor increments of a thread in flight together (see P2)
+    int sl[8], v[8], pos[8], sg[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sl[u] = slot[i0 + u * TPB < n ? i0 + u * TPB : i0];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = hvox[sl[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) sg[u] = vseg[v[u]];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) pos[u] = i0 + u * TPB < n ? atomicAdd(&vcursor[v[u]], 1) : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u * TPB < n) member[sg[u] + pos[u]] = i0 + u * TPB;
+  }
+  __syncthreads();
+  SUB_STAMP(6);
   // ---- P7: ordered sums
   float* vbary = W.vbary + (int64_t)off * 3;
   float* vfeat = fdim > 0 ? W.vfeat + (int64_t)off * fdim : nullptr;
@@ -306,20 +367,54 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   for (int v = tid; v < M; v += TPB) {
     int* m = member + vseg[v];
     const int c = ld_agent(&vcount[v]);
-    for (int a = 1; a < c; ++a) {  // insertion sort by point index
-      int key = m[a], z = a - 1;
-      while (z >= 0 && m[z] > key) {
-        m[z + 1] = m[z];
-        --z;
-      }
-      m[z + 1] = key;
-    }
     float sx = 0.f, sy = 0.f, sz = 0.f;
-    for (int a = 0; a < c; ++a) {
-      const float* p = P + (int64_t)m[a] * 3;
-      sx += p[0];
-      sy += p[1];
-      sz += p[2];
+    if (c <= 8) {
+      // the common case (a voxel holds ~4 points): members into registers in one round of loads, sorted there by an
+      // odd-even transposition network, the eight point loads issued together, the sums added in input order as before
+      int mm[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) mm[a] = m[a < c ? a : 0];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) mm[a] = a < c ? mm[a] : 0x7fffffff;
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int a = r & 1; a + 1 < 8; a += 2) {
+          const int lo = min(mm[a], mm[a + 1]), hi = max(mm[a], mm[a + 1]);
+          mm[a] = lo;
+          mm[a + 1] = hi;
+        }
+      float px[8], py[8], pz[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const float* pp = P + (int64_t)(a < c ? mm[a] : mm[0]) * 3;
+        px[a] = pp[0];
+        py[a] = pp[1];
+        pz[a] = pp[2];
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+        if (a < c) {
+          m[a] = mm[a];          // (the feature / label sums below read the sorted members from memory)
+          sx += px[a];
+          sy += py[a];
+          sz += pz[a];
+        }
+    } else {
+      for (int a = 1; a < c; ++a) {  // insertion sort by point index
+        int key = m[a], z = a - 1;
+        while (z >= 0 && m[z] > key) {
+          m[z + 1] = m[z];
+          --z;
+        }
+        m[z + 1] = key;
+      }
+      for (int a = 0; a < c; ++a) {
+        const float* p = P + (int64_t)m[a] * 3;
+        sx += p[0];
+        sy += p[1];
+        sz += p[2];
+      }
     }
     const float r = (float)(1.0 / (double)c);  // :87, cloud.h:120
     vbary[v * 3] = sx * r;
@@ -357,6 +452,7 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   }
   __syncthreads();
 
+  SUB_STAMP(7);
   // ---- P8: unordered_map iteration order
   // The epochs are inherently sequential (the final order depends on every rehash), and each one is a handful of
   // block-wide phases of atomics and scans over its live elements: with the per-epoch arrays in HBM every phase was a
@@ -406,18 +502,22 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
       nextb[v] = atomicExch(&bhead[bk], v);
     }
     __syncthreads();
+    // (LDS epochs: the arrays are the workgroup's own memory, plain loads are coherent after the barrier and several can be
+    // in flight; HBM epochs: agent-scope loads of words the L2-side atomics updated)
+    auto LD = [&](const int* q) -> int { return use_lds ? *q : ld_agent(q); };
     for (int v = tid; v < end; v += TPB) {
       const int bk = (int)(vkey[v] % nb);
-      if (ld_agent(&ft[bk]) == tau[v]) tarr[tau[v]] = ld_agent(&bcnt[bk]);
+      if (LD(&ft[bk]) == tau[v]) tarr[tau[v]] = LD(&bcnt[bk]);
     }
     __syncthreads();
-    block_scan_array(tarr, end, sh, true);  // tarr[t] = #elements in buckets first touched after t
+    if (use_lds) block_scan_array_lds(tarr, end, sh, true);  // tarr[t] = #elements in buckets first touched after t
+    else block_scan_array_g(tarr, end, sh, true);
     for (int v = tid; v < end; v += TPB) {
       const int bk = (int)(vkey[v] % nb);
       const int tv = tau[v];
       int later = 0;
-      for (int u = ld_agent(&bhead[bk]); u >= 0; u = nextb[u]) later += (tau[u] > tv);
-      posnew[v] = tarr[ld_agent(&ft[bk])] + later;
+      for (int u = LD(&bhead[bk]); u >= 0; u = nextb[u]) later += (tau[u] > tv);
+      posnew[v] = tarr[LD(&ft[bk])] + later;
     }
     __syncthreads();
     for (int v = tid; v < end; v += TPB) tau[v] = posnew[v];
@@ -426,6 +526,7 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
     nb = sched.nb[++epoch];
   }
   const int* tau = in_lds ? l_tau : tau_g;
+  SUB_STAMP(8);
   // ---- P9: staging rows in iteration order
   float* sp = W.stage_pts + (int64_t)off * 3;
   float* sf = fdim > 0 ? W.stage_feat + (int64_t)off * fdim : nullptr;
@@ -438,6 +539,7 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
     for (int d = 0; d < ldim; ++d) W.stage_lab[((int64_t)off + o) * ldim + d] = W.vlab[((int64_t)off + v) * ldim + d];
   }
   if (tid == 0) W.out_count[b] = M;
+  SUB_STAMP(9);
 }
 
 // Compacts the per-cloud staging rows into the stacked output and applies max_p
@@ -639,8 +741,24 @@ int subsample_run(const float* pts, int64_t N, const int32_t* lens_host, int B, 
   for (int e = 1; e < 48; ++e) sched.nb[e] = mvk_next_bkt(2 * sched.nb[e - 1]);
   MVK_CHECK_HIP(hipMemcpyAsync(offs_d, offs_h, sizeof(int) * (B + 1), hipMemcpyHostToDevice, st));
   MVK_CHECK_HIP(hipMemsetAsync(W.errflag, 0, sizeof(int), st));
+  static const bool timing = getenv("MVK_SUB_TIMING") != nullptr;
+  static long long* dbg_dev = nullptr;
+  if (timing && B <= 64) {
+    if (!dbg_dev) MVK_CHECK_HIP(hipMalloc(&dbg_dev, sizeof(long long) * 64 * 16));
+    W.dbg = dbg_dev;
+  }
   hipLaunchKernelGGL(subsample_cloud_kernel, dim3(B), dim3(TPB), 0, st, pts, feats, fdim, labels, ldim, offs_d, dl, W,
                      B, sched);
+  if (W.dbg) {
+    long long h[16];
+    MVK_CHECK_HIP(hipMemcpyAsync(h, dbg_dev, sizeof(h), hipMemcpyDeviceToHost, st));
+    MVK_CHECK_HIP(hipStreamSynchronize(st));
+    fprintf(stderr, "subsample timing (cloud 0, n = %d, us):", lens_host[0]);
+    static const char* names[9] = {"P1 minmax", "P2 hash", "P3 flags+scan", "P4 counts", "P5 offsets", "P6 members", "P7 sums",
+                                   "P8 order", "P9 write"};
+    for (int k = 0; k < 9; ++k) fprintf(stderr, " %s %.1f |", names[k], (h[k + 1] - h[k]) / 100.0);
+    fprintf(stderr, " total %.1f\n", (h[9] - h[0]) / 100.0);
+  }
   int gx = (int)cdiv64(n, 256 * (int64_t)B);
   if (gx < 1) gx = 1;
   if (gx > 64) gx = 64;

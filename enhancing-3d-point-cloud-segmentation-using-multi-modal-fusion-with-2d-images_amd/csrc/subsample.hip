@@ -72,6 +72,13 @@ struct SubWs {
   int* stage_lab;
   // development (MVK_SUB_TIMING=1): [cloud][16] wall-clock stamps (100 MHz) at the phase boundaries, or null
   long long* dbg;
+  // multi-workgroup front end (round 4): phases 0-7 of a cloud run as launches over all its points (sub_*_kernel below);
+  // the per-cloud kernel then starts at phase 8 with the voxel count from mdev
+  int multi;
+  int chunks;            // 256-point chunks per cloud in those launches
+  unsigned int* bbox;    // B x 6: order-preserving integer images of min xyz / max xyz (atomicMin / atomicMax)
+  int* wgcnt;            // B x chunks: first occurrences per chunk
+  int* mdev;             // B: voxels per cloud
 };
 
 #define SUB_STAMP(k)                                                         \
@@ -135,6 +142,341 @@ __device__ int label_vote(const int* L, const int* Cn, int nd, const Schedule& s
   return best;
 }
 
+// Phase 7 for ONE voxel: its members sorted by point index, the float32 sums in input order (grid_subsampling.h:74-79),
+// barycentre, feature means, label vote. m = the voxel's segment of `member`, c = its point count.
+__device__ void voxel_accumulate(int v, int* m, int c, const float* __restrict__ P, const float* __restrict__ F, int fdim,
+                                 const int* __restrict__ labels, int ldim, int off, const int* vseg, float* vbary,
+                                 float* vfeat, const SubWs& W, const Schedule& sched) {
+    float sx = 0.f, sy = 0.f, sz = 0.f;
+    if (c <= 8) {
+      // the common case (a voxel holds ~4 points): members into registers in one round of loads, sorted there by an
+      // odd-even transposition network, the eight point loads issued together, the sums added in input order as before
+      int mm[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) mm[a] = m[a < c ? a : 0];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) mm[a] = a < c ? mm[a] : 0x7fffffff;
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int a = r & 1; a + 1 < 8; a += 2) {
+          const int lo = min(mm[a], mm[a + 1]), hi = max(mm[a], mm[a + 1]);
+          mm[a] = lo;
+          mm[a + 1] = hi;
+        }
+      float px[8], py[8], pz[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        const float* pp = P + (int64_t)(a < c ? mm[a] : mm[0]) * 3;
+        px[a] = pp[0];
+        py[a] = pp[1];
+        pz[a] = pp[2];
+      }
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+        if (a < c) {
+          m[a] = mm[a];          // (the feature / label sums below read the sorted members from memory)
+          sx += px[a];
+          sy += py[a];
+          sz += pz[a];
+        }
+    } else {
+      for (int a = 1; a < c; ++a) {  // insertion sort by point index
+        int key = m[a], z = a - 1;
+        while (z >= 0 && m[z] > key) {
+          m[z + 1] = m[z];
+          --z;
+        }
+        m[z + 1] = key;
+      }
+      for (int a = 0; a < c; ++a) {
+        const float* p = P + (int64_t)m[a] * 3;
+        sx += p[0];
+        sy += p[1];
+        sz += p[2];
+      }
+    }
+    const float r = (float)(1.0 / (double)c);  // :87, cloud.h:120
+    vbary[v * 3] = sx * r;
+    vbary[v * 3 + 1] = sy * r;
+    vbary[v * 3 + 2] = sz * r;
+    if (fdim > 0) {
+      const float cf = (float)c;
+      for (int d = 0; d < fdim; ++d) {
+        float s = 0.f;
+        for (int a = 0; a < c; ++a) s += F[(int64_t)m[a] * fdim + d];
+        vfeat[(int64_t)v * fdim + d] = s / cf;  // :90-94
+      }
+    }
+    for (int d = 0; d < ldim; ++d) {  // label histograms in first-seen order (grid_subsampling.h:44-52)
+      int* Lk = W.lab_key + off + vseg[v];
+      int* Lc = W.lab_cnt + off + vseg[v];
+      int nd = 0;
+      for (int a = 0; a < c; ++a) {
+        const int l = labels[((int64_t)off + m[a]) * ldim + d];
+        int z = 0;
+        while (z < nd && Lk[z] != l) ++z;
+        if (z == nd) {
+          Lk[nd] = l;
+          Lc[nd] = 0;
+          ++nd;
+        }
+        Lc[z] += 1;
+      }
+      if (nd > MAXLAB) {
+        atomicExch(W.errflag, 1);
+        nd = MAXLAB;
+      }
+      W.vlab[((int64_t)off + v) * ldim + d] = label_vote(Lk, Lc, nd, sched);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Multi-workgroup front end (round 4). One workgroup per cloud is bound by what ONE compute unit's memory pipeline
+// retires (phases 2-7 of a 19 464-point cloud: ~100 k scattered accesses each, 35-80 us per phase whatever is in flight);
+// here phases 0-7 run as launches over ALL points of all clouds (grid = 256-point chunks x clouds), the same data
+// structures in the same workspace, and the per-cloud kernel starts at phase 8 (the unordered_map order is sequential
+// by nature and lives in LDS). Results are bit-identical: the voxel keys, first occurrences, member lists and the
+// per-voxel arithmetic are the same; only WHO computes them changes.
+
+__device__ __forceinline__ void cloud_range(const SubWs& W, const int* __restrict__ offs, int b, int& off, int& n) {
+  if (W.lens_dev) {
+    off = 0;
+    for (int i = 0; i < b; ++i) off += max(W.lens_dev[i], 0);
+    n = max(W.lens_dev[b], 0);
+  } else {
+    off = offs[b];
+    n = offs[b + 1] - off;
+  }
+}
+
+// order-preserving integer image of a float (atomicMin / atomicMax on unsigned words)
+__device__ __forceinline__ unsigned int f2ord(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u >> 31) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned int k) { return __uint_as_float((k >> 31) ? (k & 0x7fffffffu) : ~k); }
+
+__device__ __forceinline__ unsigned int table_size(int n) {
+  unsigned int T = 2;
+  while (T < 2u * (unsigned)n) T <<= 1;
+  return T;
+}
+
+// phase "-1": empty hash table, zero voxel counters, neutral bounding box
+__global__ __launch_bounds__(256) void sub_prep_kernel(const int* __restrict__ offs, SubWs W) {
+  const int b = blockIdx.y;
+  int off, n;
+  cloud_range(W, offs, b, off, n);
+  const unsigned int i = blockIdx.x * 256u + threadIdx.x;
+  if (i == 0) {
+    for (int c = 0; c < 3; ++c) {
+      W.bbox[b * 6 + c] = 0xffffffffu;
+      W.bbox[b * 6 + 3 + c] = 0u;
+    }
+    W.mdev[b] = 0;
+  }
+  if (n == 0) return;
+  if (i < table_size(n)) {
+    W.hkey[(int64_t)off * 4 + i] = EMPTY_KEY;
+    W.hfirst[(int64_t)off * 4 + i] = 0x7fffffff;
+  }
+  if (i < (unsigned)n) {
+    W.vcount[off + i] = 0;
+    W.vcursor[off + i] = 0;
+  }
+}
+
+// phases 0-1: grid orientation (device-lens entry), min / max corner
+__global__ __launch_bounds__(256) void sub_minmax_kernel(const float* __restrict__ pts, const int* __restrict__ offs, SubWs W) {
+  const int b = blockIdx.y;
+  int off, n;
+  cloud_range(W, offs, b, off, n);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float p[3] = {INFINITY, INFINITY, INFINITY}, q[3] = {-INFINITY, -INFINITY, -INFINITY};
+  if (i < n) {
+    const float* P = pts + ((int64_t)off + i) * 3;
+    float v[3] = {P[0], P[1], P[2]};
+    if (W.rot_dev) {
+      const float* M = W.rot_dev + b * 9;
+      float* Q = W.rot_pts + ((int64_t)off + i) * 3;
+      const float p0 = v[0], p1 = v[1], p2 = v[2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        v[c] = (p0 * M[0 * 3 + c] + p1 * M[1 * 3 + c]) + p2 * M[2 * 3 + c];
+        Q[c] = v[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = q[c] = v[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    for (int o = 32; o >= 1; o >>= 1) {
+      p[c] = fminf(p[c], __shfl_xor(p[c], o));
+      q[c] = fmaxf(q[c], __shfl_xor(q[c], o));
+    }
+  }
+  if ((threadIdx.x & 63) == 0 && blockIdx.x * 256 + (threadIdx.x & ~63) < n) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      atomicMin(&W.bbox[b * 6 + c], f2ord(p[c]));
+      atomicMax(&W.bbox[b * 6 + 3 + c], f2ord(q[c]));
+    }
+  }
+}
+
+// phase 2: voxel key, hash insert, first occurrence
+__global__ __launch_bounds__(256) void sub_insert_kernel(const float* __restrict__ pts, const int* __restrict__ offs, float dl,
+                                                         SubWs W) {
+  const int b = blockIdx.y;
+  int off, n;
+  cloud_range(W, offs, b, off, n);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* P = (W.rot_dev ? W.rot_pts : pts) + (int64_t)off * 3;
+  const float inv = 1 / dl;  // grid_subsampling.cpp:27
+  float o3[3], m3[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    o3[c] = floorf(ord2f(W.bbox[b * 6 + c]) * inv) * dl;
+    m3[c] = ord2f(W.bbox[b * 6 + 3 + c]);
+  }
+  const unsigned long long NX = (unsigned long long)floorf((m3[0] - o3[0]) / dl) + 1;  // :30
+  const unsigned long long NY = (unsigned long long)floorf((m3[1] - o3[1]) / dl) + 1;  // :31
+  const unsigned long long iX = (unsigned long long)floorf((P[i * 3] - o3[0]) / dl);      // :53
+  const unsigned long long iY = (unsigned long long)floorf((P[i * 3 + 1] - o3[1]) / dl);  // :54
+  const unsigned long long iZ = (unsigned long long)floorf((P[i * 3 + 2] - o3[2]) / dl);  // :55
+  const unsigned long long key = iX + NX * iY + NX * NY * iZ;                             // :56
+  const unsigned int T = table_size(n);
+  unsigned long long* hkey = W.hkey + (int64_t)off * 4;
+  unsigned int h = hash64(key) & (T - 1);
+  unsigned long long prev = atomicCAS(&hkey[h], EMPTY_KEY, key);
+  while (!(prev == EMPTY_KEY || prev == key)) {       // occupied by another voxel: linear probing
+    h = (h + 1) & (T - 1);
+    prev = atomicCAS(&hkey[h], EMPTY_KEY, key);
+  }
+  W.slot[off + i] = (int)h;
+  atomicMin(&W.hfirst[(int64_t)off * 4 + h], i);
+}
+
+// phase 3a: first-occurrence flags and their count per chunk
+__global__ __launch_bounds__(256) void sub_flag_kernel(const int* __restrict__ offs, SubWs W) {
+  __shared__ int wsum[4];
+  const int b = blockIdx.y;
+  int off, n;
+  cloud_range(W, offs, b, off, n);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  int f = 0;
+  if (i < n) {
+    f = W.hfirst[(int64_t)off * 4 + W.slot[off + i]] == i ? 1 : 0;
+    W.scan[off + i] = f;
+  }
+  const int cnt = __popcll(__ballot(f));
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) W.wgcnt[(int64_t)b * W.chunks + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// phase 3b: voxel ids in first-occurrence order (exclusive prefix of the flags: chunk base + scan inside the chunk)
+__global__ __launch_bounds__(256) void sub_vox_kernel(const int* __restrict__ offs, SubWs W) {
+  __shared__ int red[256];
+  __shared__ int wsum[4];
+  const int b = blockIdx.y;
+  int off, n;
+  cloud_range(W, offs, b, off, n);
+  const int* cnts = W.wgcnt + (int64_t)b * W.chunks;
+  int part = 0, all = 0;
+  for (int c = threadIdx.x; c < W.chunks; c += 256) {
+    const int v = cnts[c];
+    all += v;
+    part += c < (int)blockIdx.x ? v : 0;
+  }
+  red[threadIdx.x] = part;
+  __syncthreads();
+  for (int o = 128; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const int base = red[0];
+  __syncthreads();
+  if (blockIdx.x == 0) {                      // the cloud's voxel count, once
+    red[threadIdx.x] = all;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+      if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) W.mdev[b] = red[0];
+  }
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int f = i < n ? W.scan[off + i] : 0;
+  const unsigned long long bal = __ballot(f);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int before = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wsum[wv] = __popcll(bal);
+  __syncthreads();
+  int wbase = 0;
+  for (int w = 0; w < wv; ++w) wbase += wsum[w];
+  if (f) {
+    const int vid = base + wbase + before;
+    const int sl = W.slot[off + i];
+    W.hvox[(int64_t)off * 4 + sl] = vid;
+    W.vkey[off + vid] = W.hkey[(int64_t)off * 4 + sl];
+  }
+}
+
+// phase 4: points per voxel
+__global__ __launch_bounds__(256) void sub_count_kernel(const int* __restrict__ offs, SubWs W) {
+  const int b = blockIdx.y;
+  int off, n;
+  cloud_range(W, offs, b, off, n);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) atomicAdd(&W.vcount[off + W.hvox[(int64_t)off * 4 + W.slot[off + i]]], 1);
+}
+
+// phase 5: segment offsets (one workgroup per cloud: a scan over the cloud's voxels)
+__global__ __launch_bounds__(TPB) void sub_offsets_kernel(const int* __restrict__ offs, SubWs W) {
+  __shared__ int sh[TPB / 64 + 2];
+  const int b = blockIdx.x;
+  int off, n;
+  cloud_range(W, offs, b, off, n);
+  const int M = W.mdev[b];
+  int* vseg = W.vseg + off;
+  const int* vcount = W.vcount + off;
+  for (int v = threadIdx.x; v < M; v += TPB) vseg[v] = vcount[v];
+  __syncthreads();
+  block_scan_array_g(vseg, M, sh, false);
+}
+
+// phase 6: member lists
+__global__ __launch_bounds__(256) void sub_scatter_kernel(const int* __restrict__ offs, SubWs W) {
+  const int b = blockIdx.y;
+  int off, n;
+  cloud_range(W, offs, b, off, n);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int v = W.hvox[(int64_t)off * 4 + W.slot[off + i]];
+  const int pos = atomicAdd(&W.vcursor[off + v], 1);
+  W.member[off + W.vseg[off + v] + pos] = i;
+}
+
+// phase 7: one thread per voxel
+__global__ __launch_bounds__(256) void sub_sums_kernel(const float* __restrict__ pts, const float* __restrict__ feats, int fdim,
+                                                       const int* __restrict__ labels, int ldim,
+                                                       const int* __restrict__ offs, SubWs W, Schedule sched) {
+  const int b = blockIdx.y;
+  int off, n;
+  cloud_range(W, offs, b, off, n);
+  const int v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= W.mdev[b]) return;
+  const float* P = (W.rot_dev ? W.rot_pts : pts) + (int64_t)off * 3;
+  const float* F = fdim > 0 ? feats + (int64_t)off * fdim : nullptr;
+  const int* vseg = W.vseg + off;
+  voxel_accumulate(v, W.member + off + vseg[v], W.vcount[off + v], P, F, fdim, labels, ldim, off, vseg,
+                   W.vbary + (int64_t)off * 3, fdim > 0 ? W.vfeat + (int64_t)off * fdim : nullptr, W, sched);
+}
+
 __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __restrict__ pts,
                                                                const float* __restrict__ feats,
                                                                int fdim, const int* __restrict__ labels,
@@ -161,6 +503,14 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
     return;
   }
   const float* P = pts + (int64_t)off * 3;
+  int M = 0;
+  unsigned long long* vkey = W.vkey + off;
+  float* vbary = W.vbary + (int64_t)off * 3;
+  float* vfeat = fdim > 0 ? W.vfeat + (int64_t)off * fdim : nullptr;
+  if (W.multi) {            // phases 0-7 ran as launches over all points (sub_*_kernel): start at the iteration order
+    M = W.mdev[b];
+    SUB_STAMP(0);
+  } else {
   if (W.rot_dev) {
     // ---- P0: the cloud in the random grid orientation (datasets/common.py:118), same arithmetic as
     // rotate_cloud_kernel -- (p0 * R[0][i] + p1 * R[1][i]) + p2 * R[2][i] -- by the cloud's own workgroup
@@ -281,8 +631,7 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
       if (i0 + u * TPB < n) scan[i0 + u * TPB] = (f[u] == i0 + u * TPB) ? 1 : 0;
   }
   __syncthreads();
-  const int M = block_scan_array_g(scan, n, sh, false);
-  unsigned long long* vkey = W.vkey + off;
+  M = block_scan_array_g(scan, n, sh, false);
   int* vcount = W.vcount + off;
   int* vseg = W.vseg + off;
   int* vcursor = W.vcursor + off;
@@ -361,96 +710,11 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   __syncthreads();
   SUB_STAMP(6);
   // ---- P7: ordered sums
-  float* vbary = W.vbary + (int64_t)off * 3;
-  float* vfeat = fdim > 0 ? W.vfeat + (int64_t)off * fdim : nullptr;
   const float* F = fdim > 0 ? feats + (int64_t)off * fdim : nullptr;
-  for (int v = tid; v < M; v += TPB) {
-    int* m = member + vseg[v];
-    const int c = ld_agent(&vcount[v]);
-    float sx = 0.f, sy = 0.f, sz = 0.f;
-    if (c <= 8) {
-      // the common case (a voxel holds ~4 points): members into registers in one round of loads, sorted there by an
-      // odd-even transposition network, the eight point loads issued together, the sums added in input order as before
-      int mm[8];
-#pragma unroll
-      for (int a = 0; a < 8; ++a) mm[a] = m[a < c ? a : 0];
-#pragma unroll
-      for (int a = 0; a < 8; ++a) mm[a] = a < c ? mm[a] : 0x7fffffff;
-#pragma unroll
-      for (int r = 0; r < 8; ++r)
-#pragma unroll
-        for (int a = r & 1; a + 1 < 8; a += 2) {
-          const int lo = min(mm[a], mm[a + 1]), hi = max(mm[a], mm[a + 1]);
-          mm[a] = lo;
-          mm[a + 1] = hi;
-        }
-      float px[8], py[8], pz[8];
-#pragma unroll
-      for (int a = 0; a < 8; ++a) {
-        const float* pp = P + (int64_t)(a < c ? mm[a] : mm[0]) * 3;
-        px[a] = pp[0];
-        py[a] = pp[1];
-        pz[a] = pp[2];
-      }
-#pragma unroll
-      for (int a = 0; a < 8; ++a)
-        if (a < c) {
-          m[a] = mm[a];          // (the feature / label sums below read the sorted members from memory)
-          sx += px[a];
-          sy += py[a];
-          sz += pz[a];
-        }
-    } else {
-      for (int a = 1; a < c; ++a) {  // insertion sort by point index
-        int key = m[a], z = a - 1;
-        while (z >= 0 && m[z] > key) {
-          m[z + 1] = m[z];
-          --z;
-        }
-        m[z + 1] = key;
-      }
-      for (int a = 0; a < c; ++a) {
-        const float* p = P + (int64_t)m[a] * 3;
-        sx += p[0];
-        sy += p[1];
-        sz += p[2];
-      }
-    }
-    const float r = (float)(1.0 / (double)c);  // :87, cloud.h:120
-    vbary[v * 3] = sx * r;
-    vbary[v * 3 + 1] = sy * r;
-    vbary[v * 3 + 2] = sz * r;
-    if (fdim > 0) {
-      const float cf = (float)c;
-      for (int d = 0; d < fdim; ++d) {
-        float s = 0.f;
-        for (int a = 0; a < c; ++a) s += F[(int64_t)m[a] * fdim + d];
-        vfeat[(int64_t)v * fdim + d] = s / cf;  // :90-94
-      }
-    }
-    for (int d = 0; d < ldim; ++d) {  // label histograms in first-seen order (grid_subsampling.h:44-52)
-      int* Lk = W.lab_key + off + vseg[v];
-      int* Lc = W.lab_cnt + off + vseg[v];
-      int nd = 0;
-      for (int a = 0; a < c; ++a) {
-        const int l = labels[((int64_t)off + m[a]) * ldim + d];
-        int z = 0;
-        while (z < nd && Lk[z] != l) ++z;
-        if (z == nd) {
-          Lk[nd] = l;
-          Lc[nd] = 0;
-          ++nd;
-        }
-        Lc[z] += 1;
-      }
-      if (nd > MAXLAB) {
-        atomicExch(W.errflag, 1);
-        nd = MAXLAB;
-      }
-      W.vlab[((int64_t)off + v) * ldim + d] = label_vote(Lk, Lc, nd, sched);
-    }
-  }
+  for (int v = tid; v < M; v += TPB)
+    voxel_accumulate(v, member + vseg[v], ld_agent(&vcount[v]), P, F, fdim, labels, ldim, off, vseg, vbary, vfeat, W, sched);
   __syncthreads();
+  }   // (!W.multi)
 
   SUB_STAMP(7);
   // ---- P8: unordered_map iteration order
@@ -634,6 +898,7 @@ int64_t ws_bytes(int64_t N, int B, int fdim, int ldim) {
   bytes += (int64_t)(B + 1) * 4 * 2;        // out_count, offs
   bytes += n * 12;                          // stage_pts
   bytes += n * 12 + 16;                     // rot_pts (oriented variant)
+  bytes += (int64_t)B * (6 + 1) * 4 + ((n + 255) / 256 + 1) * (int64_t)B * 4 + 64;   // bbox, mdev, wgcnt (multi-workgroup front end)
   return bytes + 64 * 32;
 }
 
@@ -670,6 +935,30 @@ __global__ void rotate_cloud_kernel(const float* __restrict__ in, float* __restr
   }
   float* q = out + (first + t) * 3;
   q[0] = o[0]; q[1] = o[1]; q[2] = o[2];
+}
+
+// Clouds of at least this many points (the largest of a call, or the capacity of a device-lens call) take the
+// multi-workgroup front end; below it one workgroup per cloud runs every phase itself (MVK_SUB_MULTI_MIN, 0 = never).
+int64_t multi_min_points() {
+  static const int64_t v = getenv("MVK_SUB_MULTI_MIN") ? atoll(getenv("MVK_SUB_MULTI_MIN")) : 8192;
+  return v;
+}
+
+// phases 0-7 as launches over all points of all clouds; maxn = the longest cloud (or the capacity)
+void launch_front_end(const float* pts, const float* feats, int fdim, const int32_t* labels, int ldim, const int* offs_d,
+                      float dl, SubWs& W, int B, int64_t maxn, const Schedule& sched, hipStream_t st) {
+  W.multi = 1;
+  W.chunks = (int)cdiv64(maxn, 256);
+  const dim3 g((unsigned)W.chunks, (unsigned)B), g4((unsigned)cdiv64(4 * maxn, 256), (unsigned)B), blk(256);
+  hipLaunchKernelGGL(sub_prep_kernel, g4, blk, 0, st, offs_d, W);
+  hipLaunchKernelGGL(sub_minmax_kernel, g, blk, 0, st, pts, offs_d, W);
+  hipLaunchKernelGGL(sub_insert_kernel, g, blk, 0, st, pts, offs_d, dl, W);
+  hipLaunchKernelGGL(sub_flag_kernel, g, blk, 0, st, offs_d, W);
+  hipLaunchKernelGGL(sub_vox_kernel, g, blk, 0, st, offs_d, W);
+  hipLaunchKernelGGL(sub_count_kernel, g, blk, 0, st, offs_d, W);
+  hipLaunchKernelGGL(sub_offsets_kernel, dim3(B), dim3(TPB), 0, st, offs_d, W);
+  hipLaunchKernelGGL(sub_scatter_kernel, g, blk, 0, st, offs_d, W);
+  hipLaunchKernelGGL(sub_sums_kernel, g, blk, 0, st, pts, feats, fdim, labels, ldim, offs_d, W, sched);
 }
 
 }  // namespace
@@ -722,6 +1011,7 @@ int subsample_run(const float* pts, int64_t N, const int32_t* lens_host, int B, 
   W.stage_feat = cv.take<float>(n * (fdim > 0 ? fdim : 0) + 1);
   W.stage_lab = cv.take<int>(n * (ldim > 0 ? ldim : 0) + 1);
   float* rot_pts = cv.take<float>(3 * n);
+  W.bbox = cv.take<unsigned int>(6 * B); W.mdev = cv.take<int>(B); W.wgcnt = cv.take<int>(((n + 255) / 256 + 1) * B);
   MVK_REQUIRE(cv.p <= cv.end, "subsample: workspace carve overflow");
   if (rot_host) {   // random grid orientation (datasets/common.py:89-118): rotate every cloud by its matrix
     for (int b = 0; b < B; ++b) {
@@ -747,6 +1037,10 @@ int subsample_run(const float* pts, int64_t N, const int32_t* lens_host, int B, 
     if (!dbg_dev) MVK_CHECK_HIP(hipMalloc(&dbg_dev, sizeof(long long) * 64 * 16));
     W.dbg = dbg_dev;
   }
+  int64_t longest = 0;
+  for (int b = 0; b < B; ++b) longest = lens_host[b] > longest ? lens_host[b] : longest;
+  if (multi_min_points() > 0 && longest >= multi_min_points())
+    launch_front_end(pts, feats, fdim, labels, ldim, offs_d, dl, W, B, longest, sched, st);
   hipLaunchKernelGGL(subsample_cloud_kernel, dim3(B), dim3(TPB), 0, st, pts, feats, fdim, labels, ldim, offs_d, dl, W,
                      B, sched);
   if (W.dbg) {
@@ -833,6 +1127,7 @@ extern "C" int mvk_grid_subsample_batch_dev(const float* pts, int64_t cap_in, co
   W.stage_feat = cv.take<float>(1);
   W.stage_lab = cv.take<int>(1);
   float* rot_pts = cv.take<float>(3 * n);
+  W.bbox = cv.take<unsigned int>(6 * B); W.mdev = cv.take<int>(B); W.wgcnt = cv.take<int>(((n + 255) / 256 + 1) * B);
   MVK_REQUIRE(cv.p <= cv.end, "subsample: workspace carve overflow");
   W.errflag = status_dev + 1;   // label overflow cannot happen without labels; shares the overflow word
 
@@ -843,6 +1138,8 @@ extern "C" int mvk_grid_subsample_batch_dev(const float* pts, int64_t cap_in, co
   W.lens_dev = lens_dev;
   W.rot_dev = rot_dev;
   W.rot_pts = rot_pts;
+  if (multi_min_points() > 0 && cap_in >= multi_min_points())       // (fixed launch geometry: the capacity decides)
+    launch_front_end(pts, nullptr, 0, nullptr, 0, nullptr, dl, W, B, cap_in, sched, st);
   hipLaunchKernelGGL(subsample_cloud_kernel, dim3(B), dim3(TPB), 0, st, pts, (const float*)nullptr, 0,
                      (const int32_t*)nullptr, 0, (const int*)nullptr, dl, W, B, sched);
   hipLaunchKernelGGL(subsample_finish_dev_kernel, dim3((unsigned)cdiv64(out_cap, 256)), dim3(256), 0, st, W, B, out_pts,

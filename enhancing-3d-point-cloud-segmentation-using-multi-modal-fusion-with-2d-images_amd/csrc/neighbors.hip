@@ -44,8 +44,10 @@ struct NbWs {
 };
 
 __host__ __device__ inline int64_t cell_cap(int64_t ns) { return 4 * ns + 4096; }
+// a cloud's cell array: cap + 1 counters, padded so that every cloud's array starts on a 16-byte boundary
+__host__ __device__ inline int64_t cell_stride(int64_t ns) { return cell_cap(ns) + 4; }
 
-__global__ __launch_bounds__(TPB) void nb_build_kernel(const float* __restrict__ s, NbWs W, float radius) {
+__global__ __launch_bounds__(TPB) void nb_build_kernel(const float* __restrict__ s, NbWs W, float radius, int grid_only) {
   __shared__ float red[6][TPB / 64];
   __shared__ CloudGrid G;
   __shared__ int sh[TPB / 64 + 2];
@@ -57,13 +59,13 @@ __global__ __launch_bounds__(TPB) void nb_build_kernel(const float* __restrict__
     for (int i = 0; i < b; ++i) {
       const int li = max(W.s_lens[i], 0);
       off += li;
-      base += cell_cap(li) + 1;
+      base += cell_stride(li);
     }
     n = max(W.s_lens[b], 0);
   } else {
     off = W.soffs[b];
     n = W.soffs[b + 1] - off;
-    for (int i = 0; i < b; ++i) base += cell_cap(W.soffs[i + 1] - W.soffs[i]) + 1;
+    for (int i = 0; i < b; ++i) base += cell_stride(W.soffs[i + 1] - W.soffs[i]);
   }
   const float* P = s + (int64_t)off * 3;
   float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(TPB) void nb_build_kernel(const float* __restrict__
     cstart[i] = 0;
     cfill[i] = 0;
   }
+  if (grid_only) return;          // multi-workgroup build: histogram, scan and scatter are launches of their own
   __syncthreads();
   const float gx = G.gmin[0], gy = G.gmin[1], gz = G.gmin[2], cell = G.cell;
   const int dx = G.dims[0], dy = G.dims[1];
@@ -148,6 +151,116 @@ __global__ __launch_bounds__(TPB) void nb_build_kernel(const float* __restrict__
     const int pos = cstart[c] + atomicAdd(&cfill[c], 1);
     W.recs[off + pos] = make_float4(x, y, z, __int_as_float(off + i));  // stacked support index
   }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Multi-workgroup build (round 4). The counting sort of one workgroup per cloud is bound by what ONE compute unit's
+// memory pipeline retires (a 19 464-point cloud: two rounds of 19 k scattered atomics and a scan over 64 k cells, ~100 us);
+// for large clouds the same grid is built by four launches: the cloud's workgroup computes the grid and clears the
+// cells, the histogram and the scatter run over 256-point chunks of all clouds, the scan in between is a kernel of its
+// own (plain loads after the kernel boundary, a thread's cells as 16-byte accesses). Same cells, same record ranges;
+// the order inside a cell is arrival order in both builds (the queries sort by (d2, index)).
+
+__device__ __forceinline__ void support_range(const NbWs& W, int b, int& off, int& n, int64_t& base) {
+  off = 0;
+  base = 0;
+  if (W.s_lens) {
+    for (int i = 0; i < b; ++i) {
+      const int li = max(W.s_lens[i], 0);
+      off += li;
+      base += cell_stride(li);
+    }
+    n = max(W.s_lens[b], 0);
+  } else {
+    off = W.soffs[b];
+    n = W.soffs[b + 1] - off;
+    for (int i = 0; i < b; ++i) base += cell_stride(W.soffs[i + 1] - W.soffs[i]);
+  }
+}
+
+__device__ __forceinline__ int cell_of(const CloudGrid& G, float x, float y, float z) {
+  const int cx = (int)floorf((x - G.gmin[0]) / G.cell), cy = (int)floorf((y - G.gmin[1]) / G.cell),
+            cz = (int)floorf((z - G.gmin[2]) / G.cell);
+  return (cz * G.dims[1] + cy) * G.dims[0] + cx;
+}
+
+__global__ __launch_bounds__(256) void nb_hist_kernel(const float* __restrict__ s, NbWs W) {
+  const int b = blockIdx.y;
+  int off, n;
+  int64_t base;
+  support_range(W, b, off, n, base);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const CloudGrid G = W.grids[b];
+  const float* P = s + ((int64_t)off + i) * 3;
+  atomicAdd(&W.cell_start[base + cell_of(G, P[0], P[1], P[2])], 1);
+}
+
+// exclusive prefix over the cloud's ncell + 1 counters, in place: a thread owns a run of 4 * Q consecutive cells
+__global__ __launch_bounds__(TPB) void nb_scan_kernel(NbWs W) {
+  __shared__ int sh[TPB / 64 + 2];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const CloudGrid G = W.grids[b];
+  const int n = G.dims[0] * G.dims[1] * G.dims[2] + 1;
+  int* arr = W.cell_start + G.cell_base;
+  constexpr int Q = 16;                       // quads per thread and pass: 64 cells, 65 536 per pass of the workgroup
+  int carry = 0;
+  if ((((uintptr_t)arr) & 15) == 0) {
+    for (int s0 = 0; s0 < n; s0 += TPB * 4 * Q) {
+      const int cnt = min(n - s0, TPB * 4 * Q);
+      const int quads = ((cnt + TPB - 1) / TPB + 3) >> 2;          // per thread, <= Q
+      const int beg = s0 + tid * quads * 4, lim = s0 + cnt;
+      int4 v[Q];
+      int sum = 0;
+#pragma unroll
+      for (int u = 0; u < Q; ++u) {
+        const int q = beg + 4 * u;
+        v[u] = (u < quads && q < lim) ? *(const int4*)(arr + q) : make_int4(0, 0, 0, 0);   // (the cell array has >= 4 words of slack)
+        if (q + 1 >= lim) v[u].y = 0;
+        if (q + 2 >= lim) v[u].z = 0;
+        if (q + 3 >= lim) v[u].w = 0;
+        sum += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+      }
+      int total;
+      int run = carry + block_exclusive_scan(sum, &total, sh);
+#pragma unroll
+      for (int u = 0; u < Q; ++u) {
+        const int q = beg + 4 * u;
+        if (u < quads && q < lim) {
+          int4 o;
+          o.x = run;
+          o.y = o.x + v[u].x;
+          o.z = o.y + v[u].y;
+          o.w = o.z + v[u].z;
+          run = o.w + v[u].w;
+          if (q + 3 < lim) *(int4*)(arr + q) = o;
+          else {
+            arr[q] = o.x;
+            if (q + 1 < lim) arr[q + 1] = o.y;
+            if (q + 2 < lim) arr[q + 2] = o.z;
+          }
+        }
+      }
+      carry += total;
+    }
+  } else {
+    block_scan_array(arr, n, sh, false);
+  }
+}
+
+__global__ __launch_bounds__(256) void nb_scatter_kernel(const float* __restrict__ s, NbWs W) {
+  const int b = blockIdx.y;
+  int off, n;
+  int64_t base;
+  support_range(W, b, off, n, base);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const CloudGrid G = W.grids[b];
+  const float* P = s + ((int64_t)off + i) * 3;
+  const float x = P[0], y = P[1], z = P[2];
+  const int c = cell_of(G, x, y, z);
+  const int pos = W.cell_start[base + c] + atomicAdd(&W.cell_fill[base + c], 1);
+  W.recs[off + pos] = make_float4(x, y, z, __int_as_float(off + i));
 }
 
 // Work list for the KPConv gather out of a built grid: the stacked support rows sorted by (cloud, cell, row) -- the
@@ -168,8 +281,14 @@ __global__ __launch_bounds__(TPB) void nb_cell_order_kernel(NbWs W, int B, int* 
   const int ncell = G.dims[0] * G.dims[1] * G.dims[2];
   const int* cstart = W.cell_start + G.cell_base;
   constexpr int CO_REG = 16;      // rows of a cell sorted in registers (a cell of the conv grid holds about a dozen)
-  for (int c = blockIdx.y * TPB + tid; c < ncell; c += gridDim.y * TPB) {      // (a cloud's cells over gridDim.y workgroups)
-    const int beg = cstart[c], end = cstart[c + 1], m = end - beg;
+  const int lane = tid & 63;
+  for (int c0 = blockIdx.y * TPB; c0 < ncell; c0 += gridDim.y * TPB) {      // (a cloud's cells over gridDim.y workgroups)
+    const int c = c0 + tid;
+    int beg = 0, m = 0;
+    if (c < ncell) {
+      beg = cstart[c];
+      m = cstart[c + 1] - beg;
+    }
     if (m <= CO_REG) {
       // all loads, then the rank of every row among the cell's rows, then all stores: no dependent round trips
       int v[CO_REG];
@@ -182,15 +301,23 @@ __global__ __launch_bounds__(TPB) void nb_cell_order_kernel(NbWs W, int B, int* 
         for (int j = 0; j < CO_REG; ++j) rank += v[j] < v[i] ? 1 : 0;      // rows are distinct; the fillers are largest
         if (i < m) order[off + beg + rank] = v[i];
       }
-    } else {
-      for (int j = beg; j < end; ++j) {
-        const int v = __float_as_int(W.recs[off + j].w);
-        int k = j;
-        while (k > beg && order[off + k - 1] > v) {
-          order[off + k] = order[off + k - 1];
-          --k;
+    }
+    // larger cells (corners of a room: a few per cloud), one at a time by the whole wavefront: a lane per row, ranks
+    // by shuffles (one thread walking such a cell with dependent loads and stores took 25 us -- the kernel's time)
+    unsigned long long big = __ballot(m > CO_REG);
+    while (big) {
+      const int src = __ffsll((long long)big) - 1;
+      big &= big - 1;
+      const int cb = __shfl(beg, src), cm = __shfl(m, src);
+      for (int r0 = 0; r0 < cm; r0 += 64) {
+        const int mine = r0 + lane < cm ? __float_as_int(W.recs[off + cb + r0 + lane].w) : 0x7fffffff;
+        int rank = 0;
+        for (int t0 = 0; t0 < cm; t0 += 64) {
+          const int other = t0 + lane < cm ? __float_as_int(W.recs[off + cb + t0 + lane].w) : 0x7fffffff;
+          const int lim = min(64, cm - t0);
+          for (int j = 0; j < lim; ++j) rank += __shfl(other, j) < mine ? 1 : 0;
         }
-        order[off + k] = v;
+        if (r0 + lane < cm) order[off + cb + rank] = mine;
       }
     }
   }
@@ -341,6 +468,29 @@ extern "C" int64_t mvk_radius_neighbors_workspace(int64_t Nq, int64_t Ns, int B)
 
 namespace {
 
+// 0 = one workgroup per cloud always; otherwise the multi-workgroup build from this many supports (longest cloud, or the
+// capacity of the device-lens entry) on
+int64_t multi_build_min() {
+  static const int64_t v = [] {
+    const char* e = getenv("MVK_NB_MULTI_MIN");
+    return e ? (int64_t)atoll(e) : (int64_t)4096;
+  }();
+  return v;
+}
+
+void launch_build(const float* s, const NbWs& W, float radius, int B, int64_t maxn, hipStream_t st) {
+  const int64_t mm = multi_build_min();
+  if (mm <= 0 || maxn < mm) {
+    hipLaunchKernelGGL(nb_build_kernel, dim3(B), dim3(TPB), 0, st, s, W, radius, 0);
+    return;
+  }
+  const dim3 g((unsigned)((maxn + 255) / 256), B);
+  hipLaunchKernelGGL(nb_build_kernel, dim3(B), dim3(TPB), 0, st, s, W, radius, 1);
+  hipLaunchKernelGGL(nb_hist_kernel, g, dim3(256), 0, st, s, W);
+  hipLaunchKernelGGL(nb_scan_kernel, dim3(B), dim3(TPB), 0, st, W);
+  hipLaunchKernelGGL(nb_scatter_kernel, g, dim3(256), 0, st, s, W);
+}
+
 // Common body. status_dev == nullptr: classic two-phase contract (synchronises, reports through
 // width_host). status_dev != nullptr: enqueue only -- the max row count / overflow flag are folded into
 // status_dev[0] / status_dev[1] on the device. reuse_grid: the workspace still holds the grid built by
@@ -391,7 +541,11 @@ int nb_run(const float* q, int64_t Nq, const float* s, int64_t Ns, const int32_t
   }
 
   MVK_CHECK_HIP(hipMemcpyAsync(hdr, hdr_h, sizeof(int) * (4 + 2 * (B + 1)), hipMemcpyHostToDevice, st));
-  if (!reuse_grid) hipLaunchKernelGGL(nb_build_kernel, dim3(B), dim3(TPB), 0, st, s, W, radius);
+  if (!reuse_grid) {
+    int64_t maxn = 0;
+    for (int b = 0; b < B; ++b) maxn = s_lens_host[b] > maxn ? s_lens_host[b] : maxn;
+    launch_build(s, W, radius, B, maxn, st);
+  }
   if (out == nullptr) {
     MVK_REQUIRE(width_host != nullptr && status_dev == nullptr, "neighbors: phase 1 needs width_host");
     if (Nq > 0)
@@ -468,7 +622,7 @@ extern "C" int mvk_radius_neighbors_dev(const float* q, int64_t Nq_cap, const fl
   W.overflow = status_dev + 1;
   W.q_lens = q_lens_dev;       // the kernels derive the offsets themselves (was: a one-thread launch per search)
   W.s_lens = s_lens_dev;
-  if (!reuse_grid) hipLaunchKernelGGL(nb_build_kernel, dim3(B), dim3(TPB), 0, st, s, W, radius);
+  if (!reuse_grid) launch_build(s, W, radius, B, Ns_cap, st);
   if (width <= 64)
     hipLaunchKernelGGL((nb_query_kernel<true, 256>), dim3((unsigned)Nq_cap), dim3(64), 0, st, q, W, B, radius,
                        (int64_t)shadow, out, width);

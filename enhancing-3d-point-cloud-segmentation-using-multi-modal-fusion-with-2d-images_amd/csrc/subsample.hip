@@ -280,11 +280,9 @@ __global__ __launch_bounds__(256) void sub_prep_kernel(const int* __restrict__ o
   if (i < table_size(n)) {
     W.hkey[(int64_t)off * 4 + i] = EMPTY_KEY;
     W.hfirst[(int64_t)off * 4 + i] = 0x7fffffff;
+    W.hvox[(int64_t)off * 4 + i] = 0;          // until phase 3b: the number of points of the slot's voxel
   }
-  if (i < (unsigned)n) {
-    W.vcount[off + i] = 0;
-    W.vcursor[off + i] = 0;
-  }
+  if (i < (unsigned)n) W.vcursor[off + i] = 0;
 }
 
 // phases 0-1: grid orientation (device-lens entry), min / max corner
@@ -317,12 +315,22 @@ __global__ __launch_bounds__(256) void sub_minmax_kernel(const float* __restrict
       q[c] = fmaxf(q[c], __shfl_xor(q[c], o));
     }
   }
-  if ((threadIdx.x & 63) == 0 && blockIdx.x * 256 + (threadIdx.x & ~63) < n) {
+  // one atomic per corner component and WORKGROUP (same-address atomics retire one after the other in L2: with one per
+  // wavefront the 1 800 of a 19 464-point cloud were the kernel's 17 us)
+  __shared__ float red[6][4];
+  if ((threadIdx.x & 63) == 0) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      atomicMin(&W.bbox[b * 6 + c], f2ord(p[c]));
-      atomicMax(&W.bbox[b * 6 + 3 + c], f2ord(q[c]));
+      red[c][threadIdx.x >> 6] = p[c];
+      red[3 + c][threadIdx.x >> 6] = q[c];
     }
+  }
+  __syncthreads();
+  if (threadIdx.x < 6 && blockIdx.x * 256 < n) {
+    const int c = threadIdx.x;
+    const float a = red[c][0], b1 = red[c][1], c2 = red[c][2], d3 = red[c][3];
+    if (c < 3) atomicMin(&W.bbox[b * 6 + c], f2ord(fminf(fminf(a, b1), fminf(c2, d3))));
+    else atomicMax(&W.bbox[b * 6 + c], f2ord(fmaxf(fmaxf(a, b1), fmaxf(c2, d3))));
   }
 }
 
@@ -358,6 +366,7 @@ __global__ __launch_bounds__(256) void sub_insert_kernel(const float* __restrict
   }
   W.slot[off + i] = (int)h;
   atomicMin(&W.hfirst[(int64_t)off * 4 + h], i);
+  atomicAdd(&W.hvox[(int64_t)off * 4 + h], 1);   // phase 4 (points per voxel) rides along: counted per slot
 }
 
 // phase 3a: first-occurrence flags and their count per chunk
@@ -378,7 +387,8 @@ __global__ __launch_bounds__(256) void sub_flag_kernel(const int* __restrict__ o
   if (threadIdx.x == 0) W.wgcnt[(int64_t)b * W.chunks + blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// phase 3b: voxel ids in first-occurrence order (exclusive prefix of the flags: chunk base + scan inside the chunk)
+// phases 3b, 4: voxel ids in first-occurrence order (exclusive prefix of the flags: chunk base + scan inside the chunk),
+// the voxel's point count from its slot
 __global__ __launch_bounds__(256) void sub_vox_kernel(const int* __restrict__ offs, SubWs W) {
   __shared__ int red[256];
   __shared__ int wsum[4];
@@ -421,18 +431,10 @@ __global__ __launch_bounds__(256) void sub_vox_kernel(const int* __restrict__ of
   if (f) {
     const int vid = base + wbase + before;
     const int sl = W.slot[off + i];
+    W.vcount[off + vid] = W.hvox[(int64_t)off * 4 + sl];
     W.hvox[(int64_t)off * 4 + sl] = vid;
     W.vkey[off + vid] = W.hkey[(int64_t)off * 4 + sl];
   }
-}
-
-// phase 4: points per voxel
-__global__ __launch_bounds__(256) void sub_count_kernel(const int* __restrict__ offs, SubWs W) {
-  const int b = blockIdx.y;
-  int off, n;
-  cloud_range(W, offs, b, off, n);
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) atomicAdd(&W.vcount[off + W.hvox[(int64_t)off * 4 + W.slot[off + i]]], 1);
 }
 
 // phase 5: segment offsets (one workgroup per cloud: a scan over the cloud's voxels)
@@ -462,13 +464,15 @@ __global__ __launch_bounds__(256) void sub_scatter_kernel(const int* __restrict_
 }
 
 // phase 7: one thread per voxel
-__global__ __launch_bounds__(256) void sub_sums_kernel(const float* __restrict__ pts, const float* __restrict__ feats, int fdim,
+// (one wavefront per workgroup: a voxel is a chain of dependent scattered loads, and 5 000 voxels in 256-thread
+// workgroups sit on 20 compute units)
+__global__ __launch_bounds__(64) void sub_sums_kernel(const float* __restrict__ pts, const float* __restrict__ feats, int fdim,
                                                        const int* __restrict__ labels, int ldim,
                                                        const int* __restrict__ offs, SubWs W, Schedule sched) {
   const int b = blockIdx.y;
   int off, n;
   cloud_range(W, offs, b, off, n);
-  const int v = blockIdx.x * 256 + threadIdx.x;
+  const int v = blockIdx.x * 64 + threadIdx.x;
   if (v >= W.mdev[b]) return;
   const float* P = (W.rot_dev ? W.rot_pts : pts) + (int64_t)off * 3;
   const float* F = fdim > 0 ? feats + (int64_t)off * fdim : nullptr;
@@ -955,10 +959,9 @@ void launch_front_end(const float* pts, const float* feats, int fdim, const int3
   hipLaunchKernelGGL(sub_insert_kernel, g, blk, 0, st, pts, offs_d, dl, W);
   hipLaunchKernelGGL(sub_flag_kernel, g, blk, 0, st, offs_d, W);
   hipLaunchKernelGGL(sub_vox_kernel, g, blk, 0, st, offs_d, W);
-  hipLaunchKernelGGL(sub_count_kernel, g, blk, 0, st, offs_d, W);
   hipLaunchKernelGGL(sub_offsets_kernel, dim3(B), dim3(TPB), 0, st, offs_d, W);
   hipLaunchKernelGGL(sub_scatter_kernel, g, blk, 0, st, offs_d, W);
-  hipLaunchKernelGGL(sub_sums_kernel, g, blk, 0, st, pts, feats, fdim, labels, ldim, offs_d, W, sched);
+  hipLaunchKernelGGL(sub_sums_kernel, dim3((unsigned)((maxn + 63) / 64), g.y), dim3(64), 0, st, pts, feats, fdim, labels, ldim, offs_d, W, sched);
 }
 
 }  // namespace

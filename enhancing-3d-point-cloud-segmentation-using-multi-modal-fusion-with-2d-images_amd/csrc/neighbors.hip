@@ -282,8 +282,12 @@ __global__ __launch_bounds__(TPB) void nb_cell_order_kernel(NbWs W, int B, int* 
   const int* cstart = W.cell_start + G.cell_base;
   constexpr int CO_REG = 16;      // rows of a cell sorted in registers (a cell of the conv grid holds about a dozen)
   const int lane = tid & 63;
-  for (int c0 = blockIdx.y * TPB; c0 < ncell; c0 += gridDim.y * TPB) {      // (a cloud's cells over gridDim.y workgroups)
-    const int c = c0 + tid;
+  // cells are dealt to the wavefronts of the cloud's workgroups round-robin (cell c -> wavefront c mod NW): the big cells
+  // of a scan lie along its walls, i.e. in runs of the x-fastest cell order, and a wavefront works them off one after the
+  // other -- with 64 consecutive cells per wavefront a few wavefronts held most of them (37 us; 7 us without big cells)
+  const int NW = gridDim.y * (blockDim.x >> 6), gw = blockIdx.y * (blockDim.x >> 6) + (tid >> 6);
+  for (int c0 = 0; c0 < ncell; c0 += 64 * NW) {
+    const int c = c0 + lane * NW + gw;
     int beg = 0, m = 0;
     if (c < ncell) {
       beg = cstart[c];
@@ -302,27 +306,51 @@ __global__ __launch_bounds__(TPB) void nb_cell_order_kernel(NbWs W, int B, int* 
         if (i < m) order[off + beg + rank] = v[i];
       }
     }
-    // larger cells (corners of a room: a few per cloud), one at a time by the whole wavefront: a lane per row, ranks
-    // by shuffles (one thread walking such a cell with dependent loads and stores took 25 us -- the kernel's time)
+    // larger cells (a sixth of the occupied cells of a room scan hold 17-33 rows), by the whole wavefront: a lane per row,
+    // the rank of a row = how many rows of the cell are smaller, the others read lane by lane (v_readlane: the lane
+    // number is wave-uniform). Four cells at a time so that their loads are in flight together -- one cell after the
+    // other, each waiting for its own load and ranking through ds_bpermute, was 51 of the kernel's 59 us at level 0.
     unsigned long long big = __ballot(m > CO_REG);
     while (big) {
-      const int src = __ffsll((long long)big) - 1;
-      big &= big - 1;
-      const int cb = __shfl(beg, src), cm = __shfl(m, src);
-      for (int r0 = 0; r0 < cm; r0 += 64) {
-        const int mine = r0 + lane < cm ? __float_as_int(W.recs[off + cb + r0 + lane].w) : 0x7fffffff;
-        int rank = 0;
-        for (int t0 = 0; t0 < cm; t0 += 64) {
-          const int other = t0 + lane < cm ? __float_as_int(W.recs[off + cb + t0 + lane].w) : 0x7fffffff;
-          const int lim = min(64, cm - t0);
-          for (int j = 0; j < lim; ++j) rank += __shfl(other, j) < mine ? 1 : 0;
+      int cb[4], cm[4], mine[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        cb[k] = 0;
+        cm[k] = 0;
+        if (big) {
+          const int src = __ffsll((long long)big) - 1;
+          big &= big - 1;
+          cb[k] = __builtin_amdgcn_readfirstlane(__shfl(beg, src));
+          cm[k] = __builtin_amdgcn_readfirstlane(__shfl(m, src));
         }
-        if (r0 + lane < cm) order[off + cb + rank] = mine;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        mine[k] = lane < cm[k] ? __float_as_int(W.recs[off + cb[k] + lane].w) : 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (cm[k] == 0) continue;
+        if (cm[k] <= 64) {
+          int rank = 0;
+          for (int j = 0; j < cm[k]; ++j) rank += __builtin_amdgcn_readlane(mine[k], j) < mine[k] ? 1 : 0;
+          if (lane < cm[k]) order[off + cb[k] + rank] = mine[k];
+        } else {                 // more than 64 rows in a cell: 64 at a time against all
+          for (int r0 = 0; r0 < cm[k]; r0 += 64) {
+            const int me = r0 + lane < cm[k] ? __float_as_int(W.recs[off + cb[k] + r0 + lane].w) : 0x7fffffff;
+            int rank = 0;
+            for (int t0 = 0; t0 < cm[k]; t0 += 64) {
+              const int other = t0 + lane < cm[k] ? __float_as_int(W.recs[off + cb[k] + t0 + lane].w) : 0x7fffffff;
+              const int lim = min(64, cm[k] - t0);
+              for (int j = 0; j < lim; ++j) rank += __builtin_amdgcn_readlane(other, j) < me ? 1 : 0;
+            }
+            if (r0 + lane < cm[k]) order[off + cb[k] + rank] = me;
+          }
+        }
       }
     }
   }
   if (b == B - 1 && blockIdx.y == 0)
-    for (int64_t i = (int64_t)off + n + tid; i < order_cap; i += TPB) order[i] = (int)i;
+    for (int64_t i = (int64_t)off + n + tid; i < order_cap; i += blockDim.x) order[i] = (int)i;
 }
 
 // max-reduction into one word shared by every query wave: read first, most waves then skip the atomic
@@ -653,8 +681,10 @@ extern "C" int mvk_neighbors_cell_order(int64_t Ns, int B, const int32_t* s_lens
   W.s_lens = s_lens_dev;
   // a thread's cells are chains of dependent loads (cell range -> records -> stores): one workgroup per cloud took
   // 150 us on the level-0 grid of a 19 464-point sphere (15 cells per thread, one after the other)
-  const unsigned chunks = (unsigned)((cell_cap(Ns) / B + TPB - 1) / TPB < 32 ? (cell_cap(Ns) / B + TPB - 1) / TPB : 32);
-  hipLaunchKernelGGL(nb_cell_order_kernel, dim3(B, chunks ? chunks : 1), dim3(TPB), 0, (hipStream_t)stream, W, B, order_out,
+  // (256-thread workgroups: the cells of a 19 464-point cloud are 10 k, i.e. ten compute units with 1024 threads each)
+  const int64_t want = (cell_cap(Ns) / B + 255) / 256;
+  const unsigned chunks = (unsigned)(want < 256 ? want : 256);
+  hipLaunchKernelGGL(nb_cell_order_kernel, dim3(B, chunks ? chunks : 1), dim3(256), 0, (hipStream_t)stream, W, B, order_out,
                      order_cap);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;

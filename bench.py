@@ -400,10 +400,20 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
 
     ops.set_row_counts(statics[0].valid)
     ops.zero_arena_high_water(reset=True)
-    for _ in range(2):                          # momentum buffers, MIOpen / hipBLASLt plans for the padded shapes
+    for it in range(2):                         # momentum buffers, MIOpen / hipBLASLt plans for the padded shapes
         opt.zero_grad(set_to_none=True)
+        if it == 1 and os.environ.get("MVK_BENCH_DIAG") == "arena":   # development: who asks for zero-filled memory
+            ops._ARENA["log"] = []
         net_step_captured(net, statics[0], cfg, params, opt, reducer)
     torch.cuda.synchronize()
+    if ops._ARENA.get("log"):
+        import collections
+        agg = collections.Counter()
+        for nbytes, shape, who in ops._ARENA["log"]:
+            agg[(who, shape)] += nbytes
+        for (who, shape), nb in agg.most_common(40):
+            print("DIAG arena %8.2f MB  %-28s %s" % (nb / 1e6, who, shape), file=sys.stderr)
+        ops._ARENA["log"] = None
     ops.step_begin()
     if os.environ.get("MVK_ZERO_ARENA", "1") == "1":
         # one fill per replay instead of ~100 (split-K outputs, scatter targets): sized from the warm-up
@@ -458,20 +468,23 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             if work:
                 side_work()
 
+        skip = os.environ.get("MVK_BENCH_SKIP", "").split(",")   # development (timing only, the step's inputs go stale):
+                                                                   # leave "enc" / "chain" / "fa" out of the side branches
+
         def side_work():
-            if enc is not None:
+            if enc is not None and "enc" not in skip:
                 with torch.cuda.stream(enc_stream):
                     if in_graph_inputs:       # the views of batch k+1 enter on this branch, not by eager launches on the network's queue
                         enc_in.copy_(torch.stack(staged['images'], 0))
                     other.feature_2d.copy_(encode(enc_in))
-            if use_chain:
+            if use_chain and "chain" not in skip:
                 with torch.cuda.stream(build_stream):
                     if in_graph_inputs:       # this step's grid orientations: a copy node reading the pinned draw of the host
                         chains[1 - statics.index(static)].upload_rotations()
                     chains[1 - statics.index(static)].build(other)
                     for _ in range(int(os.environ.get("MVK_BENCH_DUMMY_LAUNCHES", "0"))):   # development: what is one more
                         _DUMMY.setdefault(dev, torch.zeros(64, device=dev)).add_(1.0)        # tiny launch on a side branch worth?
-            if fa_ahead:        # needs both: the encoder's features and the chain's 3-NN pixels of batch k+1
+            if fa_ahead and "fa" not in skip:        # needs both: the encoder's features and the chain's 3-NN pixels of batch k+1
                 enc_stream.wait_stream(build_stream)
                 with torch.cuda.stream(enc_stream):
                     if stack_ahead:     # the network's input features in one go: [feature_3d | lifted features]

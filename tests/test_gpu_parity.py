@@ -580,8 +580,14 @@ def test_cell_order_of_the_neighbour_search_is_a_sorted_permutation(ops):
     again = ops.neighbors_cell_order(len(pts), len(pts), 3, device=P.device)
     o = out.cpu().numpy()
     assert np.array_equal(o[len(pts):], np.arange(len(pts), cap)) and np.array_equal(o[:len(pts)], again.cpu().numpy())
+    _check_cell_order(o, pts, lens, r)
+
+
+def _check_cell_order(o, pts, lens, r):
     off = 0
     for n in lens:
+        if n == 0:
+            continue
         seg = o[off:off + n].astype(np.int64)
         assert np.array_equal(np.sort(seg), np.arange(off, off + n))
         p = pts[seg]
@@ -593,6 +599,65 @@ def test_cell_order_of_the_neighbour_search_is_a_sorted_permutation(ops):
         key = lin * (1 << 32) + seg
         assert np.all(np.diff(key) > 0)
         off += n
+
+
+def test_cell_order_with_crowded_cells(ops):
+    """Cells of 17-64 rows (ranked by a wavefront, one lane per row) and of more than 64 rows (64 at a time against all),
+    in runs of neighbouring cells and next to empty ones, two clouds of which the second starts mid-wavefront."""
+    rng = np.random.default_rng(78)
+    r = 0.1
+    blobs = []
+    for k, n in enumerate((17, 33, 64, 65, 200, 31, 16, 129)):              # rows per crowded cell
+        centre = np.asarray([0.05 + 0.1003 * k, 0.05, 0.05], np.float32)     # neighbouring cells along x
+        blobs.append(centre + (rng.random((n, 3)).astype(np.float32) - 0.5) * 0.02)
+    sparse = (rng.random((3000, 3)) * [2.0, 1.0, 0.5]).astype(np.float32)
+    a = np.concatenate(blobs + [sparse])
+    a = a[rng.permutation(len(a))]
+    b = np.concatenate([blobs[4] + 3.0, (rng.random((700, 3)) * 0.7).astype(np.float32) + 3.0])
+    b = b[rng.permutation(len(b))]
+    pts = np.ascontiguousarray(np.concatenate([a, b]), np.float32)
+    lens = np.asarray([len(a), len(b)], np.int32)
+    P = T(pts)
+    ops.radius_neighbors_batch(P, P, lens, lens, r, limit=8)
+    o = ops.neighbors_cell_order(len(pts), len(pts), 2, device=P.device).cpu().numpy()
+    _check_cell_order(o, pts, lens, r)
+
+
+def test_neighbors_grid_of_more_than_one_scan_pass(ops):
+    """A support grid of more than 65 536 cells (the scan kernel of the multi-workgroup build takes 65 536 cells per pass
+    of its workgroup) beside a small cloud and an empty one: rows vs the CPU port, cell order a sorted permutation."""
+    from oracle import cport
+    rng = np.random.default_rng(79)
+    big = (rng.random((30000, 3)) * [3.0, 3.0, 1.3]).astype(np.float32)      # 0.05 cells: 60 x 60 x 26 = 93 600
+    small = (rng.random((900, 3)) * 0.4).astype(np.float32) + 7.0
+    s = np.concatenate([big, small])
+    sl = np.asarray([30000, 0, 900], np.int32)
+    q = np.concatenate([big[:3000], small[:200]])
+    ql = np.asarray([3000, 0, 200], np.int32)
+    r = 0.05
+    want = cport.radius_neighbors_batch(q, s, ql, sl, r)
+    got = ops.radius_neighbors_batch(T(q), T(s), ql, sl, r).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    S = T(s)
+    ops.radius_neighbors_batch(S, S, sl, sl, r, limit=4)
+    o = ops.neighbors_cell_order(len(s), len(s), 3, device=S.device).cpu().numpy()
+    _check_cell_order(o, s, sl, r)
+
+
+def test_input_kernels_on_both_paths_at_every_size():
+    """The subsampling and neighbour suites once more in child processes with the multi-workgroup front ends forced for
+    every cloud (thresholds 1: empty, one-point and ragged clouds included) and switched off (0): the two paths of
+    csrc/subsample.hip and csrc/neighbors.hip give the same bits as the goldens and the CPU port whatever the size."""
+    import subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for thr in ("1", "0"):
+        env = dict(os.environ, MVK_SUB_MULTI_MIN=thr, MVK_NB_MULTI_MIN=thr, MVK_PARITY_LOG=os.devnull)
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                            os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_golden_pipeline.py"),
+                            "-k", "(subsample or neighbors or cell_order or pyramid or scene_load) and not both_paths"],
+                           env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, "thresholds %s:\n%s" % (thr, (r.stdout + r.stderr)[-3000:])
+        assert " passed" in r.stdout and "failed" not in r.stdout
 
 
 @pytest.mark.parametrize("name,modulated", [("g4_kpconv_deform", False), ("g4_kpconv_deform_mod", True)])

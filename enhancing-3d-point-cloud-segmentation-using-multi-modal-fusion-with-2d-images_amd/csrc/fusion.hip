@@ -199,25 +199,51 @@ struct PrunedWs {
   int* nvalid;     // [1]
 };
 
-__global__ void pk_count_kernel(const float* __restrict__ q, int64_t nq, const double* __restrict__ keys,
-                                const uint8_t* __restrict__ kvalid, int64_t nk, PrunedWs ws) {
+// One counter update per wavefront and distinct cell, not per element: neighbouring pixels unproject into the same 10 cm
+// cell (a cell close to a camera holds thousands of keys), and returning atomics on one address retire one after the other
+// -- with an atomic per key the hottest cell set the kernel's time (177 us for 96 000 keys of five views, 25 us for three
+// views). The lanes of a wavefront are grouped by cell with ballots first (no memory traffic), then every group's first
+// lane adds the group's size once and the others take their rank from its return value.
+__global__ __launch_bounds__(256) void pk_count_kernel(const float* __restrict__ q, int64_t nq, const double* __restrict__ keys,
+                                                       const uint8_t* __restrict__ kvalid, int64_t nk, PrunedWs ws) {
   const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= nq + nk) return;
-  int set, c;
-  if (e < nq) {
-    set = 0;
-    c = morton_cell(q[e * 3], q[e * 3 + 1], q[e * 3 + 2]);
-  } else {
-    const int64_t j = e - nq;
-    if (kvalid && !kvalid[j]) {
-      ws.cell[e] = -1;
-      return;
+  const int lane = threadIdx.x & 63;
+  bool valid = e < nq + nk;
+  int key = -1;                                  // set * PNC + cell
+  if (valid) {
+    if (e < nq) {
+      key = morton_cell(q[e * 3], q[e * 3 + 1], q[e * 3 + 2]);
+    } else {
+      const int64_t j = e - nq;
+      if (kvalid && !kvalid[j]) {
+        ws.cell[e] = -1;
+        valid = false;
+      } else {
+        key = PNC + morton_cell((float)keys[j * 3], (float)keys[j * 3 + 1], (float)keys[j * 3 + 2]);
+      }
     }
-    set = 1;
-    c = morton_cell((float)keys[j * 3], (float)keys[j * 3 + 1], (float)keys[j * 3 + 2]);
   }
-  ws.cell[e] = c;
-  ws.rank[e] = atomicAdd(ws.cnt + set * PNC + c, 1);
+  int leader = lane, before = 0, group = 1;
+  unsigned long long todo = __ballot(valid);
+  while (todo) {
+    const int first = __ffsll((long long)todo) - 1;
+    const int k0 = __shfl(key, first);
+    const bool mine = valid && key == k0;
+    const unsigned long long same = __ballot(mine);
+    if (mine) {
+      leader = first;
+      before = __popcll(same & ((1ull << lane) - 1ull));
+      group = __popcll(same);
+    }
+    todo &= ~same;
+  }
+  int base = 0;
+  if (valid && leader == lane) base = atomicAdd(ws.cnt + key, group);
+  base = __shfl(base, leader);
+  if (valid) {
+    ws.cell[e] = key >= PNC ? key - PNC : key;
+    ws.rank[e] = base + before;
+  }
 }
 
 // exclusive scan of the PNC cell counts of one set (blockIdx.x), 1024 threads x 32 cells

@@ -7,7 +7,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/benc
 F=$(ls $O/kt/*/*_kernel_trace.csv | head -1)
 python3 $R/tools/trace_steady.py $F 10 90 > $O/${TAG}_steady_state_per_step.txt
 python3 $R/tools/trace_by_grid.py $F kpconv_gather_vec > $O/${TAG}_gather_by_grid.txt
-for k in kpconv_lane_channel gemm_f32_mfma subsample_cloud_kernel nb_query_kernel nb_build_kernel bn_finish_apply sgd_clip_kernel; do
+for k in kpconv_lane_channel gemm_f32_mfma subsample_cloud_kernel sub_ nb_query_kernel nb_build_kernel nb_hist_kernel nb_scan_kernel nb_scatter_kernel nb_cell_order_kernel rev_fill_kernel pk_count_kernel knn_pruned_kernel bn_finish_apply sgd_clip_kernel; do
   echo "== $k"; python3 $R/tools/trace_by_grid.py $F $k | head -24
 done > $O/${TAG}_kernels_by_grid.txt
 python3 $R/tools/trace_queues.py $F > $O/${TAG}_hw_queues_per_step.txt 2>&1
@@ -53,4 +53,10 @@ cd $R && python3 bench.py --spheres 5 --views 5 --steps 20 --warmup 3 --no-cpu-b
   for e in X=0 MVK_REVERSE_DX=0; do echo -n "8 spheres, $e: "; env $e python3 $R/bench.py --spheres 8 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done; } > $O/${TAG}_modes.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 $R/tools/park_probe.hip -o /tmp/park_probe 2>/dev/null && timeout -k 10 120 /tmp/park_probe > $O/${TAG}_park_probe.txt 2>&1
 bash $R/tools/env_knobs.sh > $O/${TAG}_env_knobs.txt 2>&1
+# 9. (round 4) what each side branch costs the step (pieces left out of the captured step: timing only), the input kernels'
+#    one-workgroup paths against the multi-workgroup front ends, and the level-0 neighbour kernels stand-alone
+cd $R
+{ for e in X=0 MVK_BENCH_SKIP=enc MVK_BENCH_SKIP=chain MVK_BENCH_SKIP=fa MVK_BENCH_SKIP=enc,chain,fa MVK_BENCH_SKIP=chain,fa MVK_BENCH_SKIP=enc,fa "MVK_SUB_MULTI_MIN=0 MVK_NB_MULTI_MIN=0" X=0; do echo -n "$e: "; env $e python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done;
+  for e in X=0 MVK_BENCH_SKIP=enc MVK_BENCH_SKIP=chain MVK_BENCH_SKIP=enc,chain,fa "MVK_SUB_MULTI_MIN=0 MVK_NB_MULTI_MIN=0"; do echo -n "5 spheres x 5 views, $e: "; env $e python3 $R/bench.py --spheres 5 --views 5 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done; } > $O/${TAG}_side_branches.txt 2>&1
+bash $R/tools/nb_probe.sh 0 > $O/${TAG}_nb_probe.txt 2>&1
 ls -la $O

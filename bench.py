@@ -605,7 +605,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                 enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
             ta = time.perf_counter()
             replays[slot][0]()
-            host = torch.empty(4, dtype=torch.int32).pin_memory() if len(pending) < 4 and os.environ.get("MVK_BENCH_STATUS_COPY", "1") == "1" else None
+            host = torch.empty(4, dtype=torch.int32).pin_memory() if len(pending) < 4 else None
             if host is not None:
                 host.copy_(chains[slot ^ 1].status4, non_blocking=True)
                 ev = torch.cuda.Event()

@@ -474,6 +474,118 @@ __global__ __launch_bounds__(64) void nb_query_kernel(const float* __restrict__ 
   for (int c = n + lane; c < width; c += 64) out[i * width + c] = (int)Ns;  // neighbors.cpp:324
 }
 
+// The same search with WV wavefronts per query, for the wide lists of the deformable levels (hundreds of in-range supports
+// per query, the whole LDS list of 1024 at the coarsest ones). One wavefront ranks its list by counting in
+// n * n / 64 steps: with n = 1000 that is 300 us for ONE query, and a level of 128 queries took as long as one of 2 304
+// -- the launch lasted as long as its slowest wavefront. Here the candidates and the ranking are dealt over 64 * WV
+// lanes (list positions from an LDS counter, one update per wavefront and round); rows come out identical: the order
+// of the list before the ranking is the only thing that differs, and (d2, index) is a total order.
+template <int WV>
+__global__ __launch_bounds__(64 * WV) void nb_query_wide_kernel(const float* __restrict__ q, NbWs W, int B, float radius,
+                                                                int64_t Ns, int* __restrict__ out, int width) {
+  constexpr int CAP = LIST_CAP, T = 64 * WV;
+  __shared__ float ld2[CAP];
+  __shared__ int lidx[CAP];
+  __shared__ int ln;
+  const int64_t i = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  int b = 0, soff = 0;
+  bool padding;
+  if (W.q_lens) {
+    int qend = max(W.q_lens[0], 0);
+    while (b + 1 < B && i >= qend) {
+      soff += max(W.s_lens[b], 0);
+      ++b;
+      qend += max(W.q_lens[b], 0);
+    }
+    padding = i >= qend;
+  } else {
+    padding = i >= W.qoffs[B];
+    while (b + 1 < B && i >= W.qoffs[b + 1]) ++b;
+    soff = W.soffs[b];
+  }
+  if (padding) {
+    for (int c = tid; c < width; c += T) out[i * width + c] = (int)Ns;
+    return;
+  }
+  if (tid == 0) ln = 0;
+  const CloudGrid G = W.grids[b];
+  const int* cstart = W.cell_start + G.cell_base;
+  const float qx = q[i * 3], qy = q[i * 3 + 1], qz = q[i * 3 + 2];
+  const float r2 = radius * radius;
+  const float fx = floorf((qx - G.gmin[0]) / G.cell), fy = floorf((qy - G.gmin[1]) / G.cell),
+              fz = floorf((qz - G.gmin[2]) / G.cell);
+  int rs = 0, re = 0;
+  if (lane < 9 && fabsf(fx) < 4.0e6f && fabsf(fy) < 4.0e6f && fabsf(fz) < 4.0e6f) {
+    const int cx = (int)fx, cy = (int)fy + (lane % 3) - 1, cz = (int)fz + (lane / 3) - 1;
+    const int x0 = max(cx - 1, 0), x1 = min(cx + 1, G.dims[0] - 1);
+    if (cy >= 0 && cy < G.dims[1] && cz >= 0 && cz < G.dims[2] && x0 <= x1) {
+      const int row = (cz * G.dims[1] + cy) * G.dims[0];
+      rs = cstart[row + x0];
+      re = cstart[row + x1 + 1];
+    }
+  }
+  int len = re - rs, pre = len;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) {
+    int y = __shfl_up(pre, o);
+    if (lane >= o) pre += y;
+  }
+  const int total = __shfl(pre, 8);
+  __syncthreads();                                   // ln = 0 is visible
+  for (int c0 = wv * 64; c0 < total; c0 += T) {      // (wave-uniform trip count: the shuffles below stay convergent)
+    const int c = c0 + lane;
+    bool hit = false;
+    float d2 = 0.f;
+    int idx = 0, rec = 0;
+#pragma unroll
+    for (int r = 0; r < 9; ++r) {
+      const int pend = __shfl(pre, r), plen = __shfl(len, r), pstart = __shfl(rs, r);
+      if (c < pend && c >= pend - plen) rec = pstart + (c - (pend - plen));
+    }
+    if (c < total) {
+      const float4 p = W.recs[soff + rec];
+      const float ddx = qx - p.x, ddy = qy - p.y, ddz = qz - p.z;
+      d2 = 0.0f;
+      d2 += ddx * ddx;
+      d2 += ddy * ddy;
+      d2 += ddz * ddz;
+      hit = d2 < r2;
+      idx = __float_as_int(p.w);
+    }
+    const unsigned long long m = __ballot(hit);
+    if (m) {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(&ln, __popcll(m));
+      base = __shfl(base, 0);
+      const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+      if (hit && pos < CAP) {
+        ld2[pos] = d2;
+        lidx[pos] = idx;
+      }
+    }
+  }
+  __syncthreads();
+  int n = ln;
+  if (tid == 0) {
+    note_count(W.maxcount, n);
+    if (n > CAP) atomicExch(W.overflow, 1);
+  }
+  n = min(n, CAP);
+  for (int e = tid; e < n; e += T) {
+    const float d = ld2[e];
+    const int id = lidx[e];
+    int rank = 0;
+    for (int u = 0; u < n; ++u) {
+      const float du = ld2[u];
+      const int iu = lidx[u];
+      rank += (du < d) || (du == d && iu < id);
+    }
+    if (rank < width) out[i * width + rank] = id;
+  }
+  for (int c = n + tid; c < width; c += T) out[i * width + c] = (int)Ns;
+}
+
 struct Carver {
   char* p;
   template <typename T>
@@ -502,6 +614,15 @@ int64_t multi_build_min() {
   static const int64_t v = [] {
     const char* e = getenv("MVK_NB_MULTI_MIN");
     return e ? (int64_t)atoll(e) : (int64_t)4096;
+  }();
+  return v;
+}
+
+// rows of more than 64 columns: eight wavefronts per query (MVK_NB_WIDE_WAVES=1: one, as for the narrow rows)
+int wide_waves() {
+  static const int v = [] {
+    const char* e = getenv("MVK_NB_WIDE_WAVES");
+    return e ? atoi(e) : 8;
   }();
   return v;
 }
@@ -590,6 +711,8 @@ int nb_run(const float* q, int64_t Nq, const float* s, int64_t Ns, const int32_t
     // through the overflow flag like a row beyond LIST_CAP
     if (status_dev && width <= 64)
       hipLaunchKernelGGL((nb_query_kernel<true, 256>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width);
+    else if (wide_waves() > 1 && width > 64)
+      hipLaunchKernelGGL((nb_query_wide_kernel<8>), dim3((unsigned)Nq), dim3(512), 0, st, q, W, B, radius, Ns, out, width);
     else
       hipLaunchKernelGGL((nb_query_kernel<true, LIST_CAP>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width);
   }
@@ -653,6 +776,9 @@ extern "C" int mvk_radius_neighbors_dev(const float* q, int64_t Nq_cap, const fl
   if (!reuse_grid) launch_build(s, W, radius, B, Ns_cap, st);
   if (width <= 64)
     hipLaunchKernelGGL((nb_query_kernel<true, 256>), dim3((unsigned)Nq_cap), dim3(64), 0, st, q, W, B, radius,
+                       (int64_t)shadow, out, width);
+  else if (wide_waves() > 1)
+    hipLaunchKernelGGL((nb_query_wide_kernel<8>), dim3((unsigned)Nq_cap), dim3(512), 0, st, q, W, B, radius,
                        (int64_t)shadow, out, width);
   else
     hipLaunchKernelGGL((nb_query_kernel<true, LIST_CAP>), dim3((unsigned)Nq_cap), dim3(64), 0, st, q, W, B, radius,

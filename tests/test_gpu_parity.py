@@ -651,7 +651,8 @@ def test_input_kernels_on_both_paths_at_every_size():
     import subprocess, sys
     here = os.path.dirname(os.path.abspath(__file__))
     for thr in ("1", "0"):
-        env = dict(os.environ, MVK_SUB_MULTI_MIN=thr, MVK_NB_MULTI_MIN=thr, MVK_PARITY_LOG=os.devnull)
+        env = dict(os.environ, MVK_SUB_MULTI_MIN=thr, MVK_NB_MULTI_MIN=thr, MVK_PARITY_LOG=os.devnull,
+                   MVK_NB_WIDE_WAVES="8" if thr == "1" else "1")      # (rows of > 64 columns: eight wavefronts per query / one)
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                             os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_golden_pipeline.py"),
                             "-k", "(subsample or neighbors or cell_order or pyramid or scene_load) and not both_paths"],

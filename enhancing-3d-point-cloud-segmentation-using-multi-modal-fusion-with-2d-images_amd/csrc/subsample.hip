@@ -513,7 +513,10 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   float* vfeat = fdim > 0 ? W.vfeat + (int64_t)off * fdim : nullptr;
   if (W.multi) {            // phases 0-7 ran as launches over all points (sub_*_kernel): start at the iteration order
     M = W.mdev[b];
-    SUB_STAMP(0);
+    if (W.dbg && threadIdx.x == 0) {          // (the front end's phases are launches of their own: no time in this kernel)
+      const unsigned long long t = wall_clock64();
+      for (int k = 0; k < 7; ++k) W.dbg[blockIdx.x * 16 + k] = t;
+    }
   } else {
   if (W.rot_dev) {
     // ---- P0: the cloud in the random grid orientation (datasets/common.py:118), same arithmetic as
@@ -725,9 +728,11 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   // The epochs are inherently sequential (the final order depends on every rehash), and each one is a handful of
   // block-wide phases of atomics and scans over its live elements: with the per-epoch arrays in HBM every phase was a
   // round of L2 atomics / agent-scope loads (~1.5 us each way), ~8 us per epoch whatever its size, and a cloud of
-  // 5 000 voxels runs 10 of them. The epochs whose bucket count fits (nb <= L_NB: 13 ... 2357, eight of the ten for
-  // the level-0 cloud, all of them for the coarser levels) keep the arrays in LDS; tau moves to HBM once they outgrow it.
-  constexpr int L_NB = 2400;
+  // 5 000 voxels runs nine of them. The epochs whose bucket count fits (nb <= L_NB: 13 ... 5087, i.e. all nine of a
+  // 19 464-point level-0 cloud and everything below) keep the arrays in LDS (7 x 5 200 words = 146 of the CU's 160 KB: the
+  // kernel is one workgroup per cloud anyway; with 2 400 the last epoch of level 0 ran on HBM arrays and was 28 of the
+  // phase's 64 us); tau moves to HBM once the table outgrows it (clouds of more than 5 087 voxels).
+  constexpr int L_NB = 5200;
   __shared__ int l_tau[L_NB], l_posnew[L_NB], l_nextb[L_NB], l_tarr[L_NB], l_ft[L_NB], l_bcnt[L_NB], l_bhead[L_NB];
   int* tau_g = W.tau + off;
   int* posnew_g = W.posnew + off;

@@ -358,6 +358,19 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     # fusion: no trainable state upstream of that point): 12 launches / 0.17 ms off the network's chain
     fa_ahead = enc is not None and getattr(net, "fa_output_detached", False) and hasattr(syn, "DeviceInputChain") \
         and os.environ.get("MVK_DEVICE_CHAIN", "1") == "1" and os.environ.get("MVK_FA_AHEAD", "1") == "1"
+    # The frozen encoder for TWO upcoming batches in one call, every other step (MVK_ENCODER_PAIR=0: one batch per step):
+    # where the network reads the lifted features that were made ahead (fa_ahead) nothing in step k touches
+    # statics[k % 2].feature_2d, so the replay of static set 0 encodes the views of batches k+1 AND k+2 (into set 1's and
+    # its own feature map) and the replay of set 1 encodes nothing. Same work per batch, half the library launches per
+    # step and larger convolutions: 3 views 1.17 ms, 6 views 1.73 ms stand-alone (tools/encoder_probe.py).
+    # Measured: 3.93-3.97 -> 3.84-3.87 ms per step at one sphere x 3 views; 12.8 -> 13.0 ms at 5 spheres x 5 views (50 views
+    # per call gain nothing over 25 and the long call sits beside one step only) -- pairs up to 12 views per call.
+    enc_pair = fa_ahead and os.environ.get("MVK_ENCODER_PAIR", "1") == "1" and os.environ.get("MVK_DEVICE_CHAIN", "1") == "1" \
+        and 2 * int(enc_in.shape[0]) * int(enc_in.shape[1]) <= int(os.environ.get("MVK_ENCODER_PAIR_MAX_VIEWS", "12"))
+    if enc_pair:
+        enc_in2 = torch.cat([enc_in, enc_in], 0).clone()            # (2 b, nv, 3, h, w): batch k+1, batch k+2
+        for _ in range(2):
+            encode(enc_in2)
     if fa_ahead:
         lift = sys.modules[type(net).__module__].lift_2d_features
 
@@ -472,7 +485,17 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
                                                                    # leave "enc" / "chain" / "fa" out of the side branches
 
         def side_work():
-            if enc is not None and "enc" not in skip:
+            if enc is not None and "enc" not in skip and enc_pair:
+                if statics.index(static) == 0:      # this replay: the views of batches k+1 (set 1) and k+2 (set 0 again)
+                    with torch.cuda.stream(enc_stream):
+                        if in_graph_inputs:
+                            views = torch.stack(staged['images'], 0)
+                            enc_in2.copy_(torch.cat([views, views], 0))
+                        both = encode(enc_in2)
+                        half = both.shape[0] // 2
+                        other.feature_2d.copy_(both[:half])
+                        static.feature_2d.copy_(both[half:])
+            elif enc is not None and "enc" not in skip:
                 with torch.cuda.stream(enc_stream):
                     if in_graph_inputs:       # the views of batch k+1 enter on this branch, not by eager launches on the network's queue
                         enc_in.copy_(torch.stack(staged['images'], 0))
@@ -602,7 +625,12 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             # replay of this chain is two steps back and has long read its own) + the views of batch k+1
             chains[slot ^ 1].draw_rotations(upload=not in_graph_inputs)
             if enc is not None and not in_graph_inputs:
-                enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
+                if enc_pair:
+                    if slot == 0:
+                        views = torch.stack(staged['images'], 0)
+                        enc_in2.copy_(torch.cat([views, views], 0))  # the views of batches k+1 and k+2
+                else:
+                    enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
             ta = time.perf_counter()
             replays[slot][0]()
             host = torch.empty(4, dtype=torch.int32).pin_memory() if len(pending) < 4 else None
@@ -633,13 +661,16 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             print("DIAG graph replay (network + encoder + input chain branches) %.2f ms | input chain alone, eager "
                   "%.2f ms" % ((t1 - t0) * 50, (t2 - t1) * 100), file=sys.stderr)
         state_ref.append(state)
-        tag = "hipGraph[net|chain%s]%s" % (("|enc2d+fa" if fa_ahead else "|enc2d") if enc is not None else "",
+        tag = "hipGraph[net|chain%s]%s" % ((("|enc2d(x2 every 2nd step)+fa" if enc_pair else "|enc2d+fa") if fa_ahead else "|enc2d")
+                                           if enc is not None else "",
                                            "" if reducer is None else
                                            "+rccl-in-graph" if getattr(reducer, "capturable", False) else "+eager-rccl(3 graphs)")
         return step_chain, (tag, "hipGraph with %s branches per step: network fwd+loss+bwd+clip+SGD on static set k%%2 | "
                             "sync-free input chain (pyramid, unprojection, 3-NN; device-side counts) of batch k+1"
                             % ("three" if enc is not None else "two")
-                            + ((" | frozen 2D encoder of batch k+1" + (", then its FeatureAggregation (the network "
+                            + (((" | frozen 2D encoder: the views of batches k+1 and k+2 in one call on every second step "
+                                 "(none on the steps between)" if enc_pair else " | frozen 2D encoder of batch k+1")
+                                + (", then its FeatureAggregation (the network "
                                                                        "detaches that output: nothing trainable is "
                                                                        "upstream of it)" if fa_ahead else ""))
                                if enc is not None else

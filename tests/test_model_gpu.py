@@ -642,6 +642,33 @@ def test_dataloader_workers_build_the_pyramid_without_forking(tmp_path):
     assert r.returncode == 0 and "WORKER PYRAMIDS OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+def test_frozen_encoder_two_batches_in_one_call_equal_two_calls():
+    """bench.py runs the frozen 2D encoder for the views of TWO upcoming batches in one call on every second step
+    (MVK_ENCODER_PAIR): a batch's feature map must not depend on what else is in the call -- eval-mode BatchNorm folded
+    into the convolutions, no cross-image operation; the library may pick other convolution plans for six views than
+    for three, so the bound is the rounding class of an f32 convolution stack, not bit equality."""
+    import mvkpconv
+    from util import check_err
+    syn = mvkpconv.sub("synthetic")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    net = syn.build_model(syn.make_config("early"), dev)
+    net.net_2d.eval()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    a = torch.rand(3, 3, 120, 160, generator=g).to(dev)
+    b = torch.rand(3, 3, 120, 160, generator=g).to(dev)
+    with torch.no_grad():
+        fa = net.net_2d({'image': a})['feature']
+        fb = net.net_2d({'image': b})['feature']
+        both = net.net_2d({'image': torch.cat([a, b], 0)})['feature']
+    assert both.shape[0] == 6 and both.shape[1:] == fa.shape[1:]
+    scale = float(fa.abs().max())
+    check_err("frozen encoder: views 0-2 of a six-view call vs a three-view call (max abs / max)",
+              float((both[:3] - fa).abs().max()) / scale, 2e-5)
+    check_err("frozen encoder: views 3-5 of a six-view call vs a three-view call (max abs / max)",
+              float((both[3:] - fb).abs().max()) / scale, 2e-5)
+
+
 def test_default_multi_gpu_step_structure_trains_like_the_single_graph_step():
     """The DEFAULT N > 1 step (three graphs -- forward + backward above the cut + pack | backward below the cut + pack |
     unpack + clip + SGD -- with eager RCCL all-reduces between them, bench.py make_graph_step) rehearsed with a one-rank
@@ -664,14 +691,20 @@ def test_default_multi_gpu_step_structure_trains_like_the_single_graph_step():
     one = run({})
     plain = run({"MVK_SPLIT_TAIL": "1"})           # opt-in: grouped dW + SGD of everything above the backward cut on a side branch
     dp = run({"MVK_BENCH_FORCE_DP": "1", "MASTER_PORT": "29531"})
-    assert one["config"]["execution"] == "hipGraph[net|chain|enc2d+fa]" and one["config"]["backend"] is None
-    assert dp["config"]["execution"] == "hipGraph[net|chain|enc2d+fa]+eager-rccl(3 graphs)", dp["config"]["execution"]
+    unpaired = run({"MVK_ENCODER_PAIR": "0"})      # the frozen encoder once per step (default: two batches on every second step)
+    tag = "hipGraph[net|chain|enc2d(x2 every 2nd step)+fa]"
+    assert one["config"]["execution"] == tag and one["config"]["backend"] is None
+    assert unpaired["config"]["execution"] == "hipGraph[net|chain|enc2d+fa]"
+    assert dp["config"]["execution"] == tag + "+eager-rccl(3 graphs)", dp["config"]["execution"]
     assert dp["config"]["backend"] == "rccl" and dp["config"]["ranks"] == 1
     assert not one["config"]["capacity_overflow"] and not dp["config"]["capacity_overflow"]
     a, b, c = one["config"]["final_loss"], dp["config"]["final_loss"], plain["config"]["final_loss"]
     print("final loss: single graph %.6f (tail on a side branch %.6f) | three graphs + eager RCCL %.6f | rel diff %.2e / %.2e"
           % (a, c, b, abs(a - c) / abs(a), abs(a - b) / abs(a)))
     assert abs(a - b) < 2e-3 * abs(a) and abs(a - c) < 2e-3 * abs(a)
+    d = unpaired["config"]["final_loss"]           # same features batch by batch (other convolution plans for six views: rounding)
+    print("final loss with the encoder once per step %.6f | rel diff %.2e" % (d, abs(a - d) / abs(a)))
+    assert abs(a - d) < 2e-3 * abs(a)
 
 
 def test_two_stage_backward_with_deformable_blocks_below_the_cut_and_deferred_weight_gradients():

@@ -12,7 +12,8 @@ cfg = syn.make_config("early")
 torch.manual_seed(0)
 net = syn.build_model(cfg, dev)
 net.net_2d.eval()
-x = torch.randn(3, 3, 120, 160, device=dev)
+NV = int(sys.argv[1]) if len(sys.argv) > 1 else 3      # views per call (6 = the views of two steps in one call)
+x = torch.randn(NV, 3, 120, 160, device=dev)
 with torch.no_grad():
     for _ in range(3):
         y = net.net_2d({'image': x})['feature']
@@ -28,4 +29,4 @@ with torch.no_grad():
     for _ in range(20):
         g.replay()
     e1.record(); torch.cuda.synchronize()
-print("encoder %.3f ms per call; checksum %.6f" % (e0.elapsed_time(e1) / 20, float(y.double().abs().mean())))
+print("encoder, %d views: %.3f ms per call; checksum %.6f" % (NV, e0.elapsed_time(e1) / 20, float(y.double().abs().mean())))

@@ -358,19 +358,31 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     # fusion: no trainable state upstream of that point): 12 launches / 0.17 ms off the network's chain
     fa_ahead = enc is not None and getattr(net, "fa_output_detached", False) and hasattr(syn, "DeviceInputChain") \
         and os.environ.get("MVK_DEVICE_CHAIN", "1") == "1" and os.environ.get("MVK_FA_AHEAD", "1") == "1"
-    # The frozen encoder for TWO upcoming batches in one call, every other step (MVK_ENCODER_PAIR=0: one batch per step):
-    # where the network reads the lifted features that were made ahead (fa_ahead) nothing in step k touches
-    # statics[k % 2].feature_2d, so the replay of static set 0 encodes the views of batches k+1 AND k+2 (into set 1's and
-    # its own feature map) and the replay of set 1 encodes nothing. Same work per batch, half the library launches per
-    # step and larger convolutions: 3 views 1.17 ms, 6 views 1.73 ms stand-alone (tools/encoder_probe.py).
-    # Measured: 3.93-3.97 -> 3.84-3.87 ms per step at one sphere x 3 views; 12.8 -> 13.0 ms at 5 spheres x 5 views (50 views
-    # per call gain nothing over 25 and the long call sits beside one step only) -- pairs up to 12 views per call.
-    enc_pair = fa_ahead and os.environ.get("MVK_ENCODER_PAIR", "1") == "1" and os.environ.get("MVK_DEVICE_CHAIN", "1") == "1" \
-        and 2 * int(enc_in.shape[0]) * int(enc_in.shape[1]) <= int(os.environ.get("MVK_ENCODER_PAIR_MAX_VIEWS", "12"))
+    # The frozen encoder for SEVERAL upcoming batches in one call (MVK_ENCODER_PAIR=0: one batch per step): where the
+    # network reads the lifted features that were made ahead (fa_ahead) nothing in step k touches
+    # statics[k % 2].feature_2d, so with a cycle of 2 the replay of static set 0 encodes the views of batches k+1 AND k+2
+    # (into set 1's and its own feature map) and the replay of set 1 encodes nothing; with a cycle of 4 the first step of
+    # four encodes batches k+1 .. k+4 (the last two into holding buffers that steps 3 and 4 copy into place). Same work per
+    # batch, a half / a quarter of the library launches per step and larger convolutions: stand-alone 1.17 ms for 3 views,
+    # 1.73 for 6, 2.71 for 12, 4.65 for 25 (tools/encoder_probe.py). Default: a cycle of 2 (MVK_ENCODER_CYCLE) while the call
+    # stays within MVK_ENCODER_PAIR_MAX_VIEWS (12) views: 3.91-3.97 -> 3.80-3.87 ms per step with 6 views per call; 12.8 ->
+    # 13.0 ms at 5 spheres x 5 views with 50 (the long call sits beside one step only), which keeps one batch per step.
+    enc_cycle = 1
+    if fa_ahead and os.environ.get("MVK_ENCODER_PAIR", "1") == "1" and os.environ.get("MVK_DEVICE_CHAIN", "1") == "1":
+        per_batch = int(enc_in.shape[0]) * int(enc_in.shape[1])
+        most = int(os.environ.get("MVK_ENCODER_PAIR_MAX_VIEWS", "12"))
+        want = int(os.environ.get("MVK_ENCODER_CYCLE", "2"))      # (4: measured slower, 4.04 against 3.80-3.85 ms -- twelve views in one
+                                                                   # call make their step longer than the three others save)
+        for c in (4, 2):
+            if c <= want and c * per_batch <= most:
+                enc_cycle = c
+                break
+    enc_pair = enc_cycle > 1
     if enc_pair:
-        enc_in2 = torch.cat([enc_in, enc_in], 0).clone()            # (2 b, nv, 3, h, w): batch k+1, batch k+2
+        enc_in2 = torch.cat([enc_in] * enc_cycle, 0).clone()         # (cycle * b, nv, 3, h, w): batches k+1 .. k+cycle
         for _ in range(2):
             encode(enc_in2)
+        enc_hold = [torch.empty_like(batch0.feature_2d) for _ in range(enc_cycle - 2)]
     if fa_ahead:
         lift = sys.modules[type(net).__module__].lift_2d_features
 
@@ -457,7 +469,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
     # on the network's stream between two replays, as up to round 3: ~45 us in front of every step's first kernel)
     in_graph_inputs = use_chain and os.environ.get("MVK_INPUTS_IN_GRAPH", "1") == "1"
 
-    def capture(static):
+    def capture(static, phase=0):
         ops.set_row_counts(static.valid)
         opt.zero_grad(set_to_none=True)         # every graph instance produces its own .grad tensors
         graph = torch.cuda.CUDAGraph()
@@ -486,15 +498,19 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
 
         def side_work():
             if enc is not None and "enc" not in skip and enc_pair:
-                if statics.index(static) == 0:      # this replay: the views of batches k+1 (set 1) and k+2 (set 0 again)
-                    with torch.cuda.stream(enc_stream):
+                with torch.cuda.stream(enc_stream):
+                    if phase == 0:      # this replay: the views of batches k+1 (other set), k+2 (this set again), k+3, k+4 (held)
                         if in_graph_inputs:
                             views = torch.stack(staged['images'], 0)
-                            enc_in2.copy_(torch.cat([views, views], 0))
-                        both = encode(enc_in2)
-                        half = both.shape[0] // 2
-                        other.feature_2d.copy_(both[:half])
-                        static.feature_2d.copy_(both[half:])
+                            enc_in2.copy_(torch.cat([views] * enc_cycle, 0))
+                        every = encode(enc_in2)
+                        one = every.shape[0] // enc_cycle
+                        other.feature_2d.copy_(every[:one])
+                        static.feature_2d.copy_(every[one:2 * one])
+                        for h, hold in enumerate(enc_hold):
+                            hold.copy_(every[(2 + h) * one:(3 + h) * one])
+                    elif phase >= 2:    # the features of batch k+1 were made two or three steps ago
+                        other.feature_2d.copy_(enc_hold[phase - 2])
             elif enc is not None and "enc" not in skip:
                 with torch.cuda.stream(enc_stream):
                     if in_graph_inputs:       # the views of batch k+1 enter on this branch, not by eager launches on the network's queue
@@ -591,7 +607,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
 
     _SEED.setdefault(dev, torch.ones((), device=dev))      # (before the captures: see backward())
     _DUMMY.setdefault(dev, torch.zeros(64, device=dev))
-    replays = [capture(s) for s in statics]
+    replays = [capture(statics[ph % 2], ph) for ph in range(max(2, enc_cycle))]      # (phase of the encoder's cycle; set = phase % 2)
     state = {"next": None, "k": 0, "free": [None, None]}
 
     if use_chain:
@@ -624,15 +640,16 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             # host draw of batch k+1's grid orientations into pinned memory (the replay's copy node reads it: the previous
             # replay of this chain is two steps back and has long read its own) + the views of batch k+1
             chains[slot ^ 1].draw_rotations(upload=not in_graph_inputs)
+            phase = state.get("phase", 0)
             if enc is not None and not in_graph_inputs:
                 if enc_pair:
-                    if slot == 0:
+                    if phase == 0:
                         views = torch.stack(staged['images'], 0)
-                        enc_in2.copy_(torch.cat([views, views], 0))  # the views of batches k+1 and k+2
+                        enc_in2.copy_(torch.cat([views] * enc_cycle, 0))  # the views of batches k+1 .. k+cycle
                 else:
                     enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
             ta = time.perf_counter()
-            replays[slot][0]()
+            replays[phase][0]()
             host = torch.empty(4, dtype=torch.int32).pin_memory() if len(pending) < 4 else None
             if host is not None:
                 host.copy_(chains[slot ^ 1].status4, non_blocking=True)
@@ -643,7 +660,8 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             replayed[slot ^ 1].record()
             state.setdefault("host", []).append((time.perf_counter() - ta, 0.0))
             state["slot"] = slot ^ 1
-            return lens0, replays[slot][1]
+            state["phase"] = (phase + 1) % len(replays)
+            return lens0, replays[phase][1]
 
         step_chain.finish = lambda: check_status(block=True)
         if os.environ.get("MVK_BENCH_DIAG") == "1":
@@ -661,15 +679,16 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer):
             print("DIAG graph replay (network + encoder + input chain branches) %.2f ms | input chain alone, eager "
                   "%.2f ms" % ((t1 - t0) * 50, (t2 - t1) * 100), file=sys.stderr)
         state_ref.append(state)
-        tag = "hipGraph[net|chain%s]%s" % ((("|enc2d(x2 every 2nd step)+fa" if enc_pair else "|enc2d+fa") if fa_ahead else "|enc2d")
+        tag = "hipGraph[net|chain%s]%s" % ((("|enc2d(x%d every %s step)+fa" % (enc_cycle, "2nd" if enc_cycle == 2 else "4th") if enc_pair else "|enc2d+fa") if fa_ahead else "|enc2d")
                                            if enc is not None else "",
                                            "" if reducer is None else
                                            "+rccl-in-graph" if getattr(reducer, "capturable", False) else "+eager-rccl(3 graphs)")
         return step_chain, (tag, "hipGraph with %s branches per step: network fwd+loss+bwd+clip+SGD on static set k%%2 | "
                             "sync-free input chain (pyramid, unprojection, 3-NN; device-side counts) of batch k+1"
                             % ("three" if enc is not None else "two")
-                            + (((" | frozen 2D encoder: the views of batches k+1 and k+2 in one call on every second step "
-                                 "(none on the steps between)" if enc_pair else " | frozen 2D encoder of batch k+1")
+                            + (((" | frozen 2D encoder: the views of batches k+1 .. k+%d in one call on every %s step "
+                                 "(none on the steps between)" % (enc_cycle, "second" if enc_cycle == 2 else "fourth")
+                                 if enc_pair else " | frozen 2D encoder of batch k+1")
                                 + (", then its FeatureAggregation (the network "
                                                                        "detaches that output: nothing trainable is "
                                                                        "upstream of it)" if fa_ahead else ""))

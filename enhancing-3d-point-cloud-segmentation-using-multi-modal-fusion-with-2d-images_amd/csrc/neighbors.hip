@@ -265,8 +265,9 @@ __global__ __launch_bounds__(256) void nb_scatter_kernel(const float* __restrict
 
 // Work list for the KPConv gather out of a built grid: the stacked support rows sorted by (cloud, cell, row) -- the
 // record order of the counting sort with the rows of a cell put in ascending order (the scatter's atomics leave them in
-// arrival order; a cell holds a dozen rows), so the list is the same on every run. Up to 32 workgroups per cloud, one
-// thread per cell; the last cloud's first workgroup appends the identity for the rows up to order_cap (capacity padding).
+// arrival order; a cell holds a dozen rows), so the list is the same on every run. Up to 256 workgroups of 256 threads
+// per cloud, one thread per cell; the last cloud's first workgroup appends the identity for the rows up to order_cap
+// (capacity padding).
 __global__ __launch_bounds__(TPB) void nb_cell_order_kernel(NbWs W, int B, int* __restrict__ order, int64_t order_cap) {
   const int b = blockIdx.x, tid = threadIdx.x;
   int off = 0, n;

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvkpconv.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -67,7 +67,7 @@ _SIGNATURES = {
     "mvk_gemm_f32_ex": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mvk_gemm_group_entry_bytes": (C.c_int64, []),
     "mvk_gemm_f32_tn_grouped_split": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
-    "mvk_gemm_f32_tn_grouped_plan": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp]),
+    "mvk_gemm_f32_tn_grouped_plan": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvk_gemm_f32_tn_grouped": (C.c_int, [_vp, _i, _i, _i64, _i64, _vp]),
     "mvk_gemm_f16": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i64, _i64, _i64, _i, _i, _i, _vp]),
     "mvk_kpconv_deform_doff": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp,

@@ -51,7 +51,7 @@ def build_library(force=False, verbose=False):
     hipcc = _hipcc()
     common = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "blockscan.h"), os.path.join(HERE, "..", "include", "mvkpconv.h"),
               os.path.join(HERE, "..", "include", "mvk_prime_list.h"), os.path.abspath(__file__)]
-    objs = []
+    objs, jobs = [], []
     for src, extra in SOURCES:
         sp = os.path.join(CSRC, src)
         if not os.path.exists(sp):
@@ -61,10 +61,19 @@ def build_library(force=False, verbose=False):
             cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-c", sp, "-o", obj] + extra
             if src.endswith(".cpp"):
                 cmd = [hipcc, "-O2", "-std=c++17", "-fPIC", "-c", sp, "-o", obj]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append(cmd)
         objs.append(obj)
+    if jobs:
+        # independent translation units: a few compilers side by side (MVK_BUILD_JOBS, default 6 or the CPU count)
+        from concurrent.futures import ThreadPoolExecutor
+        n = max(1, min(int(os.environ.get("MVK_BUILD_JOBS", "6")), os.cpu_count() or 1, len(jobs)))
+
+        def run(cmd):
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        with ThreadPoolExecutor(n) as pool:
+            list(pool.map(run, jobs))
     if force or _stale(OUT, objs):
         cmd = [hipcc, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", OUT] + objs
         if verbose:

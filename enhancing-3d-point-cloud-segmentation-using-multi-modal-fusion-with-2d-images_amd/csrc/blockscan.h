@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include "common.h"
+
 constexpr int TPB = 1024;
 
 // Loads of words that other lanes of the workgroup update with (L2-side) atomics: bypass L1.
@@ -12,26 +14,26 @@ __device__ __forceinline__ unsigned long long ld_agent(const unsigned long long*
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// The same loads for GLOBAL memory with N of them in flight. The compiler waits for every relaxed ATOMIC load before it
-// issues the next (one L2 round trip per element: the one-workgroup-per-cloud kernels are chains of such trips); these are
-// plain `global_load ... sc1` instructions written as inline assembly, one wait behind the last, every register pinned after
-// the wait so that no use is scheduled above it. Callers clamp out-of-range addresses instead of branching around the
-// call (a register written by an untracked load must not pass through a join before the wait). NOT for LDS pointers.
+// The same loads for arrays in GLOBAL memory with N of them in flight. The compiler waits for every relaxed ATOMIC load
+// before it issues the next (one L2 round trip per element: the one-workgroup-per-cloud kernels are chains of such trips);
+// these are raw buffer loads with the sc1 cache-policy bit (common.h: park_*), which the compiler counts like any other
+// load -- N back to back, one counted wait in front of each use (round 5: no inline assembly). `base` must be
+// wave-uniform (an array of the workgroup's cloud), `idx` are element indices into it. NOT for LDS pointers.
 template <int N>
-__device__ __forceinline__ void ldg_agent(int (&v)[N], const int* const (&p)[N]) {
+__device__ __forceinline__ void ldg_agent(int (&v)[N], const int* base, const int (&idx)[N]) {
+  const __amdgpu_buffer_rsrc_t r = park_rsrc(base);
 #pragma unroll
-  for (int u = 0; u < N; ++u) asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v[u]) : "v"(p[u]) : "memory");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int u = 0; u < N; ++u) asm volatile("" : "+v"(v[u]));
+  for (int u = 0; u < N; ++u) v[u] = park_load1i(r, (uint32_t)idx[u] * 4u);
 }
 template <int N>
-__device__ __forceinline__ void ldg_agent(unsigned long long (&v)[N], const unsigned long long* const (&p)[N]) {
+__device__ __forceinline__ void ldg_agent(unsigned long long (&v)[N], const unsigned long long* base, const int (&idx)[N]) {
+  const __amdgpu_buffer_rsrc_t r = park_rsrc(base);
 #pragma unroll
-  for (int u = 0; u < N; ++u) asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=v"(v[u]) : "v"(p[u]) : "memory");
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-  for (int u = 0; u < N; ++u) asm volatile("" : "+v"(v[u]));
+  for (int u = 0; u < N; ++u) {
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 w = __builtin_amdgcn_raw_buffer_load_b64(r, (uint32_t)idx[u] * 8u, 0, MVK_AUX_SC1);
+    v[u] = ((unsigned long long)w[1] << 32) | w[0];
+  }
 }
 
 __device__ __forceinline__ int block_exclusive_scan(int v, int* total, int* sh /* TPB/64 + 1 */) {
@@ -99,28 +101,28 @@ __device__ int block_scan_array_g(int* arr, int n, int* sh, bool suffix) {
   const int beg = min(n, (int)threadIdx.x * per), end = min(n, beg + per);
   int s = 0;
   for (int i0 = beg; i0 < end; i0 += 8) {
-    const int* ap[8];
+    int ai[8];
     int v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + u < end ? i0 + u : end - 1;
-      ap[u] = arr + (suffix ? n - 1 - i : i);
+      ai[u] = suffix ? n - 1 - i : i;
     }
-    ldg_agent<8>(v, ap);
+    ldg_agent<8>(v, arr, ai);
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += i0 + u < end ? v[u] : 0;
   }
   int total;
   int base = block_exclusive_scan(s, &total, sh);
   for (int i0 = beg; i0 < end; i0 += 8) {
-    const int* ap[8];
+    int ai[8];
     int v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + u < end ? i0 + u : end - 1;
-      ap[u] = arr + (suffix ? n - 1 - i : i);
+      ai[u] = suffix ? n - 1 - i : i;
     }
-    ldg_agent<8>(v, ap);
+    ldg_agent<8>(v, arr, ai);
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (i0 + u < end) {

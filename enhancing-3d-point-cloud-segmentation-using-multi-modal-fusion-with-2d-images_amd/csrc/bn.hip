@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(256) void bias_lrelu_bwd_k(const float* __restrict_
   if (rl == 0 && col < C) {
     for (int i = 1; i < RL; ++i) s += part[i * CP + col];
     if (park)
-      park_store1(park + (int64_t)blockIdx.x * C + col, s);
+      park_store1(park_rsrc(park + (int64_t)blockIdx.x * C), (uint32_t)col * 4u, s);
     else
       atomicAdd(dbias + col, s);
   }
@@ -1334,15 +1334,13 @@ __global__ __launch_bounds__(256) void bias_lrelu_bwd_k(const float* __restrict_
     const int nb = (int)gridDim.x;
     for (int b0 = rl; b0 < nb; b0 += 16 * RL) {
       float v[16];
-      // (no branch around the loads, see the split reduction of csrc/gemm.hip: blocks past the end are clamped, then skipped)
+      // (all sixteen loads issued before the first add: blocks past the end are clamped, then skipped)
+      const __amdgpu_buffer_rsrc_t pr = park_rsrc(park);
 #pragma unroll
       for (int u = 0; u < 16; ++u) {
         const int b = b0 + u * RL < nb ? b0 + u * RL : nb - 1;
-        park_load1(v[u], park + (int64_t)b * C + col);
+        v[u] = park_load1(pr, ((uint32_t)b * (uint32_t)C + (uint32_t)col) * 4u);
       }
-      park_wait();
-#pragma unroll
-      for (int u = 0; u < 16; ++u) park_pin(v[u]);
 #pragma unroll
       for (int u = 0; u < 16; ++u)
         if (b0 + u * RL < nb) t += v[u];
@@ -1400,7 +1398,7 @@ extern "C" int mvk_bias_lrelu_bwd(const float* y, const float* g, int64_t R, int
   int* counter = nullptr;
   const int64_t blocks = cdiv64(R, 64);
   if (mvk_gemm_split_ordered())
-    MVK_REQUIRE(mvk_internal_arena_take(blocks * C, 1, &park, &counter), "bias_lrelu: the arena of ordered reductions is too small");
+    MVK_REQUIRE(mvk_internal_arena_take(stream, blocks * C, 1, &park, &counter), "bias_lrelu: the arena of ordered reductions is too small");
   hipLaunchKernelGGL(bias_lrelu_bwd_k, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, y, g, R, C,
                      pow2_ge(C), slope, dx, dbias, park, counter);
   MVK_CHECK_HIP(hipGetLastError());

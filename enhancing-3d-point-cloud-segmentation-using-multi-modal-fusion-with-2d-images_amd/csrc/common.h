@@ -30,8 +30,9 @@ static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // Slices of the arena of ordered reductions (mvk_gemm_split_arena, csrc/gemm.hip) for kernels outside the GEMM that sum
 // per-workgroup partials in a fixed order: `floats` of parking space, `counters` zeroed int32 words that the kernel must
-// leave at zero. False: no arena is set (the caller keeps its atomic path) or the request does not fit.
-bool mvk_internal_arena_take(int64_t floats, int64_t counters, float** ws, int** cnt);
+// leave at zero, for a launch on `stream` (a capturing stream keeps its slices for good, gemm.hip). False: no arena is
+// set (the caller keeps its atomic path) or the request cannot be served.
+bool mvk_internal_arena_take(void* stream, int64_t floats, int64_t counters, float** ws, int** cnt);
 
 // A pointer the compiler cannot trace to a kernel argument (read from a table in memory) is "generic": its loads
 // become flat_load, which also counts on lgkmcnt. Device allocations are global memory: reading the table slot AS a
@@ -47,32 +48,38 @@ __device__ __forceinline__ T* load_global_ptr(T* const* slot) {
 }
 
 // Parking space of the ordered reductions: AGENT-SCOPE loads / stores (gfx950: the sc1 bit -- served at the memory side,
-// past the XCD-private L2s) written as inline assembly so that the compiler neither serialises them (it waits for every
-// relaxed ATOMIC load before issuing the next: one memory round trip per element) nor needs a fence around them (an
-// agent-scope fence writes back / invalidates the whole L2 of the XCD). The compiler does not count these operations:
-// park_wait() before the first use of loaded values (and before the barrier that publishes stores), park_pin() on every
-// loaded register after the wait so that no use is scheduled above it. Untracked operations only make the compiler's
-// own counted waits conservative (memory operations of one kind retire in order).
+// past the XCD-private L2s), so that neither a fence is needed around them (an agent-scope fence writes back / invalidates
+// the whole L2 of the XCD) nor relaxed ATOMIC loads (the compiler waits for each before issuing the next: one memory round
+// trip per element). Round 5: these are raw BUFFER accesses with the sc1 cache-policy bit (aux bit 4 on gfx94x / gfx950)
+// through the compiler's own intrinsics instead of inline assembly -- the compiler counts them (exact vmcnt waits in front
+// of every use, its hazard recogniser pads the wide stores), so no register written by a load can be copied, spilled or
+// merged at a join before the data has arrived (the hand-placed `s_nop 2` and the pin statements are gone).
+// A buffer resource = a wave-uniform base (SGPRs) + a 32-bit byte offset per lane: callers pass the base of their slice.
+// park_wait() is still required before the barrier that PUBLISHES stores (the compiler does not know that another
+// workgroup will read them): s_waitcnt vmcnt(0) -- stores count on vmcnt on gfx9.
 typedef float mvk_f32x4 __attribute__((ext_vector_type(4)));
-// (s_nop: a VALU instruction must not overwrite the data registers of a store wider than 8 bytes within two wait states
-// of its issue -- the store reads them late. The compiler's hazard recogniser pads its own stores; it cannot see into
-// inline assembly, and without the padding the first two components of lanes 12-15 of every 16 left as the NEXT
-// instruction's result: found with tools/park_debug.py)
-__device__ __forceinline__ void park_store4(float* p, mvk_f32x4 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+typedef unsigned mvk_u32x4 __attribute__((ext_vector_type(4)));
+constexpr int MVK_AUX_SC1 = 16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t park_rsrc(const void* base) {
+  // raw buffer (stride 0), no range limit, gfx9 data format word
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffffu, 0x00020000);
 }
-__device__ __forceinline__ void park_store1(float* p, float v) {
-  asm volatile("global_store_dword %0, %1, off sc1\n\ts_nop 2" ::"v"(p), "v"(v) : "memory");
+__device__ __forceinline__ void park_store4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, mvk_f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(mvk_u32x4, v), r, byte_off, 0, MVK_AUX_SC1);
 }
-__device__ __forceinline__ void park_load4(mvk_f32x4& v, const float* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+__device__ __forceinline__ void park_store1(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_off, 0, MVK_AUX_SC1);
 }
-__device__ __forceinline__ void park_load1(float& v, const float* p) {
-  asm volatile("global_load_dword %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+__device__ __forceinline__ mvk_f32x4 park_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(mvk_f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, MVK_AUX_SC1));
+}
+__device__ __forceinline__ float park_load1(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, MVK_AUX_SC1));
+}
+__device__ __forceinline__ int park_load1i(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return (int)__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, MVK_AUX_SC1);
 }
 __device__ __forceinline__ void park_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ void park_pin(mvk_f32x4& v) { asm volatile("" : "+v"(v)); }
-__device__ __forceinline__ void park_pin(float& v) { asm volatile("" : "+v"(v)); }
 
 // neighbour index load: int32 or int64 storage, -1 for shadow / out of range
 template <bool IDX64>

@@ -28,6 +28,7 @@
 //     accumulators -- the separate statistics pass over the GEMM output disappears.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -352,17 +353,22 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   }
 
   if (a.det_ws) {
-    // Slots are written and read with agent-scope (sc1) accesses (park_* of common.h), the counter with a relaxed
+    // Slots are written and read with agent-scope (sc1) buffer accesses (park_* of common.h), the counter with a relaxed
     // agent-scope atomic: no fence, no L2 write-back. Order: a workgroup's slot stores are complete (park_wait + barrier)
     // before thread 0 bumps the tile's counter; the last arriver reads the slots only after its own bump returned the
-    // full count. Slot layout [accumulator block][thread][4]: one 16-byte access per lane.
+    // full count (its loads are issued after the barrier that follows the bump: program order, and the compiler does not
+    // move memory operations across the barrier). Slot layout [accumulator block][thread][4]: one 16-byte access per lane.
     constexpr int NB = PM * QN, SLOT = NB * 4 * 256;
     const int64_t tile = (int64_t)by * a.det_gx + bx;
-    float* const mine = a.det_ws + (tile * a.det_nsplit + bz) * SLOT + tid * 4;
+    // the tile's slots as one buffer resource (uniform base in SGPRs; offsets inside it stay far below 4 GB: <= 64 slots
+    // of <= 32 KB); the accesses are counted by the compiler (common.h)
+    const __amdgpu_buffer_rsrc_t slots = park_rsrc(a.det_ws + tile * a.det_nsplit * SLOT);
+    const uint32_t lane_off = (uint32_t)tid * 16u;
 #pragma unroll
     for (int p = 0; p < PM; ++p)
 #pragma unroll
-      for (int q = 0; q < QN; ++q) park_store4(mine + (p * QN + q) * 1024, acc[p][q]);
+      for (int q = 0; q < QN; ++q)
+        park_store4(slots, (uint32_t)bz * (SLOT * 4u) + (uint32_t)(p * QN + q) * 4096u + lane_off, acc[p][q]);
     park_wait();
     __syncthreads();              // every thread's stores have arrived; the operand tiles in LDS are dead
     int* const flag = reinterpret_cast<int*>(lds);
@@ -376,7 +382,6 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
     const int last = *flag;
     __syncthreads();              // (the statistics epilogue reuses lds)
     if (!last) return;
-    const float* const all = a.det_ws + tile * a.det_nsplit * SLOT + tid * 4;
 #pragma unroll
     for (int p = 0; p < PM; ++p)
 #pragma unroll
@@ -384,20 +389,14 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
     constexpr int ZC = NB >= 8 ? 2 : 4;      // slots in flight: up to 16 loads per thread and round trip
     for (int z0 = 0; z0 < a.det_nsplit; z0 += ZC) {
       f32x4 t[ZC][NB];
-      // no branch around the loads: a register written by an untracked load must not pass through a join before the
-      // wait (the compiler would copy it there, before the data has arrived); slots beyond the split are clamped to
-      // the last one and skipped when adding
+      // all loads of a round issued before the first add (slots beyond the split are clamped to the last one and skipped
+      // when adding: no branch around a load keeps them back to back)
 #pragma unroll
       for (int zz = 0; zz < ZC; ++zz) {
         const int z = z0 + zz < a.det_nsplit ? z0 + zz : a.det_nsplit - 1;
 #pragma unroll
-        for (int b = 0; b < NB; ++b) park_load4(t[zz][b], all + (int64_t)z * SLOT + b * 1024);
+        for (int b = 0; b < NB; ++b) t[zz][b] = park_load4(slots, (uint32_t)z * (SLOT * 4u) + (uint32_t)b * 4096u + lane_off);
       }
-      park_wait();
-#pragma unroll
-      for (int zz = 0; zz < ZC; ++zz)
-#pragma unroll
-        for (int b = 0; b < NB; ++b) park_pin(t[zz][b]);
 #pragma unroll
       for (int zz = 0; zz < ZC; ++zz)
         if (z0 + zz < a.det_nsplit) {
@@ -596,40 +595,84 @@ struct Plan {
 };
 
 // Arena of the ordered split reductions (mvk_gemm_split_arena): the host layer hands over one large slot buffer and one
-// zero-initialised counter buffer; every split product takes the next slice of both (bump allocation, wrapping around at
-// the end). A slice is in use only while its launch runs, the counters return to zero by themselves, so nothing is ever
-// cleared; two launches could only collide if a whole arena's worth of later split products were enqueued while the
-// first was still running. A captured graph keeps the slices its nodes were given.
+// zero-initialised counter buffer; every split product takes a slice of both. A slice is in use only while its launch
+// runs and the counters return to zero by themselves, so nothing is ever cleared -- what must never happen is two
+// launches that may run CONCURRENTLY sharing a slice (wrong sums, a wrong "last arriver", a counter left non-zero for
+// good). Round 5 makes that a checked property instead of an assumption about sizes:
+//   * a launch on a CAPTURING stream takes its slices from the TOP of the arena, downwards, and keeps them for good: the
+//     nodes of a graph replay again and again, and branches of one graph run side by side;
+//   * an eager launch takes its slices from the BOTTOM, upwards. When the bottom region is used up (it would run into
+//     the reserved top) the library waits for the device (hipDeviceSynchronize: every earlier owner has finished) and
+//     starts again at offset 0 -- once per arena's worth of split products;
+//   * a request that cannot be served without breaking these rules fails loudly ("arena too small ... MVK_GEMM_ARENA_MB").
+// Host state behind a mutex: ctypes calls drop the GIL.
 struct SplitArena {
   float* ws = nullptr;
   int* cnt = nullptr;
-  int64_t ws_floats = 0, n_cnt = 0, ws_off = 0, cnt_off = 0;
+  int64_t ws_floats = 0, n_cnt = 0;
+  int64_t ws_off = 0, cnt_off = 0;        // next eager slice (bottom region, grows upwards)
+  int64_t ws_top = 0, cnt_top = 0;        // start of the region reserved by captured launches (grows downwards)
 };
 SplitArena g_arena;
+std::mutex g_arena_mu;
 
 bool ordered_splits() { return g_arena.ws != nullptr; }
 
-// slices for `tiles` output tiles of `slot` floats each, split `split` ways; false: the request does not fit the arena
-bool arena_take(int64_t tiles, int split, int64_t slot, float** ws, int** cnt) {
-  const int64_t need = tiles * split * slot;
-  if (need > g_arena.ws_floats || tiles > g_arena.n_cnt) return false;
-  if (g_arena.ws_off + need > g_arena.ws_floats) g_arena.ws_off = 0;
-  if (g_arena.cnt_off + tiles > g_arena.n_cnt) g_arena.cnt_off = 0;
+// slices for `tiles` output tiles of `slot` floats each, split `split` ways, for a launch on `st`.
+// 0: ok; 1: the request does not fit the arena at all; 2: the captured launches have used the arena up; -2: HIP error
+int arena_take(hipStream_t st, int64_t tiles, int split, int64_t slot, float** ws, int** cnt) {
+  const int64_t need = (tiles * split * slot + 63) / 64 * 64;
+  std::lock_guard<std::mutex> lock(g_arena_mu);
+  if (need > g_arena.ws_floats || tiles > g_arena.n_cnt) return 1;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    cap = hipStreamCaptureStatusNone;
+  }
+  if (cap != hipStreamCaptureStatusNone) {
+    // reserved for good; must not reach into what eager launches may still be using
+    if (g_arena.ws_top - need < g_arena.ws_off || g_arena.cnt_top - tiles < g_arena.cnt_off) return 2;
+    g_arena.ws_top -= need;
+    g_arena.cnt_top -= tiles;
+    *ws = g_arena.ws + g_arena.ws_top;
+    *cnt = g_arena.cnt + g_arena.cnt_top;
+    return 0;
+  }
+  if (g_arena.ws_off + need > g_arena.ws_top || g_arena.cnt_off + tiles > g_arena.cnt_top) {
+    if (need > g_arena.ws_top || tiles > g_arena.cnt_top) return 2;
+    if (hipDeviceSynchronize() != hipSuccess) return -2;     // every earlier owner of the bottom region has finished
+    g_arena.ws_off = 0;
+    g_arena.cnt_off = 0;
+  }
   *ws = g_arena.ws + g_arena.ws_off;
   *cnt = g_arena.cnt + g_arena.cnt_off;
-  g_arena.ws_off += (need + 63) / 64 * 64;
+  g_arena.ws_off += need;
   g_arena.cnt_off += tiles;
-  return true;
+  return 0;
 }
 
-// gives a split product its slices (or leaves it on the atomic path when no arena is set); false: arena too small
-bool make_ordered(GemmArgs& a, int split, int gx, int64_t gy, int64_t tm, int64_t tn) {
-  a.det_ws = nullptr; a.det_cnt = nullptr; a.det_gx = gx; a.det_nsplit = split;
-  if (split <= 1 || !ordered_splits()) return true;
-  if (!arena_take((int64_t)gx * gy, split, tm * tn, &a.det_ws, &a.det_cnt)) return false;
-  a.atomic_out = 0;
-  return true;
+const char* arena_error(int rc) {
+  return rc == 1 ? "the split-reduction arena is smaller than one product's parking space (MVK_GEMM_ARENA_MB)"
+         : rc == 2 ? "the split-reduction arena is used up by the slices captured graphs hold for good: too small for the "
+                     "captured steps of this process (MVK_GEMM_ARENA_MB)"
+                   : "hipDeviceSynchronize failed while recycling the split-reduction arena";
 }
+
+// gives a split product its slices (or leaves it on the atomic path when no arena is set); != 0: arena_error(rc)
+int make_ordered(hipStream_t st, GemmArgs& a, int split, int gx, int64_t gy, int64_t tm, int64_t tn) {
+  a.det_ws = nullptr; a.det_cnt = nullptr; a.det_gx = gx; a.det_nsplit = split;
+  if (split <= 1 || !ordered_splits()) return 0;
+  const int rc = arena_take(st, (int64_t)gx * gy, split, tm * tn, &a.det_ws, &a.det_cnt);
+  if (rc != 0) return rc;
+  a.atomic_out = 0;
+  return 0;
+}
+
+#define MVK_ORDERED(call)                                      \
+  do {                                                         \
+    const int _rc = (call);                                    \
+    MVK_REQUIRE(_rc == 0, "gemm: %s", arena_error(_rc));       \
+  } while (0)
 
 // Measured on MI355X (tools/gemm_bench.py --sweep, device time of graph-captured launches): for every product
 // shape of the networks the fastest tiles are the SMALL ones -- 32 rows per workgroup for wide outputs (PM = 2),
@@ -754,9 +797,9 @@ int fill_args(GemmArgs& a, const Plan& p, const float* A, const float* B, float*
 
 }  // namespace
 
-bool mvk_internal_arena_take(int64_t floats, int64_t counters, float** ws, int** cnt) {
+bool mvk_internal_arena_take(void* stream, int64_t floats, int64_t counters, float** ws, int** cnt) {
   if (!ordered_splits() || floats < 0 || counters < 0) return false;
-  return arena_take(counters > 0 ? counters : 1, 1, cdiv64(floats, counters > 0 ? counters : 1), ws, cnt);
+  return arena_take((hipStream_t)stream, counters > 0 ? counters : 1, 1, cdiv64(floats, counters > 0 ? counters : 1), ws, cnt) == 0;
 }
 
 // Hands the library the arena of its ordered split reductions: `ws` (bytes, HBM) for the parked partial tiles, `counters`
@@ -767,12 +810,15 @@ extern "C" int mvk_gemm_split_arena(void* ws, int64_t ws_bytes, void* counters, 
   MVK_REQUIRE((ws == nullptr) == (counters == nullptr) && ws_bytes >= 0 && n_counters >= 0, "gemm arena: bad arguments");
   MVK_REQUIRE(ws == nullptr || (ws_bytes >= (1 << 20) && n_counters >= 4096 && (uintptr_t)ws % 256 == 0),
               "gemm arena: at least 1 MB of 256-byte aligned slots and 4096 counters");
+  std::lock_guard<std::mutex> lock(g_arena_mu);
   g_arena.ws = (float*)ws;
   g_arena.cnt = (int*)counters;
   g_arena.ws_floats = ws ? ws_bytes / 4 : 0;
   g_arena.n_cnt = ws ? n_counters : 0;
   g_arena.ws_off = 0;
   g_arena.cnt_off = 0;
+  g_arena.ws_top = g_arena.ws_floats;
+  g_arena.cnt_top = g_arena.n_cnt;
   return 0;
 }
 
@@ -813,7 +859,7 @@ extern "C" int mvk_gemm_f32_dual(const float* A, const float* B, const float* A2
   a.vecB2 = ((a.ldb2 % 4 == 0) && ((uintptr_t)B2 % 16 == 0)) ? 4 : ((a.ldb2 % 2 == 0) && ((uintptr_t)B2 % 8 == 0)) ? 2 : 1;
   MVK_REQUIRE(cdiv64(M, 32) < 65536 && split < 65536, "gemm: grid too large");
   dim3 grid((unsigned)cdiv64(N, 64), (unsigned)cdiv64(M, 32), (unsigned)split);
-  MVK_REQUIRE(make_ordered(a, split, (int)grid.x, grid.y, 32, 64), "gemm: the split-reduction arena is too small");
+  MVK_ORDERED(make_ordered(st, a, split, (int)grid.x, grid.y, 32, 64));
   hipLaunchKernelGGL((gemm_f32_mfma_dual<false, false, 2, 1, 1, 4>), grid, dim3(256), 0, st, a);
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
@@ -856,8 +902,8 @@ extern "C" int mvk_gemm_f32_pair(const float* A, const float* B0, const float* B
   const int64_t tm = 16 * p0.pm, tn = 64;
   MVK_REQUIRE(cdiv64(M, tm) < 65536 && s0 < 65536 && s1 < 65536, "gemm: grid too large");
   const int gx0 = (int)cdiv64(N0, tn), gx1 = (int)cdiv64(N1, tn);
-  MVK_REQUIRE(make_ordered(a0, s0, gx0, cdiv64(M, tm), tm, tn) && make_ordered(a1, s1, gx1, cdiv64(M, tm), tm, tn),
-              "gemm: the split-reduction arena is too small");
+  MVK_ORDERED(make_ordered(st, a0, s0, gx0, cdiv64(M, tm), tm, tn));
+  MVK_ORDERED(make_ordered(st, a1, s1, gx1, cdiv64(M, tm), tm, tn));
   MVK_REQUIRE(ord || ((s0 == 1 || !a0.bn_part) && (s1 == 1 || !a1.bn_part)), "gemm pair: statistics of a split product");
   dim3 grid((unsigned)(gx0 + gx1), (unsigned)cdiv64(M, tm), (unsigned)(s0 > s1 ? s0 : s1));
   const bool ok = transB ? launch_pair_cfg<false, true>(p0, grid, st, a0, a1, gx0, s0, s1)
@@ -992,7 +1038,7 @@ int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int
   const int64_t tm = p.narrow ? 64 * p.pm : 16 * p.pm, tn = p.narrow ? 16 * p.qn : 64 * p.qn;
   MVK_REQUIRE(cdiv64(M, tm) < 65536 && split < 65536, "gemm: grid too large");
   dim3 grid((unsigned)cdiv64(N, tn), (unsigned)cdiv64(M, tm), (unsigned)split);
-  MVK_REQUIRE(make_ordered(a, split, (int)grid.x, grid.y, tm, tn), "gemm: the split-reduction arena is too small");
+  MVK_ORDERED(make_ordered(st, a, split, (int)grid.x, grid.y, tm, tn));
   MVK_REQUIRE(!(bn_part && split > 1 && !a.det_ws), "gemm: BatchNorm statistics of a split product need the ordered reduction");
   bool ok;
   if (!transA && !transB) ok = launch_cfg<false, false>(p, grid, st, a);
@@ -1052,7 +1098,8 @@ extern "C" int mvk_gemm_f32_tn_grouped_split(int64_t M, int64_t N, int64_t Kd) {
 // Fills `table_host` (n * mvk_gemm_group_entry_bytes() bytes, narrow problems first) for the device-side grouped launch
 // and reports how many of the problems are narrow (N <= 32) and the workgroup counts of the two launches.
 extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* table_host, int* n_narrow,
-                                            int64_t* wgs_narrow, int64_t* wgs_wide, int32_t* splits /* [n] out */) {
+                                            int64_t* wgs_narrow, int64_t* wgs_wide, int32_t* splits /* [n] out */,
+                                            void* stream /* the stream mvk_gemm_f32_tn_grouped will launch on */) {
   MVK_REQUIRE(n >= 0 && problems && table_host && n_narrow && wgs_narrow && wgs_wide && splits, "grouped gemm: bad arguments");
   const MvkGemmProblem* pr = (const MvkGemmProblem*)problems;
   GroupEntry* tab = (GroupEntry*)table_host;
@@ -1099,7 +1146,7 @@ extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* t
     e.gx = (int)cdiv64(q.N, tn);
     e.gy = (int)cdiv64(q.M, tm);
     e.gz = split;
-    MVK_REQUIRE(make_ordered(e.args, split, e.gx, e.gy, tm, tn), "grouped gemm: the split-reduction arena is too small");
+    MVK_ORDERED(make_ordered((hipStream_t)stream, e.args, split, e.gx, e.gy, tm, tn));
     const int64_t wgs = (int64_t)e.gx * e.gy * e.gz;
     if (narrow) {
       e.wg_begin = (int)wn;

@@ -253,7 +253,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void store_f4_hidden(float* p, float4 v) {
   typedef float f4v __attribute__((ext_vector_type(4)));
   const f4v q = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
+  // s_nop 2: the store reads its data registers late; a VALU write to them within two wait states would be stored
+  // instead (the compiler pads its own wide stores, it cannot see into this one -- common.h, round 4)
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" : : "v"(p), "v"(q) : "memory");
 }
 
 template <int CT, int SW, int NS>

@@ -34,7 +34,9 @@ struct S32Args {
 __device__ __forceinline__ void store_f4_hidden32(float* p, float4 v) {     // see gemm16.hip: store_f4_hidden
   typedef float f4v __attribute__((ext_vector_type(4)));
   const f4v q = {v.x, v.y, v.z, v.w};
-  asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(q) : "memory");
+  // s_nop 2: the store reads its data registers late; a VALU write to them within two wait states would be stored
+  // instead (the compiler pads its own wide stores, it cannot see into this one -- common.h, round 4)
+  asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" : : "v"(p), "v"(q) : "memory");
 }
 
 __device__ __forceinline__ void wave_lds_handoff() {   // LDS hand-off inside ONE wave (its own region)

@@ -628,11 +628,11 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   // ---- P3: first-occurrence flags -> voxel ids in insertion order
   int* scan = W.scan + off;
   for (int i0 = tid; i0 < n; i0 += 8 * TPB) {          // eight dependent slot -> first chains of a thread in flight together
-    const int* ap[8];
+    int ai[8];
     int f[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) ap[u] = hfirst + slot[i0 + u * TPB < n ? i0 + u * TPB : i0];
-    ldg_agent<8>(f, ap);
+    for (int u = 0; u < 8; ++u) ai[u] = slot[i0 + u * TPB < n ? i0 + u * TPB : i0];
+    ldg_agent<8>(f, hfirst, ai);
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (i0 + u * TPB < n) scan[i0 + u * TPB] = (f[u] == i0 + u * TPB) ? 1 : 0;
@@ -643,18 +643,12 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   int* vseg = W.vseg + off;
   int* vcursor = W.vcursor + off;
   for (int i0 = tid; i0 < n; i0 += 4 * TPB) {
-    const int* ap[4];
-    const unsigned long long* kp[4];
     int f[4], sl[4];
     unsigned long long kv[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      sl[u] = slot[i0 + u * TPB < n ? i0 + u * TPB : i0];
-      ap[u] = hfirst + sl[u];
-      kp[u] = hkey + sl[u];
-    }
-    ldg_agent<4>(f, ap);
-    ldg_agent<4>(kv, kp);
+    for (int u = 0; u < 4; ++u) sl[u] = slot[i0 + u * TPB < n ? i0 + u * TPB : i0];
+    ldg_agent<4>(f, hfirst, sl);
+    ldg_agent<4>(kv, hkey, sl);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int i = i0 + u * TPB;
@@ -686,11 +680,11 @@ __global__ __launch_bounds__(TPB) void subsample_cloud_kernel(const float* __res
   SUB_STAMP(4);
   // ---- P5: segment offsets
   for (int v0 = tid; v0 < M; v0 += 8 * TPB) {
-    const int* ap[8];
+    int ai[8];
     int c[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) ap[u] = vcount + (v0 + u * TPB < M ? v0 + u * TPB : v0);
-    ldg_agent<8>(c, ap);
+    for (int u = 0; u < 8; ++u) ai[u] = v0 + u * TPB < M ? v0 + u * TPB : v0;
+    ldg_agent<8>(c, vcount, ai);
 #pragma unroll
     for (int u = 0; u < 8; ++u)
       if (v0 + u * TPB < M) vseg[v0 + u * TPB] = c[u];

@@ -126,6 +126,11 @@ def set_deterministic(flag, device=None):
 
 
 def is_deterministic():
+    """True when the ordered reductions are on. With MVK_DETERMINISTIC=1 the arena used to appear only with the first
+    product, so a pyramid built before it saw False (rows in arrival order, no transposed upsampling lists: the first
+    step of an env-enabled run was not bit-reproducible): the first question creates the arena."""
+    if _DET["on"] and not _SPLIT_ARENA and torch.cuda.is_available() and not torch.cuda.is_current_stream_capturing():
+        split_arena_prepare(torch.device("cuda", torch.cuda.current_device()))
     return bool(_DET["on"] and _SPLIT_ARENA)
 
 
@@ -632,7 +637,8 @@ def _flush_deferred(items=None):
     nn, wn, ww = C.c_int(0), C.c_int64(0), C.c_int64(0)
     splits = np.zeros(n, np.int32)
     check(lib().mvk_gemm_f32_tn_grouped_plan(prob.ctypes.data_as(C.c_void_p), n, C.c_void_p(slot["host"].data_ptr()),
-                                             C.byref(nn), C.byref(wn), C.byref(ww), splits.ctypes.data_as(C.c_void_p)))
+                                             C.byref(nn), C.byref(wn), C.byref(ww), splits.ctypes.data_as(C.c_void_p),
+                                             _stream()))
     for i, item in enumerate(items):
         if splits[i] > 1 and not item[3] and not lib().mvk_gemm_split_ordered():
             raise RuntimeError("defer_weight_grads: the grouped plan splits a product whose output was not zero-initialised")
@@ -1111,6 +1117,7 @@ def full_count(rows, device):
             raise RuntimeError("ops.full_count: the constant row-count table does not exist yet and cannot be created "
                                "inside a graph capture; run one eager step first or call ops.full_count_prepare(device)")
         t = torch.arange(_COUNT_TABLE_ROWS, dtype=torch.int32, device=device)
+        torch.cuda.current_stream(device).synchronize()      # other streams read views of it without any event
         _COUNT_TABLE[device.index] = t
     if 0 <= rows < _COUNT_TABLE_ROWS:
         return t[rows:rows + 1]
@@ -1121,6 +1128,7 @@ def full_count(rows, device):
             raise RuntimeError("ops.full_count: %d rows lie beyond the constant table; request this count once outside "
                                "the capture" % rows)
         w = torch.full((1,), rows, dtype=torch.int32, device=device)
+        torch.cuda.current_stream(device).synchronize()
         _BIG_COUNTS[key] = w
     return w
 
@@ -1790,6 +1798,7 @@ def neighbors_cell_order(Nq, Ns, B, out=None, s_lens_dev=None, device=None):
 
 
 _REV_COUNTS = {}      # device index -> persistent zero int32 buffer of mvk_reverse_neighbors (self-cleaning)
+_REV_COUNTS_RETIRED = []      # outgrown buffers: a graph captured earlier still adds into and zeroes its old address
 REVERSE_DX = os.environ.get("MVK_REVERSE_DX", "1") == "1"      # development switch: 0 = the scatter backward everywhere
 
 
@@ -1802,7 +1811,11 @@ def _rev_counts(n, device):
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError("ops.reverse_neighbors: the counter buffer of this device does not exist yet (or is too "
                                "small) and cannot be created inside a graph capture; build one batch eagerly first")
+        if buf is not None:
+            # never handed back to the allocator: replays of earlier captures keep using it
+            _REV_COUNTS_RETIRED.append(buf)
         buf = torch.zeros(max(int(n), 1 << 16), dtype=torch.int32, device=device)
+        torch.cuda.current_stream(device).synchronize()      # zero before any other stream's build uses it
         _REV_COUNTS[key] = buf
     return buf
 
@@ -1870,6 +1883,10 @@ def remember_reverse(inds, rev, first_column=False):
     entry holds a weak reference to THAT tensor object: another matrix of the same shape at a recycled address never
     matches (a wrong reverse list would be a silently wrong gradient, unlike a stale work list)."""
     key = _rev_key(inds, first_column)
+    if len(_REVERSES) >= 16:
+        # entries whose index matrix is gone hold tens of MB each at level 0: drop them now, not 256 batches later
+        for k in [k for k, e in _REVERSES.items() if e[0]() is None]:
+            del _REVERSES[k]
     _REVERSES[key] = (weakref.ref(inds), rev)
     _REVERSES.move_to_end(key)
     while len(_REVERSES) > _REVERSES_KEPT:

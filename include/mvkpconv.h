@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVK_ABI_VERSION 6   /* 6: ordered split reductions (mvk_gemm_split_arena), reverse neighbour lists; 5: gather with a work list (mvk_kpconv_gather_fwd_ordered); 4: fp16 mode on gfx950 forms: padded fp16 aggregate rows, streaming contraction (v_mfma_f32_16x16x32_f16) with statistics epilogue, one-launch weight rounding; 3: gemm plan / BatchNorm-statistics epilogue, BatchNorm takes epilogue partials, fused clip + SGD, offset gradient + regulariser, segmentation loss, gather launch plan, strided gather-rows backward, channels-last fusion gather; 2: masked BatchNorm takes the batch counter and a residual addend; enqueue-only / device-lens pyramid entry points; fp16-feature mode; capacity padding */
+#define MVK_ABI_VERSION 7   /* 7: BatchNorm folded into the GEMMs around it (statistics finished by the producer, apply in the consumer's operand load), reverse lists out of the neighbour search, grouped plan takes the stream; 6: ordered split reductions (mvk_gemm_split_arena), reverse neighbour lists; 5: gather with a work list (mvk_kpconv_gather_fwd_ordered); 4: fp16 mode on gfx950 forms: padded fp16 aggregate rows, streaming contraction (v_mfma_f32_16x16x32_f16) with statistics epilogue, one-launch weight rounding; 3: gemm plan / BatchNorm-statistics epilogue, BatchNorm takes epilogue partials, fused clip + SGD, offset gradient + regulariser, segmentation loss, gather launch plan, strided gather-rows backward, channels-last fusion gather; 2: masked BatchNorm takes the batch counter and a residual addend; enqueue-only / device-lens pyramid entry points; fp16-feature mode; capacity padding */
 
 /* influence / aggregation codes (blocks.py:329-354) */
 #define MVK_INFL_CONSTANT 0
@@ -134,8 +134,12 @@ int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t
  * partial tiles in a slice of `ws` and the workgroup that arrives last at a tile adds them in the fixed order of the
  * splits -- bit-identical from run to run, C needs no zero fill (every element is written), `accumulate` adds onto C
  * once, and the BatchNorm-statistics epilogue works on split plans too (mvk_gemm_f32_plan then reports rows > 0 with
- * split > 1). Slices are handed out in call order and wrap around at the end of the arena; a product larger than the
- * whole arena fails with an error. ws == NULL restores the atomic path. mvk_gemm_split_ordered() = 1 while an arena
+ * split > 1). Slices (round 5): a launch on a CAPTURING stream takes its slices from the top of the arena and keeps
+ * them for good (graph nodes replay, graph branches run side by side); an eager launch takes the next slice of the
+ * bottom region, and when that region is used up the library waits for the device once (hipDeviceSynchronize) and
+ * starts it again from offset 0. A request that cannot be served under these rules -- a product larger than the arena,
+ * or an arena used up by captured slices -- fails with an error; two launches that may run concurrently never share a
+ * slice. The host state is mutex-protected. ws == NULL restores the atomic path. mvk_gemm_split_ordered() = 1 while an arena
  * is set. (The reference's products are single ATen matmuls: deterministic. This makes ours so.) */
 int mvk_gemm_split_arena(void* ws, int64_t ws_bytes, void* counters, int64_t n_counters);
 int mvk_gemm_split_ordered(void);
@@ -215,7 +219,7 @@ int mvk_gemm_f32_tn_grouped_split(int64_t M, int64_t N, int64_t Kd);
  * that copy to mvk_gemm_f32_tn_grouped together with the three counts the plan returned. */
 int64_t mvk_gemm_group_entry_bytes(void);
 int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* table_host, int* n_narrow, int64_t* wgs_narrow,
-                                 int64_t* wgs_wide, int32_t* splits);
+                                 int64_t* wgs_wide, int32_t* splits, void* stream /* the launch's stream (ABI 7) */);
 int mvk_gemm_f32_tn_grouped(const void* table_dev, int n, int n_narrow, int64_t wgs_narrow, int64_t wgs_wide,
                             void* stream);
 

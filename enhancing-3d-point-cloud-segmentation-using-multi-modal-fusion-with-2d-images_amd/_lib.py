@@ -29,6 +29,17 @@ class BnBwdProblem(C.Structure):
                 ("y_out", _vp), ("d_addend", _vp)]
 
 
+class BnFinish(C.Structure):
+    """mvk_bn_finish: the producer's half of a folded BatchNorm (statistics finished inside the GEMM launch)."""
+    _fields_ = [("counters", _vp), ("eps", _f), ("momentum", _f), ("mean", _vp), ("invstd", _vp), ("running_mean", _vp),
+                ("running_var", _vp), ("num_batches_tracked", _vp)]
+
+
+class ATransform(C.Structure):
+    """mvk_a_transform: the consumer's half (BatchNorm + LeakyReLU applied while the A operand is staged)."""
+    _fields_ = [("mean", _vp), ("invstd", _vp), ("gamma", _vp), ("beta", _vp), ("slope", _f), ("n_valid", _vp), ("out", _vp)]
+
+
 _SIGNATURES = {
     "mvk_abi_version": (C.c_int, []),
     "mvk_last_error": (C.c_char_p, []),
@@ -65,6 +76,9 @@ _SIGNATURES = {
     "mvk_gemm_f32_pair_plan": (C.c_int, [_i64, _i64, _i64, _i64, _i, _vp]),
     "mvk_gemm_f32_pair": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _i, _vp, _vp, _vp, _vp]),
     "mvk_gemm_f32_ex": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mvk_gemm_f32_bn": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i, _vp, _vp, C.POINTER(BnFinish), C.POINTER(ATransform), _vp]),
+    "mvk_gemm_f32_pair_bn": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i, _vp, _vp, _vp,
+                                       C.POINTER(BnFinish), C.POINTER(BnFinish), _vp]),
     "mvk_gemm_group_entry_bytes": (C.c_int64, []),
     "mvk_gemm_f32_tn_grouped_split": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "mvk_gemm_f32_tn_grouped_plan": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -357,9 +357,18 @@ __device__ __forceinline__ void bn_finish_apply_body(const float* __restrict__ x
   const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   const int n = min(*n_valid, R);
+  if (ext_rows < 0) {
+    // statistics FINISHED by the producing GEMM (mvk_bn_finish, csrc/gemm.hip): mean / invstd are inputs, the running
+    // statistics and the batch counter have been updated there -- nothing to reduce, nothing to publish
+    if (pr == 0 && c < D) {
+      smu[cl] = mean[c];
+      sis[cl] = invstd[c];
+    }
+  }
   float p1, p2;
-  const bool owner = ext_rows > 0 ? bn_sum_partials_m2(part, R, ext_rows, n, D, &p1, &p2)
-                                  : bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, &p1, &p2);   // lanes pr == 0, c < D
+  const bool owner = ext_rows < 0 ? false
+                     : ext_rows > 0 ? bn_sum_partials_m2(part, R, ext_rows, n, D, &p1, &p2)
+                                    : bn_sum_partials(part, (R + BN_ROWS - 1) / BN_ROWS, D, &p1, &p2);   // lanes pr == 0, c < D
   if (owner) {
     float mu = 0.f, is = 0.f, var = 0.f;
     if (n > 0 && ext_rows > 0) {
@@ -386,7 +395,7 @@ __device__ __forceinline__ void bn_finish_apply_body(const float* __restrict__ x
       }
     }
   }
-  if (nbt && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *nbt += 1;
+  if (nbt && ext_rows >= 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *nbt += 1;
   __syncthreads();
   if (c >= D) return;
   const float mu = smu[cl], is = sis[cl], ga = gamma[c], be = beta[c];
@@ -1066,9 +1075,18 @@ extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t 
                                 int64_t* num_batches_tracked, const float* addend, const float* ext_part, int ext_rows,
                                 void* stream) {
   MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
-  MVK_REQUIRE((ext_part == nullptr) == (ext_rows == 0) && ext_rows >= 0, "bn: ext_part and ext_rows go together");
+  MVK_REQUIRE((ext_part == nullptr) == (ext_rows <= 0) && ext_rows >= -1, "bn: ext_part and ext_rows go together (-1: finished statistics)");
   if (R == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  if (ext_rows < 0) {      // mean / invstd finished by the producing GEMM: the apply pass alone, whatever the row count
+    MVK_REQUIRE(bn_fused_finish(), "bn: finished statistics need the fused apply kernel (MVK_BN_FUSED_FINISH=1)");
+    const unsigned gyr = (unsigned)cdiv64(R, BN_ROWS);
+    const unsigned gy = gyr < (unsigned)bn_fused_gy() ? gyr : (unsigned)bn_fused_gy();
+    hipLaunchKernelGGL(bn_finish_apply, dim3((unsigned)cdiv64(D, 64), gy), dim3(1024), 0, st, x, n_valid, (int)R, D, nullptr,
+                       eps, momentum, gamma, beta, slope, mean, invstd, nullptr, nullptr, nullptr, addend, y, -1);
+    MVK_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   if (R > bn_small_rows() && R <= bn_mid_rows() && D % 4 == 0 &&
       aligned16(x, y, addend, gamma, beta, mean, invstd, running_mean) &&
       aligned16(running_var, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr)) {
@@ -1157,6 +1175,7 @@ extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n
 namespace {
 
 int bn_family_fwd(const mvk_bn_fwd_problem& p) {
+  if (p.ext_rows < 0) return 2;          // finished statistics: the apply kernel alone
   if (p.R <= bn_small_rows()) return 0;
   if (p.R <= bn_mid_rows() && p.D % 4 == 0 &&
       aligned16(p.x, p.y, p.addend, p.gamma, p.beta, p.mean, p.invstd, p.running_mean) &&
@@ -1196,7 +1215,8 @@ extern "C" int mvk_bn_lrelu_fwd_pair(const mvk_bn_fwd_problem* pa, const mvk_bn_
     return bn_fwd_single(b, stream);
   }
   MVK_REQUIRE(a.D > 0 && b.D > 0 && a.R < (1ll << 31), "bn: bad sizes");
-  MVK_REQUIRE((a.ext_part == nullptr) == (a.ext_rows == 0) && (b.ext_part == nullptr) == (b.ext_rows == 0),
+  MVK_REQUIRE((a.ext_part == nullptr) == (a.ext_rows <= 0) && (b.ext_part == nullptr) == (b.ext_rows <= 0) &&
+                  a.ext_rows >= -1 && b.ext_rows >= -1,
               "bn: ext_part and ext_rows go together");
   hipStream_t st = (hipStream_t)stream;
   const int R = (int)a.R, Dm = a.D > b.D ? a.D : b.D;
@@ -1215,7 +1235,7 @@ extern "C" int mvk_bn_lrelu_fwd_pair(const mvk_bn_fwd_problem* pa, const mvk_bn_
   } else {
     const unsigned gyr = (unsigned)cdiv64(R, BN_ROWS);
     for (const mvk_bn_fwd_problem* p : {pa, pb})
-      if (p->ext_part == nullptr)       // no statistics from the producing GEMM (a split reduction): its own pass
+      if (p->ext_part == nullptr && p->ext_rows == 0)       // no statistics from the producing GEMM (a split reduction): its own pass
         hipLaunchKernelGGL(bn_stats_partial, dim3((unsigned)cdiv64(p->D, 64), gyr), dim3(BN_T), 0, st, p->x, p->n_valid, R,
                            p->D, p->scratch2D);
     const unsigned gy = gyr < (unsigned)bn_fused_gy() ? gyr : (unsigned)bn_fused_gy();

@@ -51,6 +51,43 @@ struct Tile {
   static constexpr int IPT = ROWS / 4;             // threads along i (row-contiguous sources)
   float4 v[NV];
 
+  // A-operand transform of a k-contiguous tile held in registers (GemmArgs (b)): xs = LDS table [k - kbase0][4] =
+  // {mean, invstd * gamma, beta, -} of this workgroup's k-range, k0 = the tile's first k, rows >= nvalid -> 0. `out`
+  // (column-tile-0 workgroups, else null): the transformed values also go to out[row * ld + k] for rows < imax, k < kmax.
+  __device__ __forceinline__ void transform(const float* __restrict__ xs, int64_t k0, int64_t kbase0, int64_t i0, int64_t imax,
+                                            int64_t kmax, int64_t nvalid, float slope, float* __restrict__ out, int64_t ld,
+                                            int tid) {
+    static_assert(CONTIG_K, "the transform is written for k-contiguous A tiles");
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+      const int f = tid + 256 * u;
+      if (NF4 % 256 == 0 || f < NF4) {
+        const int i = f >> 3, kq = (f & 7) * 4;
+        const int64_t gi = i0 + i, gk = k0 + kq;
+        const float* t = xs + (gk - kbase0) * 4;
+        float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float4 q = *reinterpret_cast<const float4*>(t + 4 * c);       // mean, invstd * gamma, beta
+          float z = (e[c] - q.x) * q.y + q.z;
+          z = z > 0.f ? z : z * slope;
+          e[c] = gi < nvalid ? z : 0.f;
+        }
+        v[u] = make_float4(e[0], e[1], e[2], e[3]);
+        if (out && gi < imax) {
+          float* o = out + gi * ld + gk;
+          if (gk + 3 < kmax && (ld & 3) == 0)
+            *reinterpret_cast<float4*>(o) = v[u];
+          else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              if (gk + c < kmax) o[c] = e[c];
+          }
+        }
+      }
+    }
+  }
+
   // vec: 4 = rows 16-byte aligned, 2 = 8-byte aligned (e.g. K*Cin = 990), 1 = scalar
   __device__ __forceinline__ void load(const float* __restrict__ src, int64_t ld, int64_t i0, int64_t imax,
                                        int64_t k0, int64_t kmax, int vec, int tid) {
@@ -219,15 +256,44 @@ struct GemmArgs {
   // gather-form feature gradient, without a transposed copy of the weights.
   int seg_shift;
   int64_t seg_extra;
+  // Round 5: the BatchNorm around a product, folded into it.
+  // (a) FINISHED statistics (fin_cnt != null; needs bn_part): after writing its partials every workgroup of a column tile
+  //     bumps fin_cnt[column tile]; the one that arrives last merges the fin_gy row-block partials of its columns in a
+  //     fixed order (parallel-variance formula, as bn_sum_partials_m2 of csrc/bn.hip) and writes mean / invstd, the
+  //     running statistics (blocks.py:456-460: nn.BatchNorm1d(momentum)) and, for column tile 0, the batch counter --
+  //     the normalising launch (or the consumer's operand load, (b)) no longer reduces anything. Counters return to zero.
+  int* fin_cnt;
+  int fin_gy;
+  float fin_eps, fin_momentum;
+  float* fin_mean;
+  float* fin_invstd;
+  float* fin_rmean;
+  float* fin_rvar;
+  long long* fin_nbt;
+  // (b) A-operand transform (XF instantiations; NT / NN products, ax_mean != null): the product reads
+  //     A'(m, k) = m < *ax_nvalid ? LeakyReLU_slope((A(m,k) - mean[k]) * invstd[k] * gamma[k] + beta[k]) : 0
+  //     i.e. the BatchNorm + activation between the producer of A and this layer (blocks.py:456-460, :639-644) applied
+  //     while the tile is staged; the column-tile-0 workgroups also write A' to ax_out [M, Kd] (the tensor the backward's
+  //     weight-gradient product reads), so nothing downstream changes.
+  const float* ax_mean;
+  const float* ax_invstd;
+  const float* ax_gamma;
+  const float* ax_beta;
+  float ax_slope;
+  const int32_t* ax_nvalid;
+  float* ax_out;
 };
 
-template <bool TA, bool TB, int PM, int QN, int WM, int WN, bool DUAL = false>
+constexpr int XF_KMAX = 512;     // longest k-range of one workgroup with an A-operand transform (LDS table of 4 floats per k)
+
+template <bool TA, bool TB, int PM, int QN, int WM, int WN, bool DUAL = false, bool XF = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const int by, const int bz) {
   static_assert(WM * WN == 4, "four waves per workgroup");
   constexpr int TM = 16 * PM * WM, TN = 16 * QN * WN;
   typedef Tile<!TA, TM> TileA;   // A tile element (m,k): TA == false -> A[m*lda + k] (k-contiguous)
   typedef Tile<TB, TN> TileB;    // B tile element (n,k): TB == false -> B[k*ldb + n] (n-contiguous)
   __shared__ __attribute__((aligned(16))) float lds[2 * (TileA::FLOATS + TileB::FLOATS)];
+  __shared__ __attribute__((aligned(16))) float xs[XF ? 4 * (XF_KMAX + BK) : 4];
   float* const As = lds;                          // two buffers of each operand
   float* const Bs = lds + 2 * TileA::FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -242,6 +308,21 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   for (int p = 0; p < PM; ++p)
 #pragma unroll
     for (int q = 0; q < QN; ++q) acc[p][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int64_t x_nvalid = 0;
+  if (XF) {
+    // this workgroup's slice of the transform table (host: k_per_split <= XF_KMAX); entries past Kd are never used by a
+    // product term that is not multiplied by a zero-filled B row, but they are read: zeros
+    for (int k = tid; k < XF_KMAX + BK; k += 256) {
+      const int64_t gk = kbeg_all + k;
+      float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gk < a.Kd && k < a.k_per_split + BK) q = make_float4(a.ax_mean[gk], a.ax_invstd[gk] * a.ax_gamma[gk], a.ax_beta[gk], 0.f);
+      *reinterpret_cast<float4*>(&xs[4 * k]) = q;
+    }
+    x_nvalid = a.ax_nvalid ? (int64_t)*a.ax_nvalid : a.M;
+    __syncthreads();
+  }
+  float* const x_out = (XF && bx == 0) ? a.ax_out : nullptr;
 
   // Two register sets: the loads of k-tile t+2 are issued before the MFMAs of tile t and written to LDS after
   // the MFMAs of tile t+1 -- two k-tiles of global-memory latency budget, two tiles of bytes in flight per
@@ -282,6 +363,11 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   auto Bat = [&](const int64_t k) -> const float* {
     return (TB && !DUAL && a.seg_shift >= 0) ? pB + (k >> a.seg_shift) * a.seg_extra : pB;
   };
+  // publishes an A tile (first k: kt) in LDS, through the operand transform in the XF instantiations
+  auto putA = [&](TileA& la, float* __restrict__ T, const int64_t kt) {
+    if constexpr (XF) la.transform(xs, kt, kbeg_all, m0, a.M, a.Kd, x_nvalid, a.ax_slope, x_out, lda, tid);
+    la.store(T, tid);
+  };
   auto pipeline = [&](auto va, auto vb, const int64_t klim) {
     constexpr int VA = decltype(va)::value, VB = decltype(vb)::value;
     if (kbeg >= klim) return;
@@ -291,7 +377,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
       la1.template fetch<VA>(pA, lda, m0, a.M, kbeg + BK, klim, vecA, tid);
       lb1.template fetch<VB>(Bat(kbeg + BK), ldb, n0, a.N, kbeg + BK, klim, vecB, tid);
     }
-    la0.store(A0, tid);
+    putA(la0, A0, kbeg);
     lb0.store(B0, tid);
     __syncthreads();
     for (int64_t k0 = kbeg; k0 < klim; k0 += 2 * BK) {
@@ -302,7 +388,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
       }
       compute(A0, B0);
       if (k0 + BK >= klim) break;
-      la1.store(A1, tid);
+      putA(la1, A1, k0 + BK);
       lb1.store(B1, tid);
       __syncthreads();
       // odd k-tile (buffer 1): fetch tile +3 into set 1, multiply, publish tile +2 (set 0) in buffer 0
@@ -312,7 +398,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
       }
       compute(A1, B1);
       if (k0 + 2 * BK >= klim) break;
-      la0.store(A0, tid);
+      putA(la0, A0, k0 + 2 * BK);
       lb0.store(B0, tid);
       __syncthreads();
     }
@@ -334,7 +420,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
     __syncthreads();
     la0.load(pA, lda, m0, a.M, kfull, kend, vecA, tid);
     lb0.load(Bat(kfull), ldb, n0, a.N, kfull, kend, vecB, tid);
-    la0.store(A0, tid);
+    putA(la0, A0, kfull);
     lb0.store(B0, tid);
     __syncthreads();
     compute(A0, B0);
@@ -460,6 +546,17 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
     const int64_t bcnt = nv - m0 < 0 ? 0 : (nv - m0 > TM ? TM : nv - m0);                                  // the block's
     const int64_t blk = m0 / TM;
     float* red = lds;                      // [WM][TN] sums, then [WM][TN] centred squares (operand tiles are dead)
+    // finished statistics: the partials cross to another workgroup inside this launch -> agent-scope stores (common.h)
+    const __amdgpu_buffer_rsrc_t part_rs = park_rsrc(a.bn_part);
+    auto put_part = [&](const int64_t col, const float sum, const float m2) {
+      if (a.fin_cnt) {
+        park_store1(part_rs, (uint32_t)(((blk * 2) * a.N + col) * 4), sum);
+        park_store1(part_rs, (uint32_t)(((blk * 2 + 1) * a.N + col) * 4), m2);
+      } else {
+        a.bn_part[(blk * 2) * a.N + col] = sum;
+        a.bn_part[(blk * 2 + 1) * a.N + col] = m2;
+      }
+    };
     if (WM > 1) __syncthreads();
     float s[QN], mu[QN];
 #pragma unroll
@@ -501,10 +598,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
         if (lane < 16) red[(WM + wm) * TN + rb + 16 * q + ci] = m2;
       } else {
         const int64_t col = n0 + rb + 16 * q + ci;
-        if (lane < 16 && col < a.N && m0 < a.M) {
-          a.bn_part[(blk * 2) * a.N + col] = s[q];
-          a.bn_part[(blk * 2 + 1) * a.N + col] = m2;
-        }
+        if (lane < 16 && col < a.N && m0 < a.M) put_part(col, s[q], m2);
       }
     }
     if (WM > 1) {
@@ -516,12 +610,94 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
 #pragma unroll
           for (int w = 0; w < WM; ++w) m2 += red[(WM + w) * TN + rb + 16 * q + ci];
           const int64_t col = n0 + rb + 16 * q + ci;
-          if (col < a.N && m0 < a.M) {
-            a.bn_part[(blk * 2) * a.N + col] = s[q];
-            a.bn_part[(blk * 2 + 1) * a.N + col] = m2;
-          }
+          if (col < a.N && m0 < a.M) put_part(col, s[q], m2);
         }
       }
+    }
+    if (a.fin_cnt) {
+      // ---- the last workgroup of this column tile finishes the statistics (GemmArgs (a)). Hand-off as in the ordered
+      // split: stores acknowledged (park_wait) + barrier, then one relaxed agent-scope bump; the bump's return value
+      // orders the last arriver's loads behind every other workgroup's stores.
+      park_wait();
+      __syncthreads();
+      int* const flag = reinterpret_cast<int*>(lds);
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(a.fin_cnt + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = old == a.fin_gy - 1;
+        if (last) __hip_atomic_store(a.fin_cnt + bx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *flag = last;
+      }
+      __syncthreads();
+      const int last = *flag;
+      __syncthreads();
+      if (!last) return;
+      // thread -> (four columns c4, row-block lane bl): its blocks bl, bl + BL, ... in that order, FP (sum, M2) pairs of
+      // float4 in flight (more would raise the register count of the small-tile instantiations above their main loop's); the BL lanes of a column meet in LDS and are added in lane order: one fixed order throughout.
+      // Merge about the mean of block 0 (bn_sum_partials_m2 of csrc/bn.hip): S = sum_b sum_b, Q = sum_b [M2_b + n_b
+      // (mean_b - ref)^2], mean = S / n, M2 = Q - n (mean - ref)^2. (host: N % 4 == 0)
+      constexpr int C4 = TN / 4, BL = 256 / C4;
+      const int c4 = tid % C4, bl = tid / C4;
+      const int64_t col0 = n0 + 4 * c4;
+      const int nb = nv > 0 ? (int)((nv + TM - 1) / TM) : 0;
+      f32x4 X = {0.f, 0.f, 0.f, 0.f}, Y = {0.f, 0.f, 0.f, 0.f}, ref = {0.f, 0.f, 0.f, 0.f};
+      if (col0 < a.N && nb > 0) {
+        const float n0f = (float)(nv < TM ? nv : TM);
+        ref = park_load4(part_rs, (uint32_t)(col0 * 4));
+        ref = ref * (1.f / n0f);
+        constexpr int FP = 4;
+        for (int i0 = bl; i0 < nb; i0 += FP * BL) {
+          f32x4 u[FP], w[FP];
+#pragma unroll
+          for (int t = 0; t < FP; ++t) {
+            const int i = i0 + t * BL < nb ? i0 + t * BL : nb - 1;        // clamped, skipped when adding
+            u[t] = park_load4(part_rs, (uint32_t)((((int64_t)i * 2) * a.N + col0) * 4));
+            w[t] = park_load4(part_rs, (uint32_t)((((int64_t)i * 2 + 1) * a.N + col0) * 4));
+          }
+#pragma unroll
+          for (int t = 0; t < FP; ++t)
+            if (i0 + t * BL < nb) {
+              const int64_t left = nv - (int64_t)(i0 + t * BL) * TM;
+              const float ni = (float)(left < TM ? left : TM);
+              const f32x4 d = u[t] * (1.f / ni) - ref;
+              X += u[t];
+              Y += w[t] + ni * d * d;
+            }
+        }
+      }
+      float* const q1 = lds;                   // [BL][TN]
+      float* const q2 = lds + 256 * 4;         // [BL][TN]   (2 x 4 KB: every instantiation has more LDS than that)
+      *reinterpret_cast<f32x4*>(&q1[bl * TN + 4 * c4]) = X;
+      *reinterpret_cast<f32x4*>(&q2[bl * TN + 4 * c4]) = Y;
+      // ref of a column: lane 0's value, through LDS as well
+      float* const qr = lds + 2 * 256 * 4;     // [TN]
+      if (bl == 0) *reinterpret_cast<f32x4*>(&qr[4 * c4]) = ref;
+      __syncthreads();
+      const int64_t col = n0 + tid;
+      if (tid < TN && col < a.N) {
+        float x = 0.f, y = 0.f;
+#pragma unroll 4
+        for (int l = 0; l < BL; ++l) {
+          x += q1[l * TN + tid];
+          y += q2[l * TN + tid];
+        }
+        float mu = 0.f, var = 0.f, is = 0.f;
+        if (nv > 0) {
+          mu = x / (float)nv;
+          const float dm = mu - qr[tid];
+          float M2 = y - (float)nv * dm * dm;
+          M2 = M2 > 0.f ? M2 : 0.f;
+          var = M2 / (float)nv;                 // biased
+          is = rsqrtf(var + a.fin_eps);
+        }
+        a.fin_mean[col] = mu;
+        a.fin_invstd[col] = is;
+        if (a.fin_rmean && nv > 0) {
+          const float unbiased = nv > 1 ? var * ((float)nv / (float)(nv - 1)) : var;
+          a.fin_rmean[col] = (1.f - a.fin_momentum) * a.fin_rmean[col] + a.fin_momentum * mu;
+          a.fin_rvar[col] = (1.f - a.fin_momentum) * a.fin_rvar[col] + a.fin_momentum * unbiased;
+        }
+      }
+      if (a.fin_nbt && bx == 0 && tid == 0) *a.fin_nbt += 1;
     }
   }
 }
@@ -529,6 +705,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
 template <bool TA, bool TB, int PM, int QN, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs a) {
   gemm_body<TA, TB, PM, QN, WM, WN>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// the same with the A-operand transform (GemmArgs (b)): wide tiles, A not transposed
+template <bool TB, int PM>
+__global__ __launch_bounds__(256) void gemm_f32_mfma_xf(const GemmArgs a) {
+  gemm_body<false, TB, PM, 1, 1, 4, false, true>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // Two independent products of the same operand layout, tile shape and row count in one launch: their column tiles side
@@ -768,6 +950,26 @@ void pair_widen(Plan& a, const Plan& b, int64_t Kd) {
   }
 }
 
+void no_bn_fold(GemmArgs& a) {
+  a.fin_cnt = nullptr; a.fin_gy = 0; a.fin_eps = 0.f; a.fin_momentum = 0.f; a.fin_mean = nullptr; a.fin_invstd = nullptr;
+  a.fin_rmean = nullptr; a.fin_rvar = nullptr; a.fin_nbt = nullptr;
+  a.ax_mean = nullptr; a.ax_invstd = nullptr; a.ax_gamma = nullptr; a.ax_beta = nullptr; a.ax_slope = 1.f;
+  a.ax_nvalid = nullptr; a.ax_out = nullptr;
+}
+
+// the producer's half of a folded BatchNorm (GemmArgs (a)); gy = row tiles of the launch
+int set_finish(GemmArgs& a, const mvk_bn_finish* fin, int64_t gy) {
+  if (!fin) return 0;
+  MVK_REQUIRE(a.bn_part != nullptr, "gemm: finished BatchNorm statistics need the statistics epilogue (plan: stat rows 0)");
+  MVK_REQUIRE(fin->counters && fin->mean && fin->invstd && a.N % 4 == 0 && (uintptr_t)a.bn_part % 16 == 0,
+              "gemm: finished statistics need counters, mean, invstd and a channel count that is a multiple of 4");
+  MVK_REQUIRE((fin->running_mean == nullptr) == (fin->running_var == nullptr), "gemm: running_mean and running_var go together");
+  a.fin_cnt = fin->counters; a.fin_gy = (int)gy; a.fin_eps = fin->eps; a.fin_momentum = fin->momentum;
+  a.fin_mean = fin->mean; a.fin_invstd = fin->invstd; a.fin_rmean = fin->running_mean; a.fin_rvar = fin->running_var;
+  a.fin_nbt = (long long*)fin->num_batches_tracked;
+  return 0;
+}
+
 // fills the arguments of one product like mvk_gemm_f32_ex does; returns its split
 int fill_args(GemmArgs& a, const Plan& p, const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd,
               int transA, int transB, float* bn_part, const int32_t* n_valid) {
@@ -792,6 +994,7 @@ int fill_args(GemmArgs& a, const Plan& p, const float* A, const float* B, float*
   a.sc_idx = nullptr; a.sc_idx64 = 0; a.sc_c1 = 0; a.sc_stride = 0; a.sc_ns = 0; a.sc_dst = nullptr; a.sc_rest = nullptr;
   a.det_ws = nullptr; a.det_cnt = nullptr; a.det_gx = 0; a.det_nsplit = split;
   a.seg_shift = -1; a.seg_extra = 0;
+  no_bn_fold(a);
   return split;
 }
 
@@ -886,9 +1089,26 @@ extern "C" int mvk_gemm_f32_pair_plan(int64_t M, int64_t N0, int64_t N1, int64_t
 // C0 [M,N0] = A . op(B0) and C1 [M,N1] = A . op(B1) in ONE launch (A [M,Kd] row-major, not transposed; transB as in
 // mvk_gemm_f32_ex); plain stores (split reductions: atomics into zero-initialised outputs), statistics partials as in
 // mvk_gemm_f32_ex where the plan gives a row-block size. Fails when mvk_gemm_f32_pair_plan does not allow the pair.
+namespace {
+int gemm_pair_run(const float* A, const float* B0, const float* B1, float* C0, float* C1, int64_t M, int64_t N0, int64_t N1,
+                  int64_t Kd, int transB, int want_stats, float* bn_part0, float* bn_part1, const int32_t* n_valid,
+                  const mvk_bn_finish* fin0, const mvk_bn_finish* fin1, void* stream);
+}
 extern "C" int mvk_gemm_f32_pair(const float* A, const float* B0, const float* B1, float* C0, float* C1, int64_t M,
                                  int64_t N0, int64_t N1, int64_t Kd, int transB, int want_stats, float* bn_part0,
                                  float* bn_part1, const int32_t* n_valid, void* stream) {
+  return gemm_pair_run(A, B0, B1, C0, C1, M, N0, N1, Kd, transB, want_stats, bn_part0, bn_part1, n_valid, nullptr, nullptr, stream);
+}
+// mvk_gemm_f32_pair with the statistics of either output finished inside the launch (fin0 / fin1, null = not)
+extern "C" int mvk_gemm_f32_pair_bn(const float* A, const float* B0, const float* B1, float* C0, float* C1, int64_t M,
+                                    int64_t N0, int64_t N1, int64_t Kd, int transB, float* bn_part0, float* bn_part1,
+                                    const int32_t* n_valid, const mvk_bn_finish* fin0, const mvk_bn_finish* fin1, void* stream) {
+  return gemm_pair_run(A, B0, B1, C0, C1, M, N0, N1, Kd, transB, 1, bn_part0, bn_part1, n_valid, fin0, fin1, stream);
+}
+namespace {
+int gemm_pair_run(const float* A, const float* B0, const float* B1, float* C0, float* C1, int64_t M, int64_t N0, int64_t N1,
+                  int64_t Kd, int transB, int want_stats, float* bn_part0, float* bn_part1, const int32_t* n_valid,
+                  const mvk_bn_finish* fin0, const mvk_bn_finish* fin1, void* stream) {
   MVK_REQUIRE(M > 0 && N0 > 0 && N1 > 0 && Kd > 0, "gemm pair: empty product");
   Plan p0 = plan_gemm(M, N0, Kd, 0, want_stats != 0), p1 = plan_gemm(M, N1, Kd, 0, want_stats != 0);
   pair_widen(p0, p1, Kd);
@@ -905,6 +1125,8 @@ extern "C" int mvk_gemm_f32_pair(const float* A, const float* B0, const float* B
   MVK_ORDERED(make_ordered(st, a0, s0, gx0, cdiv64(M, tm), tm, tn));
   MVK_ORDERED(make_ordered(st, a1, s1, gx1, cdiv64(M, tm), tm, tn));
   MVK_REQUIRE(ord || ((s0 == 1 || !a0.bn_part) && (s1 == 1 || !a1.bn_part)), "gemm pair: statistics of a split product");
+  if (int e = set_finish(a0, fin0, cdiv64(M, tm))) return e;
+  if (int e = set_finish(a1, fin1, cdiv64(M, tm))) return e;
   dim3 grid((unsigned)(gx0 + gx1), (unsigned)cdiv64(M, tm), (unsigned)(s0 > s1 ? s0 : s1));
   const bool ok = transB ? launch_pair_cfg<false, true>(p0, grid, st, a0, a1, gx0, s0, s1)
                          : launch_pair_cfg<false, false>(p0, grid, st, a0, a1, gx0, s0, s1);
@@ -912,6 +1134,7 @@ extern "C" int mvk_gemm_f32_pair(const float* A, const float* B0, const float* B
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }
+}  // namespace
 
 // Plan of mvk_gemm_f32_ex for a shape: the split of the reduction it will use (the caller zeroes C when > 1)
 // and the row-block size of the BatchNorm partials (0: no statistics are produced for this shape).
@@ -939,13 +1162,24 @@ struct ScatterOut {
 };
 int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA, int transB,
              int accumulate, int split_k, float* bn_part, const int32_t* n_valid, const float* bias, float act_slope,
-             void* stream, const ScatterOut* scatter = nullptr, int seg_shift = -1, int64_t seg_extra = 0, int64_t ldb = 0);
+             void* stream, const ScatterOut* scatter = nullptr, int seg_shift = -1, int64_t seg_extra = 0, int64_t ldb = 0,
+             const mvk_bn_finish* fin = nullptr, const mvk_a_transform* ax = nullptr);
 }
 
 extern "C" int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd,
                                int transA, int transB, int accumulate, int split_k, float* bn_part,
                                const int32_t* n_valid, void* stream) {
   return gemm_run(A, B, C, M, N, Kd, transA, transB, accumulate, split_k, bn_part, n_valid, nullptr, 1.f, stream);
+}
+
+// mvk_gemm_f32_ex (A not transposed, plain store) with the BatchNorm on either side of the product folded into it
+// (include/mvkpconv.h): fin = the statistics of C finished inside this launch (needs bn_part: ask mvk_gemm_f32_plan),
+// ax = the BatchNorm + LeakyReLU between A's producer and this layer applied while A is staged.
+extern "C" int mvk_gemm_f32_bn(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transB,
+                               float* bn_part, const int32_t* n_valid, const mvk_bn_finish* fin, const mvk_a_transform* ax,
+                               void* stream) {
+  MVK_REQUIRE(M > 0 && N > 0 && Kd > 0, "gemm bn: empty product");
+  return gemm_run(A, B, C, M, N, Kd, 0, transB, 0, 0, bn_part, n_valid, nullptr, 1.f, stream, nullptr, -1, 0, 0, fin, ax);
 }
 
 // C = LeakyReLU_slope(A . op(B) + bias[col]) (slope 1: the bias alone): a BatchNorm-less layer (blocks.py:462-463, the two
@@ -990,7 +1224,8 @@ extern "C" int mvk_gemm_f32_scatter_cat(const float* A, const float* B, int64_t 
 namespace {
 int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA, int transB,
              int accumulate, int split_k, float* bn_part, const int32_t* n_valid, const float* bias, float act_slope,
-             void* stream, const ScatterOut* scatter, int seg_shift, int64_t seg_extra, int64_t ldb) {
+             void* stream, const ScatterOut* scatter, int seg_shift, int64_t seg_extra, int64_t ldb,
+             const mvk_bn_finish* fin, const mvk_a_transform* ax) {
   MVK_REQUIRE(M >= 0 && N >= 0 && Kd >= 0, "gemm: negative size");
   if (M == 0 || N == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -1031,6 +1266,7 @@ int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int
   a.sc_idx = nullptr; a.sc_idx64 = 0; a.sc_c1 = 0; a.sc_stride = 0; a.sc_ns = 0; a.sc_dst = nullptr; a.sc_rest = nullptr;
   a.seg_shift = seg_shift;
   a.seg_extra = seg_extra;
+  no_bn_fold(a);
   if (scatter) {
     a.sc_idx = scatter->idx; a.sc_idx64 = scatter->idx64; a.sc_c1 = scatter->c1; a.sc_stride = scatter->stride;
     a.sc_ns = scatter->ns; a.sc_dst = scatter->dst; a.sc_rest = scatter->rest;
@@ -1040,6 +1276,19 @@ int gemm_run(const float* A, const float* B, float* C, int64_t M, int64_t N, int
   dim3 grid((unsigned)cdiv64(N, tn), (unsigned)cdiv64(M, tm), (unsigned)split);
   MVK_ORDERED(make_ordered(st, a, split, (int)grid.x, grid.y, tm, tn));
   MVK_REQUIRE(!(bn_part && split > 1 && !a.det_ws), "gemm: BatchNorm statistics of a split product need the ordered reduction");
+  if (int e = set_finish(a, fin, grid.y)) return e;
+  if (ax) {
+    // the consumer's half of a folded BatchNorm (GemmArgs (b)): wide NT tiles, the workgroup's k-range inside the table
+    MVK_REQUIRE(!transA && transB && !p.narrow && p.qn == 1 && (p.pm == 2 || p.pm == 4) && k_per_split <= XF_KMAX && !scatter &&
+                    seg_shift < 0 && ax->mean && ax->invstd && ax->gamma && ax->beta && ax->slope > 0.f,
+                "gemm: the operand transform needs an NT product of more than 32 columns with k-ranges <= %d", XF_KMAX);
+    a.ax_mean = ax->mean; a.ax_invstd = ax->invstd; a.ax_gamma = ax->gamma; a.ax_beta = ax->beta; a.ax_slope = ax->slope;
+    a.ax_nvalid = ax->n_valid; a.ax_out = ax->out;
+    if (p.pm == 2) hipLaunchKernelGGL((gemm_f32_mfma_xf<true, 2>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_f32_mfma_xf<true, 4>), grid, dim3(256), 0, st, a);
+    MVK_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   bool ok;
   if (!transA && !transB) ok = launch_cfg<false, false>(p, grid, st, a);
   else if (!transA && transB) ok = launch_cfg<false, true>(p, grid, st, a);
@@ -1142,6 +1391,7 @@ extern "C" int mvk_gemm_f32_tn_grouped_plan(const void* problems, int n, void* t
     e.args.sc_idx = nullptr; e.args.sc_idx64 = 0; e.args.sc_c1 = 0; e.args.sc_stride = 0; e.args.sc_ns = 0;
     e.args.sc_dst = nullptr; e.args.sc_rest = nullptr;
     e.args.seg_shift = -1; e.args.seg_extra = 0;
+    no_bn_fold(e.args);
     const int64_t tm = narrow ? 64 : 16 * group_wide_pm(), tn = narrow ? 32 : 64;      // plan tiles: narrow (pm 1, qn 2), wide (pm 2, qn 1)
     e.gx = (int)cdiv64(q.N, tn);
     e.gy = (int)cdiv64(q.M, tm);

@@ -33,6 +33,7 @@ _FUSED_BIAS = os.environ.get("MVK_FUSED_BIAS", "1") == "1"      # bias + LeakyRe
 _FUSED_OPERANDS = os.environ.get("MVK_FUSED_DEFORM_OPERANDS", "1") == "1"   # development switch: 0 = the tensor ops
 _GEMM_PAIR = os.environ.get("MVK_GEMM_PAIR", "1") == "1"        # unary1 and the shortcut layer of a block (same input) as one GEMM launch
 _BN_PAIR = os.environ.get("MVK_BN_PAIR", "1") == "1"            # a block's two independent BatchNorms (convolution, shortcut) as one launch each way
+_BN_FOLD_CONV = os.environ.get("MVK_BN_FOLD_CONV", "1") == "1"  # batch_norm_conv + LeakyReLU inside unary2's operand load (needs MVK_BN_FOLD)
 _ORDER_LOOKUP = os.environ.get("MVK_GATHER_ORDER", "1") != "0"   # gather work lists found by their points tensor (ops.work_order_for)
 
 
@@ -133,11 +134,12 @@ class KPConv(nn.Module):
         kp = load_kernels(self.radius, self.K, dimension=self.p_dim, fixed=self.fixed_kernel_points)
         return Parameter(torch.tensor(kp, dtype=torch.float32), requires_grad=False)
 
-    def forward(self, q_pts, s_pts, neighb_inds, x, stats_n_valid=None, order=None, rev=None, rev_order=None):
+    def forward(self, q_pts, s_pts, neighb_inds, x, stats_n_valid=None, order=None, rev=None, rev_order=None, bn=None):
         """stats_n_valid: DEVICE row count of the BatchNorm that follows this convolution (the contraction
         then delivers its statistics, ops.bn_stats_of); order: work list of the query points for the gather
         (ops.kpconv); rev / rev_order: the transposed neighbour matrix and the support level's work list for the
-        gather-form feature gradient (ops.reverse_neighbors). None of them is part of the reference signature."""
+        gather-form feature gradient (ops.reverse_neighbors); bn: the nn.BatchNorm1d that follows -- the contraction then
+        FINISHES its statistics (ops.kpconv). None of them is part of the reference signature."""
         if self.KP_influence not in ops.INFLUENCE:
             raise ValueError('Unknown influence function type (config.KP_influence)')
         if self.aggregation_mode not in ops.AGGREGATION:
@@ -162,7 +164,7 @@ class KPConv(nn.Module):
         y, min_d2 = ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent,
                                self.KP_influence, self.aggregation_mode, offsets, modulations,
                                stats_n_valid=stats_n_valid, order=order, rev=None if self.deformable else rev,
-                               rev_order=rev_order)
+                               rev_order=rev_order, bn=bn)
         if self.deformable:
             self.min_d2 = min_d2                                      # blocks.py:303
         return y
@@ -265,10 +267,11 @@ class UnaryBlock(nn.Module):
             return ops.linear_bias_lrelu(x, self.mlp.weight, self.batch_norm.bias, 1.0 if self.no_relu else 0.1)
         if _MFMA_LINEAR and x.is_cuda:
             nv = _bn_rows(x, self, self.use_bn) if _GEMM_STATS else None
+            bn = self.batch_norm.batch_norm if (self.use_bn and nv is not None) else None    # statistics finished by the product
             if passthrough and _FUSE_FANOUT and x.requires_grad:
-                y, alias = ops.linear(x, self.mlp.weight, stats_n_valid=nv, passthrough=True)
+                y, alias = ops.linear(x, self.mlp.weight, stats_n_valid=nv, passthrough=True, bn=bn)
             else:
-                y = ops.linear(x, self.mlp.weight, stats_n_valid=nv)
+                y = ops.linear(x, self.mlp.weight, stats_n_valid=nv, bn=bn)
         else:
             y = self.mlp(x)
         if join is not None:
@@ -281,7 +284,23 @@ class UnaryBlock(nn.Module):
         """forward(cat([closest_pool(x, inds), skip], 1)): the decoder's upsampling + concatenation + this layer
         (architectures.py:334-337) with the backward of all three as one product (ops.upsample_cat_linear)."""
         nv = _bn_rows(skip, self, self.use_bn) if _GEMM_STATS else None
-        y = ops.upsample_cat_linear(x, inds, skip, self.mlp.weight, stats_n_valid=nv)
+        y = ops.upsample_cat_linear(x, inds, skip, self.mlp.weight, stats_n_valid=nv,
+                                    bn=self.batch_norm.batch_norm if (self.use_bn and nv is not None) else None)
+        return self.batch_norm(y, None if self.no_relu else 0.1)
+
+    def forward_normalised(self, x_raw, n_valid, bn_in, slope_in, join=None):
+        """forward(bn_lrelu(x_raw, n_valid, bn_in, slope_in), join=join) with the apply pass of bn_in folded into this
+        layer's product (ops.bn_lrelu_linear), or None when x_raw does not carry finished statistics."""
+        if not (_MFMA_LINEAR and self.use_bn and x_raw.is_cuda):
+            return None
+        nv = _bn_rows(x_raw, self, True) if _GEMM_STATS else None
+        res = ops.bn_lrelu_linear(x_raw, n_valid, bn_in, slope_in, self.mlp.weight, stats_n_valid=nv,
+                                  bn_out=self.batch_norm.batch_norm if nv is not None else None)
+        if res is None:
+            return None
+        y = res[0]
+        if join is not None:
+            return self.batch_norm(y, join[1], addend=join[0])
         return self.batch_norm(y, None if self.no_relu else 0.1)
 
     def __repr__(self):
@@ -351,7 +370,8 @@ class SimpleBlock(nn.Module):
         rev, rev_order = _reverse_list(self.block_name, self.layer_ind, batch) if x.requires_grad else (None, None)
         return self.batch_norm(self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv,
                                            order=_work_order(self.block_name, self.layer_ind, batch), rev=rev,
-                                           rev_order=rev_order), 0.1)
+                                           rev_order=rev_order,
+                                           bn=self.batch_norm.batch_norm if (self.use_bn and nv is not None) else None), 0.1)
 
 
 class ResnetBottleneckBlock(nn.Module):
@@ -388,7 +408,9 @@ class ResnetBottleneckBlock(nn.Module):
                 and isinstance(self.unary1, UnaryBlock) and isinstance(us, UnaryBlock)):
             # unary1 and the shortcut layer read the same rows: their two products as one launch (ops.linear_pair)
             nv_in = _bn_rows(features, self, self.use_bn) if _GEMM_STATS else None
-            pair = ops.linear_pair(features, self.unary1.mlp.weight, us.mlp.weight, nv_in)
+            pair = ops.linear_pair(features, self.unary1.mlp.weight, us.mlp.weight, nv_in,
+                                   bn0=self.unary1.batch_norm.batch_norm if (self.use_bn and nv_in is not None) else None,
+                                   bn1=us.batch_norm.batch_norm if (self.use_bn and nv_in is not None) else None)
             if pair is not None:
                 ys = pair[1]
                 x = self.unary1.batch_norm(pair[0], 0.1)
@@ -400,7 +422,8 @@ class ResnetBottleneckBlock(nn.Module):
         nv = _bn_rows(q_pts, self, self.use_bn) if _GEMM_STATS else None
         rev, rev_order = _reverse_list(self.block_name, self.layer_ind, batch)
         conv = self.KPConv(q_pts, s_pts, inds, x, stats_n_valid=nv, order=_work_order(self.block_name, self.layer_ind, batch),
-                           rev=rev, rev_order=rev_order)
+                           rev=rev, rev_order=rev_order,
+                           bn=self.batch_norm_conv.batch_norm if (self.use_bn and nv is not None) else None)
         self.skip_alias = None
         if 'strided' in self.block_name and _FUSE_FANOUT and features.is_cuda:
             # the block's input is also the decoder's skip tensor (architectures.py:328-329): the alias handed out here
@@ -409,6 +432,19 @@ class ResnetBottleneckBlock(nn.Module):
         else:
             shortcut = max_pool(features, inds) if 'strided' in self.block_name else features
         n_valid = _bn_rows(conv, self, self.use_bn) if (_BN_PAIR and _HIP_BN and _MFMA_LINEAR) else None
+        if _BN_FOLD_CONV and _FUSE_ADD and n_valid is not None and ops.bn_finished(conv):
+            # the convolution's statistics were finished by its contraction: its BatchNorm + LeakyReLU ride in unary2's
+            # operand load (ops.bn_lrelu_linear) -- no normalising launch for the convolution at all
+            if isinstance(us, UnaryBlock):
+                sc = us(shortcut) if ys is None else us.batch_norm(ys, None)
+            else:
+                sc = shortcut
+            out = self.unary2.forward_normalised(conv, n_valid, self.batch_norm_conv.batch_norm, 0.1, join=(sc, 0.1))
+            if out is not None:
+                return out
+            shortcut = sc
+            x = self.batch_norm_conv(conv, 0.1)
+            return self.unary2(x, join=(shortcut, 0.1))
         if n_valid is not None and isinstance(us, UnaryBlock) and us.use_bn:
             # the BatchNorm of the convolution and the one of the shortcut are independent problems over the same rows:
             # one launch each way for the pair (ops.bn_lrelu_pair)

@@ -207,6 +207,66 @@ def bn_single_launch_rows(D):
     return lib().mvk_bn_single_launch_rows(int(D))
 
 
+# --------------------------------------------------------------------------------------------
+# BatchNorm folded into the products around it (round 5; csrc/gemm.hip GemmArgs (a), (b))
+# --------------------------------------------------------------------------------------------
+# The producer's half: a product that writes the statistics partials of its output can also FINISH them (mean, invstd,
+# running statistics, batch counter) -- the workgroup that arrives last at a column tile's counter merges the partials.
+# The op wrappers (linear, linear_pair, kpconv, upsample_cat_linear) take `bn=` (the nn.BatchNorm1d that follows) and
+# park it here around their autograd node; gemm() picks it up and reports the result, which travels with the output as
+# the third element of `_mvk_bn_stats`. The consumer's half: bn_lrelu_linear().
+# MEASURED SLOWER on the one-sphere step and therefore OFF by default (MVK_BN_FOLD=1 / ops.BN_FOLD = True turn it on):
+# network chain 2.85 -> 2.94 ms with finished statistics alone, 2.96 ms with the operand fold on top (round 5,
+# profiles/r05_bn_fold_chain.txt). The last-arriver hand-off at the tail of a producing product costs
+# +5..13 us per launch (store acknowledge, counter round trip, 3-5 dependent rounds of memory-side loads over up to 305
+# partials) against the 2-4 us the normalising launch saves by not reducing them, and in a bottleneck block with a
+# shortcut layer the convolution's BatchNorm already shares its launch with the shortcut's.
+BN_FOLD = os.environ.get("MVK_BN_FOLD", "0") == "1"
+_FIN = {"req": None, "done": None}
+_AX = {"req": None}
+
+
+def _fin_counters(bn, device):
+    """Persistent zero int32 words of one BatchNorm module (the kernel returns them to zero): one per column tile."""
+    c = getattr(bn, "_mvk_fin_counters", None)
+    if c is None or c.device != device:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("ops: the finish counters of a BatchNorm do not exist yet and cannot be created inside a "
+                               "graph capture; run one eager step first")
+        c = torch.zeros(128, dtype=torch.int32, device=device)
+        torch.cuda.current_stream(device).synchronize()
+        bn._mvk_fin_counters = c
+    return c
+
+
+def _fin_request(bn):
+    """Parks the BatchNorm that follows the product about to be issued (None: no request). Only training-mode modules
+    with per-rank statistics qualify; anything else keeps the separate statistics pass."""
+    ok = (BN_FOLD and bn is not None and bn.training and _SYNC_BN["group"] is None and bn.num_features % 4 == 0)
+    _FIN["req"] = bn if ok else None
+    _FIN["done"] = None
+
+
+def _fin_take():
+    done = _FIN["done"]
+    _FIN["req"] = None
+    _FIN["done"] = None
+    return done
+
+
+def _fin_struct(bn, N, device):
+    from ._lib import BnFinish
+    if bn.num_features != N:
+        raise RuntimeError("ops: the BatchNorm handed to a product has %d channels, the product %d columns" % (bn.num_features, N))
+    mean = torch.empty(N, device=device, dtype=torch.float32)
+    invstd = torch.empty(N, device=device, dtype=torch.float32)
+    track = bn.track_running_stats and bn.running_mean is not None
+    fin = BnFinish(_p(_fin_counters(bn, device)), float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.0),
+                   _p(mean), _p(invstd), _p(bn.running_mean) if track else None, _p(bn.running_var) if track else None,
+                   _p(bn.num_batches_tracked) if track else None)
+    return fin, (mean, invstd)
+
+
 def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=None, keep=False, stats_n_valid=None):
     """C = op(A) @ op(B) on v_mfma_f32_16x16x4_f32 (mvk_gemm_f32_ex). split_k=None lets the library pick the
     row tile and the split of the reduction so that small-M / deep-K products (the coarse KPConv layers:
@@ -214,24 +274,51 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
     becomes .grad), so it must not be a slice of the per-step zero arena.
     stats_n_valid (DEVICE int32 [1]): also produce the column statistics of C over its first n_valid rows for
     the BatchNorm that follows; returns (C, (partials, rows per block)) -- or (C, None) when the chosen plan
-    splits the reduction."""
+    splits the reduction. A BatchNorm parked by _fin_request() is finished inside the launch when the product carries the
+    statistics epilogue (result in _FIN["done"]); an operand transform parked by bn_lrelu_linear() is applied to A."""
     _dev(A, B)
     A, B = _f32c(A), _f32c(B)
     M, Kd = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
     N = B.shape[0] if transB else B.shape[1]
     assert (B.shape[1] if transB else B.shape[0]) == Kd, "gemm: inner dimensions differ"
     want = stats_n_valid is not None
+    ax = _AX["req"]
+    if ax is not None:
+        _AX["req"] = None
+        if ax["lazy"].data_ptr() != A.data_ptr() or transA or not transB or out is not None or accumulate or M == 0:
+            raise RuntimeError("ops.gemm: a parked operand transform did not meet its product")
     if M == 0 or N == 0 or Kd == 0:
         res = out.zero_() if out is not None else torch.zeros((M, N), device=A.device, dtype=torch.float32)
         return (res, None) if want else res
     split_arena_prepare(A.device)
-    split, rows = gemm_plan(M, N, Kd, split_k, want and out is None and not accumulate and M > bn_single_launch_rows(N)
-                            and M <= _STATS_EPILOGUE_ROWS)
+    req = _FIN["req"]
+    # a finished BatchNorm needs the epilogue statistics whatever the row count (the one-launch BatchNorm kernels of few
+    # rows would otherwise do statistics + normalisation themselves: with a fold there is no such launch)
+    stats_ok = want and out is None and not accumulate and M <= _STATS_EPILOGUE_ROWS
+    if req is None and ax is None:
+        stats_ok = stats_ok and M > bn_single_launch_rows(N)
+    split, rows = gemm_plan(M, N, Kd, split_k, stats_ok)
     if out is None:
         out = _split_out((M, N), A.device, split, keep)
     part = torch.empty(((M + rows - 1) // rows, 2, N), device=A.device, dtype=torch.float32) if rows > 0 else None
-    check(lib().mvk_gemm_f32_ex(_p(A), _p(B), _p(out), M, N, Kd, int(transA), int(transB), int(accumulate),
-                                int(split), _p(part), _p(stats_n_valid) if part is not None else None, _stream()))
+    fin = None
+    if req is not None and part is not None and not transA and split_k is None:
+        fin, _FIN["done"] = _fin_struct(req, N, A.device)
+        _FIN["req"] = None
+    if fin is not None or ax is not None:
+        xf = None
+        if ax is not None:
+            from ._lib import ATransform
+            xf = ATransform(_p(ax["mean"]), _p(ax["invstd"]), _p(ax["gamma"]), _p(ax["beta"]), float(ax["slope"]),
+                            _p(ax["n_valid"]), _p(ax["lazy"]))
+            A = ax["raw"]
+        check(lib().mvk_gemm_f32_bn(_p(A), _p(B), _p(out), M, N, Kd, int(transB), _p(part),
+                                    _p(stats_n_valid) if part is not None else None,
+                                    C.byref(fin) if fin is not None else None, C.byref(xf) if xf is not None else None,
+                                    _stream()))
+    else:
+        check(lib().mvk_gemm_f32_ex(_p(A), _p(B), _p(out), M, N, Kd, int(transA), int(transB), int(accumulate),
+                                    int(split), _p(part), _p(stats_n_valid) if part is not None else None, _stream()))
     if want:
         return out, ((part, rows) if part is not None else None)
     return out
@@ -929,13 +1016,19 @@ def set_feature_dtype(dtype):
     _FEATURE_DTYPE["dtype"] = dtype
 
 
+def bn_finished(t):
+    """True when t carries BatchNorm statistics FINISHED by its producer (mean, invstd; see _fin_request)."""
+    e = getattr(t, "_mvk_bn_stats", None)
+    return e is not None and len(e) > 2 and e[2] is not None
+
+
 def bn_stats_of(t):
     """(partials, rows per block) a producing GEMM attached to its output for the BatchNorm that follows, or None."""
     return getattr(t, "_mvk_bn_stats", None)
 
 
 def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", offsets=None, modulations=None,
-           feature_dtype=None, stats_n_valid=None, order=None, rev=None, rev_order=None):
+           feature_dtype=None, stats_n_valid=None, order=None, rev=None, rev_order=None, bn=None):
     """Returns (y [Nq,Cout], min_d2 [Nq,K] or None). feature_dtype: None = the mode set by
     set_feature_dtype(). stats_n_valid (DEVICE int32 [1]): the contraction also produces the column statistics
     of y over its first n_valid rows for the BatchNorm that follows (picked up by bn_lrelu via bn_stats_of).
@@ -943,7 +1036,8 @@ def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", o
     through the query points in (kpconv_gather); the layer's result does not depend on it.
     rev (int32 [Ns, Hr], reverse_neighbors(idx, Ns)) and rev_order (a work list of the SUPPORT level): rigid f32 layers
     with a power-of-two Cout >= 32 then compute the feature gradient as a gather over the transposed relation (fixed
-    summation order, no atomics) instead of the atomic scatter."""
+    summation order, no atomics) instead of the atomic scatter.
+    bn: the nn.BatchNorm1d that normalises y; its statistics are then FINISHED by the contraction (see _fin_request)."""
     if rev is not None and (rev.dtype != torch.int32 or rev.dim() != 2 or not rev.is_contiguous()):
         raise RuntimeError("kpconv: rev must be a contiguous int32 [Ns, Hr] matrix (ops.reverse_neighbors)")
     if influence not in INFLUENCE:
@@ -951,11 +1045,15 @@ def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", o
     if aggregation not in AGGREGATION:
         raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
     fn = _KPConv16Fn if (feature_dtype or _FEATURE_DTYPE["dtype"]) == torch.float16 else _KPConvFn
-    y, min_d2, part = fn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation,
-                               stats_n_valid, order, rev, rev_order)
+    _fin_request(bn if (fn is _KPConvFn and stats_n_valid is not None) else None)
+    try:
+        y, min_d2, part = fn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation,
+                                   stats_n_valid, order, rev, rev_order)
+    finally:
+        fin = _fin_take()
     if part is not None:        # rows per statistics block of the launch that just ran (set by the node's forward)
         rows = _LAST_STATS_ROWS[0]
-        y._mvk_bn_stats = (part, rows)
+        y._mvk_bn_stats = (part, rows, fin)
     return y, min_d2
 
 
@@ -1138,6 +1236,13 @@ def full_count_prepare(device):
     full_count(0, torch.device(device))
 
 
+def _ext3(ext):
+    """(partials, rows per block, finished (mean, invstd) or None) of a `_mvk_bn_stats` record (None: nothing attached)."""
+    if ext is None:
+        return None, 0, None
+    return (ext[0], ext[1], ext[2] if len(ext) > 2 else None)
+
+
 class _BNLReLUFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n_valid, gamma, beta, running_mean, running_var, eps, momentum, slope, training, nbt=None,
@@ -1154,14 +1259,21 @@ class _BNLReLUFn(torch.autograd.Function):
         invstd = torch.empty(D, device=x.device, dtype=torch.float32)
         if not training:
             raise RuntimeError("masked BatchNorm is a training-mode op; use nn.BatchNorm1d in eval mode")
-        ext_part, ext_rows = ext if ext is not None else (None, 0)
+        ext_part, ext_rows, fin = _ext3(ext)
         if ext_part is not None and (ext_part.shape[2] != D or ext_part.shape[0] != (R + ext_rows - 1) // ext_rows):
             raise RuntimeError("bn_lrelu: the statistics partials do not belong to this tensor")
-        scratch = None if ext_part is not None else torch.empty(((R + 63) // 64) * 2 * D, device=x.device,
-                                                                dtype=torch.float32)
-        check(lib().mvk_bn_lrelu_fwd(_p(x), _p(n_valid), R, D, _p(gamma), _p(beta), float(eps), float(momentum),
-                                     float(slope), _p(running_mean), _p(running_var), _p(mean), _p(invstd),
-                                     _p(scratch), _p(y), _p(nbt), _p(addend), _p(ext_part), int(ext_rows), _stream()))
+        if fin is not None:
+            # statistics finished by the producing product (mean, invstd, running statistics, batch counter): apply only
+            mean, invstd = fin
+            check(lib().mvk_bn_lrelu_fwd(_p(x), _p(n_valid), R, D, _p(gamma), _p(beta), float(eps), float(momentum),
+                                         float(slope), None, None, _p(mean), _p(invstd), None, _p(y), None, _p(addend),
+                                         None, -1, _stream()))
+        else:
+            scratch = None if ext_part is not None else torch.empty(((R + 63) // 64) * 2 * D, device=x.device,
+                                                                    dtype=torch.float32)
+            check(lib().mvk_bn_lrelu_fwd(_p(x), _p(n_valid), R, D, _p(gamma), _p(beta), float(eps), float(momentum),
+                                         float(slope), _p(running_mean), _p(running_var), _p(mean), _p(invstd),
+                                         _p(scratch), _p(y), _p(nbt), _p(addend), _p(ext_part), int(ext_rows), _stream()))
         ctx.save_for_backward(x, n_valid, gamma, beta, mean, invstd, y if addend is not None else None)
         ctx.slope = float(slope)
         return y
@@ -1238,6 +1350,60 @@ def bn_lrelu(x, n_valid, bn, slope=1.0, addend=None):
                             bn_stats_of(x))
 
 
+class _BNLazyFn(torch.autograd.Function):
+    """y = LeakyReLU_slope(BatchNorm(x)) with FINISHED statistics whose forward launches nothing: the product that consumes
+    y applies the transform while it stages its A operand and writes y on the way (mvk_a_transform, bn_lrelu_linear).
+    The backward is the masked BatchNorm's own (_BNLReLUFn.backward without an addend)."""
+
+    @staticmethod
+    def forward(ctx, x, n_valid, gamma, beta, mean, invstd, slope):
+        y = torch.empty_like(x)
+        ctx.save_for_backward(x, n_valid, gamma, beta, mean, invstd)
+        ctx.slope = float(slope)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, n_valid, gamma, beta, mean, invstd = ctx.saved_tensors
+        g = _f32c(g)
+        R, D = x.shape
+        dgb = torch.empty(2 * D, device=x.device, dtype=torch.float32)
+        scratch = torch.empty(((R + 63) // 64) * 2 * D, device=x.device, dtype=torch.float32)
+        dx = torch.empty_like(x)
+        check(lib().mvk_bn_lrelu_bwd(_p(x), _p(g), _p(n_valid), R, D, _p(gamma), _p(beta), _p(mean), _p(invstd),
+                                     ctx.slope, _p(scratch), _p(dgb), _p(dx), None, None, _stream()))
+        return dx, None, dgb[D:], dgb[:D], None, None, None
+
+
+XF_KMAX = 512        # csrc/gemm.hip: longest reduction a product with an operand transform takes
+
+
+def bn_lrelu_linear(x, n_valid, bn, slope, W, stats_n_valid=None, bn_out=None):
+    """linear(bn_lrelu(x, n_valid, bn, slope), W, stats_n_valid=..., bn=bn_out) with the BatchNorm's apply pass folded
+    into the product's operand load (blocks.py:639-644: batch_norm_conv + LeakyReLU + unary2): x must carry statistics
+    FINISHED by its producer (kpconv(..., bn=bn) / linear(..., bn=bn)). Returns (y, activations) -- the activations are
+    the tensor bn_lrelu would have returned, written by the product -- or None when the fold does not apply (the caller
+    then runs the two steps)."""
+    ext = bn_stats_of(x)
+    fin = ext[2] if (ext is not None and len(ext) > 2) else None
+    R, Kd = x.shape
+    if (fin is None or not BN_FOLD or _SYNC_BN["group"] is not None or not x.is_cuda or x.dtype != torch.float32
+            or not x.is_contiguous() or W.dtype != torch.float32 or not W.is_contiguous() or W.shape[1] != Kd
+            or W.shape[0] <= 32 or Kd > XF_KMAX or Kd % 4 != 0 or R == 0 or not slope > 0):
+        return None
+    mean, invstd = fin
+    lazy = _BNLazyFn.apply(x, n_valid, bn.weight, bn.bias, mean, invstd, float(slope))
+    _AX["req"] = {"raw": x.detach(), "mean": mean, "invstd": invstd, "gamma": bn.weight.detach(), "beta": bn.bias.detach(),
+                  "slope": float(slope), "n_valid": n_valid, "lazy": lazy}
+    try:
+        y = linear(lazy, W, stats_n_valid=stats_n_valid, bn=bn_out)
+    finally:
+        pending, _AX["req"] = _AX["req"], None
+    if pending is not None:
+        raise RuntimeError("bn_lrelu_linear: the product did not take the operand transform")
+    return y, lazy
+
+
 class _BNLReLUPairFn(torch.autograd.Function):
     """Two masked BatchNorm (+ LeakyReLU) problems of the same row count, one launch each way (mvk_bn_lrelu_fwd_pair /
     _bwd_pair): the convolution output and the shortcut of a bottleneck block. No residual addend in either."""
@@ -1257,9 +1423,16 @@ class _BNLReLUPairFn(torch.autograd.Function):
             y = torch.empty_like(x)
             mean = torch.empty(D, device=x.device, dtype=torch.float32)
             invstd = torch.empty(D, device=x.device, dtype=torch.float32)
-            ext_part, ext_rows = ext if ext is not None else (None, 0)
+            ext_part, ext_rows, fin = _ext3(ext)
             if ext_part is not None and (ext_part.shape[2] != D or ext_part.shape[0] != (R + ext_rows - 1) // ext_rows):
                 raise RuntimeError("bn_lrelu_pair: the statistics partials do not belong to this tensor")
+            if fin is not None:       # finished by the producing product: apply only (see _BNLReLUFn)
+                mean, invstd = fin
+                scratch = None
+                probs.append(BnFwdProblem(_p(x), _p(n_valid), R, D, _p(g), _p(b), float(eps), float(mom), float(slope), None,
+                                          None, _p(mean), _p(invstd), None, _p(y), None, None, None, -1))
+                keep.append((y, mean, invstd, scratch))
+                continue
             scratch = None if ext_part is not None else torch.empty(((R + 63) // 64) * 2 * D, device=x.device,
                                                                     dtype=torch.float32)
             probs.append(BnFwdProblem(_p(x), _p(n_valid), R, D, _p(g), _p(b), float(eps), float(mom), float(slope), _p(rm),
@@ -1606,11 +1779,15 @@ class _UpsampleCatLinearFn(torch.autograd.Function):
         return (dx if ctx.needs_input_grad[0] else None), None, (d_skip if ctx.needs_input_grad[2] else None), dW, None
 
 
-def upsample_cat_linear(x, inds, skip, W, stats_n_valid=None):
+def upsample_cat_linear(x, inds, skip, W, stats_n_valid=None, bn=None):
     """linear(upsample_cat(x, inds, skip), W, stats_n_valid=...) with a one-launch backward for x and skip."""
-    y, part = _UpsampleCatLinearFn.apply(x, inds, skip, W, stats_n_valid)
+    _fin_request(bn if stats_n_valid is not None else None)
+    try:
+        y, part = _UpsampleCatLinearFn.apply(x, inds, skip, W, stats_n_valid)
+    finally:
+        fin = _fin_take()
     if part is not None:
-        y._mvk_bn_stats = (part, gemm_plan(y.shape[0], y.shape[1], W.shape[1], None, True)[1])
+        y._mvk_bn_stats = (part, gemm_plan(y.shape[0], y.shape[1], W.shape[1], None, True)[1], fin)
     return y
 
 
@@ -2204,8 +2381,22 @@ class _LinearPairFn(torch.autograd.Function):
         for N, sp, rows in ((N0, s0, r0), (N1, s1, r1)):
             outs.append(_split_out((M, N), x.device, sp))
             parts.append(torch.empty(((M + rows - 1) // rows, 2, N), device=x.device, dtype=torch.float32) if rows > 0 else None)
-        check(lib().mvk_gemm_f32_pair(_p(x), _p(W0), _p(W1), _p(outs[0]), _p(outs[1]), M, N0, N1, Kd, 1, int(want),
-                                      _p(parts[0]), _p(parts[1]), _p(stats_n_valid) if want else None, _stream()))
+        req = _FIN.get("req_pair")
+        fins = [None, None]
+        if req is not None and want:
+            done = [None, None]
+            for i, (bn, part, N) in enumerate(((req[0], parts[0], N0), (req[1], parts[1], N1))):
+                if bn is not None and part is not None:
+                    fins[i], done[i] = _fin_struct(bn, N, x.device)
+            _FIN["done_pair"] = tuple(done)
+        if fins[0] is not None or fins[1] is not None:
+            check(lib().mvk_gemm_f32_pair_bn(_p(x), _p(W0), _p(W1), _p(outs[0]), _p(outs[1]), M, N0, N1, Kd, 1,
+                                             _p(parts[0]), _p(parts[1]), _p(stats_n_valid),
+                                             C.byref(fins[0]) if fins[0] is not None else None,
+                                             C.byref(fins[1]) if fins[1] is not None else None, _stream()))
+        else:
+            check(lib().mvk_gemm_f32_pair(_p(x), _p(W0), _p(W1), _p(outs[0]), _p(outs[1]), M, N0, N1, Kd, 1, int(want),
+                                          _p(parts[0]), _p(parts[1]), _p(stats_n_valid) if want else None, _stream()))
         ctx.save_for_backward(x, W0, W1)
         ctx.set_materialize_grads(False)
         for part in parts:
@@ -2234,7 +2425,7 @@ class _LinearPairFn(torch.autograd.Function):
         return dx, dW0, dW1, None, None
 
 
-def linear_pair(x, W0, W1, stats_n_valid=None):
+def linear_pair(x, W0, W1, stats_n_valid=None, bn0=None, bn1=None):
     """(linear(x, W0), linear(x, W1)) in one launch, or None when the two products cannot share one (different tile
     classes: the caller then runs them one after the other). Outputs carry their BatchNorm statistics like linear()'s."""
     _dev(x, W0, W1, stats_n_valid)
@@ -2243,28 +2434,44 @@ def linear_pair(x, W0, W1, stats_n_valid=None):
         return None
     M, Kd = x.shape
     split_arena_prepare(x.device)
-    want = stats_n_valid is not None and M > bn_single_launch_rows(W0.shape[0]) and M > bn_single_launch_rows(W1.shape[0]) \
-        and M <= _STATS_EPILOGUE_ROWS
+    fold = BN_FOLD and (bn0 is not None or bn1 is not None)       # finished statistics: the epilogue whatever the row count
+    want = stats_n_valid is not None and M <= _STATS_EPILOGUE_ROWS and \
+        (fold or (M > bn_single_launch_rows(W0.shape[0]) and M > bn_single_launch_rows(W1.shape[0])))
     plan = (C.c_int * 5)()
     check(lib().mvk_gemm_f32_pair_plan(M, W0.shape[0], W1.shape[0], Kd, int(want), plan))
     if not plan[0]:
         return None
     plan = tuple(int(v) for v in plan)
-    y0, p0, y1, p1 = _LinearPairFn.apply(x, W0, W1, stats_n_valid if want else None, plan)
+
+    def ok(bn):
+        return bn if (BN_FOLD and bn is not None and bn.training and _SYNC_BN["group"] is None
+                      and bn.num_features % 4 == 0) else None
+    _FIN["req_pair"] = (ok(bn0), ok(bn1)) if want else None
+    _FIN["done_pair"] = None
+    try:
+        y0, p0, y1, p1 = _LinearPairFn.apply(x, W0, W1, stats_n_valid if want else None, plan)
+    finally:
+        done = _FIN.get("done_pair") or (None, None)
+        _FIN["req_pair"] = None
+        _FIN["done_pair"] = None
     if p0 is not None:
-        y0._mvk_bn_stats = (p0, plan[3])
+        y0._mvk_bn_stats = (p0, plan[3], done[0])
     if p1 is not None:
-        y1._mvk_bn_stats = (p1, plan[4])
+        y1._mvk_bn_stats = (p1, plan[4], done[1])
     return y0, y1
 
 
-def linear(x, W, x_is_transposed=False, stats_n_valid=None, passthrough=False):
+def linear(x, W, x_is_transposed=False, stats_n_valid=None, passthrough=False, bn=None):
     """nn.Linear without bias / a 1x1 convolution over rows, on gemm_f32_mfma. stats_n_valid: see kpconv().
     passthrough=True returns (y, x') with x' an alias of x whose gradient is summed into x's inside the backward GEMM
-    (use x' for the other consumer of x)."""
-    y, part, alias = _LinearFn.apply(x, W, x_is_transposed, stats_n_valid, passthrough)
+    (use x' for the other consumer of x). bn: the nn.BatchNorm1d that follows (statistics finished by the product)."""
+    _fin_request(bn if stats_n_valid is not None else None)
+    try:
+        y, part, alias = _LinearFn.apply(x, W, x_is_transposed, stats_n_valid, passthrough)
+    finally:
+        fin = _fin_take()
     if part is not None:        # the plan is a pure function of the shape: the same rows the product just used
-        y._mvk_bn_stats = (part, gemm_plan(y.shape[0], y.shape[1], W.shape[1], None, True)[1])
+        y._mvk_bn_stats = (part, gemm_plan(y.shape[0], y.shape[1], W.shape[1], None, True)[1], fin)
     return (y, alias) if passthrough else y
 
 

@@ -125,6 +125,45 @@ int mvk_gemm_f32_plan(int64_t M, int64_t N, int64_t Kd, int split_k, int want_st
 int mvk_gemm_f32_ex(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transA,
                     int transB, int accumulate, int split_k, float* bn_part, const int32_t* n_valid, void* stream);
 
+/* BatchNorm folded into the products around it (round 5; the reference normalises every KPConv / unary output with
+ * nn.BatchNorm1d over the stacked point axis followed by LeakyReLU, KPConv-PyTorch/models/blocks.py:430-467, :549-561,
+ * :621-649 -- as separate launches that is one more read + write of every activation and ~40 % of the launches of a step).
+ *   mvk_bn_finish: the PRODUCER's half. A product that writes the statistics partials (bn_part, mvk_gemm_f32_plan:
+ *     *out_stat_rows > 0; N % 4 == 0) also finishes them: the workgroup that arrives last at counters[column tile] (int32,
+ *     >= ceil(N / 16) words, ZERO on entry, returned to zero by the kernel: a persistent buffer per BatchNorm) merges the
+ *     partials in a fixed order and writes mean / invstd [N] (biased variance, eps), updates running_mean / running_var
+ *     (nullable pair; unbiased variance, momentum) and adds 1 to *num_batches_tracked (nullable) -- exactly what
+ *     mvk_bn_lrelu_fwd does in its own statistics pass. The normalising launch then only applies (mvk_bn_lrelu_fwd with
+ *     ext_rows = -1) or disappears:
+ *   mvk_a_transform: the CONSUMER's half. The product reads A'(m,k) = m < *n_valid ? LeakyReLU_slope((A(m,k) - mean[k]) *
+ *     invstd[k] * gamma[k] + beta[k]) : 0 instead of A (NT products of more than 32 columns, Kd <= 512 per split) and also
+ *     writes A' to `out` [M, Kd] (nullable) -- the activation tensor the backward's weight-gradient product reads.
+ * mvk_gemm_f32_bn = mvk_gemm_f32_ex (A not transposed, plain store, the library's own split) with either half;
+ * mvk_gemm_f32_pair_bn = mvk_gemm_f32_pair with want_stats = 1 and the producer's half per output. */
+typedef struct mvk_bn_finish {
+  int32_t* counters;
+  float eps, momentum;
+  float* mean;
+  float* invstd;
+  float* running_mean;
+  float* running_var;
+  int64_t* num_batches_tracked;
+} mvk_bn_finish;
+typedef struct mvk_a_transform {
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  float slope;
+  const int32_t* n_valid;
+  float* out;
+} mvk_a_transform;
+int mvk_gemm_f32_bn(const float* A, const float* B, float* C, int64_t M, int64_t N, int64_t Kd, int transB, float* bn_part,
+                    const int32_t* n_valid, const mvk_bn_finish* fin, const mvk_a_transform* ax, void* stream);
+int mvk_gemm_f32_pair_bn(const float* A, const float* B0, const float* B1, float* C0, float* C1, int64_t M, int64_t N0,
+                         int64_t N1, int64_t Kd, int transB, float* bn_part0, float* bn_part1, const int32_t* n_valid,
+                         const mvk_bn_finish* fin0, const mvk_bn_finish* fin1, void* stream);
+
 /* Ordered split reductions (round 4). By default a split product adds its partial sums with f32 atomics onto a
  * zero-initialised C: the value depends on the order the workgroups ran in (rounding only, but a LeakyReLU input within
  * an ulp of zero then flips, and two runs of the same network differ). mvk_gemm_split_arena hands the library `ws`

@@ -29,6 +29,11 @@ class BnBwdProblem(C.Structure):
                 ("y_out", _vp), ("d_addend", _vp)]
 
 
+class RevList(C.Structure):
+    """mvk_rev_list: one reverse list for mvk_reverse_finish_many."""
+    _fields_ = [("rev", _vp), ("counts", _vp), ("status", _vp), ("rows", _i64), ("width", C.c_int32), ("shadow", C.c_int32)]
+
+
 class BnFinish(C.Structure):
     """mvk_bn_finish: the producer's half of a folded BatchNorm (statistics finished inside the GEMM launch)."""
     _fields_ = [("counters", _vp), ("eps", _f), ("momentum", _f), ("mean", _vp), ("invstd", _vp), ("running_mean", _vp),
@@ -121,6 +126,9 @@ _SIGNATURES = {
                                                _vp]),
     "mvk_radius_neighbors_dev": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _i, _vp, _i, _vp, _i64,
                                            _vp]),
+    "mvk_radius_neighbors_dev_rev": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _i, _vp, _i, _vp, _i64,
+                                               _vp, _i, _vp, _vp, _vp]),
+    "mvk_reverse_finish_many": (C.c_int, [C.POINTER(RevList), _i, _vp]),
     "mvk_neighbors_cell_order": (C.c_int, [_i64, _i, _vp, _vp, _i64, _vp, _i64, _vp]),
     "mvk_radius_neighbors_workspace": (C.c_int64, [_i64, _i64, _i]),
     "mvk_radius_neighbors_batch": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _vp,

@@ -361,10 +361,23 @@ __device__ __forceinline__ void note_count(int* maxcount, int n) {
 
 // CAP = in-range neighbours a query can hold in LDS (8 bytes each): 1024 in general, 256 when the caller
 // keeps at most 64 columns (the conv-radius searches: more waves per CU)
-template <bool FILL, int CAP>
+// Round 5: the transposed relation out of the search itself (REV; csrc/revlist.hip has the stand-alone form). The lanes
+// that write row i of `out` hold every kept pair (i, id) in registers: each takes its slot in rev[id] with the same
+// INTEGER atomic rev_fill_kernel uses (the count does not depend on the order, the slot does -- arrival order, which is
+// all the default mode asks for), so the second pass over the finished matrix (as long as the search that produced it:
+// 47.6 against 42.7 us at level 0) disappears. Tails and counters are finished for all lists of a pyramid by ONE
+// launch afterwards (mvk_reverse_finish_many).
+struct RevOut {
+  int32_t* rev;      // [Ns_cap, Hr]
+  int32_t* count;    // [Ns_cap], zero on entry
+  int32_t* status;   // [2]: longest row, overflow
+  int Hr;
+};
+
+template <bool FILL, int CAP, bool REV = false>
 __global__ __launch_bounds__(64) void nb_query_kernel(const float* __restrict__ q, NbWs W, int B,
                                                       float radius, int64_t Ns, int* __restrict__ out,
-                                                      int width) {
+                                                      int width, RevOut R) {
   __shared__ float ld2[FILL ? CAP : 1];
   __shared__ int lidx[FILL ? CAP : 1];
   const int64_t i = blockIdx.x;
@@ -470,7 +483,16 @@ __global__ __launch_bounds__(64) void nb_query_kernel(const float* __restrict__ 
       const int iu = lidx[u];
       rank += (du < d) || (du == d && iu < id);
     }
-    if (rank < width) out[i * width + rank] = id;
+    if (rank < width) {
+      out[i * width + rank] = id;
+      if (REV) {
+        const int slot = atomicAdd(R.count + id, 1);
+        if (slot < R.Hr)
+          R.rev[(int64_t)id * R.Hr + slot] = (int32_t)i;
+        else
+          atomicOr(R.status + 1, 1);
+      }
+    }
   }
   for (int c = n + lane; c < width; c += 64) out[i * width + c] = (int)Ns;  // neighbors.cpp:324
 }
@@ -700,7 +722,7 @@ int nb_run(const float* q, int64_t Nq, const float* s, int64_t Ns, const int32_t
     MVK_REQUIRE(width_host != nullptr && status_dev == nullptr, "neighbors: phase 1 needs width_host");
     if (Nq > 0)
       hipLaunchKernelGGL((nb_query_kernel<false, LIST_CAP>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns,
-                         (int*)nullptr, 0);
+                         (int*)nullptr, 0, RevOut{});
     MVK_CHECK_HIP(hipGetLastError());
     MVK_CHECK_HIP(hipMemcpyAsync(width_host, W.maxcount, sizeof(int), hipMemcpyDeviceToHost, st));
     MVK_CHECK_HIP(hipStreamSynchronize(st));
@@ -711,11 +733,11 @@ int nb_run(const float* q, int64_t Nq, const float* s, int64_t Ns, const int32_t
     // enqueue-only mode with a column limit: a row holding more than 4x the calibrated limit is reported
     // through the overflow flag like a row beyond LIST_CAP
     if (status_dev && width <= 64)
-      hipLaunchKernelGGL((nb_query_kernel<true, 256>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width);
+      hipLaunchKernelGGL((nb_query_kernel<true, 256>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width, RevOut{});
     else if (wide_waves() > 1 && width > 64)
       hipLaunchKernelGGL((nb_query_wide_kernel<8>), dim3((unsigned)Nq), dim3(512), 0, st, q, W, B, radius, Ns, out, width);
     else
-      hipLaunchKernelGGL((nb_query_kernel<true, LIST_CAP>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width);
+      hipLaunchKernelGGL((nb_query_kernel<true, LIST_CAP>), dim3((unsigned)Nq), dim3(64), 0, st, q, W, B, radius, Ns, out, width, RevOut{});
   }
   MVK_CHECK_HIP(hipGetLastError());
   if (status_dev) return 0;
@@ -748,11 +770,42 @@ extern "C" int mvk_radius_neighbors_enqueue(const float* q, int64_t Nq, const fl
                 workspace, workspace_bytes, stream);
 }
 
+namespace {
+int nb_dev_run(const float* q, int64_t Nq_cap, const float* s, int64_t Ns_cap, const int32_t* q_lens_dev,
+               const int32_t* s_lens_dev, int B, float radius, int32_t* out, int width, int32_t shadow, int32_t* status_dev,
+               int reuse_grid, void* workspace, int64_t workspace_bytes, const RevOut* rev, void* stream);
+}
+
 extern "C" int mvk_radius_neighbors_dev(const float* q, int64_t Nq_cap, const float* s, int64_t Ns_cap,
                                         const int32_t* q_lens_dev, const int32_t* s_lens_dev, int B,
                                         float radius, int32_t* out, int width, int32_t shadow,
                                         int32_t* status_dev, int reuse_grid, void* workspace,
                                         int64_t workspace_bytes, void* stream) {
+  return nb_dev_run(q, Nq_cap, s, Ns_cap, q_lens_dev, s_lens_dev, B, radius, out, width, shadow, status_dev, reuse_grid,
+                    workspace, workspace_bytes, nullptr, stream);
+}
+
+// mvk_radius_neighbors_dev that also fills the TRANSPOSED relation while it writes the rows (width <= 64): rev
+// [Ns_cap, rev_width] int32 receives, in row j, the query rows whose list holds support j, in order of arrival;
+// rev_counts [Ns_cap] int32 (ZERO on entry) end up holding the row lengths; rev_status [2] as in mvk_reverse_neighbors.
+// The tails of the rows are NOT written and the counters NOT reset here: mvk_reverse_finish_many does both for all the
+// lists of a pyramid in one launch.
+extern "C" int mvk_radius_neighbors_dev_rev(const float* q, int64_t Nq_cap, const float* s, int64_t Ns_cap,
+                                            const int32_t* q_lens_dev, const int32_t* s_lens_dev, int B, float radius,
+                                            int32_t* out, int width, int32_t shadow, int32_t* status_dev, int reuse_grid,
+                                            void* workspace, int64_t workspace_bytes, int32_t* rev, int rev_width,
+                                            int32_t* rev_counts, int32_t* rev_status, void* stream) {
+  MVK_REQUIRE(rev && rev_counts && rev_status && rev_width >= 1 && rev_width <= 512 && width <= 64,
+              "neighbors: the fused reverse list needs rev, counters, a status word and at most 64 columns");
+  const RevOut R{rev, rev_counts, rev_status, rev_width};
+  return nb_dev_run(q, Nq_cap, s, Ns_cap, q_lens_dev, s_lens_dev, B, radius, out, width, shadow, status_dev, reuse_grid,
+                    workspace, workspace_bytes, &R, stream);
+}
+
+namespace {
+int nb_dev_run(const float* q, int64_t Nq_cap, const float* s, int64_t Ns_cap, const int32_t* q_lens_dev,
+               const int32_t* s_lens_dev, int B, float radius, int32_t* out, int width, int32_t shadow, int32_t* status_dev,
+               int reuse_grid, void* workspace, int64_t workspace_bytes, const RevOut* rev, void* stream) {
   MVK_REQUIRE(B >= 1 && B <= 4096 && Nq_cap >= 1 && Ns_cap >= 1 && Nq_cap < (1ll << 31) && Ns_cap < (1ll << 29),
               "neighbors: bad sizes");
   MVK_REQUIRE(radius > 0.f && width >= 1 && out && status_dev, "neighbors: bad arguments");
@@ -775,18 +828,22 @@ extern "C" int mvk_radius_neighbors_dev(const float* q, int64_t Nq_cap, const fl
   W.q_lens = q_lens_dev;       // the kernels derive the offsets themselves (was: a one-thread launch per search)
   W.s_lens = s_lens_dev;
   if (!reuse_grid) launch_build(s, W, radius, B, Ns_cap, st);
-  if (width <= 64)
+  if (width <= 64 && rev)
+    hipLaunchKernelGGL((nb_query_kernel<true, 256, true>), dim3((unsigned)Nq_cap), dim3(64), 0, st, q, W, B, radius,
+                       (int64_t)shadow, out, width, *rev);
+  else if (width <= 64)
     hipLaunchKernelGGL((nb_query_kernel<true, 256>), dim3((unsigned)Nq_cap), dim3(64), 0, st, q, W, B, radius,
-                       (int64_t)shadow, out, width);
+                       (int64_t)shadow, out, width, RevOut{});
   else if (wide_waves() > 1)
     hipLaunchKernelGGL((nb_query_wide_kernel<8>), dim3((unsigned)Nq_cap), dim3(512), 0, st, q, W, B, radius,
                        (int64_t)shadow, out, width);
   else
     hipLaunchKernelGGL((nb_query_kernel<true, LIST_CAP>), dim3((unsigned)Nq_cap), dim3(64), 0, st, q, W, B, radius,
-                       (int64_t)shadow, out, width);
+                       (int64_t)shadow, out, width, RevOut{});
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }
+}  // namespace
 
 // The supports of the grid the workspace holds (built by the last search on it: same Ns, B and lengths), as a work
 // list for mvk_kpconv_gather_fwd_ordered: order_out[0 .. total) = the stacked rows sorted by cloud, grid cell

@@ -86,7 +86,76 @@ __global__ __launch_bounds__(256) void rev_sort_kernel(int64_t Ns, int32_t* __re
   }
 }
 
+// The tails of up to MVK_REV_MANY lists in ONE launch (round 5): the lists' rows were filled by the neighbour searches
+// themselves (mvk_radius_neighbors_dev_rev), their counters hold the row lengths. One wavefront per row of the
+// concatenated row range: pads the tail with the list's shadow value, returns the counter to zero, reports the longest row.
+struct RevManyArgs {
+  mvk_rev_list l[MVK_REV_MANY];
+  int64_t row_end[MVK_REV_MANY];      // prefix sums of the lists' row counts
+  int n;
+};
+
+__global__ __launch_bounds__(256) void rev_finish_many_kernel(const RevManyArgs A) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t total = A.row_end[A.n - 1];
+  int longest[MVK_REV_MANY];
+#pragma unroll
+  for (int k = 0; k < MVK_REV_MANY; ++k) longest[k] = 0;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < total; r += (int64_t)gridDim.x * 4) {
+    int k = 0;
+    while (k + 1 < A.n && r >= A.row_end[k]) ++k;                 // wave-uniform: a handful of lists
+    const int64_t j = r - (k > 0 ? A.row_end[k - 1] : 0);
+    const mvk_rev_list& L = A.l[k];
+    const int c_all = L.counts[j];
+    const int c = c_all < L.width ? c_all : L.width;
+    int32_t* row = L.rev + j * L.width;
+    for (int i = c + lane; i < L.width; i += 64) row[i] = L.shadow;
+    if (lane == 0 && c_all != 0) L.counts[j] = 0;
+#pragma unroll
+    for (int kk = 0; kk < MVK_REV_MANY; ++kk)
+      if (kk == k) longest[kk] = c_all > longest[kk] ? c_all : longest[kk];
+  }
+#pragma unroll
+  for (int k = 0; k < MVK_REV_MANY; ++k) {
+    if (k >= A.n || !A.l[k].status) continue;
+    int v = longest[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const int t = __shfl_xor(v, o);
+      v = t > v ? t : v;
+    }
+    if (lane == 0 && v > 0 && v > A.l[k].status[0]) atomicMax(A.l[k].status, v);
+  }
+}
+
 }  // namespace
+
+// Finishes n <= MVK_REV_MANY reverse lists whose rows were filled by mvk_radius_neighbors_dev_rev (or by any producer
+// that left the row lengths in `counts`): tails padded with `shadow`, counters back at zero, status[0] = max(status[0],
+// longest row). One launch.
+extern "C" int mvk_reverse_finish_many(const mvk_rev_list* lists, int n, void* stream) {
+  MVK_REQUIRE(lists && n >= 1 && n <= MVK_REV_MANY, "reverse finish: 1..%d lists", MVK_REV_MANY);
+  RevManyArgs A;
+  int64_t rows = 0;
+  for (int k = 0; k < MVK_REV_MANY; ++k) {
+    if (k < n) {
+      MVK_REQUIRE(lists[k].rev && lists[k].counts && lists[k].rows >= 0 && lists[k].width >= 1 && lists[k].width <= 512,
+                  "reverse finish: bad list %d", k);
+      A.l[k] = lists[k];
+      rows += lists[k].rows;
+    } else {
+      A.l[k] = mvk_rev_list{nullptr, nullptr, nullptr, 0, 0, 0};
+    }
+    A.row_end[k] = rows;
+  }
+  A.n = n;
+  if (rows == 0) return 0;
+  const int64_t want = cdiv64(rows, 4);
+  const unsigned blocks = (unsigned)(want < 8192 ? want : 8192);
+  hipLaunchKernelGGL(rev_finish_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, A);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 // rev [Ns, Hr] int32 <- the transposed relation of idx (Nq rows of H entries, row n at idx + n * idx_stride; int32 /
 // int64; entries outside [0, Ns) are shadow entries and are skipped): row j lists the rows n of idx that hold j --

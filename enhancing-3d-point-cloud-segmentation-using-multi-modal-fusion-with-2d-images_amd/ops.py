@@ -1944,18 +1944,49 @@ def grid_subsample_dev(points, lens_dev, dl, out_points, out_lens_dev, status, r
                                              _p(out_lens_dev), _p(total_out), _p(status), _p(ws), ws.numel(), _stream()))
 
 
-def radius_neighbors_dev(queries, supports, q_lens_dev, s_lens_dev, radius, out, shadow, status, reuse_grid=False):
-    """Capturable neighbour search (mvk_radius_neighbors_dev) into the fixed matrix out [Nq_cap, width] int32."""
-    _dev(queries, supports, q_lens_dev, s_lens_dev, out, status)
+def radius_neighbors_dev(queries, supports, q_lens_dev, s_lens_dev, radius, out, shadow, status, reuse_grid=False,
+                         rev=None, rev_counts=None, rev_status=None):
+    """Capturable neighbour search (mvk_radius_neighbors_dev) into the fixed matrix out [Nq_cap, width] int32.
+    rev [Ns_cap, Hr] int32 + rev_counts [Ns_cap] int32 (zero) + rev_status [2]: the search also fills the transposed
+    relation while it writes the rows (mvk_radius_neighbors_dev_rev, width <= 64; rows in order of arrival); finish the
+    lists of the whole pyramid with reverse_finish_many()."""
+    _dev(queries, supports, q_lens_dev, s_lens_dev, out, status, rev, rev_counts, rev_status)
     q, s = _f32c(queries), _f32c(supports)
     if out.dtype != torch.int32 or not out.is_contiguous() or out.shape[0] != q.shape[0]:
         raise RuntimeError("radius_neighbors_dev: out must be a contiguous int32 [Nq_cap, width] tensor")
     B = int(q_lens_dev.shape[0])
     ws = _workspace("nb", lib().mvk_radius_neighbors_workspace(q.shape[0], s.shape[0], B), q.device)
-    check(lib().mvk_radius_neighbors_dev(_p(q), q.shape[0], _p(s), s.shape[0], _p(q_lens_dev), _p(s_lens_dev), B,
-                                         float(radius), _p(out), out.shape[1], int(shadow), _p(status),
-                                         int(bool(reuse_grid)), _p(ws), ws.numel(), _stream()))
+    if rev is not None:
+        if (rev.dtype != torch.int32 or not rev.is_contiguous() or rev.dim() != 2 or rev.shape[0] < s.shape[0]
+                or rev_counts is None or rev_counts.dtype != torch.int32 or rev_counts.numel() < s.shape[0] or rev_status is None):
+            raise RuntimeError("radius_neighbors_dev: rev must be a contiguous int32 [>= Ns_cap, Hr] matrix with int32 "
+                               "counters [>= Ns_cap] and a status word")
+        check(lib().mvk_radius_neighbors_dev_rev(_p(q), q.shape[0], _p(s), s.shape[0], _p(q_lens_dev), _p(s_lens_dev), B,
+                                                 float(radius), _p(out), out.shape[1], int(shadow), _p(status),
+                                                 int(bool(reuse_grid)), _p(ws), ws.numel(), _p(rev), rev.shape[1],
+                                                 _p(rev_counts), _p(rev_status), _stream()))
+    else:
+        check(lib().mvk_radius_neighbors_dev(_p(q), q.shape[0], _p(s), s.shape[0], _p(q_lens_dev), _p(s_lens_dev), B,
+                                             float(radius), _p(out), out.shape[1], int(shadow), _p(status),
+                                             int(bool(reuse_grid)), _p(ws), ws.numel(), _stream()))
     _NB_GRID.pop(q.device.index, None)
+
+
+REV_MANY = 12      # include/mvkpconv.h: MVK_REV_MANY
+
+
+def reverse_finish_many(lists, status=None):
+    """lists: [(rev [rows, Hr] int32, counts [>= rows] int32, rows, shadow)] filled by radius_neighbors_dev(rev=...): pads the
+    tails, returns the counters to zero and accumulates the longest row into status[0] -- one launch for up to 12 lists
+    (mvk_reverse_finish_many)."""
+    from ._lib import RevList
+    for i0 in range(0, len(lists), REV_MANY):
+        chunk = lists[i0:i0 + REV_MANY]
+        arr = (RevList * len(chunk))()
+        for k, (rev, counts, rows, shadow) in enumerate(chunk):
+            _dev(rev, counts, status)
+            arr[k] = RevList(_p(rev), _p(counts), _p(status), int(rows), int(rev.shape[1]), int(shadow))
+        check(lib().mvk_reverse_finish_many(arr, len(chunk), _stream()))
 
 
 def neighbors_cell_order(Nq, Ns, B, out=None, s_lens_dev=None, device=None):

@@ -6,6 +6,8 @@ Host-side NumPy only generates RAW inputs (points, colours, labels, depth maps, 
 on the hot path (subsampling, neighbours, unprojection, k-NN, network) then runs through the HIP
 library (``build_batch``).
 """
+import os
+
 import numpy as np
 import torch
 
@@ -391,6 +393,9 @@ class StaticBatch:
         ops.pad_index_rows(src, shadow_src, dst, shadow_dst)
 
 
+_REV_FUSED = os.environ.get("MVK_REV_FUSED", "1") == "1"      # development switch: 0 = two launches per reverse list, after its search
+
+
 class DeviceInputChain:
     """The input side of one step -- centring, pyramid (oriented subsampling + neighbour searches),
     unprojection, 3-NN -- as a fixed sequence of launches with DEVICE-side counts that writes straight
@@ -424,6 +429,19 @@ class DeviceInputChain:
                                  for a in range(L) for b in range(L) if abs(a - b) <= 1), dev)
         ops._workspace("sub", ops.lib().mvk_grid_subsample_workspace(caps[0], self.B, 0, 0), dev)
 
+    def _rev_counts(self, k, rows, device):
+        """Counter slice of the k-th fused reverse list of a build: persistent zero words of its own (the lists of a pyramid
+        are finished together at the end, so they cannot share counters like the two-launch form does)."""
+        pool = self.__dict__.setdefault('_rev_count_pool', {})
+        buf = pool.get(k)
+        if buf is None or buf.numel() < rows:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("DeviceInputChain: build one batch eagerly before capturing (reverse-list counters)")
+            buf = torch.zeros(int(rows), dtype=torch.int32, device=device)
+            torch.cuda.current_stream(device).synchronize()
+            pool[k] = buf
+        return buf
+
     def draw_rotations(self, rotations=None, upload=True):
         """Host side of a step: one random rotation per cloud and level (or the given ones), staged in
         pinned memory and (upload) copied to the device asynchronously on the current stream. upload=False: the copy is
@@ -448,33 +466,48 @@ class DeviceInputChain:
         L = len(static.points)
         grid_of = (None, None)
 
-        def search(ql, sl, radius, out, limit_layer):
+        # Round 5: the searches fill the transposed matrices themselves and ONE launch finishes all of them (18 launches
+        # -> 1, ops.reverse_finish_many); deterministic mode keeps the two-launch form, which also sorts the rows
+        fused = _REV_FUSED and not ops.is_deterministic()
+        pending = []
+
+        def search(ql, sl, radius, out, limit_layer, rev=None, rev_shadow=None):
             nonlocal grid_of
             reuse = grid_of == (sl, np.float32(radius))
             grid_of = (sl, np.float32(radius))
+            if rev is not None and fused and out.shape[1] <= 64:
+                counts = self._rev_counts(len(pending), caps[sl], out.device)
+                ops.radius_neighbors_dev(static.points[ql], static.points[sl], self.lens[ql], self.lens[sl], radius,
+                                         out, caps[sl], self.status, reuse_grid=reuse, rev=rev, rev_counts=counts,
+                                         rev_status=self.rev_status)
+                pending.append((rev, counts, caps[sl], rev_shadow))
+                return True
             ops.radius_neighbors_dev(static.points[ql], static.points[sl], self.lens[ql], self.lens[sl], radius,
                                      out, caps[sl], self.status, reuse_grid=reuse)
+            return False
 
         for l in range(L):
             e = plan[l]
             if e['conv_r'] is not None:
-                search(l, l, e['conv_r'], static.neighbors[l], l)
+                rv = static.rev_neighbors[l] if static.rev_neighbors else None
+                done = search(l, l, e['conv_r'], static.neighbors[l], l, rev=rv, rev_shadow=caps[l])
                 if static.orders and static.orders[l] is not None:     # the workspace holds this search's grid
                     ops.neighbors_cell_order(caps[l], caps[l], self.B, static.orders[l], self.lens[l])
-                if static.rev_neighbors and static.rev_neighbors[l] is not None:
-                    ops.reverse_neighbors(static.neighbors[l], caps[l], out=static.rev_neighbors[l], status=self.rev_status,
-                                          shadow=caps[l])
+                if rv is not None and not done:
+                    ops.reverse_neighbors(static.neighbors[l], caps[l], out=rv, status=self.rev_status, shadow=caps[l])
             if e['pool'] and l + 1 < L:
                 ops.grid_subsample_dev(static.points[l], self.lens[l], e['dl'], static.points[l + 1], self.lens[l + 1],
                                        self.status, rotations_dev=self.rot[l], total_out=static._counts[l + 1])
-                search(l + 1, l, e['pool_r'], static.pools[l], l)
-                if static.rev_pools and static.rev_pools[l] is not None:
-                    ops.reverse_neighbors(static.pools[l], caps[l], out=static.rev_pools[l], status=self.rev_status,
-                                          shadow=caps[l + 1])
+                rv = static.rev_pools[l] if static.rev_pools else None
+                done = search(l + 1, l, e['pool_r'], static.pools[l], l, rev=rv, rev_shadow=caps[l + 1])
+                if rv is not None and not done:
+                    ops.reverse_neighbors(static.pools[l], caps[l], out=rv, status=self.rev_status, shadow=caps[l + 1])
                 search(l, l + 1, e['up_r'], static.upsamples[l], l + 1)
                 if l in static.rev_ups:
                     ops.reverse_neighbors(static.upsamples[l], caps[l + 1], out=static.rev_ups[l], status=self.rev_status,
                                           shadow=caps[l], first_column=True)
+        if pending:
+            ops.reverse_finish_many(pending, self.rev_status)
         torch.cat(st['labels'], 0, out=static.labels)
         ones = torch.ones_like(stacked_world[:, :1])
         z = stacked_world[:, 2:3]

@@ -198,6 +198,28 @@ int mvk_gemm_split_ordered(void);
  *   weights, read in place), Cout a power of two >= 32. */
 int mvk_reverse_neighbors(const void* idx, int idx64, int64_t Nq, int H, int64_t idx_stride, int64_t Ns, int32_t* rev, int Hr,
                           int32_t shadow, int sort, int32_t* counts, int32_t* status, void* stream);
+
+/* Round 5: the transposed relation out of the neighbour search itself. mvk_radius_neighbors_dev_rev is
+ * mvk_radius_neighbors_dev (width <= 64) whose lanes also take their slot in rev [Ns_cap, rev_width] for every kept pair
+ * (query row, support) -- rows in order of arrival, row lengths left in rev_counts [Ns_cap] (ZERO on entry),
+ * rev_status [2] = [longest row, overflow] as in mvk_reverse_neighbors; tails are not written and counters not reset.
+ * mvk_reverse_finish_many then pads the tails with each list's shadow value, returns the counters to zero and reports
+ * the longest rows of up to MVK_REV_MANY lists in ONE launch (the nine lists of a five-level pyramid: 18 launches -> 1
+ * on top of the searches). The ascending order deterministic mode needs stays with mvk_reverse_neighbors(sort = 1). */
+#define MVK_REV_MANY 12
+typedef struct mvk_rev_list {
+  int32_t* rev;        /* [rows, width] */
+  int32_t* counts;     /* [rows] */
+  int32_t* status;     /* [2] or NULL */
+  int64_t rows;
+  int32_t width;
+  int32_t shadow;
+} mvk_rev_list;
+int mvk_radius_neighbors_dev_rev(const float* q, int64_t Nq_cap, const float* s, int64_t Ns_cap, const int32_t* q_lens_dev,
+                                 const int32_t* s_lens_dev, int B, float radius, int32_t* out, int width, int32_t shadow,
+                                 int32_t* status_dev, int reuse_grid, void* workspace, int64_t workspace_bytes, int32_t* rev,
+                                 int rev_width, int32_t* rev_counts, int32_t* rev_status, void* stream);
+int mvk_reverse_finish_many(const mvk_rev_list* lists, int n, void* stream);
 int mvk_gemm_f32_kp_transposed(const float* A, const float* W, float* dx, int64_t M, int K, int Cin, int Cout, void* stream);
 
 /* The other scatter backwards of the network as gathers over a reverse list (deterministic mode; every output element is

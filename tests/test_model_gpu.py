@@ -464,6 +464,22 @@ def test_device_input_chain_equals_eager_input_side(variant, deformable, nsphere
     if want.knn_list is not None:
         for a, b in zip(got.knn_list, want.knn_list):
             assert torch.equal(a, b)
+    # the transposed matrices the searches filled on the way (round 5: slots taken inside nb_query_kernel, one finishing
+    # launch per pyramid): every row holds exactly the query rows whose list names that support (any order: arrival),
+    # the tail is the shadow value, the counters are back at zero -- against the stand-alone two-launch form, sorted
+    ops.check_reverse_status(chain.rev_status)
+    checked = 0
+    for revs, mats, qcap in ((got.rev_neighbors, got.neighbors, lambda l: got.caps[l]),
+                             (got.rev_pools, got.pools, lambda l: got.caps[min(l + 1, L - 1)])):
+        for l, rev in enumerate(revs or []):
+            if rev is None:
+                continue
+            ref = ops.reverse_neighbors(mats[l], got.caps[l], width=rev.shape[1], shadow=qcap(l), sort=True)
+            assert torch.equal(torch.sort(rev, dim=1).values, torch.sort(ref, dim=1).values), l
+            checked += 1
+    assert checked >= (0 if deformable else 5)
+    for buf in getattr(chain, "_rev_count_pool", {}).values():
+        assert int(buf.abs().sum()) == 0
 
 
 @pytest.mark.parametrize("device_chain", [False, True])

@@ -487,10 +487,9 @@ def test_graph_replay_trains_like_eager(device_chain):
     """bench.py's hipGraph step (capacity-padded static batch, masked BatchNorm, input pyramid one batch
     ahead on a second stream) follows the same trajectory as plain eager steps: with the grid rotations
     pinned (so every batch is identical) the losses and the weights after 5 optimizer steps agree."""
-    import importlib
     import types
     import mvkpconv
-    bench = importlib.import_module("bench")
+    bench = mvkpconv.sub("step")          # the step executor lives in the package since round 5 (was bench.py)
     syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
     dev = torch.device("cuda:0")
     torch.cuda.set_stream(torch.cuda.Stream())
@@ -553,9 +552,8 @@ def test_graph_replay_trains_like_eager(device_chain):
 def test_graph_capture_refuses_the_default_stream():
     """Guard of the round-1 abort (segfault in capture_end): make_graph_step under the legacy default stream must
     raise instead of starting a capture that cannot succeed."""
-    import importlib
     import mvkpconv
-    bench = importlib.import_module("bench")
+    bench = mvkpconv.sub("step")
     torch.cuda.set_stream(torch.cuda.default_stream())
     staged = {"points": [torch.zeros(4, 3, device="cuda")]}
     with pytest.raises(RuntimeError, match="non-default stream"):

@@ -7,6 +7,7 @@ mkdir -p gpurun_out
 for spec in "$@"; do
   label="${spec%%=*}"; rest="${spec#*=}"; envs="${rest%%|*}"; args=""
   case "$rest" in *"|"*) args="${rest#*|}";; esac
+  case "$envs" in *MVK_BENCH_*) args="$args --dev";; esac      # knobs that change the captured step need the explicit flag
   err="gpurun_out/ab_${label}.err"
   out="$(env $envs python bench.py --no-cpu-baseline $args 2>"$err" | tail -1)"
   rc=$?

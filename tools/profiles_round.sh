@@ -24,7 +24,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAV
 python3 $R/tools/pmc_mfma.py $(ls $O/pm/*/*_counter_collection.csv | head -1) $O/${TAG}_pmc_mfma.json > $O/pmc_mfma.log 2>&1
 rm -rf $O/pm
 # 4. the network branch alone, kernel by kernel in launch order
-MVK_BENCH_DIAG=noside rocprofv3 --kernel-trace --output-format csv -d $O/kn -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/kn.err
+MVK_BENCH_DIAG=noside rocprofv3 --kernel-trace --output-format csv -d $O/kn -- python3 $R/bench.py --dev --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/kn.err
 python3 $R/tools/trace_chain.py $(ls $O/kn/*/*_kernel_trace.csv | head -1) > $O/${TAG}_chain_noside.txt 2>&1
 rm -rf $O/kn
 # 5. operator benches (device time of graph-captured launches) and workload lines
@@ -49,14 +49,14 @@ python3 $R/tools/trace_steady.py $F5 5 90 > $O/${TAG}_steady_state_5spheres.txt
 rm -rf $O/k5
 cd $R && python3 bench.py --spheres 5 --views 5 --steps 20 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_line_5spheres.json 2> $O/b5.err; cp $R/gpurun_out/bench_detail.json $O/${TAG}_bench_detail_5spheres.json; cd /tmp
 # 8. (round 4) deterministic mode against the default, gather-form feature gradient against the atomic scatter
-{ for e in X=0 MVK_DETERMINISTIC=1 MVK_REVERSE_DX=0 MVK_INPUTS_IN_GRAPH=0 MVK_BENCH_DUMMY_LAUNCHES=100; do echo -n "$e: "; env $e python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done;
+{ for e in X=0 MVK_DETERMINISTIC=1 MVK_REVERSE_DX=0 MVK_INPUTS_IN_GRAPH=0 MVK_BENCH_DUMMY_LAUNCHES=100; do echo -n "$e: "; env $e python3 $R/bench.py --dev --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done;
   for e in X=0 MVK_REVERSE_DX=0; do echo -n "8 spheres, $e: "; env $e python3 $R/bench.py --spheres 8 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done; } > $O/${TAG}_modes.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 $R/tools/park_probe.hip -o /tmp/park_probe 2>/dev/null && timeout -k 10 120 /tmp/park_probe > $O/${TAG}_park_probe.txt 2>&1
 bash $R/tools/env_knobs.sh > $O/${TAG}_env_knobs.txt 2>&1
 # 9. (round 4) what each side branch costs the step (pieces left out of the captured step: timing only), the input kernels'
 #    one-workgroup paths against the multi-workgroup front ends, and the level-0 neighbour kernels stand-alone
 cd $R
-{ for e in X=0 MVK_BENCH_SKIP=enc MVK_BENCH_SKIP=chain MVK_BENCH_SKIP=fa MVK_BENCH_SKIP=enc,chain,fa MVK_BENCH_SKIP=chain,fa MVK_BENCH_SKIP=enc,fa "MVK_SUB_MULTI_MIN=0 MVK_NB_MULTI_MIN=0" X=0; do echo -n "$e: "; env $e python3 $R/bench.py --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done;
-  for e in X=0 MVK_BENCH_SKIP=enc MVK_BENCH_SKIP=chain MVK_BENCH_SKIP=enc,chain,fa "MVK_SUB_MULTI_MIN=0 MVK_NB_MULTI_MIN=0"; do echo -n "5 spheres x 5 views, $e: "; env $e python3 $R/bench.py --spheres 5 --views 5 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done; } > $O/${TAG}_side_branches.txt 2>&1
+{ for e in X=0 MVK_BENCH_SKIP=enc MVK_BENCH_SKIP=chain MVK_BENCH_SKIP=fa MVK_BENCH_SKIP=enc,chain,fa MVK_BENCH_SKIP=chain,fa MVK_BENCH_SKIP=enc,fa "MVK_SUB_MULTI_MIN=0 MVK_NB_MULTI_MIN=0" X=0; do echo -n "$e: "; env $e python3 $R/bench.py --dev --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done;
+  for e in X=0 MVK_BENCH_SKIP=enc MVK_BENCH_SKIP=chain MVK_BENCH_SKIP=enc,chain,fa "MVK_SUB_MULTI_MIN=0 MVK_NB_MULTI_MIN=0"; do echo -n "5 spheres x 5 views, $e: "; env $e python3 $R/bench.py --dev --spheres 5 --views 5 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done; } > $O/${TAG}_side_branches.txt 2>&1
 bash $R/tools/nb_probe.sh 0 > $O/${TAG}_nb_probe.txt 2>&1
 ls -la $O

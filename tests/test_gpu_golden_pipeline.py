@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from conftest import load_golden
-from util import bits_equal, rel_err, check_err
+from util import referee_check, REFEREE_FACTOR, REFEREE_FLOOR, bits_equal, rel_err, check_err
 from test_oracle_vs_golden import check_pyramid, g5_config, g5b_config, g5_batch, _Cfg, g12_inputs, g12_check_gradients
 
 pytestmark = pytest.mark.gpu
@@ -59,6 +59,11 @@ def test_reference_kpfcnn_state_dict_runs_on_the_hip_path():
     worst = max((rel_err(named[k[5:]].grad.cpu().numpy(), g[k]), k) for k in g if k.startswith("grad/"))
     # parameter gradients through 5 levels of train-mode BatchNorm (the reference's own float32 run is the fixture)
     check_err("G5 KPFCNN worst parameter gradient (%s)" % worst[1][5:], worst[0], G5_GRAD_TOL)
+    # the float64 referee: the HIP path is no further from the float64 network than the reference's own float32 run
+    r = load_golden("g14_f64_referee")
+    referee_check("G5 logits", out.detach().cpu().numpy(), g["logits"], r["g5/logits"])
+    for k in sorted(k for k in g if k.startswith("grad/")):
+        referee_check("G5 grad %s" % k[5:], named[k[5:]].grad.cpu().numpy(), g[k], r["g5/" + k])
 
 
 @pytest.mark.parametrize("name", ["g5b_kpfcnn_deform", "g5b_kpfcnn_deform_mod"])
@@ -97,6 +102,11 @@ def test_reference_deformable_kpfcnn_state_dict_runs_on_the_hip_path(name):
         # kink (make_golden.py seed loop): on such inputs the two float32 paths take different slopes and the END-TO-END
         # gradient is discontinuous -- what is bounded here is rounding, not that discontinuity
         check_err("G5b %s worst parameter gradient (%s)" % (tag, worst[1][5:]), worst[0], G5_GRAD_TOL)
+        r = load_golden("g14_f64_referee")
+        rt = "g5b_deform_mod" if int(g["modulated"]) else "g5b_deform"
+        referee_check("G5b %s logits" % tag, out.detach().cpu().numpy(), g["logits"], r[rt + "/logits"])
+        for k in sorted(k for k in g if k.startswith("grad/")):
+            referee_check("G5b %s grad %s" % (tag, k[5:]), named[k[5:]].grad.cpu().numpy(), g[k], r["%s/%s" % (rt, k)])
 
 
 @pytest.mark.parametrize("variant", ["early", "middle", "late"])
@@ -135,6 +145,27 @@ def test_fusion_networks_vs_reference_forward_texts(variant):
         grads = {n: p.grad.cpu().numpy() for n, p in net.named_parameters() if p.grad is not None}
         assert any(k.startswith("feat_aggreg.") for k in grads) == (variant == "late")
         g12_check_gradients(g, variant, grads, tag, 5e-3, 2e-3)
+        # the float64 referee on the same digest: per parameter the 64 fixed elements and the norm -- the wide bounds above
+        # are the REFERENCE's own float32 distance from the float64 network (early: 1.8e-3 in one norm), not the HIP path's
+        r = load_golden("g14_f64_referee")
+        referee_check("G12 %s logits" % tag, out.detach().cpu().numpy(), g[variant + "/logits"], r["g12/%s/logits" % variant])
+        scale = max(float(r[k]) for k in r if k.startswith("g12/%s/gnorm/" % variant))
+        worst = (0.0, 0.0, "")
+        for n in sorted(k[len(variant) + 7:] for k in g if k.startswith(variant + "/gnorm/")):
+            n64, v64 = float(r["g12/%s/gnorm/%s" % (variant, n)]), r["g12/%s/gval/%s" % (variant, n)]
+            if n64 < 1e-3 * scale:          # analytically ~0 (a bias in front of a BatchNorm): bounded absolutely above
+                continue
+            got = np.asarray(grads[n], np.float64).reshape(-1)
+            idx = g["%s/gidx/%s" % (variant, n)]
+            # digest elements relative to the tensor's norm (64 of its elements, so ||.|| / norm is the comparable scale)
+            e_hip = float(np.linalg.norm(got[idx] - v64) / n64) + abs(np.linalg.norm(got) / n64 - 1.0)
+            e_ref = float(np.linalg.norm(g["%s/gval/%s" % (variant, n)].astype(np.float64) - v64) / n64) + \
+                abs(float(g["%s/gnorm/%s" % (variant, n)]) / n64 - 1.0)
+            assert e_hip <= REFEREE_FACTOR * e_ref + REFEREE_FLOOR, (n, e_hip, e_ref)
+            if e_hip - REFEREE_FACTOR * e_ref > worst[0] - REFEREE_FACTOR * worst[1] or not worst[2]:
+                worst = (e_hip, e_ref, n)
+        check_err("G12 %s: parameter closest to its referee bound (%s): HIP vs float64 (reference float32 vs float64: %.3e)"
+                  % (tag, worst[2], worst[1]), worst[0], REFEREE_FACTOR * worst[1] + REFEREE_FLOOR)
 
 
 @pytest.mark.parametrize("name,variant,deformable,radius", [("g13_early_19k", "early", False, 1.2),

@@ -1113,6 +1113,48 @@ def _gather_form_gradient(ops, q, s, idx, x, W, g, kp, Nq, Ns, H, C):
         assert rel_err(res[1][2].cpu().numpy(), dW) < FP_TOL
 
 
+@pytest.mark.parametrize("Nq,Ns,H,C,strided", [(2500, 2500, 30, 32, False), (600, 2500, 28, 64, True), (19464, 19464, 45, 32, False)])
+def test_kpconv_gather_form_feature_gradient_default_mode_arrival_order(ops, Nq, Ns, H, C, strided):
+    """The same operator-level check in the DEFAULT mode: reverse lists whose rows are in order of
+    ARRIVAL (no sort: what the bench and the input chain use), products with atomic split reductions. The feature
+    gradient is held to the float64 NumPy restatement at the north_star tolerance and to the atomic scatter at 1e-5;
+    it is NOT bit-identical between runs (the rows' order is not) -- only its distance from float64 is bounded."""
+    from oracle import npref
+    assert not ops.is_deterministic()
+    rng = np.random.default_rng(Nq + C + 1)
+    s = (rng.random((Ns, 3)) * 0.5).astype(np.float32)
+    q = s.copy() if not strided else s[rng.choice(Ns, Nq, replace=False)] + rng.normal(0, 0.01, (Nq, 3)).astype(np.float32)
+    if Nq * Ns < 4e7:
+        d2 = ((q[:, None, :] - s[None, :, :]) ** 2).sum(-1)
+        idx = np.argsort(d2, axis=1)[:, :H].astype(np.int32)
+        idx[np.take_along_axis(d2, idx.astype(np.int64), 1) > 0.05 ** 2] = Ns
+    else:
+        idx = ((rng.integers(0, Ns + Ns // 4, (Nq, 1)) + np.cumsum(rng.integers(1, 7, (Nq, H)), 1)) % (Ns + Ns // 4)).astype(np.int32)
+        idx[idx >= Ns] = Ns
+    K = 15
+    kp = (rng.normal(size=(K, 3)) * 0.02).astype(np.float32)
+    x = rng.normal(size=(Ns, C)).astype(np.float32)
+    W = (rng.normal(size=(K, C, C)) * 0.05).astype(np.float32)
+    g = rng.normal(size=(Nq, C)).astype(np.float32)
+    rev = ops.reverse_neighbors(T(idx), Ns, sort=False)                   # arrival order
+    srt = ops.reverse_neighbors(T(idx), Ns, sort=True)
+    assert torch.equal(torch.sort(rev, 1).values, torch.sort(srt, 1).values)
+    res = []
+    for r in (None, rev):
+        xt, Wt = T(x).requires_grad_(True), T(W).requires_grad_(True)
+        y, _ = ops.kpconv(T(q), T(s), T(idx), xt, T(kp), Wt, 0.03, rev=r)
+        (y * T(g)).sum().backward()
+        res.append((xt.grad.clone(), Wt.grad.clone()))
+    check_err("default-mode gather-form dx vs atomic scatter (Nq %d, C %d)" % (Nq, C),
+              rel_err(res[1][0].cpu().numpy(), res[0][0].cpu().numpy()), 1e-5)
+    if Nq * H * C < 3e7:
+        a64 = [q.astype(np.float64), s.astype(np.float64), idx.astype(np.int64), x.astype(np.float64), kp.astype(np.float64),
+               W.astype(np.float64), 0.03]
+        dx, dW = npref.kpconv_backward(*a64, g.astype(np.float64))
+        check_err("default-mode gather-form dx vs float64 oracle (Nq %d, C %d)" % (Nq, C), rel_err(res[1][0].cpu().numpy(), dx), FP_TOL)
+        check_err("default-mode dW vs float64 oracle (Nq %d, C %d)" % (Nq, C), rel_err(res[1][1].cpu().numpy(), dW), FP_TOL)
+
+
 def test_deferred_weight_gradients_run_as_one_grouped_launch(ops):
     """ops.defer_weight_grads(): the dW products recorded during a backward pass (TN, wide and narrow outputs, ragged
     sizes, split and unsplit reductions) come out of the grouped launch equal to the individual products; under

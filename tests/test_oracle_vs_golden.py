@@ -343,3 +343,33 @@ def test_reprojection_oracle_vs_sklearn_kdtree_golden():
     g = load_golden("g10_reprojection")
     nn = cport.knn_f64(g["points"].astype(np.float64), g["sub_points"].astype(np.float64), k=1)[0][:, 0]
     assert np.array_equal(nn.astype(np.int32), g["proj_inds"])
+
+
+def test_float64_referee_fixture_is_what_the_port_computes():
+    """tests/golden/g14_f64_referee.npz (make_f64_referee.py): the CPU port run in float64 on fixture G5's inputs
+    reproduces the stored logits and gradients (1e-12), and the two float32 evaluations of the same network -- the
+    REFERENCE's (the fixture) and the port's -- lie at comparable distances from it: the referee separates rounding of a
+    float32 run from a wiring error (which would show as a distance orders above both)."""
+    import torch
+    from oracle import torch_port
+    from util import l2_err
+    g, r = load_golden("g5_kpfcnn"), load_golden("g14_f64_referee")
+    cfg, b = g5_config(), g5_batch(g)
+    names = [k[5:] for k in g if k.startswith("grad/")]
+    runs = {}
+    for dt in (torch.float64, torch.float32):
+        sd = {k[3:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd/")}
+        sd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd.items()}
+        leaf = {k: sd[k].clone().requires_grad_(True) for k in names}
+        sd.update(leaf)
+        bb = {k: ([t.to(dt) if t.is_floating_point() else t for t in v] if isinstance(v, list)
+                  else (v.to(dt) if torch.is_tensor(v) and v.is_floating_point() else v)) for k, v in b.items()}
+        out, reg = torch_port.forward(sd, cfg, bb, None, True)
+        torch_port.loss_fn(out, bb["labels"], reg, cfg).backward()
+        runs[dt] = (out.detach().numpy(), {k: v.grad.numpy() for k, v in leaf.items()})
+    assert l2_err(runs[torch.float64][0], r["g5/logits"]) < 1e-12
+    for k in names:
+        f64 = r["g5/grad/" + k]
+        assert l2_err(runs[torch.float64][1][k], f64) < 1e-10, k
+        e_ref, e_port = l2_err(g["grad/" + k], f64), l2_err(runs[torch.float32][1][k], f64)
+        assert e_ref < 2e-4 and e_port < 2e-4 and e_port < 4 * e_ref + 1e-5 and e_ref < 4 * e_port + 1e-5, (k, e_ref, e_port)

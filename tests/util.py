@@ -128,3 +128,22 @@ def g13_state(shapes, variant, deformable, kernel_points):
             if n.endswith("offset_conv.weights"):
                 sd[n] = (sd[n] * np.float32(0.2)).astype(np.float32)
     return sd
+
+
+REFEREE_FACTOR = 2.0      # err(HIP, float64) <= REFEREE_FACTOR x err(reference float32, float64) + REFEREE_FLOOR
+REFEREE_FLOOR = 1e-5      # relative to the tensor's largest element: a few float32 roundings of sums of 10^3 .. 10^4 terms
+
+
+def l2_err(a, b):
+    """||a - b|| / ||b|| in float64."""
+    a, b = np.asarray(a, np.float64).reshape(-1), np.asarray(b, np.float64).reshape(-1)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def referee_check(label, hip, ref32, f64, factor=REFEREE_FACTOR, floor=REFEREE_FLOOR):
+    """The float64 referee (tests/golden/make_f64_referee.py): the HIP path must be no further from the float64 value of
+    the same network than `factor` x the distance of the REFERENCE's own float32 run (the fixture), plus a floor. Both
+    columns are logged next to each other (profiles/rNN_parity_errors.txt)."""
+    e_hip, e_ref = l2_err(hip, f64), l2_err(ref32, f64)
+    check_err("%s: HIP vs float64 (reference float32 vs float64: %.3e)" % (label, e_ref), e_hip, factor * e_ref + floor)
+    return e_hip, e_ref

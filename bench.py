@@ -494,7 +494,7 @@ def pmc_traffic(best):
     import mvkpconv
     grid_threads = mvkpconv.sub("ops").kpconv_gather_plan(sh["Nq"], sh["Ns"], sh["H"], sh["Cin"])["grid_threads"]
     for l in prof["launches"]:
-        if l["kernel"].startswith("kpconv_gather_vec") and l["grid_threads"] == grid_threads:
+        if l["kernel"].startswith(("kpconv_gather_vec", "kpconv_gather_mfma")) and l["grid_threads"] == grid_threads:
             return l["traffic_bytes"], "%s (%s)" % (os.path.basename(path), prof.get("command", ""))
     return None, "%s holds no launch with this run's grid" % os.path.basename(path)
 

@@ -148,6 +148,164 @@ __device__ __forceinline__ int phase_a(const KPParams& P, int64_t n0, int h0, in
 }
 
 // ---------------------------------------------------------------------------
+// MFMA gather kernel (round 5; rigid layers, linear influence + sum aggregation, f32): the aggregation
+//   A[n, k, c] = sum_h w[n, h, k] x[idx[n, h], c]
+// of ONE query point is a [K x H] . [H x Cin] product, and with K = 15 it fits the 16 x 16 x 4 f32 matrix instruction
+// exactly: v_mfma_f32_16x16x4_f32 takes A[i][kk] from lane (i = lane & 15, kk = lane >> 4) and B[kk][j] from lane
+// (kk = lane >> 4, j = lane & 15) -- so lane (m, kq) computes ONE correlation weight, that of kernel point m for the kq-th
+// neighbour of the current group of four, and loads ONE feature value per 16-channel tile, channel m of that neighbour's
+// row. No LDS, no phase A / phase B hand-off, no per-neighbour loop of 15 x 4 FMAs per lane: per group of four
+// neighbours a wave issues 5 cross-lane reads (the neighbour's row and relative position, read once per 64 columns by the
+// lane of that column), ~12 VALU instructions for its weight, T dword loads (16 lanes = 64 contiguous bytes of a row) and
+// T MFMAs. The vector kernel below is bound by its own instruction stream (15 x 4 v_pk_fma_f32 per neighbour and lane:
+// 57 us for 19 464 x 66 against a 28 us floor of pure FMA issue); here the products run on the matrix
+// pipe (exact f32 products, f32 accumulation -- four neighbours per step instead of one: another summation order,
+// ~1e-7), 56 MFMAs of 32 cycles per point of that layer = 14 us chip-wide.
+// One wave per query point (waves of a workgroup are independent), T accumulator tiles of 16 channels (4 VGPRs each);
+// rows wider than 16 T channels run as gridDim.y channel blocks. The work list / XCD runs are those of the vector kernel.
+// ---------------------------------------------------------------------------
+typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
+
+// MODE: which channel each lane feeds to tile t -- any assignment works as long as the stores use the same one (column
+// j of D depends on column j of B alone), and the texture addresser handles a wave's load at ~16 cycles per instruction
+// whatever its width (one CU's addresser serves four matrix pipes), so the loads must be WIDE:
+//   1  rows of a multiple of 16 T channels: lane m takes the T consecutive channels c0 + T m .. of its neighbour as
+//      8- / 16-byte loads (tile t = its t-th channel): T / 4 load instructions per group instead of T (measured with
+//      one dword load per tile: 51 us for 19 464 x 66, 40 us for x 64 -- the addresser, not the matrix pipe, set the pace);
+//   2  even rows of 66 .. 80 channels (the early-fusion net's first layer: 64 + 2): channels 4 m .. 4 m + 3 as two
+//      8-byte loads (rows are 8-byte aligned) for tiles 0-3, tile 4 = channel 64 + m by a dword load;
+//   0  any other row length: tile t = channel c0 + 16 t + m, one dword load per tile.
+template <int T, int MODE, bool IDX64>
+__global__ __launch_bounds__(256) void kpconv_gather_mfma(KPParams P) {
+  static_assert(MODE != 2 || T == 5, "mode 2 is the 64 + tail layout");
+  static_assert(MODE != 1 || T == 2 || T % 4 == 0, "mode 1: 8- or 16-byte vectors");
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  int64_t blk = blockIdx.x;
+  if ((int)blockIdx.x < P.xcd_blocks) {      // XCD x works on one contiguous run of the work list (see kpconv_gather_vec)
+    const int xq = P.xcd_blocks >> 3, xr = P.xcd_blocks & 7, xc = blockIdx.x & 7;
+    blk = (int64_t)xc * xq + min(xc, xr) + (blockIdx.x >> 3);
+  }
+  const int64_t slot = blk * 4 + wid;
+  if (slot >= P.Nq) return;                  // (no barrier anywhere: the waves of a workgroup never meet)
+  const int n = __builtin_amdgcn_readfirstlane(P.order ? P.order[slot] : (int)slot);
+  const int c0 = blockIdx.y * (16 * T);      // first channel of this wave's block
+  const float* __restrict__ X = P.x;
+  const float qx = P.q[(int64_t)n * 3], qy = P.q[(int64_t)n * 3 + 1], qz = P.q[(int64_t)n * 3 + 2];
+  // this lane's kernel point (rows 15.. of the 16-row tile: a point no neighbour is near -> weight 0)
+  float kx = 1e9f, ky = 1e9f, kz = 1e9f;
+  if (m < P.K) {
+    kx = P.kp[m * 3];
+    ky = P.kp[m * 3 + 1];
+    kz = P.kp[m * 3 + 2];
+  }
+  const float inv_ext = 1.0f / P.extent;
+  // MODE 0: channel of tile t in this lane, clamped into the row: a lane beyond the row's end loads the last channel again
+  // and feeds an output column that is never stored -- no branch, no mask. MODE 1 / 2: first channel of the lane's vector.
+  uint32_t chan[MODE == 0 ? T : 1];
+  if (MODE == 0) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) chan[t] = (uint32_t)min(c0 + 16 * t + m, P.Cin - 1);
+  } else {
+    chan[0] = MODE == 1 ? (uint32_t)(c0 + T * m) : (uint32_t)(4 * m);
+  }
+  const uint32_t tailc = MODE == 2 ? (uint32_t)min(64 + m, P.Cin - 1) : 0u;
+  mfma_f32x4 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) acc[t] = (mfma_f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int h0 = 0; h0 < P.H; h0 += 64) {
+    // column h0 + lane of the row: neighbour index, its position relative to the query, the offset of its feature row
+    int jl = -1;
+    if (h0 + lane < P.H) jl = load_idx<IDX64>(P.idx, (int64_t)n * P.H + h0 + lane, P.Ns);
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (jl >= 0) {
+      const float* sp = P.s + (int64_t)jl * 3;
+      rx = sp[0] - qx;
+      ry = sp[1] - qy;
+      rz = sp[2] - qz;
+    }
+    const unsigned long long live = __ballot(jl >= 0);
+    if (live == 0ull) continue;
+    const int groups = (64 - __builtin_clzll(live) + 3) >> 2;        // up to the last real entry of the chunk (wave-uniform)
+    const uint32_t roff = (uint32_t)(jl >= 0 ? jl : 0) * (uint32_t)P.Cin;      // (host: Ns * Cin < 2^32)
+    // Group g: lane (m, kq) works on column 4 g + kq. Two register sets, the loop unrolled by two: the cross-lane reads
+    // and the feature loads of the NEXT group are issued before the MFMAs of the current one, nothing in the body is
+    // conditional (a branch around a load makes the compiler wait for everything in flight). A group beyond `groups`
+    // (odd counts; columns >= 64 wrap around in the cross-lane read) has weight 0: its columns are shadow entries.
+    auto fetch = [&](const int g, float& w, float (&xv)[T]) {
+      const int src = 4 * g + kq;
+      const int j = __shfl(jl, src);
+      const float gx = __shfl(rx, src) - kx, gy = __shfl(ry, src) - ky, gz = __shfl(rz, src) - kz;
+      const uint32_t off = (uint32_t)__shfl((int)roff, src);
+      const float d = __builtin_amdgcn_sqrtf(gx * gx + gy * gy + gz * gz);          // blocks.py:294-297, :333-335
+      w = (j >= 0 && src < 64) ? fmaxf(1.0f - d * inv_ext, 0.0f) : 0.0f;
+      if (MODE == 0) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) xv[t] = X[off + chan[t]];
+      } else if (MODE == 1 && T == 2) {
+        const float2 v = *reinterpret_cast<const float2*>(X + off + chan[0]);
+        xv[0] = v.x;
+        xv[1] = v.y;
+      } else if (MODE == 1) {
+#pragma unroll
+        for (int u = 0; u < T / 4; ++u) {
+          const float4 v = *reinterpret_cast<const float4*>(X + off + chan[0] + 4 * u);
+          xv[4 * u] = v.x;
+          xv[4 * u + 1] = v.y;
+          xv[4 * u + 2] = v.z;
+          xv[4 * u + 3] = v.w;
+        }
+      } else {
+        const float2 v0 = *reinterpret_cast<const float2*>(X + off + chan[0]);
+        const float2 v1 = *reinterpret_cast<const float2*>(X + off + chan[0] + 2);
+        xv[0] = v0.x;
+        xv[1] = v0.y;
+        xv[2] = v1.x;
+        xv[3] = v1.y;
+        xv[T - 1] = X[off + tailc];
+      }
+    };
+    float wa, wb;
+    float xa[T], xb[T];
+    fetch(0, wa, xa);
+    for (int g = 0; g < groups; g += 2) {
+      fetch(g + 1, wb, xb);
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xa[t], acc[t], 0, 0, 0);
+      fetch(g + 2, wa, xa);
+#pragma unroll
+      for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb, xb[t], acc[t], 0, 0, 0);
+    }
+  }
+  // D[i][j]: lane (j = m, i = 4 kq + r) holds kernel point 4 kq + r in register r of tile t, i.e. of the channel the lane
+  // fed to tile t
+  float* __restrict__ out = P.A + (int64_t)n * P.K * P.Cin;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int kpt = 4 * kq + r;
+    if (kpt >= P.K) continue;
+    float* __restrict__ o = out + (int64_t)kpt * P.Cin;
+    if (MODE == 0) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+        if (c0 + 16 * t + m < P.Cin) o[c0 + 16 * t + m] = acc[t][r];
+    } else if (MODE == 1 && T == 2) {
+      *reinterpret_cast<float2*>(o + c0 + 2 * m) = make_float2(acc[0][r], acc[1][r]);
+    } else if (MODE == 1) {
+#pragma unroll
+      for (int u = 0; u < T / 4; ++u)
+        *reinterpret_cast<float4*>(o + c0 + T * m + 4 * u) =
+            make_float4(acc[4 * u][r], acc[4 * u + 1][r], acc[4 * u + 2][r], acc[4 * u + 3][r]);
+    } else {
+      *reinterpret_cast<float2*>(o + 4 * m) = make_float2(acc[0][r], acc[1][r]);
+      *reinterpret_cast<float2*>(o + 4 * m + 2) = make_float2(acc[2][r], acc[3][r]);
+      if (64 + m < P.Cin) o[64 + m] = acc[T - 1][r];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // Vector gather kernel (rigid KPConv, any Cin <= 4*64*NCH).
 //   LPP lanes own one query point (4 channels per lane and channel chunk), PPW = 64/LPP points per
 //   wave, neighbours in chunks of HC = 64/PPW per point. LPP/PPW/HC are launch parameters so that
@@ -973,6 +1131,41 @@ int launch_vec(KPParams P, int idx64, hipStream_t st) {
   return 0;
 }
 
+// channel tiles per wave of the MFMA gather for rows of Cin channels (0: the layer stays on the vector kernels)
+int mfma_tiles(int64_t Ns, int Cin, int K, int influence, int aggregation) {
+  static const bool on = getenv("MVK_GATHER_MFMA") == nullptr || atoi(getenv("MVK_GATHER_MFMA")) != 0;
+  if (!on || influence != MVK_INFL_LINEAR || aggregation != MVK_AGG_SUM || K > 16 || Cin < 5) return 0;
+  if ((uint64_t)Ns * (uint64_t)Cin >= (1ull << 32) - 4096) return 0;
+  if (Cin <= 32) return 2;
+  if (Cin <= 64) return 4;
+  if (Cin <= 80) return 5;            // 66: the early-fusion net's first layer
+  if (Cin <= 128) return 8;
+  return 16;                          // wider rows: gridDim.y blocks of 256 channels
+}
+
+bool launch_mfma(KPParams P, int idx64, hipStream_t st) {
+  const int T = mfma_tiles(P.Ns, P.Cin, P.K, P.influence, P.aggregation);
+  if (T == 0) return false;
+  static const bool xcd_runs = getenv("MVK_GATHER_XCD_RUNS") == nullptr || atoi(getenv("MVK_GATHER_XCD_RUNS")) != 0;
+  const int64_t wgs = cdiv64(P.Nq, 4);
+  P.xcd_blocks = (P.order != nullptr && xcd_runs) ? (int)wgs : 0;
+  dim3 grid((unsigned)wgs, (unsigned)cdiv64(P.Cin, 16 * T)), block(256);
+#define LM(TT, MD)                                                                               \
+  if (idx64) hipLaunchKernelGGL((kpconv_gather_mfma<TT, MD, true>), grid, block, 0, st, P);          \
+  else hipLaunchKernelGGL((kpconv_gather_mfma<TT, MD, false>), grid, block, 0, st, P)
+  // wide loads where the row length allows them (kernel comment): rows of a multiple of 16 T channels from a 16-byte
+  // aligned table; the 64 + tail layout for even rows of 66 .. 80 channels; one dword per tile otherwise
+  const bool wide = P.Cin % (16 * T) == 0 && ((uintptr_t)P.x & 15) == 0 && ((uintptr_t)P.A & 15) == 0;
+  const bool tail5 = T == 5 && P.Cin > 64 && P.Cin % 2 == 0 && ((uintptr_t)P.x & 7) == 0 && ((uintptr_t)P.A & 7) == 0;
+  if (T == 2) { if (wide) { LM(2, 1); } else { LM(2, 0); } }
+  else if (T == 4) { if (wide) { LM(4, 1); } else { LM(4, 0); } }
+  else if (T == 5) { if (tail5) { LM(5, 2); } else { LM(5, 0); } }
+  else if (T == 8) { if (wide) { LM(8, 1); } else { LM(8, 0); } }
+  else { if (wide) { LM(16, 1); } else { LM(16, 0); } }
+#undef LM
+  return true;
+}
+
 template <int MODE, bool DEFORM>
 int launch_lane_channel(const KPParams& P, int idx64, hipStream_t st) {
   // scatter of a layer with more than one 64-neighbour chunk (searched at the deform radius): four waves per point
@@ -1081,6 +1274,8 @@ extern "C" int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const f
       if (fast) hipLaunchKernelGGL((kpconv_gather_small<false, true>), grid, block, 0, st, P);
       else hipLaunchKernelGGL((kpconv_gather_small<false, false>), grid, block, 0, st, P);
     }
+  } else if (launch_mfma(P, idx64, st)) {
+    // (the aggregation on the matrix pipe: linear influence, sum aggregation, 5 <= Cin, feature table < 2^32 elements)
   } else if (Cin <= 256) {
     launch_vec<1>(P, idx64, st);
   } else if (Cin <= 512) {
@@ -1129,7 +1324,15 @@ extern "C" int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s
 extern "C" int mvk_kpconv_gather_plan(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, int deformable,
                                       int64_t* out) {
   MVK_REQUIRE(out != nullptr && (elem_bytes == 2 || elem_bytes == 4), "kpconv plan: bad arguments");
-  for (int i = 0; i < 7; ++i) out[i] = 0;
+  for (int i = 0; i < 8; ++i) out[i] = 0;
+  if (!deformable && elem_bytes == 4) {
+    const int T = mfma_tiles(Ns, Cin, 15, MVK_INFL_LINEAR, MVK_AGG_SUM);
+    if (Nq > 0 && T > 0) {        // the MFMA gather: one wave per point, four per workgroup, channel blocks in gridDim.y
+      out[0] = 64; out[1] = 1; out[2] = T; out[3] = 0; out[4] = 4; out[5] = cdiv64(Nq, 4) * cdiv64(Cin, 16 * T);
+      out[6] = out[5] * 256; out[7] = 1;
+      return 0;
+    }
+  }
   if (Nq <= 0 || Cin <= 0 || Cin > 512 || (deformable && Cin < 13) || (!deformable && elem_bytes == 4 && Cin <= 4)) return 0;
   const VecPlan v = plan_vec(Nq, Ns, H, Cin, elem_bytes, true, elem_bytes == 4 || (Cin & 1) == 0, deformable != 0);
   out[0] = v.LPP; out[1] = v.PPW; out[2] = v.fub; out[3] = v.B1; out[4] = v.nw; out[5] = v.wgs;

@@ -186,10 +186,10 @@ def kpconv_gather_plan(Nq, Ns, H, Cin, elem_bytes=4, deformable=False):
     """Launch geometry of the gather kernel for a (linear, sum) layer (mvk_kpconv_gather_plan): dict with the
     lanes per point, points per wave, rows per batch, first sharing workgroup, waves per workgroup, workgroups and
     grid threads; 'workgroups' 0 means the layer runs on the one-point-per-wave kernel."""
-    out = (C.c_int64 * 7)()
+    out = (C.c_int64 * 8)()
     check(lib().mvk_kpconv_gather_plan(int(Nq), int(Ns), int(H), int(Cin), int(elem_bytes), int(bool(deformable)), out))
     keys = ("lanes_per_point", "points_per_wave", "rows_per_batch", "first_sharing_workgroup", "waves_per_workgroup",
-            "workgroups", "grid_threads")
+            "workgroups", "grid_threads", "mfma")
     return dict(zip(keys, [int(v) for v in out]))
 
 
@@ -478,6 +478,8 @@ def _gather_kernel_label(Nq, Ns, H, Cin, deform, elem_bytes=4):
     p = kpconv_gather_plan(Nq, Ns, H, Cin, elem_bytes, deform)
     if p["workgroups"] == 0:
         return _gather_kernel_name(Cin, deform)
+    if p.get("mfma"):
+        return "kpconv_gather_mfma<T=%d>(1 point per wave)" % p["rows_per_batch"]
     tail = Cin - 4 * p["lanes_per_point"] if 4 * p["lanes_per_point"] < Cin else 0
     return "kpconv_gather_vec<NCH=%d%s>(LPP=%d,PPW=%d%s)" % (1 if Cin <= 256 else 2, ",deform" if deform else "",
                                                              p["lanes_per_point"], p["points_per_wave"],

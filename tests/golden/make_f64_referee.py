@@ -10,6 +10,7 @@ on the SAME inputs and weights -- taken from the committed fixtures, nothing of 
     g5/..., g5b_deform/..., g5b_deform_mod/...   logits, loss, every gradient the float32 fixture holds (float64)
     g12/<variant>/...                            logits, loss, per parameter: float64 gradient norm + the float64 values
                                                  at the fixture's 64 digest indices
+    g13_early_19k/..., g13_late_deform_mod_55k/... the same digest (256 elements) at BASELINE's own sizes
 
 The GPU tests then assert, per parameter, err(HIP, float64) <= 2 x err(reference float32, float64) (+ a floor of one
 float32 rounding of the tensor's scale) and log both columns.   Usage:  python tests/golden/make_f64_referee.py
@@ -24,6 +25,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, HERE)
 
 from conftest import load_golden  # noqa: E402
 from oracle import torch_port  # noqa: E402
@@ -86,6 +88,37 @@ def main():
                 worst = max(worst, abs(ref_norm / np.linalg.norm(got) - 1.0))
         print("g12", variant, "float64 loss", loss, "| fixture", float(g[variant + "/loss"]),
               "| worst fixture-vs-f64 |norm ratio - 1|", worst)
+    # G13: BASELINE's own sizes. The fixture is ONE float32 run of the CPU port; here the same port in float64 on the same
+    # batch (rebuilt by make_golden.g13_case_inputs with the fixture's limits and rotations) and weights.
+    import importlib
+    import time
+    import util
+    import make_golden
+    cases = [("g13_early_19k", "early", False, 1.2)]
+    if os.environ.get("MVK_REFEREE_55K", "1") == "1":
+        cases.append(("g13_late_deform_mod_55k", "late", True, 1.7))
+    for name, variant, deformable, radius in cases:
+        t0 = time.time()
+        g = load_golden(name)
+        cfg, b, limits, rots = make_golden.g13_case_inputs(variant, deformable, deformable, radius,
+                                                           limits=[int(v) for v in g["limits"]], rotations=list(g["rotations"]))
+        shapes = {str(n): tuple(int(v) for v in str(sh).split(",") if v) for n, sh in zip(g["param_names"], g["param_shapes"])}
+        kp = {k[3:]: g[k] for k in g if k.startswith("kp/")}
+        sd = util.g13_state(shapes, variant, deformable, kp)
+        sdt = {k: torch.from_numpy(v) for k, v in sd.items()}
+        names = [k for k, v in sdt.items() if v.dtype == torch.float32 and not k.endswith(("running_mean", "running_var", "kernel_points"))]
+        logits, ce, loss, grads = run64(sdt, cfg, b, names)
+        arrs[name + "/loss"] = np.float64(loss)
+        arrs[name + "/logits"] = logits[g["logit_rows"]]
+        worst = 0.0
+        for n in sorted(k[6:] for k in g if k.startswith("gnorm/")):
+            got = grads[n].reshape(-1)
+            arrs["%s/gnorm/%s" % (name, n)] = np.float64(np.linalg.norm(got))
+            arrs["%s/gval/%s" % (name, n)] = got[g["gidx/" + n]].astype(np.float64)
+            if np.linalg.norm(got) > 0:
+                worst = max(worst, abs(float(g["gnorm/" + n]) / np.linalg.norm(got) - 1.0))
+        print(name, "float64 loss", loss, "| fixture", float(g["loss"]), "| worst fixture-vs-f64 |norm ratio - 1|", worst,
+              "| %.0f s" % (time.time() - t0), flush=True)
     path = os.path.join(HERE, "g14_f64_referee.npz")
     np.savez_compressed(path, **arrs)
     print("wrote", path, os.path.getsize(path), "bytes,", len(arrs), "arrays")

@@ -342,6 +342,10 @@ def test_kpconv_gather_launches_with_sharing_workgroups_vs_numpy_oracle(ops, Nq,
     against the float64 numpy restatement."""
     from oracle import npref
     plan = ops.kpconv_gather_plan(Nq, 3000, H, cin, elem_bytes=2 if f16 else 4)
+    if plan["mfma"]:
+        # round 5: rigid f32 layers run on the MFMA gather (one wave per point, no sharing workgroups) -- the same rows
+        # are checked all the same (shadow entries in the middle of rows, ragged last workgroup)
+        plan = dict(plan, first_sharing_workgroup=Nq // 8, points_per_wave=1)
     assert 0 < plan["first_sharing_workgroup"] < plan["workgroups"], plan       # the case this test is about
     rng = np.random.default_rng(Nq + cin)
     Ns, K = 3000, 15
@@ -1153,6 +1157,37 @@ def test_kpconv_gather_form_feature_gradient_default_mode_arrival_order(ops, Nq,
         dx, dW = npref.kpconv_backward(*a64, g.astype(np.float64))
         check_err("default-mode gather-form dx vs float64 oracle (Nq %d, C %d)" % (Nq, C), rel_err(res[1][0].cpu().numpy(), dx), FP_TOL)
         check_err("default-mode dW vs float64 oracle (Nq %d, C %d)" % (Nq, C), rel_err(res[1][1].cpu().numpy(), dW), FP_TOL)
+
+
+@pytest.mark.parametrize("b,n1,n2,transpose", [(2, 512, 1024, True), (3, 513, 1025, True), (3, 513, 1025, False), (3, 31, 63, True)])
+def test_knn_replays_the_reference_knn_distance_test(ops, b, n1, n2, transpose):
+    """mvpnet/ops/tests/test_knn_distance.py:37-54 replayed through the product's exact 3-NN (mvk_knn_f64): the reference
+    test's shapes, layouts and seed (np.random.seed(0), randn queries / keys, k = 3), its expectation restated as in the
+    test itself -- the full float32 distance matrix, torch.topk(largest=False, sorted=True) -- exact indices, distances
+    to 1e-6. (The product searches in float64, the reference's CUDA op in float32: on these inputs no two candidates
+    lie within float32 rounding of each other at the 3rd / 4th place, which the float64 brute force below confirms.)"""
+    np.random.seed(0)
+    k = 3
+    if transpose:
+        query_np = np.random.randn(b, 3, n1).astype(np.float32)
+        key_np = np.random.randn(b, 3, n2).astype(np.float32)
+        qs, ks = np.transpose(query_np, (0, 2, 1)), np.transpose(key_np, (0, 2, 1))
+    else:
+        query_np = np.random.randn(b, n1, 3).astype(np.float32)
+        key_np = np.random.randn(b, n2, 3).astype(np.float32)
+        qs, ks = query_np, key_np
+    for i in range(b):
+        q, kk = torch.from_numpy(np.ascontiguousarray(qs[i])).cuda(), torch.from_numpy(np.ascontiguousarray(ks[i])).cuda()
+        # the reference test's expectation (bpdist2 + topk, float32)
+        dist = ((q.unsqueeze(1) - kk.unsqueeze(0)) ** 2).sum(2)
+        d_want, i_want = torch.topk(dist, k, dim=1, largest=False, sorted=True)
+        got = ops.knn_pixels(q, kk.double().view(1, n2, 1, 3), torch.ones((1, n2, 1), dtype=torch.bool, device="cuda"), k=k)
+        d64 = ((qs[i].astype(np.float64)[:, None, :] - ks[i].astype(np.float64)[None, :, :]) ** 2).sum(2)
+        exact = np.argsort(d64, axis=1, kind="stable")[:, :k]
+        assert np.array_equal(got.cpu().numpy(), exact)
+        np.testing.assert_equal(got.cpu().numpy(), i_want.cpu().numpy())
+        d_got = torch.gather(dist, 1, got)
+        np.testing.assert_allclose(d_got.cpu().numpy(), d_want.cpu().numpy(), atol=1e-6)
 
 
 def test_deferred_weight_gradients_run_as_one_grouped_launch(ops):

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 TAG=$1; shift
 rm -rf $R/gpurun_out/prof_$TAG
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --dev --steps 20 --warmup 3 --no-cpu-baseline "$@" > $R/gpurun_out/prof_$TAG.json 2> $R/gpurun_out/prof_$TAG.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG -- python3 $R/bench.py --dev --no-eager-line --steps 20 --warmup 3 --no-cpu-baseline "$@" > $R/gpurun_out/prof_$TAG.json 2> $R/gpurun_out/prof_$TAG.err
 F=$(ls $R/gpurun_out/prof_$TAG/*/*_kernel_trace.csv | head -1)
 python3 $R/tools/trace_chain.py $F > $R/gpurun_out/chain_$TAG.txt
 python3 $R/tools/trace_chain.py $F all > $R/gpurun_out/chain_all_$TAG.txt

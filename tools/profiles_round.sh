@@ -24,7 +24,7 @@ rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAV
 python3 $R/tools/pmc_mfma.py $(ls $O/pm/*/*_counter_collection.csv | head -1) $O/${TAG}_pmc_mfma.json > $O/pmc_mfma.log 2>&1
 rm -rf $O/pm
 # 4. the network branch alone, kernel by kernel in launch order
-MVK_BENCH_DIAG=noside rocprofv3 --kernel-trace --output-format csv -d $O/kn -- python3 $R/bench.py --dev --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/kn.err
+MVK_BENCH_DIAG=noside rocprofv3 --kernel-trace --output-format csv -d $O/kn -- python3 $R/bench.py --dev --no-eager-line --steps 20 --warmup 3 --no-cpu-baseline > /dev/null 2> $O/kn.err
 python3 $R/tools/trace_chain.py $(ls $O/kn/*/*_kernel_trace.csv | head -1) > $O/${TAG}_chain_noside.txt 2>&1
 rm -rf $O/kn
 # 5. operator benches (device time of graph-captured launches) and workload lines

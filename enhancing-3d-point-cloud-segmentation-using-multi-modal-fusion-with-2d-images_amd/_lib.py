@@ -89,6 +89,7 @@ _SIGNATURES = {
     "mvk_gemm_f32_tn_grouped_plan": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvk_gemm_f32_tn_grouped": (C.c_int, [_vp, _i, _i, _i64, _i64, _vp]),
     "mvk_gemm_f16": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i64, _i64, _i64, _i, _i, _i, _vp]),
+    "mvk_kpconv_gather_rev_deform": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "mvk_kpconv_deform_doff": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp,
                                         _vp, _vp]),
     "mvk_deform_regularizer": (C.c_int, [_vp, _vp, _vp, _i64, _i, _f, _f, _f, _vp, _vp, _vp, _vp]),

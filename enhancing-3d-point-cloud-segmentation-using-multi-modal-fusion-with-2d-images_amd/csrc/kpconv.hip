@@ -44,6 +44,11 @@ struct KPParams {
   const int32_t* order;  // vector gather (rigid): work list -- the wave working on slots w .. w+PPW-1 takes the points order[w ..] (a
                          // spatially sorted permutation of 0 .. Nq-1); results land in the points' own rows. null: slot = point
   int xcd_blocks;        // with `order`: the first xcd_blocks workgroups are dealt to the 8 XCDs as 8 contiguous runs of the work list
+  // MFMA gather, KPM = 2 (gather-form feature gradient of a deformable layer): the kernel points belong to the NEIGHBOUR
+  // rows -- nb_offsets [rows of s, K, 3] are added to kp (and the sum is used negated: the relation is transposed) -- and
+  // every weight is multiplied by nb_mod [rows of s, K] (modulated layers; null: 1)
+  const float* nb_offsets;
+  const float* nb_mod;
 };
 
 __device__ __forceinline__ float influence_w(float d2, float extent, int influence) {
@@ -175,10 +180,30 @@ typedef float mfma_f32x4 __attribute__((ext_vector_type(4)));
 //   2  even rows of 66 .. 80 channels (the early-fusion net's first layer: 64 + 2): channels 4 m .. 4 m + 3 as two
 //      8-byte loads (rows are 8-byte aligned) for tiles 0-3, tile 4 = channel 64 + m by a dword load;
 //   0  any other row length: tile t = channel c0 + 16 t + m, one dword load per tile.
-template <int T, int MODE, bool IDX64>
+// KPM: whose kernel points a weight is measured from.
+//   0  rigid layer: kernel point m of the layer (P.kp);
+//   1  deformable layer, forward (blocks.py:286-327): kernel point m of THIS query point, kp[m] + offsets[n, m] -- one
+//      per-lane load per point --, and the layer's second output, min over ALL columns (shadow entries at 1e6 included,
+//      blocks.py:303) of the squared distance to each deformed kernel point with the first arg-min column: lane (m, kq)
+//      sees columns 4 g + kq in ascending order, the four kq lanes of a kernel point meet at the end. The in-range
+//      filter of blocks.py:306-325 needs no code: with the linear influence a neighbour out of range of every kernel
+//      point has weight 0 for all of them;
+//   2  deformable layer, gather-form feature gradient (the transposed relation: `s` holds the layer's QUERY rows): kernel
+//      point m of the NEIGHBOUR row, -(kp[m] + nb_offsets[j, m]), times the modulation nb_mod[j, m] -- two more gathered
+//      loads per group, issued with the feature loads.
+//
+// SW = 4 (launches of few points with long rows: the coarse levels, and every deformable layer -- hundreds of points with
+// hundreds of columns at the deform radius): the four waves of a workgroup SHARE one point, wave w takes the group pairs
+// w, w + 4, ...; waves 1-3 hand their accumulators (and running minima) to wave 0 through LDS, which adds them in wave
+// order (a fixed order) and stores. One wave per point would be a serial chain of H / 4 groups on a fraction of the SIMDs.
+template <int T, int MODE, bool IDX64, int KPM = 0, bool SHARE = false>
 __global__ __launch_bounds__(256) void kpconv_gather_mfma(KPParams P) {
   static_assert(MODE != 2 || T == 5, "mode 2 is the 64 + tail layout");
   static_assert(MODE != 1 || T == 2 || T % 4 == 0, "mode 1: 8- or 16-byte vectors");
+  constexpr int SW = SHARE ? 4 : 1;        // (a template parameter: the one-wave-per-point instantiations keep their registers)
+  __shared__ float red_acc[SHARE ? 3 : 1][SHARE ? T * 4 : 1][SHARE ? 64 : 1];
+  __shared__ float red_min[SHARE ? 3 : 1][SHARE ? 64 : 1];
+  __shared__ int red_arg[SHARE ? 3 : 1][SHARE ? 64 : 1];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int m = lane & 15, kq = lane >> 4;
   int64_t blk = blockIdx.x;
@@ -186,18 +211,26 @@ __global__ __launch_bounds__(256) void kpconv_gather_mfma(KPParams P) {
     const int xq = P.xcd_blocks >> 3, xr = P.xcd_blocks & 7, xc = blockIdx.x & 7;
     blk = (int64_t)xc * xq + min(xc, xr) + (blockIdx.x >> 3);
   }
-  const int64_t slot = blk * 4 + wid;
-  if (slot >= P.Nq) return;                  // (no barrier anywhere: the waves of a workgroup never meet)
+  const int64_t slot = SW > 1 ? blk : blk * 4 + wid;
+  if (slot >= P.Nq) return;                  // (SW 1: the waves of a workgroup never meet; SW 4: the whole workgroup leaves)
+  const int gfirst = SW > 1 ? 2 * wid : 0, gstep = 2 * SW;      // this wave's group pairs
   const int n = __builtin_amdgcn_readfirstlane(P.order ? P.order[slot] : (int)slot);
   const int c0 = blockIdx.y * (16 * T);      // first channel of this wave's block
   const float* __restrict__ X = P.x;
   const float qx = P.q[(int64_t)n * 3], qy = P.q[(int64_t)n * 3 + 1], qz = P.q[(int64_t)n * 3 + 2];
   // this lane's kernel point (rows 15.. of the 16-row tile: a point no neighbour is near -> weight 0)
+  const int mk = m < P.K ? m : P.K - 1;
   float kx = 1e9f, ky = 1e9f, kz = 1e9f;
   if (m < P.K) {
     kx = P.kp[m * 3];
     ky = P.kp[m * 3 + 1];
     kz = P.kp[m * 3 + 2];
+    if (KPM == 1) {
+      const float* o = P.offsets + ((int64_t)n * P.K + m) * 3;
+      kx += o[0];
+      ky += o[1];
+      kz += o[2];
+    }
   }
   const float inv_ext = 1.0f / P.extent;
   // MODE 0: channel of tile t in this lane, clamped into the row: a lane beyond the row's end loads the last channel again
@@ -213,10 +246,13 @@ __global__ __launch_bounds__(256) void kpconv_gather_mfma(KPParams P) {
   mfma_f32x4 acc[T];
 #pragma unroll
   for (int t = 0; t < T; ++t) acc[t] = (mfma_f32x4){0.f, 0.f, 0.f, 0.f};
+  float run_min = INFINITY;                  // KPM 1: min over this lane's columns of d2 to kernel point m, first arg-min
+  int run_arg = 0x7fffffff;
 
   for (int h0 = 0; h0 < P.H; h0 += 64) {
-    // column h0 + lane of the row: neighbour index, its position relative to the query, the offset of its feature row
-    int jl = -1;
+    // column h0 + lane of the row: neighbour index (-1: shadow entry, -2: beyond the row), its position relative to the
+    // query, the offset of its feature row
+    int jl = -2;
     if (h0 + lane < P.H) jl = load_idx<IDX64>(P.idx, (int64_t)n * P.H + h0 + lane, P.Ns);
     float rx = 0.f, ry = 0.f, rz = 0.f;
     if (jl >= 0) {
@@ -224,10 +260,16 @@ __global__ __launch_bounds__(256) void kpconv_gather_mfma(KPParams P) {
       rx = sp[0] - qx;
       ry = sp[1] - qy;
       rz = sp[2] - qz;
+    } else if (KPM == 1) {                  // shadow support point (1e6, 1e6, 1e6), blocks.py:277: it takes part in min_d2
+      rx = 1e6f - qx;
+      ry = 1e6f - qy;
+      rz = 1e6f - qz;
     }
     const unsigned long long live = __ballot(jl >= 0);
-    if (live == 0ull) continue;
-    const int groups = (64 - __builtin_clzll(live) + 3) >> 2;        // up to the last real entry of the chunk (wave-uniform)
+    if (KPM != 1 && live == 0ull) continue;
+    // KPM 1 walks every column of the row (the shadow entries count for min_d2), the others stop at the last real entry
+    const int ncol = min(64, P.H - h0);
+    const int groups = KPM == 1 ? (ncol + 3) >> 2 : (64 - __builtin_clzll(live) + 3) >> 2;        // wave-uniform
     const uint32_t roff = (uint32_t)(jl >= 0 ? jl : 0) * (uint32_t)P.Cin;      // (host: Ns * Cin < 2^32)
     // Group g: lane (m, kq) works on column 4 g + kq. Two register sets, the loop unrolled by two: the cross-lane reads
     // and the feature loads of the NEXT group are issued before the MFMAs of the current one, nothing in the body is
@@ -236,10 +278,29 @@ __global__ __launch_bounds__(256) void kpconv_gather_mfma(KPParams P) {
     auto fetch = [&](const int g, float& w, float (&xv)[T]) {
       const int src = 4 * g + kq;
       const int j = __shfl(jl, src);
-      const float gx = __shfl(rx, src) - kx, gy = __shfl(ry, src) - ky, gz = __shfl(rz, src) - kz;
+      float gx = __shfl(rx, src), gy = __shfl(ry, src), gz = __shfl(rz, src);
       const uint32_t off = (uint32_t)__shfl((int)roff, src);
-      const float d = __builtin_amdgcn_sqrtf(gx * gx + gy * gy + gz * gz);          // blocks.py:294-297, :333-335
-      w = (j >= 0 && src < 64) ? fmaxf(1.0f - d * inv_ext, 0.0f) : 0.0f;
+      float wmod = 1.0f;
+      if (KPM == 2) {
+        // the neighbour row's own kernel point m (clamped indices: the loads are unconditional), used negated
+        const int jr = j >= 0 ? j : 0;
+        const float* o = P.nb_offsets + ((int64_t)jr * P.K + mk) * 3;
+        gx += kx + o[0];
+        gy += ky + o[1];
+        gz += kz + o[2];
+        if (P.nb_mod) wmod = P.nb_mod[(int64_t)jr * P.K + mk];
+      } else {
+        gx -= kx;
+        gy -= ky;
+        gz -= kz;
+      }
+      const float d2 = gx * gx + gy * gy + gz * gz;                                  // blocks.py:294-297
+      const float d = __builtin_amdgcn_sqrtf(d2);                                    // :333-335
+      w = (j >= 0 && src < 64) ? fmaxf(1.0f - d * inv_ext, 0.0f) * wmod : 0.0f;
+      if (KPM == 1 && j >= -1 && src < 64 && m < P.K && d2 < run_min) {             // ascending columns: strict <
+        run_min = d2;
+        run_arg = h0 + src;
+      }
       if (MODE == 0) {
 #pragma unroll
         for (int t = 0; t < T; ++t) xv[t] = X[off + chan[t]];
@@ -268,14 +329,62 @@ __global__ __launch_bounds__(256) void kpconv_gather_mfma(KPParams P) {
     };
     float wa, wb;
     float xa[T], xb[T];
-    fetch(0, wa, xa);
-    for (int g = 0; g < groups; g += 2) {
-      fetch(g + 1, wb, xb);
+    // (KPM 1: a group is fetched exactly once -- fetch also updates the running minimum -- so the look-ahead stops at
+    // the last group; the other modes may fetch one group past the end, whose weights are zero)
+    if (gfirst >= groups) continue;
+    fetch(gfirst, wa, xa);
+    for (int g = gfirst; g < groups; g += gstep) {
+      if (KPM != 1 || g + 1 < groups) fetch(g + 1, wb, xb);
+      else wb = 0.0f;
 #pragma unroll
       for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa, xa[t], acc[t], 0, 0, 0);
-      fetch(g + 2, wa, xa);
+      if (KPM != 1 || g + gstep < groups) fetch(g + gstep, wa, xa);
+      if (KPM != 1 || g + 1 < groups) {
 #pragma unroll
-      for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb, xb[t], acc[t], 0, 0, 0);
+        for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wb, xb[t], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  if (SHARE) {
+    // waves 1 .. 3 park their partial results, wave 0 adds them in wave order
+    if (wid > 0) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red_acc[wid - 1][t * 4 + r][lane] = acc[t][r];
+      red_min[wid - 1][lane] = run_min;
+      red_arg[wid - 1][lane] = run_arg;
+    }
+    __syncthreads();
+    if (wid > 0) return;
+    for (int w = 0; w < SW - 1; ++w) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[t][r] += red_acc[w][t * 4 + r][lane];
+      const float od = red_min[w][lane];
+      const int oa = red_arg[w][lane];
+      if (od < run_min || (od == run_min && oa < run_arg)) {
+        run_min = od;
+        run_arg = oa;
+      }
+    }
+  }
+  if (KPM == 1 && P.min_d2 != nullptr && blockIdx.y == 0) {
+    // the four column residues of kernel point m: smaller distance wins, equal distances the smaller column (the FIRST
+    // arg-min over all columns, like the sequential scan of the vector kernel)
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1) {
+      const float od = __shfl_xor(run_min, o);
+      const int oa = __shfl_xor(run_arg, o);
+      if (od < run_min || (od == run_min && oa < run_arg)) {
+        run_min = od;
+        run_arg = oa;
+      }
+    }
+    if (kq == 0 && m < P.K) {
+      P.min_d2[(int64_t)n * P.K + m] = run_min;
+      if (P.min_arg) P.min_arg[(int64_t)n * P.K + m] = run_arg;
     }
   }
   // D[i][j]: lane (j = m, i = 4 kq + r) holds kernel point 4 kq + r in register r of tile t, i.e. of the channel the lane
@@ -1143,25 +1252,34 @@ int mfma_tiles(int64_t Ns, int Cin, int K, int influence, int aggregation) {
   return 16;                          // wider rows: gridDim.y blocks of 256 channels
 }
 
+template <int KPM>
 bool launch_mfma(KPParams P, int idx64, hipStream_t st) {
   const int T = mfma_tiles(P.Ns, P.Cin, P.K, P.influence, P.aggregation);
   if (T == 0) return false;
   static const bool xcd_runs = getenv("MVK_GATHER_XCD_RUNS") == nullptr || atoi(getenv("MVK_GATHER_XCD_RUNS")) != 0;
-  const int64_t wgs = cdiv64(P.Nq, 4);
+  // few points with long rows: the four waves of a workgroup share one point (kernel comment)
+  static const int sw_env = getenv("MVK_GATHER_MFMA_SHARE") ? atoi(getenv("MVK_GATHER_MFMA_SHARE")) : -1;
+  const int64_t blocks_y = cdiv64(P.Cin, 16 * T);
+  const bool can_share = T >= 4 && T != 5;          // (instantiated for the tile counts the coarse levels use)
+  const int SW = !can_share ? 1 : (sw_env >= 0 ? (sw_env > 1 ? 4 : 1) : ((P.H >= 128 || (P.Nq * blocks_y <= 512 && P.H >= 32)) ? 4 : 1));
+  const int64_t wgs = SW > 1 ? P.Nq : cdiv64(P.Nq, 4);
   P.xcd_blocks = (P.order != nullptr && xcd_runs) ? (int)wgs : 0;
-  dim3 grid((unsigned)wgs, (unsigned)cdiv64(P.Cin, 16 * T)), block(256);
-#define LM(TT, MD)                                                                               \
-  if (idx64) hipLaunchKernelGGL((kpconv_gather_mfma<TT, MD, true>), grid, block, 0, st, P);          \
-  else hipLaunchKernelGGL((kpconv_gather_mfma<TT, MD, false>), grid, block, 0, st, P)
+  dim3 grid((unsigned)wgs, (unsigned)blocks_y), block(256);
+#define LM1(TT, MD, SH)                                                                              \
+  if (idx64) hipLaunchKernelGGL((kpconv_gather_mfma<TT, MD, true, KPM, SH>), grid, block, 0, st, P);     \
+  else hipLaunchKernelGGL((kpconv_gather_mfma<TT, MD, false, KPM, SH>), grid, block, 0, st, P)
+#define LM(TT, MD)                                          \
+  if (SW > 1 && TT >= 4 && TT != 5) { LM1(TT, MD, (TT >= 4 && TT != 5)); } else { LM1(TT, MD, false); }
   // wide loads where the row length allows them (kernel comment): rows of a multiple of 16 T channels from a 16-byte
   // aligned table; the 64 + tail layout for even rows of 66 .. 80 channels; one dword per tile otherwise
   const bool wide = P.Cin % (16 * T) == 0 && ((uintptr_t)P.x & 15) == 0 && ((uintptr_t)P.A & 15) == 0;
   const bool tail5 = T == 5 && P.Cin > 64 && P.Cin % 2 == 0 && ((uintptr_t)P.x & 7) == 0 && ((uintptr_t)P.A & 7) == 0;
   if (T == 2) { if (wide) { LM(2, 1); } else { LM(2, 0); } }
   else if (T == 4) { if (wide) { LM(4, 1); } else { LM(4, 0); } }
-  else if (T == 5) { if (tail5) { LM(5, 2); } else { LM(5, 0); } }
+  else if (T == 5) { if (tail5 && KPM == 0) { LM(5, 2); } else { LM(5, 0); } }
   else if (T == 8) { if (wide) { LM(8, 1); } else { LM(8, 0); } }
   else { if (wide) { LM(16, 1); } else { LM(16, 0); } }
+#undef LM1
 #undef LM
   return true;
 }
@@ -1257,7 +1375,12 @@ extern "C" int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const f
   }
   if (offsets != nullptr) {
     static const bool vec_deform = getenv("MVK_DEFORM_VEC") == nullptr || atoi(getenv("MVK_DEFORM_VEC")) != 0;
-    if (vec_deform && Cin >= 13 && Cin <= 256) {          // 64 / ceil(Cin/4) <= DPPW points per wave
+    static const bool mfma_deform = getenv("MVK_DEFORM_MFMA") == nullptr || atoi(getenv("MVK_DEFORM_MFMA")) != 0;
+    KPParams Pm = P;
+    Pm.order = nullptr;           // (the deformable levels are the coarse ones: no work list)
+    if (mfma_deform && launch_mfma<1>(Pm, idx64, st)) {
+      // (round 5: the deformable forward on the matrix pipe as well, KPM 1 of kpconv_gather_mfma)
+    } else if (vec_deform && Cin >= 13 && Cin <= 256) {          // 64 / ceil(Cin/4) <= DPPW points per wave
       launch_vec<1, float, true, true>(P, idx64, st);
     } else if (vec_deform && Cin > 256 && Cin <= 512) {
       launch_vec<2, float, true, true>(P, idx64, st);
@@ -1274,7 +1397,7 @@ extern "C" int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const f
       if (fast) hipLaunchKernelGGL((kpconv_gather_small<false, true>), grid, block, 0, st, P);
       else hipLaunchKernelGGL((kpconv_gather_small<false, false>), grid, block, 0, st, P);
     }
-  } else if (launch_mfma(P, idx64, st)) {
+  } else if (launch_mfma<0>(P, idx64, st)) {
     // (the aggregation on the matrix pipe: linear influence, sum aggregation, 5 <= Cin, feature table < 2^32 elements)
   } else if (Cin <= 256) {
     launch_vec<1>(P, idx64, st);
@@ -1283,6 +1406,37 @@ extern "C" int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const f
   } else {
     launch_lane_channel<0, false>(P, idx64, st);
   }
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
+
+// Gather-form feature gradient of a DEFORMABLE KPConv (round 5; blocks.py:286-327, :360 through autograd). With the
+// transposed neighbourhood relation rev [Ns, Hr] (row j = the query rows n whose list holds support j; entries outside
+// [0, Nq) are shadow entries), g [Nq, C] the gradient of the layer's output and the layer's own deformed kernel points
+// kp [K, 3] + offsets [Nq, K, 3] and modulations mod [Nq, K] (null: not modulated):
+//   A2 [Ns, K, C] [j, k, :] = sum over n in rev[j] of max(0, 1 - |s_j - q_n - kp_k - offsets[n, k]| / extent) mod[n, k] g[n, :]
+// i.e. the forward aggregation over the transposed relation with the kernel points of the NEIGHBOUR rows; the feature
+// gradient is then dx = sum_k A2[:, k, :] . W[k]^T (mvk_gemm_f32_kp_transposed) -- no atomics, a fixed summation order per
+// row of rev. Linear influence, sum aggregation, 5 <= C, Nq * C < 2^32 (returns an error otherwise: the caller keeps
+// mvk_kpconv_scatter_bwd). order: a work list over the Ns rows or NULL.
+extern "C" int mvk_kpconv_gather_rev_deform(const float* s, int64_t Ns, const float* q, int64_t Nq, const void* rev, int rev64,
+                                            int Hr, const float* g, int C, const float* kp, int K, float extent,
+                                            const float* offsets, const float* mod, float* A2, const int32_t* order,
+                                            void* stream) {
+  if (int e = check_common(Ns, Nq, Hr, C, K, MVK_INFL_LINEAR, MVK_AGG_SUM)) return e;
+  MVK_REQUIRE(offsets != nullptr && A2 != nullptr, "kpconv rev deform: offsets and an output are required");
+  if (Ns == 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (Hr == 0 || Nq == 0) {
+    MVK_CHECK_HIP(hipMemsetAsync(A2, 0, sizeof(float) * Ns * K * C, st));
+    return 0;
+  }
+  KPParams P{};
+  // roles transposed: the "queries" of the launch are the layer's supports, its "supports" the layer's query rows
+  P.q = s; P.s = q; P.idx = rev; P.x = g; P.kp = kp; P.A = A2; P.Nq = Ns; P.Ns = Nq; P.H = Hr; P.Cin = C; P.K = K;
+  P.extent = extent; P.influence = MVK_INFL_LINEAR; P.aggregation = MVK_AGG_SUM; P.ldA = (int64_t)K * C;
+  P.order = order; P.nb_offsets = offsets; P.nb_mod = mod;
+  MVK_REQUIRE(launch_mfma<2>(P, rev64, st), "kpconv rev deform: shape not supported by the MFMA gather (C >= 5, Nq * C < 2^32)");
   MVK_CHECK_HIP(hipGetLastError());
   return 0;
 }
@@ -1328,7 +1482,9 @@ extern "C" int mvk_kpconv_gather_plan(int64_t Nq, int64_t Ns, int H, int Cin, in
   if (!deformable && elem_bytes == 4) {
     const int T = mfma_tiles(Ns, Cin, 15, MVK_INFL_LINEAR, MVK_AGG_SUM);
     if (Nq > 0 && T > 0) {        // the MFMA gather: one wave per point, four per workgroup, channel blocks in gridDim.y
-      out[0] = 64; out[1] = 1; out[2] = T; out[3] = 0; out[4] = 4; out[5] = cdiv64(Nq, 4) * cdiv64(Cin, 16 * T);
+      const int64_t by = cdiv64(Cin, 16 * T);
+      const bool share = T >= 4 && T != 5 && (H >= 128 || (Nq * by <= 512 && H >= 32));        // (launch_mfma: four waves share a point)
+      out[0] = 64; out[1] = 1; out[2] = T; out[3] = share ? 0 : -1; out[4] = 4; out[5] = (share ? Nq : cdiv64(Nq, 4)) * by;
       out[6] = out[5] * 256; out[7] = 1;
       return 0;
     }

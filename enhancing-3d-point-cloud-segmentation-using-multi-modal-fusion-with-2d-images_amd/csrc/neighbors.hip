@@ -795,7 +795,7 @@ extern "C" int mvk_radius_neighbors_dev_rev(const float* q, int64_t Nq_cap, cons
                                             int32_t* out, int width, int32_t shadow, int32_t* status_dev, int reuse_grid,
                                             void* workspace, int64_t workspace_bytes, int32_t* rev, int rev_width,
                                             int32_t* rev_counts, int32_t* rev_status, void* stream) {
-  MVK_REQUIRE(rev && rev_counts && rev_status && rev_width >= 1 && rev_width <= 512 && width <= 64,
+  MVK_REQUIRE(rev && rev_counts && rev_status && rev_width >= 1 && rev_width <= MVK_REV_MAX_WIDTH && width <= 64,
               "neighbors: the fused reverse list needs rev, counters, a status word and at most 64 columns");
   const RevOut R{rev, rev_counts, rev_status, rev_width};
   return nb_dev_run(q, Nq_cap, s, Ns_cap, q_lens_dev, s_lens_dev, B, radius, out, width, shadow, status_dev, reuse_grid,

@@ -139,7 +139,7 @@ extern "C" int mvk_reverse_finish_many(const mvk_rev_list* lists, int n, void* s
   int64_t rows = 0;
   for (int k = 0; k < MVK_REV_MANY; ++k) {
     if (k < n) {
-      MVK_REQUIRE(lists[k].rev && lists[k].counts && lists[k].rows >= 0 && lists[k].width >= 1 && lists[k].width <= 512,
+      MVK_REQUIRE(lists[k].rev && lists[k].counts && lists[k].rows >= 0 && lists[k].width >= 1 && lists[k].width <= MVK_REV_MAX_WIDTH,
                   "reverse finish: bad list %d", k);
       A.l[k] = lists[k];
       rows += lists[k].rows;
@@ -162,11 +162,14 @@ extern "C" int mvk_reverse_finish_many(const mvk_rev_list* lists, int n, void* s
 // ASCENDING when sort != 0, in order of arrival otherwise -- and its tail is `shadow`.
 // counts [Ns] int32 must be ZERO on entry and is zero again when the launches have run (a persistent buffer).
 // status (int32 [2], may be null): [0] = max over calls of the longest row (atomicMax), [1] |= 1 when a row is longer
-// than Hr (its surplus entries are dropped: the caller must treat that as an error). Hr <= 512. Two launches.
+// than Hr (its surplus entries are dropped: the caller must treat that as an error). Hr <= 512 when sort != 0, <= MVK_REV_MAX_WIDTH
+// otherwise. Two launches.
 extern "C" int mvk_reverse_neighbors(const void* idx, int idx64, int64_t Nq, int H, int64_t idx_stride, int64_t Ns, int32_t* rev,
                                      int Hr, int32_t shadow, int sort, int32_t* counts, int32_t* status, void* stream) {
-  MVK_REQUIRE(Nq >= 0 && H >= 0 && Ns >= 0 && Hr >= 1 && Hr <= 512 && rev && counts && idx_stride >= H,
-              "reverse neighbours: bad arguments");
+  // (sorted rows are ranked by counting in registers: <= 512 entries; rows in order of arrival -- the default mode, and the
+  // only one the wide relations of the deformable layers use -- have no such limit)
+  MVK_REQUIRE(Nq >= 0 && H >= 0 && Ns >= 0 && Hr >= 1 && Hr <= (sort ? 512 : MVK_REV_MAX_WIDTH) && rev && counts && idx_stride >= H,
+              "reverse neighbours: bad arguments (rows of at most 512 entries when sorted, %d otherwise)", MVK_REV_MAX_WIDTH);
   MVK_REQUIRE(Nq * (int64_t)H < (1ll << 40) && Ns < (1ll << 31), "reverse neighbours: too large");
   if (Ns == 0) return 0;
   hipStream_t st = (hipStream_t)stream;

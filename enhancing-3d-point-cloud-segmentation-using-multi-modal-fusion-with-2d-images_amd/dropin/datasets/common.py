@@ -201,9 +201,10 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
             pool_i, up_i = empty_idx(), empty_idx()
             pool_p = torch.zeros((0, 3), dtype=torch.float32, device=dev)
             pool_b = np.zeros((0,), dtype=np.int32)
-        # transposed relations for the gather-form feature gradient of the RIGID convolutions (ops.reverse_neighbors);
-        # the deformable layers (searched at the wide deform radius) keep the scatter
-        rigid = want_rev and not deform_layer and pts.is_cuda
+        # transposed relations for the gather-form feature gradient (ops.reverse_neighbors): rigid convolutions, and since
+        # round 5 the deformable ones too (searched at the wide deform radius: rows of up to 512 entries;
+        # MVK_REVERSE_DX_DEFORM=0 keeps their atomic scatter)
+        rigid = want_rev and pts.is_cuda and (not deform_layer or (ops.REVERSE_DX_DEFORM and not ops.is_deterministic()))
 
         def reverse(m):
             if not rigid or m.shape[0] == 0 or m.shape[1] == 0:
@@ -212,7 +213,8 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
                 return ops.reverse_neighbors(m, pts.shape[0])               # exact width (one read-back)
             if 'rev_status' not in out:                                     # sync-free pyramid: fixed width, one status word
                 out['rev_status'] = torch.zeros(2, dtype=torch.int32, device=dev)
-            return ops.reverse_neighbors(m, pts.shape[0], width=min(512, 2 * m.shape[1] + 16), status=out['rev_status'])
+            return ops.reverse_neighbors(m, pts.shape[0], width=min(ops.reverse_width_cap(), 2 * m.shape[1] + 16),
+                                         status=out['rev_status'])
 
         out['rev_neighbors'].append(reverse(conv_i))
         out['rev_pools'].append(reverse(pool_i))

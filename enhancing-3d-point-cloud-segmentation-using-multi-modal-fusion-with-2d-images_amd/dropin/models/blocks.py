@@ -147,7 +147,7 @@ class KPConv(nn.Module):
         offsets = modulations = None
         if self.deformable:
             # offsets from an inner rigid KPConv (blocks.py:243-266)
-            raw = self.offset_conv(q_pts, s_pts, neighb_inds, x, order=order)
+            raw = self.offset_conv(q_pts, s_pts, neighb_inds, x, order=order, rev=rev, rev_order=rev_order)
             if _FUSED_OPERANDS and raw.is_cuda:        # bias, scale, kernel points (and 2 sigmoid) in one launch
                 self.offset_features, offsets, self.deformed_KP, modulations = ops.deform_operands(
                     raw, self.offset_bias, self.kernel_points, self.KP_extent, self.modulated)
@@ -163,8 +163,7 @@ class KPConv(nn.Module):
                 self.deformed_KP = offsets + self.kernel_points          # blocks.py:287
         y, min_d2 = ops.kpconv(q_pts, s_pts, neighb_inds, x, self.kernel_points, self.weights, self.KP_extent,
                                self.KP_influence, self.aggregation_mode, offsets, modulations,
-                               stats_n_valid=stats_n_valid, order=order, rev=None if self.deformable else rev,
-                               rev_order=rev_order, bn=bn)
+                               stats_n_valid=stats_n_valid, order=order, rev=rev, rev_order=rev_order, bn=bn)
         if self.deformable:
             self.min_d2 = min_d2                                      # blocks.py:303
         return y

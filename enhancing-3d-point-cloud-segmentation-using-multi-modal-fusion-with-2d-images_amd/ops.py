@@ -572,6 +572,44 @@ def kpconv_scatter(q, s, idx, dA, kp, extent, influence="linear", aggregation="s
     return dx, d_off
 
 
+def kpconv_deform_doff(q, s, idx, x, kp, extent, offsets, dA, g_min_d2=None, min_arg=None):
+    """d_offsets [Nq,K,3] of a deformable KPConv alone (mvk_kpconv_deform_doff; kpconv_scatter runs it together with the
+    atomic dx scatter): what is left of the scatter entry point once dx is a gather (kpconv_gather_rev_deform)."""
+    _dev(q, s, idx, x, kp, offsets, dA, g_min_d2, min_arg)
+    q, s, x, kp, offsets, dA = _f32c(q), _f32c(s), _f32c(x), _f32c(kp), _f32c(offsets), _f32c(dA)
+    idx, i64 = _idx(idx)
+    Nq, Ns, H, K, Cin = q.shape[0], s.shape[0], idx.shape[1], kp.shape[0], dA.shape[2]
+    if Nq == 0 or H == 0:
+        return torch.zeros((Nq, K, 3), device=q.device, dtype=torch.float32)
+    d_off = torch.empty((Nq, K, 3), device=q.device, dtype=torch.float32)
+    if g_min_d2 is not None:
+        g_min_d2 = _f32c(g_min_d2)
+        if min_arg is None:
+            raise RuntimeError("kpconv_deform_doff: the min_d2 gradient needs the forward's arg-min columns")
+    check(lib().mvk_kpconv_deform_doff(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, _p(x), Cin, _p(kp), K, float(extent),
+                                       INFLUENCE["linear"], _p(offsets), _p(dA), _p(g_min_d2), _p(min_arg), _p(d_off),
+                                       _stream()))
+    return d_off
+
+
+def kpconv_gather_rev_deform(s, q, rev, g, kp, extent, offsets, modulations=None, order=None):
+    """A2 [Ns, K, C]: the forward aggregation of g [Nq, C] over the transposed relation rev [Ns, Hr] with the kernel points
+    of the neighbour (query) rows, kp + offsets [Nq,K,3], times modulations [Nq,K] (mvk_kpconv_gather_rev_deform): the
+    gather form of a deformable layer's feature gradient, dx = kp_transposed_contraction(A2, W)."""
+    _dev(s, q, rev, g, kp, offsets, modulations, order)
+    s, q, g, kp, offsets = _f32c(s), _f32c(q), _f32c(g), _f32c(kp), _f32c(offsets)
+    if modulations is not None:
+        modulations = _f32c(modulations)
+    rev, r64 = _idx(rev)
+    Ns, Nq, Hr, Cc, K = s.shape[0], q.shape[0], rev.shape[1], g.shape[1], kp.shape[0]
+    if rev.shape[0] != Ns or g.shape[0] != Nq or offsets.shape != (Nq, K, 3):
+        raise RuntimeError("kpconv_gather_rev_deform: rev [Ns,Hr], g [Nq,C] and offsets [Nq,K,3] expected")
+    A2 = torch.empty(Ns * K * Cc + 64, device=s.device, dtype=torch.float32)[:Ns * K * Cc].view(Ns, K, Cc)
+    check(lib().mvk_kpconv_gather_rev_deform(_p(s), Ns, _p(q), Nq, _p(rev), r64, Hr, _p(g), Cc, _p(kp), K, float(extent),
+                                             _p(offsets), _p(modulations), _p(A2), _p(order), _stream()))
+    return A2
+
+
 # --------------------------------------------------------------------------------------------
 # weight-gradient products off the critical chain
 # --------------------------------------------------------------------------------------------
@@ -850,8 +888,9 @@ class _KPConvFn(torch.autograd.Function):
             dW = _dw_gemm(Am.view(Nq, K * Cin), gy, target=W).view(K, Cin, Cout)
         need_dA = ctx.needs_input_grad[3] or (offsets is not None)
         rev, rev_order = ctx.rev
-        if (need_dA and rev is not None and offsets is None and modulations is None and REVERSE_DX
-                and Cout >= 32 and (Cout & (Cout - 1)) == 0 and rev.shape[0] >= s.shape[0]):
+        gather_form = (need_dA and rev is not None and REVERSE_DX and rev.shape[0] >= s.shape[0] and Cout >= 5
+                       and influence == "linear" and aggregation == "sum")
+        if gather_form and offsets is None and modulations is None and (Cout >= 32 or REVERSE_DX_ANY_COUT):
             # gather form (csrc/revlist.hip): the forward kernel over the transposed neighbourhood relation with the
             # kernel points negated, then the per-kernel-point transposed contraction -- no atomics, fixed summation order
             if rev.shape[0] != s.shape[0]:
@@ -859,6 +898,22 @@ class _KPConvFn(torch.autograd.Function):
             A2, _ = kpconv_gather(s, q, rev, gy, _neg_kernel_points(kp), extent, influence, aggregation, order=rev_order,
                                   tag="[dx]")
             dx = kp_transposed_contraction(A2, W)
+        elif gather_form and offsets is not None and REVERSE_DX_DEFORM:
+            # deformable layer (round 5): the same gather with the kernel points -- and modulations -- of the NEIGHBOUR rows
+            # (mvk_kpconv_gather_rev_deform); dA is still needed, by the offset gradient and the modulation gradient
+            if rev.shape[0] != s.shape[0]:
+                rev = rev[:s.shape[0]]
+            dAm = gemm(gy, W.reshape(K * Cin, Cout), transB=True).view(Nq, K, Cin)
+            if modulations is not None:
+                if ctx.needs_input_grad[7]:
+                    d_mod = (dAm * A).sum(dim=2)
+                dA = dAm * modulations.unsqueeze(2)
+            else:
+                dA = dAm
+            d_off = kpconv_deform_doff(q, s, idx, x, kp, extent, offsets, dA, g_min_d2, ctx.min_arg)
+            if ctx.needs_input_grad[3]:
+                A2 = kpconv_gather_rev_deform(s, q, rev, gy, kp, extent, offsets, modulations, order=rev_order)
+                dx = kp_transposed_contraction(A2, W)
         elif need_dA:
             dAm = gemm(gy, W.reshape(K * Cin, Cout), transB=True).view(Nq, K, Cin)
             if modulations is not None:
@@ -2010,6 +2065,8 @@ def neighbors_cell_order(Nq, Ns, B, out=None, s_lens_dev=None, device=None):
 _REV_COUNTS = {}      # device index -> persistent zero int32 buffer of mvk_reverse_neighbors (self-cleaning)
 _REV_COUNTS_RETIRED = []      # outgrown buffers: a graph captured earlier still adds into and zeroes its old address
 REVERSE_DX = os.environ.get("MVK_REVERSE_DX", "1") == "1"      # development switch: 0 = the scatter backward everywhere
+REVERSE_DX_DEFORM = os.environ.get("MVK_REVERSE_DX_DEFORM", "1") == "1"     # 0: deformable layers keep the atomic scatter
+REVERSE_DX_ANY_COUT = os.environ.get("MVK_REVERSE_DX_ANY_COUT", "1") == "1"  # 0: gather form only for Cout a power of two >= 32
 
 
 def _rev_counts(n, device):
@@ -2028,6 +2085,16 @@ def _rev_counts(n, device):
         torch.cuda.current_stream(device).synchronize()      # zero before any other stream's build uses it
         _REV_COUNTS[key] = buf
     return buf
+
+
+REV_MAX_WIDTH = 8192      # include/mvkpconv.h: MVK_REV_MAX_WIDTH
+
+
+def reverse_width_cap(sort=None):
+    """Longest row a reverse list may have: 512 when its rows are sorted (deterministic mode: ranked in registers), 8192 in
+    order of arrival -- the wide relations of the deformable layers (a support near the middle of a coarse level is a
+    neighbour of almost every query at the deform radius)."""
+    return 512 if (is_deterministic() if sort is None else bool(sort)) else REV_MAX_WIDTH
 
 
 def reverse_neighbors(idx, Ns, width=None, out=None, status=None, shadow=None, sort=None, first_column=False):
@@ -2065,13 +2132,14 @@ def reverse_neighbors(idx, Ns, width=None, out=None, status=None, shadow=None, s
         run(rev, rev.shape[1], status)
         return rev
     st = torch.zeros(2, dtype=torch.int32, device=dev)
-    w = max(8, min(512, 2 * H + 8))
+    cap = reverse_width_cap(do_sort)
+    w = max(8, min(cap, 2 * H + 8))
     rev = torch.empty((Ns, w), device=dev, dtype=torch.int32)
     run(rev, w, st)
     longest, ovf = (int(v) for v in st.cpu())
     if ovf:
-        if longest > 512:
-            raise RuntimeError("reverse_neighbors: a support has %d reverse neighbours (> 512)" % longest)
+        if longest > cap:
+            raise RuntimeError("reverse_neighbors: a support has %d reverse neighbours (> %d)" % (longest, cap))
         rev = torch.empty((Ns, longest), device=dev, dtype=torch.int32)
         run(rev, longest, None)
         return rev
@@ -2170,13 +2238,17 @@ def _neg_kernel_points(kp):
 
 
 def kp_transposed_contraction(A2, W):
-    """dx [M, Cin] = sum_k A2[:, k, :] . W[k]^T for A2 [M, K, Cout], W [K, Cin, Cout] (mvk_gemm_f32_kp_transposed)."""
+    """dx [M, Cin] = sum_k A2[:, k, :] . W[k]^T for A2 [M, K, Cout], W [K, Cin, Cout] (mvk_gemm_f32_kp_transposed; a Cout
+    that is not a power of two >= 32 -- the 45 / 60 offset channels of a deformable layer's inner convolution -- takes a
+    transposed copy of the weights and the plain product)."""
     _dev(A2, W)
     A2, W = _f32c(A2), _f32c(W)
     M, K, Cout = A2.shape
     Cin = W.shape[1]
     if W.shape[0] != K or W.shape[2] != Cout:
         raise RuntimeError("kp_transposed_contraction: A2 [M,K,Cout] and W [K,Cin,Cout] expected")
+    if Cout < 32 or (Cout & (Cout - 1)) != 0:
+        return gemm(A2.view(M, K * Cout), W.permute(0, 2, 1).reshape(K * Cout, Cin).contiguous())
     split_arena_prepare(A2.device)
     split = gemm_plan(M, Cin, K * Cout)[0] if M > 0 else 1
     dx = _split_out((M, Cin), A2.device, split)

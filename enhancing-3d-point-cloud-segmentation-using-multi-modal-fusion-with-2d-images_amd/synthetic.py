@@ -323,7 +323,7 @@ class StaticBatch:
                 if l >= len(src) or src[l] is None:
                     mats.append(None)
                     continue
-                w = min(512, -(-int(src[l].shape[1] * 1.35 + 8) // 8) * 8)
+                w = min(ops.reverse_width_cap(), -(-int(src[l].shape[1] * 1.35 + 8) // 8) * 8)
                 mats.append(torch.full((caps[l], w), caps[shadow_of(l)], dtype=torch.int32, device=dev))
             return mats
         self.rev_neighbors = rev_static('rev_neighbors', lambda l: l)

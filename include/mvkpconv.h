@@ -90,6 +90,16 @@ int mvk_kpconv_gather_fwd_f16_ld(const float* q, int64_t Nq, const float* s, int
  * f32 layers of >= 5 channels -- one wave per point, out[2] = its 16-channel accumulator tiles), 0: the vector kernel. */
 int mvk_kpconv_gather_plan(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, int deformable, int64_t* out /* [8] */);
 
+/* Gather-form feature gradient of a DEFORMABLE KPConv (round 5): A2 [Ns, K, C] = the forward aggregation over the
+ * transposed neighbourhood relation rev [Ns, Hr] (mvk_reverse_neighbors of the layer's neighbour matrix) of g [Nq, C], the
+ * gradient of the layer's output, with the kernel points of the NEIGHBOUR (query) rows: kp [K,3] + offsets [Nq,K,3], times
+ * mod [Nq,K] (NULL: not modulated); dx = sum_k A2[:,k,:] . W[k]^T follows (mvk_gemm_f32_kp_transposed). Replaces the atomic
+ * scatter of mvk_kpconv_scatter_bwd for deformable layers (KPConv-PyTorch/models/blocks.py:286-327, :360 through autograd);
+ * linear influence, sum aggregation, C >= 5. order: work list over the Ns rows or NULL. */
+int mvk_kpconv_gather_rev_deform(const float* s, int64_t Ns, const float* q, int64_t Nq, const void* rev, int rev64, int Hr,
+                                 const float* g, int C, const float* kp, int K, float extent, const float* offsets,
+                                 const float* mod, float* A2, const int32_t* order, void* stream);
+
 /* dx[idx[n,h], c] += sum_k w[n,h,k] * dA[n,k,c]   (shadow rows discarded).
  * dx [Ns,Cin] must be zero-initialised by the caller (accumulated with f32 atomics).
  * Deformable extras (all NULL for rigid):
@@ -208,6 +218,7 @@ int mvk_reverse_neighbors(const void* idx, int idx64, int64_t Nq, int H, int64_t
  * the longest rows of up to MVK_REV_MANY lists in ONE launch (the nine lists of a five-level pyramid: 18 launches -> 1
  * on top of the searches). The ascending order deterministic mode needs stays with mvk_reverse_neighbors(sort = 1). */
 #define MVK_REV_MANY 12
+#define MVK_REV_MAX_WIDTH 8192   /* longest row of an UNSORTED reverse list (sorted rows: 512) */
 typedef struct mvk_rev_list {
   int32_t* rev;        /* [rows, width] */
   int32_t* counts;     /* [rows] */

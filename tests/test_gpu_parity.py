@@ -665,8 +665,14 @@ def test_input_kernels_on_both_paths_at_every_size():
         assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+@pytest.mark.parametrize("use_rev", [False, True])
 @pytest.mark.parametrize("name,modulated", [("g4_kpconv_deform", False), ("g4_kpconv_deform_mod", True)])
-def test_kpconv_deformable_golden(ops, name, modulated):
+def test_kpconv_deformable_golden(ops, name, modulated, use_rev):
+    """The reference's deformable (and modulated) KPConv, forward and every gradient (fixture G4 from models.blocks.KPConv).
+    use_rev: the feature gradient of BOTH convolutions -- the inner rigid one that makes the offsets (45 / 60 output
+    channels) and the deformable one -- as gathers over the transposed neighbourhood relation (round 5:
+    mvk_kpconv_gather_rev_deform with the kernel points and modulations of the neighbour rows) instead of the atomic
+    scatter; same fixture, same tolerance."""
     g = load_golden(name)
     K = 15
     q, s, idx = T(g["q"]), T(g["s"]), T(g["idx"])
@@ -675,14 +681,15 @@ def test_kpconv_deformable_golden(ops, name, modulated):
     Wo = T(g["offset_weights"]).requires_grad_(True)
     bo = T(g["offset_bias"]).requires_grad_(True)
     ext = float(g["extent"])
-    feat, _ = ops.kpconv(q, s, idx, x, T(g["offset_kernel_points"]), Wo, ext)
+    rev = ops.reverse_neighbors(idx, s.shape[0]) if use_rev else None
+    feat, _ = ops.kpconv(q, s, idx, x, T(g["offset_kernel_points"]), Wo, ext, rev=rev)
     feat = feat + bo
     if modulated:
         off = feat[:, :3 * K].reshape(-1, K, 3) * ext
         mod = 2 * torch.sigmoid(feat[:, 3 * K:])
     else:
         off, mod = feat.reshape(-1, K, 3) * ext, None
-    y, min_d2 = ops.kpconv(q, s, idx, x, T(g["kernel_points"]), W, ext, offsets=off, modulations=mod)
+    y, min_d2 = ops.kpconv(q, s, idx, x, T(g["kernel_points"]), W, ext, offsets=off, modulations=mod, rev=rev)
     dKP = off + T(g["kernel_points"])
     loss = (y * T(g["g"])).sum() + (min_d2.sum() + (dKP ** 2).sum()) * 0.5
     loss.backward()

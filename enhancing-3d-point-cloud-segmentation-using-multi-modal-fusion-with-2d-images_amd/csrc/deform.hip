@@ -254,6 +254,174 @@ __global__ __launch_bounds__(64 * WPB) void kpconv_deform_doff(const DoffParams 
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// The same gradient with B on the matrix pipe (round 5; Cin % 4 == 0). One workgroup of four waves per query point.
+// Pass 1 is the column walk above (lane = neighbour column, kept neighbours compacted into per-wave LDS lists read as
+// one sequence). Pass 2 takes the kept neighbours 16 at a time, wave w the tiles w, w + 4, ...:
+//     B[16 neighbours x 16 kernel points] = X[16 x Cin] . dA[n]^T[Cin x 16]
+// as Cin / 4 v_mfma_f32_16x16x4_f32: lane (i = lane & 15, kq = lane >> 4) loads the float4 x[j_i, c0 + 4 kq ..] (the A
+// operand of four MFMAs: their contraction index stands for the channels c0 + 4 kq + r) and the float4
+// dA[n, m = lane & 15, c0 + 4 kq ..] (the B operand of the same four; row m = 15 is zero): 16 channels of 16 feature
+// rows per wave load, no LDS staging of dA (the block is 15 x Cin floats read by <= 4 waves: L1 / L2 hits), no
+// per-lane accumulator rows. The result lands as D[neighbour 4 kq + r, kernel point m]: the lane holds ITS kernel
+// point's three offset-gradient sums over the neighbours 4 kq + r of every tile (3 accumulators instead of 45), the
+// neighbours' relative positions come from the lanes that loaded them (ds_bpermute), two xor-shuffles fold kq at the
+// end, the four waves meet in LDS in wave order (a fixed summation order: results do not depend on timing).
+typedef float doff_f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool IDX64>
+__global__ __launch_bounds__(256) void kpconv_deform_doff_mfma(const DoffParams P, int list_cap) {
+  constexpr int WPB = 4;
+  extern __shared__ __attribute__((aligned(16))) float dsm[];   // [WPB][list_cap] lists, [WPB][48] partials, [16] float4 kernel points
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int m = lane & 15, kq = lane >> 4;
+  const int64_t n = blockIdx.x;
+  int* lists = reinterpret_cast<int*>(dsm);
+  int* list = lists + (size_t)wid * list_cap;
+  float* red = dsm + (size_t)WPB * list_cap;                     // [WPB][48]
+  float4* kd = reinterpret_cast<float4*>(red + WPB * 48);        // deformed kernel points (blocks.py:287), 1e9 beyond K
+  const float qx = P.q[n * 3], qy = P.q[n * 3 + 1], qz = P.q[n * 3 + 2];
+  float mx = 1e9f, my = 1e9f, mz = 1e9f;                         // this lane's kernel point m
+  if (m < P.K) {
+    const float* o = P.offsets + (n * P.K + m) * 3;
+    mx = P.kp[m * 3] + o[0];
+    my = P.kp[m * 3 + 1] + o[1];
+    mz = P.kp[m * 3 + 2] + o[2];
+  }
+  if (threadIdx.x < 16) kd[threadIdx.x] = make_float4(mx, my, mz, 0.f);
+  __syncthreads();
+  const float ext2 = P.extent * P.extent;
+
+  // ---- pass 1 (as in kpconv_deform_doff): all H entries -> lists of the kept neighbours
+  int nkept = 0;
+  int jn = wid * 64 + lane < P.H ? load_idx<IDX64>(P.idx, n * P.H + wid * 64 + lane, P.Ns) : -2;
+  for (int h0 = wid * 64; h0 < P.H; h0 += 64 * WPB) {
+    const int j = jn;
+    jn = h0 + 64 * WPB + lane < P.H ? load_idx<IDX64>(P.idx, n * P.H + h0 + 64 * WPB + lane, P.Ns) : -2;
+    bool keep = false;
+    if (j >= 0) {
+      const float* sp = P.s + (int64_t)j * 3;
+      const float rx = sp[0] - qx, ry = sp[1] - qy, rz = sp[2] - qz;
+#pragma unroll
+      for (int kk = 0; kk < DKMAX - 1; ++kk) {
+        const float4 k4 = kd[kk];                                 // broadcast read
+        const float dx = rx - k4.x, dy = ry - k4.y, dz = rz - k4.z;
+        keep = keep || (dx * dx + dy * dy + dz * dz < ext2);
+      }
+    }
+    const unsigned long long bal = __ballot(keep);
+    if (keep) {
+      const int pos = nkept + __builtin_popcountll(bal & ((1ull << lane) - 1ull));
+      if (pos < list_cap) list[pos] = j;
+    }
+    nkept += __builtin_popcountll(bal);
+  }
+  nkept = nkept < list_cap ? nkept : list_cap;
+  int pre[WPB + 1];
+  pre[0] = 0;
+  if (lane == 0) red[wid] = __int_as_float(nkept);
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < WPB; ++w) pre[w + 1] = pre[w] + __float_as_int(red[w]);
+  __syncthreads();
+  const int total = pre[WPB];
+
+  // ---- pass 2: tiles of 16 kept neighbours
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  const float* dArow = P.dA + (n * P.K + (m < P.K ? m : 0)) * P.Cin + 4 * kq;
+  const bool m_on = m < P.K;
+  for (int t0 = wid * 16; t0 < total; t0 += 16 * WPB) {
+    const int gi = t0 + m;
+    const bool on = gi < total;
+    int j = 0;
+    if (on) {
+      int r = 0;
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) r += gi >= pre[w] ? 1 : 0;
+      int base = 0;
+#pragma unroll
+      for (int w = 1; w < WPB; ++w) base = r >= w ? pre[w] : base;
+      j = lists[(size_t)r * list_cap + (gi - base)];
+    }
+    float rx = 0.f, ry = 0.f, rz = 0.f;
+    if (on) {
+      const float* sp = P.s + (int64_t)j * 3;
+      rx = sp[0] - qx; ry = sp[1] - qy; rz = sp[2] - qz;
+    }
+    const float* xr = P.x + (int64_t)j * P.Cin + 4 * kq;
+    doff_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    constexpr int UB = 4;                                         // 4 + 4 float4 loads in flight
+    for (int c0 = 0; c0 < P.Cin; c0 += 16 * UB) {
+      float4 xv[UB], dv[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        const bool cin = c0 + 16 * u + 4 * kq < P.Cin;
+        xv[u] = (on && cin) ? *reinterpret_cast<const float4*>(xr + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dv[u] = (m_on && cin) ? *reinterpret_cast<const float4*>(dArow + c0 + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u) {
+        if (c0 + 16 * u < P.Cin) {        // wave uniform
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].x, dv[u].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].y, dv[u].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].z, dv[u].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[u].w, dv[u].w, acc, 0, 0, 0);
+        }
+      }
+    }
+    // D[row 4 kq + r, col m]: the neighbours 4 kq + r of this tile against kernel point m
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int src = 4 * kq + r;
+      const float nx = __shfl(rx, src), ny = __shfl(ry, src), nz = __shfl(rz, src);
+      const bool von = t0 + src < total;
+      const float dx = nx - mx, dy = ny - my, dz = nz - mz;
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      // d w / d off[k,:] = sc * (rel - kpdef):  linear  w = 1 - sqrt(d2)/ext (w > 0): sc = 1 / (ext sqrt(d2));
+      //                                         gaussian w = exp(-d2/den):            sc = 2 w / den;  constant: 0
+      float sc = 0.f;
+      if (P.influence == MVK_INFL_LINEAR) {
+        const float dist = sqrtf(d2);
+        sc = (1.0f - dist / P.extent > 0.f && d2 > 0.f) ? 1.0f / (P.extent * dist) : 0.f;
+      } else if (P.influence == MVK_INFL_GAUSSIAN) {
+        const float sig = P.extent * 0.3f, den = 2.0f * sig * sig + 1e-9f;
+        sc = 2.0f * expf(-d2 / den) / den;
+      }
+      const float f = (von && m_on) ? sc * acc[r] : 0.f;
+      gx = fmaf(f, dx, gx);
+      gy = fmaf(f, dy, gy);
+      gz = fmaf(f, dz, gz);
+    }
+  }
+  // fold kq (lanes m, m + 16, m + 32, m + 48), then the waves in wave order
+  gx += __shfl_xor(gx, 16); gy += __shfl_xor(gy, 16); gz += __shfl_xor(gz, 16);
+  gx += __shfl_xor(gx, 32); gy += __shfl_xor(gy, 32); gz += __shfl_xor(gz, 32);
+  if (lane < 16) {
+    red[wid * 48 + lane * 3 + 0] = gx;
+    red[wid * 48 + lane * 3 + 1] = gy;
+    red[wid * 48 + lane * 3 + 2] = gz;
+  }
+  __syncthreads();
+  if (wid == 0 && lane < P.K * 3) {
+    float v = red[lane];
+#pragma unroll
+    for (int w = 1; w < WPB; ++w) v += red[w * 48 + lane];
+    // ---- min_d2 path: d min_d2[n,k] / d off[n,k,:] = -2 (rel[h*] - kpdef[k]) at the forward's arg-min column h*
+    //      (shadow entries included, like torch.min over dim 1)
+    if (P.g_min_d2 != nullptr && P.H > 0) {
+      const int k = lane / 3, e = lane - 3 * k;
+      const int hs = P.min_arg[n * P.K + k];
+      const int j = load_idx<IDX64>(P.idx, n * P.H + hs, P.Ns);
+      const float qe = e == 0 ? qx : (e == 1 ? qy : qz);
+      const float rel = j >= 0 ? P.s[(int64_t)j * 3 + e] - qe : 1e6f - qe;
+      const float4 k4 = kd[k];
+      const float ke = e == 0 ? k4.x : (e == 1 ? k4.y : k4.z);
+      v += -2.f * P.g_min_d2[n * P.K + k] * (rel - ke);
+    }
+    P.d_offsets[n * P.K * 3 + lane] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // regulariser: one lane per (point, kernel point): 16-lane groups hold one point's deformed kernel points and
 // exchange them by shuffles
 __global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __restrict__ min_d2, const float* __restrict__ dkp,
@@ -332,6 +500,16 @@ extern "C" int mvk_kpconv_deform_doff(const float* q, int64_t Nq, const float* s
   P.g_min_d2 = g_min_d2; P.min_arg = min_arg; P.d_offsets = d_offsets; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K;
   P.extent = extent; P.influence = influence;
   const int Cin4 = (Cin + 3) & ~3;
+  static const bool mfma_on = getenv("MVK_DOFF_MFMA") == nullptr || atoi(getenv("MVK_DOFF_MFMA")) != 0;
+  if (mfma_on && (Cin & 3) == 0) {
+    const int chunks = (H + 63) / 64;
+    const int list_cap = ((chunks + 3) / 4) * 64 > 64 ? ((chunks + 3) / 4) * 64 : 64;      // columns one wave walks
+    const size_t lds = sizeof(int) * 4 * (size_t)list_cap + sizeof(float) * 4 * 48 + sizeof(float4) * 16;
+    if (idx64) hipLaunchKernelGGL((kpconv_deform_doff_mfma<true>), dim3((unsigned)Nq), dim3(256), lds, st, P, list_cap);
+    else hipLaunchKernelGGL((kpconv_deform_doff_mfma<false>), dim3((unsigned)Nq), dim3(256), lds, st, P, list_cap);
+    MVK_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   static const bool split_on = getenv("MVK_DOFF_SPLIT") == nullptr || atoi(getenv("MVK_DOFF_SPLIT")) != 0;
   // four waves per point only where points are few (the coarse levels searched at the deform radius: 750 / 160 / 36
   // points x 420 / 349 / 124 columns): with thousands of points the chip is full anyway and the per-wave overhead

@@ -34,6 +34,12 @@ class RevList(C.Structure):
     _fields_ = [("rev", _vp), ("counts", _vp), ("status", _vp), ("rows", _i64), ("width", C.c_int32), ("shadow", C.c_int32)]
 
 
+class RegLayer(C.Structure):
+    """mvk_reg_layer: one deformable layer for mvk_deform_regularizer_many."""
+    _fields_ = [("min_d2", _vp), ("deformed_kp", _vp), ("n_valid", _vp), ("d_min_d2", _vp), ("d_deformed_kp", _vp),
+                ("N", _i64), ("extent", _f), ("repulse_extent", _f), ("power", _f)]
+
+
 class BnFinish(C.Structure):
     """mvk_bn_finish: the producer's half of a folded BatchNorm (statistics finished inside the GEMM launch)."""
     _fields_ = [("counters", _vp), ("eps", _f), ("momentum", _f), ("mean", _vp), ("invstd", _vp), ("running_mean", _vp),
@@ -130,6 +136,7 @@ _SIGNATURES = {
     "mvk_radius_neighbors_dev_rev": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _i, _vp, _i, _vp, _i64,
                                                _vp, _i, _vp, _vp, _vp]),
     "mvk_reverse_finish_many": (C.c_int, [C.POINTER(RevList), _i, _vp]),
+    "mvk_deform_regularizer_many": (C.c_int, [C.POINTER(RegLayer), _i, _i, _vp, _vp, _vp]),
     "mvk_neighbors_cell_order": (C.c_int, [_i64, _i, _vp, _vp, _i64, _vp, _i64, _vp]),
     "mvk_radius_neighbors_workspace": (C.c_int64, [_i64, _i64, _i]),
     "mvk_radius_neighbors_batch": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i, _f, _vp, _i, _vp,

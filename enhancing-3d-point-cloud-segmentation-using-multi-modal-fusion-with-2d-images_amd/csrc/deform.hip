@@ -424,15 +424,15 @@ __global__ __launch_bounds__(256) void kpconv_deform_doff_mfma(const DoffParams 
 // ---------------------------------------------------------------------------------------------------------
 // regulariser: one lane per (point, kernel point): 16-lane groups hold one point's deformed kernel points and
 // exchange them by shuffles
-__global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __restrict__ min_d2, const float* __restrict__ dkp,
-                                                                const int32_t* __restrict__ n_valid, int64_t N, int K,
-                                                                float extent, float repulse, float power,
-                                                                float* __restrict__ loss /* [1], += ; or null */,
-                                                                const float* __restrict__ gscale /* [1] or null: 1 */,
-                                                                float* __restrict__ d_min_d2 /* [N,K] or null */,
-                                                                float* __restrict__ d_dkp /* [N,K,3] or null */) {
+__device__ __forceinline__ void deform_regularizer_body(const int64_t block, const float* __restrict__ min_d2,
+                                                        const float* __restrict__ dkp, const int32_t* __restrict__ n_valid,
+                                                        int64_t N, int K, float extent, float repulse, float power,
+                                                        float* __restrict__ loss /* [1], += ; or null */,
+                                                        const float* __restrict__ gscale /* [1] or null: 1 */,
+                                                        float* __restrict__ d_min_d2 /* [N,K] or null */,
+                                                        float* __restrict__ d_dkp /* [N,K,3] or null */) {
   __shared__ float red[4];
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t t = block * blockDim.x + threadIdx.x;
   const int64_t n = t >> 4;
   const int i = (int)(t & 15);
   int64_t nv = n_valid ? (int64_t)*n_valid : N;
@@ -480,7 +480,49 @@ __global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __
   if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1]) + (red[2] + red[3]));
 }
 
+__global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __restrict__ min_d2, const float* __restrict__ dkp,
+                                                                const int32_t* __restrict__ n_valid, int64_t N, int K,
+                                                                float extent, float repulse, float power,
+                                                                float* __restrict__ loss, const float* __restrict__ gscale,
+                                                                float* __restrict__ d_min_d2, float* __restrict__ d_dkp) {
+  deform_regularizer_body(blockIdx.x, min_d2, dkp, n_valid, N, K, extent, repulse, power, loss, gscale, d_min_d2, d_dkp);
+}
+
+// every deformable layer of a network in ONE launch (ten launches of a few hundred rows each were ten launch
+// boundaries on the step's chain, twice per step): blockIdx.y = layer, the blocks beyond a layer's rows leave
+struct RegManyArgs {
+  mvk_reg_layer l[MVK_REG_MANY];
+};
+__global__ __launch_bounds__(256) void deform_regularizer_many_kernel(const RegManyArgs a, int K, float* __restrict__ loss,
+                                                                     const float* __restrict__ gscale) {
+  const mvk_reg_layer& L = a.l[blockIdx.y];
+  if ((int64_t)blockIdx.x * 16 >= L.N) return;          // (uniform)
+  deform_regularizer_body(blockIdx.x, L.min_d2, L.deformed_kp, L.n_valid, L.N, K, L.extent, L.repulse_extent, L.power, loss,
+                          gscale, L.d_min_d2, L.d_deformed_kp);
+}
+
 }  // namespace
+
+extern "C" int mvk_deform_regularizer_many(const mvk_reg_layer* layers, int n, int K, float* loss_accum,
+                                           const float* grad_scale, void* stream) {
+  MVK_REQUIRE(n >= 0 && n <= MVK_REG_MANY && K >= 1 && K < DKMAX, "regulariser: at most %d layers per call", MVK_REG_MANY);
+  RegManyArgs a{};
+  int64_t most = 0;
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const mvk_reg_layer& L = layers[i];
+    MVK_REQUIRE(L.N >= 0 && L.extent > 0.f, "regulariser: bad sizes");
+    if (L.N == 0) continue;          // an empty level contributes nothing (its tensors have no storage)
+    MVK_REQUIRE(L.min_d2 && L.deformed_kp && (loss_accum || L.d_min_d2 || L.d_deformed_kp), "regulariser: null operand");
+    a.l[m++] = L;
+    most = L.N > most ? L.N : most;
+  }
+  if (m == 0) return 0;
+  hipLaunchKernelGGL(deform_regularizer_many_kernel, dim3((unsigned)cdiv64(most * 16, 256), (unsigned)m), dim3(256), 0,
+                     (hipStream_t)stream, a, K, loss_accum, grad_scale);
+  MVK_CHECK_HIP(hipGetLastError());
+  return 0;
+}
 
 extern "C" int mvk_kpconv_deform_doff(const float* q, int64_t Nq, const float* s, int64_t Ns, const void* idx,
                                       int idx64, int H, const float* x, int Cin, const float* kp, int K, float extent,

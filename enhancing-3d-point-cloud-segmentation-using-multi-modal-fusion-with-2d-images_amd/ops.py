@@ -1183,6 +1183,23 @@ def deform_operands(raw, bias, kernel_points, extent, modulated=False):
     return _DeformOperandsFn.apply(raw, bias, kernel_points, extent, modulated)
 
 
+def _reg_many(cfgs, ts, grads, loss, gscale):
+    """mvk_deform_regularizer_many over the layers (min_d2, deformed_kp) = ts[2i], ts[2i+1], REG_MANY per launch (layers
+    of another K get their own launch)."""
+    from ._lib import RegLayer
+    by_k = {}
+    for i, (extent, repulse, power, nv) in enumerate(cfgs):
+        m, d = ts[2 * i], ts[2 * i + 1]
+        L = RegLayer(_p(m), _p(d), _p(nv), _p(grads[2 * i]) if grads else None, _p(grads[2 * i + 1]) if grads else None,
+                     m.shape[0], float(extent), float(repulse), float(power))
+        by_k.setdefault(int(m.shape[1]), []).append(L)
+    for K, layers in by_k.items():
+        for b in range(0, len(layers), REG_MANY):
+            part = layers[b:b + REG_MANY]
+            arr = (RegLayer * len(part))(*part)
+            check(lib().mvk_deform_regularizer_many(arr, len(part), K, _p(loss), _p(gscale), _stream()))
+
+
 class _DeformRegAllFn(torch.autograd.Function):
     """The regulariser terms of ALL deformable layers of a network as one autograd node: every layer's forward launch
     accumulates into one scalar (no additions of per-layer losses), the backward launches the same kernel with the
@@ -1193,10 +1210,7 @@ class _DeformRegAllFn(torch.autograd.Function):
         ts = [_f32c(t) for t in tensors]
         _dev(*ts)
         loss = _zeros((1,), ts[0].device)
-        for i, (extent, repulse, power, nv) in enumerate(cfgs):
-            m, d = ts[2 * i], ts[2 * i + 1]
-            check(lib().mvk_deform_regularizer_ex(_p(m), _p(d), _p(nv), m.shape[0], m.shape[1], float(extent), float(repulse),
-                                                  float(power), _p(loss), None, None, None, _stream()))
+        _reg_many(cfgs, ts, None, loss, None)
         ctx.save_for_backward(*ts)
         ctx.cfgs = cfgs
         return loss.reshape(())
@@ -1205,13 +1219,8 @@ class _DeformRegAllFn(torch.autograd.Function):
     def backward(ctx, g):
         ts = ctx.saved_tensors
         g = _f32c(g).reshape(1)
-        grads = []
-        for i, (extent, repulse, power, nv) in enumerate(ctx.cfgs):
-            m, d = ts[2 * i], ts[2 * i + 1]
-            d_min, d_dkp = torch.empty_like(m), torch.empty_like(d)
-            check(lib().mvk_deform_regularizer_ex(_p(m), _p(d), _p(nv), m.shape[0], m.shape[1], float(extent), float(repulse),
-                                                  float(power), None, _p(g), _p(d_min), _p(d_dkp), _stream()))
-            grads += [d_min, d_dkp]
+        grads = [torch.empty_like(t) for t in ts]
+        _reg_many(ctx.cfgs, ts, grads, None, g)
         return (None, *grads)
 
 
@@ -2029,6 +2038,7 @@ def radius_neighbors_dev(queries, supports, q_lens_dev, s_lens_dev, radius, out,
     _NB_GRID.pop(q.device.index, None)
 
 
+REG_MANY = 16           # mvkpconv.h MVK_REG_MANY
 REV_MANY = 12      # include/mvkpconv.h: MVK_REV_MANY
 
 

@@ -373,6 +373,22 @@ int mvk_deform_regularizer_ex(const float* min_d2, const float* deformed_kp, con
                               float extent, float repulse_extent, float power, float* loss_accum, const float* grad_scale,
                               float* d_min_d2, float* d_deformed_kp, void* stream);
 
+/* Every deformable layer of a network in one launch (a forward call: loss_accum only; a backward call: grad_scale and
+ * the gradient outputs of each layer). At most MVK_REG_MANY layers per call; all layers share K. Layers with N == 0 are
+ * skipped. */
+#define MVK_REG_MANY 16
+typedef struct mvk_reg_layer {
+  const float* min_d2;        /* [N,K] */
+  const float* deformed_kp;   /* [N,K,3] */
+  const int32_t* n_valid;     /* DEVICE row count or NULL (= N) */
+  float* d_min_d2;            /* [N,K] or NULL */
+  float* d_deformed_kp;       /* [N,K,3] or NULL */
+  int64_t N;
+  float extent, repulse_extent, power;
+} mvk_reg_layer;
+int mvk_deform_regularizer_many(const mvk_reg_layer* layers, int n, int K, float* loss_accum, const float* grad_scale,
+                                void* stream);
+
 /* ---------------- frozen 2D encoder: pointwise epilogue of a convolution --- */
 
 /* y = act(x + bias[c] (+ res (+ bias2[c]))) over a channels-last (N,H,W,C) f32 tensor, C % 4 == 0: what is left of

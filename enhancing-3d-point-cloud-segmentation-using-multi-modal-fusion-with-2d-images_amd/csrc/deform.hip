@@ -424,7 +424,8 @@ __global__ __launch_bounds__(256) void kpconv_deform_doff_mfma(const DoffParams 
 // ---------------------------------------------------------------------------------------------------------
 // regulariser: one lane per (point, kernel point): 16-lane groups hold one point's deformed kernel points and
 // exchange them by shuffles
-__device__ __forceinline__ void deform_regularizer_body(const int64_t block, const float* __restrict__ min_d2,
+template <bool ATOMIC = true>
+__device__ __forceinline__ float deform_regularizer_body(const int64_t block, const float* __restrict__ min_d2,
                                                         const float* __restrict__ dkp, const int32_t* __restrict__ n_valid,
                                                         int64_t N, int K, float extent, float repulse, float power,
                                                         float* __restrict__ loss /* [1], += ; or null */,
@@ -472,12 +473,14 @@ __device__ __forceinline__ void deform_regularizer_body(const int64_t block, con
       o[0] = f * gx; o[1] = f * gy; o[2] = f * gz;
     }
   }
-  if (loss == nullptr) return;          // (uniform)
+  if (loss == nullptr) return 0.f;          // (uniform)
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) part += __shfl_xor(part, m);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1]) + (red[2] + red[3]));
+  const float sum = (red[0] + red[1]) + (red[2] + red[3]);
+  if (ATOMIC && threadIdx.x == 0) atomicAdd(loss, sum);
+  return sum;           // (!ATOMIC: the caller adds the workgroup sums itself and keeps `red` apart between two calls)
 }
 
 __global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __restrict__ min_d2, const float* __restrict__ dkp,
@@ -493,6 +496,22 @@ __global__ __launch_bounds__(256) void deform_regularizer_kernel(const float* __
 struct RegManyArgs {
   mvk_reg_layer l[MVK_REG_MANY];
 };
+// the ordered mode (mvk_gemm_split_ordered): ONE workgroup walks every layer and every 16-point block in order and adds
+// the block sums itself -- the loss has the same bits from run to run (float atomics add in order of arrival)
+__global__ __launch_bounds__(256) void deform_regularizer_serial_kernel(const RegManyArgs a, int n, int K, float* __restrict__ loss,
+                                                                       const float* __restrict__ gscale) {
+  float total = 0.f;
+  for (int k = 0; k < n; ++k) {
+    const mvk_reg_layer& L = a.l[k];
+    for (int64_t b = 0; b * 16 < L.N; ++b) {
+      total += deform_regularizer_body<false>(b, L.min_d2, L.deformed_kp, L.n_valid, L.N, K, L.extent, L.repulse_extent, L.power,
+                                              loss, gscale, L.d_min_d2, L.d_deformed_kp);
+      __syncthreads();
+    }
+  }
+  if (loss != nullptr && threadIdx.x == 0) loss[0] += total;
+}
+
 __global__ __launch_bounds__(256) void deform_regularizer_many_kernel(const RegManyArgs a, int K, float* __restrict__ loss,
                                                                      const float* __restrict__ gscale) {
   const mvk_reg_layer& L = a.l[blockIdx.y];
@@ -518,6 +537,11 @@ extern "C" int mvk_deform_regularizer_many(const mvk_reg_layer* layers, int n, i
     most = L.N > most ? L.N : most;
   }
   if (m == 0) return 0;
+  if (loss_accum != nullptr && mvk_gemm_split_ordered()) {
+    hipLaunchKernelGGL(deform_regularizer_serial_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a, m, K, loss_accum, grad_scale);
+    MVK_CHECK_HIP(hipGetLastError());
+    return 0;
+  }
   hipLaunchKernelGGL(deform_regularizer_many_kernel, dim3((unsigned)cdiv64(most * 16, 256), (unsigned)m), dim3(256), 0,
                      (hipStream_t)stream, a, K, loss_accum, grad_scale);
   MVK_CHECK_HIP(hipGetLastError());
@@ -669,6 +693,7 @@ extern "C" int mvk_deform_operands_bwd(const float* g_offsets, const float* g_de
   const int64_t rows_per = 256 / DP;
   int64_t g = cdiv64(N, rows_per * 4);          // ~4 rows per thread
   g = g < 1 ? 1 : (g > 256 ? 256 : g);
+  if (mvk_gemm_split_ordered()) g = 1;          // ordered mode: one workgroup, one (ordered) sum per column of d_bias
   hipLaunchKernelGGL(deform_operands_bwd_k, dim3((unsigned)g), dim3(256), 0, (hipStream_t)stream, g_offsets, g_deformed_kp,
                      g_modulations, modulations, g_feat, N, K, D, extent, d_raw, d_bias);
   MVK_CHECK_HIP(hipGetLastError());

@@ -86,6 +86,33 @@ __global__ __launch_bounds__(256) void rev_sort_kernel(int64_t Ns, int32_t* __re
   }
 }
 
+// Sorted rows wider than 512 entries (the relations of the deformable layers, searched at the deform radius, in the
+// deterministic mode): one WORKGROUP per row, the row staged in LDS, every thread ranks its entries tid, tid + 256, ...
+// by counting and writes them to their places. Same contract as rev_sort_kernel<.., true>.
+__global__ __launch_bounds__(256) void rev_sort_wide_kernel(int64_t Ns, int32_t* __restrict__ rev, int Hr, int32_t shadow,
+                                                            int32_t* __restrict__ count, int32_t* __restrict__ status) {
+  __shared__ int32_t buf[MVK_REV_MAX_WIDTH];
+  int longest = 0;
+  for (int64_t j = blockIdx.x; j < Ns; j += gridDim.x) {
+    const int c_all = count[j];
+    const int c = c_all < Hr ? c_all : Hr;
+    longest = c_all > longest ? c_all : longest;
+    int32_t* row = rev + j * Hr;
+    for (int i = threadIdx.x; i < c; i += 256) buf[i] = row[i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < c; i += 256) {
+      const int32_t v = buf[i];
+      int rank = 0;
+      for (int t = 0; t < c; ++t) rank += buf[t] < v ? 1 : 0;          // broadcast reads; the entries are distinct
+      row[rank] = v;
+    }
+    for (int i = c + threadIdx.x; i < Hr; i += 256) row[i] = shadow;
+    __syncthreads();                                                     // the row's counter was read by everyone; buf is free
+    if (threadIdx.x == 0 && c_all != 0) count[j] = 0;
+  }
+  if (status && threadIdx.x == 0 && longest > 0 && longest > status[0]) atomicMax(status, longest);
+}
+
 // The tails of up to MVK_REV_MANY lists in ONE launch (round 5): the lists' rows were filled by the neighbour searches
 // themselves (mvk_radius_neighbors_dev_rev), their counters hold the row lengths. One wavefront per row of the
 // concatenated row range: pads the tail with the list's shadow value, returns the counter to zero, reports the longest row.
@@ -162,14 +189,14 @@ extern "C" int mvk_reverse_finish_many(const mvk_rev_list* lists, int n, void* s
 // ASCENDING when sort != 0, in order of arrival otherwise -- and its tail is `shadow`.
 // counts [Ns] int32 must be ZERO on entry and is zero again when the launches have run (a persistent buffer).
 // status (int32 [2], may be null): [0] = max over calls of the longest row (atomicMax), [1] |= 1 when a row is longer
-// than Hr (its surplus entries are dropped: the caller must treat that as an error). Hr <= 512 when sort != 0, <= MVK_REV_MAX_WIDTH
-// otherwise. Two launches.
+// than Hr (its surplus entries are dropped: the caller must treat that as an error). Hr <= MVK_REV_MAX_WIDTH.
+// Two launches.
 extern "C" int mvk_reverse_neighbors(const void* idx, int idx64, int64_t Nq, int H, int64_t idx_stride, int64_t Ns, int32_t* rev,
                                      int Hr, int32_t shadow, int sort, int32_t* counts, int32_t* status, void* stream) {
-  // (sorted rows are ranked by counting in registers: <= 512 entries; rows in order of arrival -- the default mode, and the
-  // only one the wide relations of the deformable layers use -- have no such limit)
-  MVK_REQUIRE(Nq >= 0 && H >= 0 && Ns >= 0 && Hr >= 1 && Hr <= (sort ? 512 : MVK_REV_MAX_WIDTH) && rev && counts && idx_stride >= H,
-              "reverse neighbours: bad arguments (rows of at most 512 entries when sorted, %d otherwise)", MVK_REV_MAX_WIDTH);
+  // (sorted rows of <= 512 entries are ranked by counting in registers, one wave per row; wider ones -- the relations of
+  // the deformable layers in the deterministic mode -- by a workgroup per row)
+  MVK_REQUIRE(Nq >= 0 && H >= 0 && Ns >= 0 && Hr >= 1 && Hr <= MVK_REV_MAX_WIDTH && rev && counts && idx_stride >= H,
+              "reverse neighbours: bad arguments (rows of at most %d entries)", MVK_REV_MAX_WIDTH);
   MVK_REQUIRE(Nq * (int64_t)H < (1ll << 40) && Ns < (1ll << 31), "reverse neighbours: too large");
   if (Ns == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
@@ -186,7 +213,8 @@ extern "C" int mvk_reverse_neighbors(const void* idx, int idx64, int64_t Nq, int
   else if (Hr <= 64) REV_SORT(1, true);
   else if (Hr <= 128) REV_SORT(2, true);
   else if (Hr <= 256) REV_SORT(4, true);
-  else REV_SORT(8, true);
+  else if (Hr <= 512) REV_SORT(8, true);
+  else hipLaunchKernelGGL(rev_sort_wide_kernel, dim3((unsigned)(Ns < 65536 ? Ns : 65536)), dim3(256), 0, st, Ns, rev, Hr, shadow, counts, status);
 #undef REV_SORT
   MVK_CHECK_HIP(hipGetLastError());
   return 0;

@@ -202,9 +202,9 @@ def segmentation_inputs_sphere(config, stacked_points, stack_lengths, neighborho
             pool_p = torch.zeros((0, 3), dtype=torch.float32, device=dev)
             pool_b = np.zeros((0,), dtype=np.int32)
         # transposed relations for the gather-form feature gradient (ops.reverse_neighbors): rigid convolutions, and since
-        # round 5 the deformable ones too (searched at the wide deform radius: rows of up to 512 entries;
+        # round 5 the deformable ones too (searched at the wide deform radius: rows of hundreds of entries;
         # MVK_REVERSE_DX_DEFORM=0 keeps their atomic scatter)
-        rigid = want_rev and pts.is_cuda and (not deform_layer or (ops.REVERSE_DX_DEFORM and not ops.is_deterministic()))
+        rigid = want_rev and pts.is_cuda and (not deform_layer or ops.REVERSE_DX_DEFORM)
 
         def reverse(m):
             if not rigid or m.shape[0] == 0 or m.shape[1] == 0:

@@ -2101,10 +2101,9 @@ REV_MAX_WIDTH = 8192      # include/mvkpconv.h: MVK_REV_MAX_WIDTH
 
 
 def reverse_width_cap(sort=None):
-    """Longest row a reverse list may have: 512 when its rows are sorted (deterministic mode: ranked in registers), 8192 in
-    order of arrival -- the wide relations of the deformable layers (a support near the middle of a coarse level is a
-    neighbour of almost every query at the deform radius)."""
-    return 512 if (is_deterministic() if sort is None else bool(sort)) else REV_MAX_WIDTH
+    """Longest row a reverse list may have (8192, sorted or not): the wide relations of the deformable layers -- a support
+    near the middle of a coarse level is a neighbour of almost every query at the deform radius."""
+    return REV_MAX_WIDTH
 
 
 def reverse_neighbors(idx, Ns, width=None, out=None, status=None, shadow=None, sort=None, first_column=False):

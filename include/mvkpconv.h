@@ -204,7 +204,8 @@ int mvk_gemm_split_ordered(void);
  * mvk_reverse_neighbors: rev [Ns, Hr] int32 <- idx [Nq, H] (int32 / int64; entries outside [0, Ns) are shadow entries):
  *   row j = the rows n of idx that contain j (ascending with sort != 0), padded with `shadow` (normally Nq). counts [Ns] int32: ZERO on
  *   entry, zero again afterwards (keep one persistent buffer). status (int32 [2] or NULL): [0] = running maximum of the
- *   row lengths, [1] |= 1 when a row is longer than Hr (entries dropped: treat as an error). Hr <= 512. Two launches.
+ *   row lengths, [1] |= 1 when a row is longer than Hr (entries dropped: treat as an error). Hr <= MVK_REV_MAX_WIDTH
+ *   (sorted rows wider than 512 entries take a workgroup per row). Two launches.
  * mvk_gemm_f32_kp_transposed: dx [M, Cin] = sum_k A[:, k, :] . W[k]^T, A [M, K, Cout], W [K, Cin, Cout] (the layer's
  *   weights, read in place), Cout a power of two >= 32. */
 int mvk_reverse_neighbors(const void* idx, int idx64, int64_t Nq, int H, int64_t idx_stride, int64_t Ns, int32_t* rev, int Hr,
@@ -218,7 +219,7 @@ int mvk_reverse_neighbors(const void* idx, int idx64, int64_t Nq, int H, int64_t
  * the longest rows of up to MVK_REV_MANY lists in ONE launch (the nine lists of a five-level pyramid: 18 launches -> 1
  * on top of the searches). The ascending order deterministic mode needs stays with mvk_reverse_neighbors(sort = 1). */
 #define MVK_REV_MANY 12
-#define MVK_REV_MAX_WIDTH 8192   /* longest row of an UNSORTED reverse list (sorted rows: 512) */
+#define MVK_REV_MAX_WIDTH 8192   /* longest row of a reverse list */
 typedef struct mvk_rev_list {
   int32_t* rev;        /* [rows, width] */
   int32_t* counts;     /* [rows] */

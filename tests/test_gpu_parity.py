@@ -1012,7 +1012,8 @@ def _weight_gradients_reproducible(ops):
 
 
 @pytest.mark.parametrize("Nq,Ns,H,idt", [(3000, 3000, 40, torch.int32), (700, 2900, 33, torch.int64), (19464, 19464, 58, torch.int32),
-                                         (50, 4000, 300, torch.int32)])
+                                         (50, 4000, 300, torch.int32),
+                                         (2000, 60, 40, torch.int32)])          # rows of ~1000 entries: a workgroup per row
 def test_reverse_neighbors_is_the_sorted_transposed_relation(ops, Nq, Ns, H, idt):
     """mvk_reverse_neighbors: row j of the result = the rows n of idx that contain j, ascending, padded with the shadow
     value -- against a NumPy transposition; the persistent counters are back at zero; a width that is too small raises the

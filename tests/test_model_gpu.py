@@ -197,13 +197,17 @@ def test_network_without_batch_norm_deferred_weight_gradients_equal_inline_ones(
     check_err("no-BN network: 1 - cosine of the whole (deferred) gradient vs CPU port", 1.0 - (A @ B).item() / (A.norm().item() * B.norm().item()), 5e-4)
 
 
-@pytest.mark.parametrize("variant,spheres", [("early", 1), ("baseline", 2), ("late", 1)])
-def test_deterministic_mode_step_is_bit_reproducible(variant, spheres):
+@pytest.mark.parametrize("variant,spheres,deformable", [("early", 1, False), ("baseline", 2, False), ("late", 1, False),
+                                                        ("late", 1, True)])
+def test_deterministic_mode_step_is_bit_reproducible(variant, spheres, deformable):
     """ops.set_deterministic(True): ordered split reductions (csrc/gemm.hip), the feature gradients of the rigid
     convolutions, of max_pool and of the nearest upsampling as gathers over sorted reverse lists (csrc/revlist.hip), the
     bias gradients in workgroup order -- two runs of the same step on the same batch give the same BITS in the logits,
     the loss and every parameter gradient (the reference's CPU path is deterministic; the default mode here trades that
-    for ~5 % of the step). The frozen 2D encoder's output enters as a fixed map (MIOpen is outside this
+    for ~5 % of the step). Deformable + modulated variant (round 5): the feature gradients of the
+    deformable convolutions and of their offset convolutions as gathers over SORTED reverse lists of the deform-radius
+    relations (rows wider than 512: rev_sort_wide_kernel), the offset gradient in a fixed order (kpconv_deform_doff_mfma),
+    the regulariser and the offset-bias gradient summed by one workgroup. The frozen 2D encoder's output enters as a fixed map (MIOpen is outside this
     library); the pyramid is built once per run from the same rotations."""
     import mvkpconv
     syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
@@ -212,7 +216,7 @@ def test_deterministic_mode_step_is_bit_reproducible(variant, spheres):
     try:
         torch.manual_seed(0)
         np.random.seed(0)
-        cfg = syn.make_config(variant)
+        cfg = syn.make_config(variant, deformable=deformable, modulated=deformable)
         sph = [syn.raw_sphere(seed=i, radius=0.7, density=3000.0) for i in range(spheres)]
         views = [syn.sphere_views(s, nv=3, h=60, w=80) for s in sph] if variant != "baseline" else None
         staged = syn.stage_spheres(sph, dev, views)

@@ -40,9 +40,6 @@ def parse():
     ap.add_argument("--views", type=int, default=3)
     ap.add_argument("--in-radius", type=float, default=1.2, help="sphere radius (1.2 -> ~20 k points, 1.7 -> ~40 k)")
     ap.add_argument("--deformable", action="store_true")
-    ap.add_argument("--features", default="f32", choices=["f32", "f16"],
-                    help="f16: BASELINE config 5's fp16-feature mode of every KPConv layer (fp16 features / aggregate / "
-                         "weights, fp16 MFMA contraction, f32 accumulation and f32 everything else)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dev", action="store_true",
                     help="development run: accept the knobs that change what a captured step contains (MVK_BENCH_DIAG, "
@@ -170,7 +167,6 @@ def main():
         torch.backends.cudnn.benchmark = True
     import mvkpconv
     syn, ops, stepmod = mvkpconv.sub("synthetic"), mvkpconv.sub("ops"), mvkpconv.sub("step")
-    ops.set_feature_dtype(torch.float16 if args.features == "f16" else torch.float32)
     torch.manual_seed(1234)           # same initial weights on every rank
     np.random.seed(1234)
     cfg = syn.make_config(args.workload, deformable=args.deformable, modulated=args.deformable and args.workload == "late")
@@ -284,7 +280,7 @@ def main():
             "metric": "input points/s through MV-KPConv KPFCNN forward+backward (pyramid + fusion + fwd + bwd + SGD)",
             "value": total_points / dt, "unit": "points/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32" if args.features == "f32" else "f16 features / f32 accumulate",
+            "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "%s_kpfcnn5_sphere%dk_x%d_per_gpu%s" % (
                 args.workload + ("_fusion" if fusion else ""), int(round(sum(lens) / max(args.spheres, 1) / 1000.0)),
@@ -297,7 +293,7 @@ def main():
                 "input_lookahead_batches": int(getattr(step, "lookahead", 0)),
                 "capacity_overflow": bool(getattr(step, "state", {}).get("overflow", False))},
             "roofline": roofline(prof),
-            "contraction": mfma_report(contraction, args.features),
+            "contraction": mfma_report(contraction),
         }
         if not args.no_cpu_baseline:           # timed on rank 0 at N = 1 only (the other ranks would sit in the barrier)
             res["cpu_baseline"] = cpu_baseline(cfg, net, staged, limits, spheres, args) if world == 1 else None
@@ -455,20 +451,17 @@ def roofline_detail(prof):
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD (= f32 vector peak)
 
 
-MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16 MFMA peak of the MI355X (the vendor's headline figure includes 2:1 sparsity)
-
-
-def mfma_report(contraction, features="f32"):
-    """The dense K x Cin x Cout contraction (forward, gemm_f32_mfma / gemm_f16_mfma NN): all launches of the
-    instrumented steps together, and the largest one, against the MFMA peak of the operand type."""
+def mfma_report(contraction):
+    """The dense K x Cin x Cout contraction (forward, gemm_f32_mfma NN / gemm_f32_stream): all launches of the
+    instrumented steps together, and the largest one, against the f32 MFMA peak."""
     if not contraction:
         return None
-    peak = MFMA_F32_PEAK_TFLOPS if features == "f32" else MFMA_F16_PEAK_TFLOPS
+    peak = MFMA_F32_PEAK_TFLOPS
     tot_f = sum(r["flops_per_launch"] * r["launches"] for r in contraction.values())
     tot_t = sum(r["total_ms"] for r in contraction.values()) * 1e-3
     (M, Kd, N), big = max(contraction.items(), key=lambda kv: kv[1]["flops_per_launch"])
     big_tf = big["flops_per_launch"] / (big["total_ms"] / big["launches"] * 1e-3) / 1e12
-    return {"bound": "mfma", "dtype": features, "achieved": tot_f / tot_t / 1e12, "peak": peak,
+    return {"bound": "mfma", "dtype": "f32", "achieved": tot_f / tot_t / 1e12, "peak": peak,
             "unit": "TFLOP/s", "frac": tot_f / tot_t / 1e12 / peak,
             "largest": {"M": M, "K": Kd, "N": N, "TFLOP/s": big_tf, "avg_launch_us": big["total_ms"] / big["launches"] * 1e3}}
 

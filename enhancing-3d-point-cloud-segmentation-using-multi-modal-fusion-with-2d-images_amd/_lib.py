@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmvkpconv.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -58,15 +58,8 @@ _SIGNATURES = {
                                         _vp, _vp, _vp, _vp, _vp]),
     "mvk_kpconv_gather_fwd_ordered": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
                                                 _vp, _vp, _vp, _vp, _vp, _vp]),
-    "mvk_kpconv_gather_fwd_f16": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
-                                            _vp, _vp]),
-    "mvk_kpconv_gather_fwd_f16_ld": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _i,
-                                               _vp, _i64, _vp]),
     "mvk_gemm_f32_stream_plan": (C.c_int, [_i64, _i, _i64, _vp]),
     "mvk_gemm_f32_stream": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i, _i64, _vp, _vp, _vp]),
-    "mvk_gemm_f16_stream_plan": (C.c_int, [_i64, _i, _i64, _vp]),
-    "mvk_gemm_f16_stream": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i64, _vp, _vp, _vp]),
-    "mvk_round_weights_f16": (C.c_int, [_vp, _i64, _i, _i64, _vp, _vp, _vp]),
     "mvk_bn_single_launch_rows": (C.c_int, [_i]),
     "mvk_kpconv_gather_plan": (C.c_int, [_i64, _i64, _i, _i, _i, _i, _vp]),
     "mvk_kpconv_scatter_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _i, _vp, _i, _f, _i, _i,
@@ -94,7 +87,6 @@ _SIGNATURES = {
     "mvk_gemm_f32_tn_grouped_split": (C.c_int, [C.c_int64, C.c_int64, C.c_int64]),
     "mvk_gemm_f32_tn_grouped_plan": (C.c_int, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mvk_gemm_f32_tn_grouped": (C.c_int, [_vp, _i, _i, _i64, _i64, _vp]),
-    "mvk_gemm_f16": (C.c_int, [_vp, _i, _vp, _i, _vp, _i, _i64, _i64, _i64, _i, _i, _i, _vp]),
     "mvk_kpconv_gather_rev_deform": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "mvk_kpconv_deform_doff": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i, _i, _vp, _i, _vp, _i, _f, _i, _vp, _vp, _vp, _vp,
                                         _vp, _vp]),

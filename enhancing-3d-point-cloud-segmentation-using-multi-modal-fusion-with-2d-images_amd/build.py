@@ -18,7 +18,6 @@ SOURCES = [
     ("error.cpp", []),
     ("kpconv.hip", []),
     ("gemm.hip", []),
-    ("gemm16.hip", []),
     ("gemm32s.hip", []),
     ("pool.hip", []),
     ("bn.hip", []),

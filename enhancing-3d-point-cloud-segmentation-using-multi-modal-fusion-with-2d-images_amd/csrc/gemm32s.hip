@@ -1,5 +1,5 @@
-// f32 streaming contraction for the big rigid layers (v_mfma_f32_16x16x4_f32, exact f32): the f32 twin of
-// gemm_f16_stream (gemm16.hip) for y [M, N] = A [M, Kd] . W [Kd, N] with M in the tens of thousands, N = 32 or 64 and
+// f32 streaming contraction for the big rigid layers (v_mfma_f32_16x16x4_f32, exact f32)
+// for y [M, N] = A [M, Kd] . W [Kd, N] with M in the tens of thousands, N = 32 or 64 and
 // Kd <= 1024 (reference shape contract models/blocks.py:370-374) -- the first layers of the network, where the tiled
 // kernel of gemm.hip (every workgroup re-stages its slice of W through LDS behind a barrier per 32-deep step) reaches
 // 0.36-0.47 of the f32 MFMA peak.
@@ -11,7 +11,7 @@
 //     permutation on both operands), two tiles in flight per wave through two register sets;
 //   * lane c owns the columns CT c .. CT c + CT - 1 (the "column tiles" of its accumulators), so a weight fragment for
 //     all of them is one 16-byte load and the partial blocks go to LDS as 16-byte rows; the eight waves' partial blocks
-//     are added in a fixed order (deterministic, no atomics) and stored as whole rows (hidden stores, see gemm16.hip);
+//     are added in a fixed order (deterministic, no atomics) and stored as whole rows (hidden stores, see store_f4_hidden32);
 //   * BatchNorm statistics of the output for the workgroup's rows in the same pass (gemm.hip's partials format).
 #include <stdlib.h>
 
@@ -31,7 +31,13 @@ struct S32Args {
   float* bn_part;
 };
 
-__device__ __forceinline__ void store_f4_hidden32(float* p, float4 v) {     // see gemm16.hip: store_f4_hidden
+// A 16-byte store the compiler does not see: global stores share the vmcnt counter with the loads and may retire out of
+// order with them, so a store the compiler knows about between a load and its use turns the counted wait in front of
+// that use into a wait for EVERYTHING in flight (measured: one drained pipeline per store phase). Hidden from its
+// bookkeeping the waits stay counted; they are still sufficient: a wait for "at most k outstanding" then returns later
+// than needed (the counter also holds the stores), never earlier -- loads return in order among themselves, so with s
+// hidden stores and j older loads, <= k outstanding means at least j + 1 loads have returned.
+__device__ __forceinline__ void store_f4_hidden32(float* p, float4 v) {
   typedef float f4v __attribute__((ext_vector_type(4)));
   const f4v q = {v.x, v.y, v.z, v.w};
   // s_nop 2: the store reads its data registers late; a VALU write to them within two wait states would be stored
@@ -225,7 +231,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gemm_f32_stream(const S32Args a) {
 
 // out[0] = 1 when C [M,N] = A [M,Kd] . B [Kd,N] runs on the streaming kernel, out[1] = 16-row tiles per workgroup
 // (= statistics block rows / 16), out[2] = workgroups, out[3] = 0.
-// Measured (tools/gemm16_bench.py, profiles/r03_gemm_stream_bench.txt): the kernel reaches 0.44 of the f32 MFMA peak
+// Measured (round 3, profiles/r03_gemm_stream_bench.txt): the kernel reaches 0.44 of the f32 MFMA peak
 // on 19 464 x 990 x 64 (35.4 us) -- no better than the tiled kernel of gemm.hip (33.8 us, 0.47) -- and 0.60 on
 // 171 000 x 990 x 64 (229 against 252 us); with 32 output columns or reductions of <= 512 it loses (15 against 13 us,
 // 44 against 33 us). Both kernels sit at what the matrix pipe sustains here with f32 operands (v_mfma_f32_16x16x4_f32:

@@ -40,7 +40,6 @@ struct KPParams {
   float extent;
   int influence, aggregation;
   int zero_skip;         // gather: neighbours without any influence become shadow entries (development switch MVK_GATHER_ZEROSKIP)
-  int64_t ldA;           // vector gather: row stride of the aggregate in elements (>= K*Cin; the columns beyond K*Cin are written as zeros)
   const int32_t* order;  // vector gather (rigid): work list -- the wave working on slots w .. w+PPW-1 takes the points order[w ..] (a
                          // spatially sorted permutation of 0 .. Nq-1); results land in the points' own rows. null: slot = point
   int xcd_blocks;        // with `order`: the first xcd_blocks workgroups are dealt to the 8 XCDs as 8 contiguous runs of the work list
@@ -433,22 +432,12 @@ __global__ __launch_bounds__(256) void kpconv_gather_mfma(KPParams P) {
 constexpr int GWPB = 4;
 
 
-// 4 consecutive channels of a feature row / of the aggregate, stored as f32 or (fp16-feature mode) f16
-typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+// 4 consecutive channels of a feature row / of the aggregate
 typedef float f4v __attribute__((ext_vector_type(4)));        // accumulator quad (a native vector: usable as an asm operand)
 __device__ __forceinline__ float4 as_float4(f4v v) { return make_float4(v.x, v.y, v.z, v.w); }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float4 ld4(const _Float16* p) {
-  const half4_t h = *reinterpret_cast<const half4_t*>(p);   // Cin even -> 4-byte aligned, enough for dwordx2
-  return make_float4((float)h[0], (float)h[1], (float)h[2], (float)h[3]);
-}
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ void st4(_Float16* p, float4 v) {
-  half4_t h;
-  h[0] = (_Float16)v.x; h[1] = (_Float16)v.y; h[2] = (_Float16)v.z; h[3] = (_Float16)v.w;
-  *reinterpret_cast<half4_t*>(p) = h;
-}
 
 // DEFORM (deformable layers, blocks.py:286-327; LPP >= 4 so that PPW <= 16): every point's deformed kernel points
 // (kernel point + its offset) live in LDS, phase A reads them instead of the wave-uniform rigid ones, drops the
@@ -473,13 +462,11 @@ constexpr int DPPW = 16;      // most points per wave of the deformable variant
 // x 15 kernel points are spread over the same lanes -- lane l < 15 keeps kernel point l's TAIL sums and adds, per
 // neighbour, ITS weight (one ds_read_b32 of the row) times the row's TAIL trailing values (the same address for the
 // whole group). A 17th lane per point for two channels would cost a quarter of the launch (3 points per wave, not 4).
-template <int NCH, bool IDX64, bool FAST, typename XT = float, bool VEC = true, bool DEFORM = false, int FUB = 0, int TAIL = 0>
+template <int NCH, bool IDX64, bool FAST, bool DEFORM = false, int FUB = 0, int TAIL = 0>
 __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec(KPParams P, int LPP, int PPW, int HC,
                                                                                   int SW, int B1) {
   constexpr bool FASTLD = FUB > 0;
-  constexpr bool PADDED = sizeof(XT) == 2;      // fp16 aggregate: rows may carry a stride (P.ldA) and a zero pad
   static_assert(TAIL == 0 || (FASTLD && NCH == 1 && !DEFORM), "trailing channels: branch-free rigid variant only");
-  static_assert(TAIL == 0 || !PADDED, "trailing channels: f32 rows only");
   constexpr int TL = TAIL > 0 ? TAIL : 1;
   // Sharing workgroups (all of them when DEFORM; with SW > 1 those from block B1 on): the waves of the workgroup
   // share the same PPW points and take every nwv-th neighbour chunk; wave 0 adds the partial aggregates through
@@ -488,9 +475,8 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
   // waves of a quarter of the length, which fill the chip.
   const int nwv = blockDim.x >> 6;
   const bool share = DEFORM || (FASTLD && SW > 1 && (int)blockIdx.x >= B1);
-  const XT* __restrict__ X = reinterpret_cast<const XT*>(P.x);      // features [Ns,Cin]
-  XT* __restrict__ Aout = reinterpret_cast<XT*>(P.A);                // aggregate [Nq,K,Cin]
-  constexpr bool vec_ok = VEC;   // false: f16 rows of odd length (2-byte aligned), scalar loads
+  const float* __restrict__ X = P.x;      // features [Ns,Cin]
+  float* __restrict__ Aout = P.A;         // aggregate [Nq,K,Cin]
   constexpr int UB = FASTLD ? FUB : (NCH == 1 ? 6 : 4);  // feature rows in flight per lane
   __shared__ __align__(16) float wl_all[GWPB][64 * 16 + 64 * 4];
   __shared__ float d2_all[DEFORM ? GWPB : 1][DEFORM ? 64 * 16 + DPPW * 16 : 1];  // squared distances of the chunk (rows skewed by point)
@@ -544,10 +530,10 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
     c_on[c] = c4 < P.Cin;
     c4e[c] = c_on[c] ? (uint32_t)min(c4, P.Cin - 4) : 0u;
   }
-  const uint32_t row_bytes = (uint32_t)P.Cin * (uint32_t)sizeof(XT);
+  const uint32_t row_bytes = (uint32_t)P.Cin * 4u;
   uint64_t batch_mask0 = 0;     // phase-A lanes of the columns 0 .. UB-1 of every point (shifted by the batch's first column)
   for (int pp = 0; pp < PPW; ++pp) batch_mask0 |= ((1ull << UB) - 1ull) << (pp * HC);
-  const uint32_t tail_bytes = (uint32_t)(P.Cin - TAIL) * (uint32_t)sizeof(XT);   // TAIL: offset of the trailing channels
+  const uint32_t tail_bytes = (uint32_t)(P.Cin - TAIL) * 4u;   // TAIL: offset of the trailing channels
   const bool t_on = cl < KMAX - 1;                                               // TAIL: this lane keeps kernel point cl
   float acc_t[TL];
 #pragma unroll
@@ -710,9 +696,9 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
       for (int hb = 0; hb < HCP; hb += UB) {
         // FASTLD: a batch whose columns are shadow entries for every point of the wave (the tail of the sorted
         // neighbour rows: H is the 90th-percentile width, the mean row holds 3/4 of it) is skipped as a whole
-        // (only in the instantiations where the extra branch leaves the register allocation alone: with fp16 rows, 5-row
+        // (only in the instantiations where the extra branch leaves the register allocation alone: with 5-row
         // batches or three trailing channels it costs 30 spilled registers and up to a third of the speed)
-        constexpr bool SKIP = FASTLD && std::is_same<XT, float>::value && NCH == 1 &&
+        constexpr bool SKIP = FASTLD && NCH == 1 &&
                               (FUB == 6 || FUB == 7 || FUB == 8 || (FUB == 4 && (TAIL == 1 || TAIL == 2)));
         if (SKIP && (live & (batch_mask0 << hb)) == 0ull) continue;
         int jj[UB];
@@ -725,11 +711,11 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
           for (int u = 0; u < UB; ++u) {
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {   // byte offset < 2^32, row index and row bytes < 2^24 (checked by the host)
-              const uint32_t off = __umul24((uint32_t)max(jj[u], 0), row_bytes) + c4e[c] * (uint32_t)sizeof(XT);
-              xv[u][c] = ld4(reinterpret_cast<const XT*>(reinterpret_cast<const char*>(X) + off));
+              const uint32_t off = __umul24((uint32_t)max(jj[u], 0), row_bytes) + c4e[c] * 4u;
+              xv[u][c] = ld4(reinterpret_cast<const float*>(reinterpret_cast<const char*>(X) + off));
             }
             if (TAIL > 0) {
-              const XT* pt = reinterpret_cast<const XT*>(reinterpret_cast<const char*>(X) +
+              const float* pt = reinterpret_cast<const float*>(reinterpret_cast<const char*>(X) +
                                                          (__umul24((uint32_t)max(jj[u], 0), row_bytes) + tail_bytes));
 #pragma unroll
               for (int t = 0; t < TL; ++t) xt[u][t] = (float)pt[t];
@@ -745,8 +731,8 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
             const int c4 = (cl + c * LPP) * 4;
             xv[u][c] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (jj[u] >= 0 && c4 < P.Cin) {
-              const XT* xr = X + (int64_t)jj[u] * P.Cin + c4;
-              if (c4 + 3 < P.Cin && vec_ok) {
+              const float* xr = X + (int64_t)jj[u] * P.Cin + c4;
+              if (c4 + 3 < P.Cin) {
                 xv[u][c] = ld4(xr);
               } else {  // ragged tail of a row whose length is not a multiple of 4
                 xv[u][c].x = (float)xr[0];
@@ -888,32 +874,23 @@ __global__ __launch_bounds__(64 * GWPB, NCH == 1 ? 4 : 2) void kpconv_gather_vec
         for (int kk = 0; kk < KMAX - 1; ++kk) {
           if (kk < P.K) {
             // (the f32 instantiations keep the dense [Nq,K,Cin] addressing: they sit at their register limit)
-            XT* o = PADDED ? Aout + n * P.ldA + kk * P.Cin + c4 : Aout + (n * P.K + kk) * P.Cin + c4;
-            if (FASTLD || (c4 + 3 < P.Cin && vec_ok)) {
+            float* o = Aout + (n * P.K + kk) * P.Cin + c4;
+            if (FASTLD || c4 + 3 < P.Cin) {
               st4(o, as_float4(acc[c][kk]));
             } else {
-              o[0] = (XT)acc[c][kk].x;
-              if (c4 + 1 < P.Cin) o[1] = (XT)acc[c][kk].y;
-              if (c4 + 2 < P.Cin) o[2] = (XT)acc[c][kk].z;
-              if (c4 + 3 < P.Cin) o[3] = (XT)acc[c][kk].w;
+              o[0] = acc[c][kk].x;
+              if (c4 + 1 < P.Cin) o[1] = acc[c][kk].y;
+              if (c4 + 2 < P.Cin) o[2] = acc[c][kk].z;
+              if (c4 + 3 < P.Cin) o[3] = acc[c][kk].w;
             }
           }
         }
       }
     }
     if (TAIL > 0 && cl < P.K && t_on) {      // lane cl holds kernel point cl's sums over the trailing channels
-      XT* o = Aout + (n * P.K + cl) * P.Cin + (P.Cin - TAIL);       // (TAIL: f32 only)
+      float* o = Aout + (n * P.K + cl) * P.Cin + (P.Cin - TAIL);
 #pragma unroll
-      for (int t = 0; t < TL; ++t) o[t] = (XT)acc_t[t];
-    }
-    if (PADDED) {
-      // padded rows (fp16 aggregate for the streaming contraction, gemm16.hip: row stride a multiple of 32 halfs):
-      // the columns beyond K*Cin are zeros, written by the point's first lanes
-      const int pad = (int)(P.ldA - (int64_t)P.K * P.Cin);
-      if (pad > 0 && cl < pad) {
-        XT* o = Aout + n * P.ldA + (int64_t)P.K * P.Cin;
-        for (int t = cl; t < pad; t += LPP) o[t] = (XT)0.f;
-      }
+      for (int t = 0; t < TL; ++t) o[t] = acc_t[t];
     }
   }
 }
@@ -1139,18 +1116,17 @@ struct VecPlan {
   int64_t wgs;        // workgroups
 };
 
-VecPlan plan_vec(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, bool fast, bool vec, bool deform) {
+VecPlan plan_vec(int64_t Nq, int64_t Ns, int H, int Cin, bool fast, bool deform) {
   VecPlan v{};
   const int NCH = Cin <= 256 ? 1 : 2;
   static const bool fastld_on = getenv("MVK_GATHER_FASTLD") == nullptr || atoi(getenv("MVK_GATHER_FASTLD")) != 0;
   static const bool tail_on = getenv("MVK_GATHER_TAIL") == nullptr || atoi(getenv("MVK_GATHER_TAIL")) != 0;
-  const bool branch_free = fastld_on && fast && vec && Ns < (1 << 24) &&
-                           (uint64_t)Ns * (uint64_t)Cin * (uint64_t)elem_bytes < (1ull << 32) - 64;
-  // first choice for f32 rows of 4 m + t channels (m >= 15, t = 1..3): m lanes per point and the t trailing channels
+  const bool branch_free = fastld_on && fast && Ns < (1 << 24) && (uint64_t)Ns * (uint64_t)Cin * 4ull < (1ull << 32) - 64;
+  // first choice for rows of 4 m + t channels (m >= 15, t = 1..3): m lanes per point and the t trailing channels
   // beside the quads -- if the resulting chunk length is a multiple of the 4-row batch; else ceil(Cin / 4) lanes
   // (measured: 19 464 points x 66 channels 72 -> 67 us; 171 k points 484 -> 495 us -- the 4-row batches hide less
   // latency once the feature table no longer sits in the caches: hence the row limit)
-  for (int with_tail = (tail_on && branch_free && !deform && elem_bytes == 4 && NCH == 1 && Cin >= 60 && Cin % 4 != 0 &&
+  for (int with_tail = (tail_on && branch_free && !deform && NCH == 1 && Cin >= 60 && Cin % 4 != 0 &&
                         Ns <= 65536) ? 1 : 0;
        with_tail >= 0; --with_tail) {
     const int c4 = with_tail ? Cin / 4 : (Cin + 3) / 4;
@@ -1203,30 +1179,30 @@ VecPlan plan_vec(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, bool fa
   return v;
 }
 
-template <int NCH, typename XT = float, bool VEC = true, bool DEFORM = false>
+template <int NCH, bool DEFORM = false>
 int launch_vec(KPParams P, int idx64, hipStream_t st) {
   const bool fast = P.influence == MVK_INFL_LINEAR && P.aggregation == MVK_AGG_SUM;
-  const VecPlan v = plan_vec(P.Nq, P.Ns, P.H, P.Cin, (int)sizeof(XT), fast, VEC, DEFORM);
+  const VecPlan v = plan_vec(P.Nq, P.Ns, P.H, P.Cin, fast, DEFORM);
   static const bool xcd_runs = getenv("MVK_GATHER_XCD_RUNS") == nullptr || atoi(getenv("MVK_GATHER_XCD_RUNS")) != 0;
   if (DEFORM) P.order = nullptr;
   P.xcd_blocks = (P.order != nullptr && xcd_runs) ? (int)(v.SW > 1 ? v.B1 : v.wgs) : 0;
   const int LPP = v.LPP, PPW = v.PPW, HC = v.HC, fub = v.fub, SW = v.SW, B1 = v.B1, tail = v.tail;
   dim3 grid((unsigned)v.wgs), block(64 * v.nw);
 #define LV(I64, F, L) \
-  hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F, XT, VEC, DEFORM, L>), grid, block, 0, st, P, LPP, PPW, HC, SW, B1)
+  hipLaunchKernelGGL((kpconv_gather_vec<NCH, I64, F, DEFORM, L>), grid, block, 0, st, P, LPP, PPW, HC, SW, B1)
 #define LVT(I64, T)                                                                                                   \
-  hipLaunchKernelGGL((kpconv_gather_vec<1, I64, true, float, true, false, 4, (TAIL_OK ? T : 0)>), grid, block, 0, st, P, LPP, \
+  hipLaunchKernelGGL((kpconv_gather_vec<1, I64, true, false, 4, (TAIL_OK ? T : 0)>), grid, block, 0, st, P, LPP, \
                      PPW, HC, SW, B1)
-  constexpr bool TAIL_OK = NCH == 1 && VEC && !DEFORM && std::is_same<XT, float>::value;
+  constexpr bool TAIL_OK = NCH == 1 && !DEFORM;
 #define LVF(I64)                                                                            \
   if (TAIL_OK && tail == 1 && fub == 4) LVT(I64, 1);                                        \
   else if (TAIL_OK && tail == 2 && fub == 4) LVT(I64, 2);                                   \
   else if (TAIL_OK && tail == 3 && fub == 4) LVT(I64, 3);                                   \
-  else if (NCH == 2 && fub == 4) LV(I64, true, (VEC && NCH == 2 ? 4 : 0));                  \
-  else if (fub == 8) LV(I64, true, (VEC && NCH == 1 ? 8 : 0));                              \
-  else if (fub == 7) LV(I64, true, (VEC && NCH == 1 ? 7 : 0));                              \
-  else if (fub == 6) LV(I64, true, (VEC && NCH == 1 ? 6 : 0));                              \
-  else if (fub == 5) LV(I64, true, (VEC && NCH == 1 ? 5 : 0));                              \
+  else if (NCH == 2 && fub == 4) LV(I64, true, (NCH == 2 ? 4 : 0));                  \
+  else if (fub == 8) LV(I64, true, (NCH == 1 ? 8 : 0));                              \
+  else if (fub == 7) LV(I64, true, (NCH == 1 ? 7 : 0));                              \
+  else if (fub == 6) LV(I64, true, (NCH == 1 ? 6 : 0));                              \
+  else if (fub == 5) LV(I64, true, (NCH == 1 ? 5 : 0));                              \
   else if (fast) LV(I64, true, 0);                                                          \
   else LV(I64, false, 0);
   if (idx64) {
@@ -1252,19 +1228,36 @@ int mfma_tiles(int64_t Ns, int Cin, int K, int influence, int aggregation) {
   return 16;                          // wider rows: gridDim.y blocks of 256 channels
 }
 
-template <int KPM>
-bool launch_mfma(KPParams P, int idx64, hipStream_t st) {
-  const int T = mfma_tiles(P.Ns, P.Cin, P.K, P.influence, P.aggregation);
-  if (T == 0) return false;
-  static const bool xcd_runs = getenv("MVK_GATHER_XCD_RUNS") == nullptr || atoi(getenv("MVK_GATHER_XCD_RUNS")) != 0;
+// launch shape of the MFMA gather (shared by the launch and by mvk_kpconv_gather_plan): T = 0: not on this kernel
+struct MfmaPlan {
+  int T, SW;               // accumulator tiles per wave; waves sharing one point (1 or 4)
+  int64_t wgs, blocks_y;   // grid
+};
+MfmaPlan plan_mfma(int64_t Nq, int64_t Ns, int H, int Cin, int K, int influence, int aggregation, bool deform) {
+  MfmaPlan m{};
+  static const bool mfma_deform = getenv("MVK_DEFORM_MFMA") == nullptr || atoi(getenv("MVK_DEFORM_MFMA")) != 0;
+  if (deform && !mfma_deform) return m;
+  m.T = mfma_tiles(Ns, Cin, K, influence, aggregation);
+  if (m.T == 0) return m;
   // few points with long rows: the four waves of a workgroup share one point (kernel comment)
   static const int sw_env = getenv("MVK_GATHER_MFMA_SHARE") ? atoi(getenv("MVK_GATHER_MFMA_SHARE")) : -1;
-  const int64_t blocks_y = cdiv64(P.Cin, 16 * T);
-  const bool can_share = T >= 4 && T != 5;          // (instantiated for the tile counts the coarse levels use)
-  const int SW = !can_share ? 1 : (sw_env >= 0 ? (sw_env > 1 ? 4 : 1) : ((P.H >= 128 || (P.Nq * blocks_y <= 512 && P.H >= 32)) ? 4 : 1));
-  const int64_t wgs = SW > 1 ? P.Nq : cdiv64(P.Nq, 4);
+  m.blocks_y = cdiv64(Cin, 16 * m.T);
+  const bool can_share = m.T >= 4 && m.T != 5;          // (instantiated for the tile counts the coarse levels use)
+  m.SW = !can_share ? 1 : (sw_env >= 0 ? (sw_env > 1 ? 4 : 1) : ((H >= 128 || (Nq * m.blocks_y <= 512 && H >= 32)) ? 4 : 1));
+  m.wgs = m.SW > 1 ? Nq : cdiv64(Nq, 4);
+  return m;
+}
+
+template <int KPM>
+bool launch_mfma(KPParams P, int idx64, hipStream_t st) {
+  const MfmaPlan mp = plan_mfma(P.Nq, P.Ns, P.H, P.Cin, P.K, P.influence, P.aggregation, KPM == 1);
+  const int T = mp.T;
+  if (T == 0) return false;
+  static const bool xcd_runs = getenv("MVK_GATHER_XCD_RUNS") == nullptr || atoi(getenv("MVK_GATHER_XCD_RUNS")) != 0;
+  const int SW = mp.SW;
+  const int64_t wgs = mp.wgs;
   P.xcd_blocks = (P.order != nullptr && xcd_runs) ? (int)wgs : 0;
-  dim3 grid((unsigned)wgs, (unsigned)blocks_y), block(256);
+  dim3 grid((unsigned)wgs, (unsigned)mp.blocks_y), block(256);
 #define LM1(TT, MD, SH)                                                                              \
   if (idx64) hipLaunchKernelGGL((kpconv_gather_mfma<TT, MD, true, KPM, SH>), grid, block, 0, st, P);     \
   else hipLaunchKernelGGL((kpconv_gather_mfma<TT, MD, false, KPM, SH>), grid, block, 0, st, P)
@@ -1366,7 +1359,7 @@ extern "C" int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const f
   P.order = order;        // used by the vector kernels of rigid layers (5 <= Cin <= 512); the other kernels work in row order
   P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets; P.min_d2 = min_d2; P.min_arg = min_arg;
   P.A = A_out; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
-  P.influence = influence; P.aggregation = aggregation; P.ldA = (int64_t)K * Cin;
+  P.influence = influence; P.aggregation = aggregation;
   static const int zero_skip = getenv("MVK_GATHER_ZEROSKIP") ? atoi(getenv("MVK_GATHER_ZEROSKIP")) : 1;
   P.zero_skip = zero_skip;
   if (H == 0) {
@@ -1375,15 +1368,14 @@ extern "C" int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const f
   }
   if (offsets != nullptr) {
     static const bool vec_deform = getenv("MVK_DEFORM_VEC") == nullptr || atoi(getenv("MVK_DEFORM_VEC")) != 0;
-    static const bool mfma_deform = getenv("MVK_DEFORM_MFMA") == nullptr || atoi(getenv("MVK_DEFORM_MFMA")) != 0;
     KPParams Pm = P;
     Pm.order = nullptr;           // (the deformable levels are the coarse ones: no work list)
-    if (mfma_deform && launch_mfma<1>(Pm, idx64, st)) {
+    if (launch_mfma<1>(Pm, idx64, st)) {
       // (round 5: the deformable forward on the matrix pipe as well, KPM 1 of kpconv_gather_mfma)
     } else if (vec_deform && Cin >= 13 && Cin <= 256) {          // 64 / ceil(Cin/4) <= DPPW points per wave
-      launch_vec<1, float, true, true>(P, idx64, st);
+      launch_vec<1, true>(P, idx64, st);
     } else if (vec_deform && Cin > 256 && Cin <= 512) {
-      launch_vec<2, float, true, true>(P, idx64, st);
+      launch_vec<2, true>(P, idx64, st);
     } else {
       launch_lane_channel<0, true>(P, idx64, st);
     }
@@ -1434,7 +1426,7 @@ extern "C" int mvk_kpconv_gather_rev_deform(const float* s, int64_t Ns, const fl
   KPParams P{};
   // roles transposed: the "queries" of the launch are the layer's supports, its "supports" the layer's query rows
   P.q = s; P.s = q; P.idx = rev; P.x = g; P.kp = kp; P.A = A2; P.Nq = Ns; P.Ns = Nq; P.H = Hr; P.Cin = C; P.K = K;
-  P.extent = extent; P.influence = MVK_INFL_LINEAR; P.aggregation = MVK_AGG_SUM; P.ldA = (int64_t)K * C;
+  P.extent = extent; P.influence = MVK_INFL_LINEAR; P.aggregation = MVK_AGG_SUM;
   P.order = order; P.nb_offsets = offsets; P.nb_mod = mod;
   MVK_REQUIRE(launch_mfma<2>(P, rev64, st), "kpconv rev deform: shape not supported by the MFMA gather (C >= 5, Nq * C < 2^32)");
   MVK_CHECK_HIP(hipGetLastError());
@@ -1454,7 +1446,7 @@ extern "C" int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s
   P.q = q; P.s = s; P.idx = idx; P.x = x; P.kp = kp; P.offsets = offsets;
   P.A = const_cast<float*>(dA); P.dx = dx; P.g_min_d2 = g_min_d2; P.d_offsets = d_offsets;
   P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
-  P.influence = influence; P.aggregation = aggregation; P.ldA = (int64_t)K * Cin;
+  P.influence = influence; P.aggregation = aggregation;
   if (offsets != nullptr) {
     MVK_REQUIRE(x != nullptr && d_offsets != nullptr, "kpconv bwd: deformable needs x and d_offsets");
     MVK_REQUIRE(aggregation == MVK_AGG_SUM, "kpconv bwd: deformable + 'closest' aggregation has no offset gradient path");
@@ -1470,67 +1462,24 @@ extern "C" int mvk_kpconv_scatter_bwd(const float* q, int64_t Nq, const float* s
   return 0;
 }
 
-// Launch geometry mvk_kpconv_gather_fwd (elem_bytes 4) / mvk_kpconv_gather_fwd_f16 (elem_bytes 2) use for a layer
+// Launch geometry mvk_kpconv_gather_fwd uses for a layer (elem_bytes: 4, the f32 rows -- the only row type)
 // with linear influence and sum aggregation: out[0..6] = lanes per point, points per wave, rows per batch of the
 // branch-free variant (0 = general variant), first sharing workgroup, waves per workgroup, workgroups, grid
 // threads (what a kernel trace reports). out[5] = 0: the layer runs on another kernel (one point per wave, or one
 // point per lane for rows of <= 4 channels).
 extern "C" int mvk_kpconv_gather_plan(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, int deformable,
                                       int64_t* out) {
-  MVK_REQUIRE(out != nullptr && (elem_bytes == 2 || elem_bytes == 4), "kpconv plan: bad arguments");
+  MVK_REQUIRE(out != nullptr && elem_bytes == 4, "kpconv plan: bad arguments (feature rows are f32: elem_bytes 4)");
   for (int i = 0; i < 8; ++i) out[i] = 0;
-  if (!deformable && elem_bytes == 4) {
-    const int T = mfma_tiles(Ns, Cin, 15, MVK_INFL_LINEAR, MVK_AGG_SUM);
-    if (Nq > 0 && T > 0) {        // the MFMA gather: one wave per point, four per workgroup, channel blocks in gridDim.y
-      const int64_t by = cdiv64(Cin, 16 * T);
-      const bool share = T >= 4 && T != 5 && (H >= 128 || (Nq * by <= 512 && H >= 32));        // (launch_mfma: four waves share a point)
-      out[0] = 64; out[1] = 1; out[2] = T; out[3] = share ? 0 : -1; out[4] = 4; out[5] = (share ? Nq : cdiv64(Nq, 4)) * by;
-      out[6] = out[5] * 256; out[7] = 1;
-      return 0;
-    }
+  const MfmaPlan mp = plan_mfma(Nq, Ns, H, Cin, 15, MVK_INFL_LINEAR, MVK_AGG_SUM, deformable != 0);
+  if (Nq > 0 && mp.T > 0) {        // the MFMA gather: four waves per workgroup (one point each, or sharing one), channel blocks in gridDim.y
+    out[0] = 64; out[1] = 1; out[2] = mp.T; out[3] = mp.SW > 1 ? 0 : -1; out[4] = 4; out[5] = mp.wgs * mp.blocks_y;
+    out[6] = out[5] * 256; out[7] = 1;
+    return 0;
   }
-  if (Nq <= 0 || Cin <= 0 || Cin > 512 || (deformable && Cin < 13) || (!deformable && elem_bytes == 4 && Cin <= 4)) return 0;
-  const VecPlan v = plan_vec(Nq, Ns, H, Cin, elem_bytes, true, elem_bytes == 4 || (Cin & 1) == 0, deformable != 0);
+  if (Nq <= 0 || Cin <= 0 || Cin > 512 || (deformable && Cin < 13) || (!deformable && Cin <= 4)) return 0;
+  const VecPlan v = plan_vec(Nq, Ns, H, Cin, true, deformable != 0);
   out[0] = v.LPP; out[1] = v.PPW; out[2] = v.fub; out[3] = v.B1; out[4] = v.nw; out[5] = v.wgs;
   out[6] = v.wgs * 64 * v.nw;
   return 0;
-}
-
-// fp16-feature mode of the rigid gather (BASELINE config 5): x [Ns,Cin] and A_out [Nq,K,Cin] are fp16 in
-// memory (half the gather and aggregate bytes), correlation weights and the aggregation sums stay f32.
-// ldA: row stride of A_out in halfs (>= K*Cin; the streaming contraction of gemm16.hip wants a multiple of 32, the
-// pad columns are written as zeros).
-extern "C" int mvk_kpconv_gather_fwd_f16_ld(const float* q, int64_t Nq, const float* s, int64_t Ns,
-                                            const void* idx, int idx64, int H, const void* x_f16, int Cin,
-                                            const float* kp, int K, float extent, int influence,
-                                            int aggregation, void* A_out_f16, int64_t ldA, void* stream) {
-  if (int e = check_common(Nq, Ns, H, Cin, K, influence, aggregation)) return e;
-  MVK_REQUIRE(Cin <= 512, "kpconv (fp16 features): Cin=%d unsupported (<= 512)", Cin);
-  MVK_REQUIRE(ldA >= (int64_t)K * Cin && (ldA - (int64_t)K * Cin) < 64 && ((ldA - (int64_t)K * Cin) == 0 || ldA % 2 == 0),
-              "kpconv (fp16 features): bad aggregate row stride");
-  if (Nq == 0) return 0;
-  hipStream_t st = (hipStream_t)stream;
-  KPParams P{};
-  P.q = q; P.s = s; P.idx = idx; P.x = (const float*)x_f16; P.kp = kp;
-  P.A = (float*)A_out_f16; P.Nq = Nq; P.Ns = Ns; P.H = H; P.Cin = Cin; P.K = K; P.extent = extent;
-  P.influence = influence; P.aggregation = aggregation; P.ldA = ldA;
-  if (H == 0) {
-    MVK_CHECK_HIP(hipMemsetAsync(A_out_f16, 0, 2 * Nq * ldA, st));
-    return 0;
-  }
-  if (Cin & 1) {   // odd row length: rows are only 2-byte aligned
-    if (Cin <= 256) launch_vec<1, _Float16, false>(P, idx64, st); else launch_vec<2, _Float16, false>(P, idx64, st);
-  } else {
-    if (Cin <= 256) launch_vec<1, _Float16, true>(P, idx64, st); else launch_vec<2, _Float16, true>(P, idx64, st);
-  }
-  MVK_CHECK_HIP(hipGetLastError());
-  return 0;
-}
-
-extern "C" int mvk_kpconv_gather_fwd_f16(const float* q, int64_t Nq, const float* s, int64_t Ns,
-                                         const void* idx, int idx64, int H, const void* x_f16, int Cin,
-                                         const float* kp, int K, float extent, int influence,
-                                         int aggregation, void* A_out_f16, void* stream) {
-  return mvk_kpconv_gather_fwd_f16_ld(q, Nq, s, Ns, idx, idx64, H, x_f16, Cin, kp, K, extent, influence, aggregation,
-                                      A_out_f16, (int64_t)K * Cin, stream);
 }

@@ -324,31 +324,6 @@ def gemm(A, B, transA=False, transB=False, out=None, accumulate=False, split_k=N
     return out
 
 
-def gemm_f16(A, B, transA=False, transB=False, split_k=None, out_f16=False):
-    """C = op(A) @ op(B) with both operands rounded to fp16 (stored as f32 or f16), fp16 MFMA, f32
-    accumulation (mvk_gemm_f16); C is f32, or fp16 with out_f16 (then without a split reduction)."""
-    _dev(A, B)
-    for t in (A, B):
-        if t.dtype not in (torch.float32, torch.float16):
-            raise RuntimeError("gemm_f16: operands must be float32 or float16")
-    A, B = A.contiguous(), B.contiguous()
-    M, Kd = (A.shape[1], A.shape[0]) if transA else (A.shape[0], A.shape[1])
-    N = B.shape[0] if transB else B.shape[1]
-    assert (B.shape[1] if transB else B.shape[0]) == Kd, "gemm_f16: inner dimensions differ"
-    odt = torch.float16 if out_f16 else torch.float32
-    if M == 0 or N == 0 or Kd == 0:
-        return torch.zeros((M, N), device=A.device, dtype=odt)
-    if split_k is None:
-        tiles = ((M + 63) // 64) * ((N + 63) // 64)
-        split_k = int(max(1, min((1000 + tiles - 1) // tiles, 32, Kd // 128)))
-    if out_f16:
-        split_k = 1
-    out = _zeros((M, N), A.device) if split_k > 1 else torch.empty((M, N), device=A.device, dtype=odt)
-    check(lib().mvk_gemm_f16(_p(A), int(A.dtype == torch.float16), _p(B), int(B.dtype == torch.float16), _p(out),
-                             int(out_f16), M, N, Kd, int(transA), int(transB), int(split_k), _stream()))
-    return out
-
-
 def gemm_f32_stream_plan(M, N, Kd):
     """(runs on the streaming kernel, 16-row tiles per workgroup, workgroups, floats needed behind A) for
     C [M,N] = A [M,Kd] . B [Kd,N] in f32 (mvk_gemm_f32_stream_plan)."""
@@ -376,51 +351,6 @@ def gemm_f32_stream(A, B, stats_n_valid=None):
     y = torch.empty((M, N), device=A.device, dtype=torch.float32)
     part = torch.empty((wgs, 2, N), device=A.device, dtype=torch.float32) if stats_n_valid is not None else None
     check(lib().mvk_gemm_f32_stream(_p(A), _slack_floats(A), _p(B), _p(y), M, N, Kd, _p(stats_n_valid), _p(part), _stream()))
-    return y, ((part, 16 * tiles) if part is not None else None)
-
-
-def gemm_f16_stream_plan(M, N, Kp):
-    """(supported, 16-row tiles per workgroup, workgroups, halfs per weight row) of mvk_gemm_f16_stream for
-    C [M,N] = A16 [M,Kp] . Wt16 [N, >= Kp]^T."""
-    out = (C.c_int64 * 4)()
-    check(lib().mvk_gemm_f16_stream_plan(int(M), int(N), int(Kp), out))
-    return bool(out[0]), int(out[1]), int(out[2]), int(out[3])
-
-
-def round_weights_f16(W2d, Kp, want_rounded=True):
-    """W [Kd,N] f32 -> (Wt16 [N,Kp] fp16: transposed, zero padded; the rounded values as f32 [Kd,N] or None), one launch."""
-    _dev(W2d)
-    W2d = _f32c(W2d)
-    Kd, N = W2d.shape
-    Wt = torch.empty((N, int(Kp)), device=W2d.device, dtype=torch.float16)
-    Wr = torch.empty((Kd, N), device=W2d.device, dtype=torch.float32) if want_rounded else None
-    check(lib().mvk_round_weights_f16(_p(W2d), Kd, N, int(Kp), _p(Wt), _p(Wr), _stream()))
-    return Wt, Wr
-
-
-def gemm_f16_stream(A16, Wt16, stats_n_valid=None, want_stats=False):
-    """y [M,N] f32 = A16 [M,Kp] . Wt16 [N,Kp]^T on v_mfma_f32_16x16x32_f16 (mvk_gemm_f16_stream: weights stationary in
-    registers, rows streamed as fragment loads). Returns (y, (partials, rows per block) or None): with stats_n_valid
-    (DEVICE int32 [1]) or want_stats the launch also produces the BatchNorm partial statistics of y."""
-    _dev(A16, Wt16, stats_n_valid)
-    if A16.dtype != torch.float16 or Wt16.dtype != torch.float16 or A16.dim() != 2 or Wt16.dim() != 2:
-        raise RuntimeError("gemm_f16_stream: operands must be 2-D float16 tensors")
-    if A16.stride(1) != 1 or Wt16.stride(1) != 1:
-        raise RuntimeError("gemm_f16_stream: operands must be k-contiguous")
-    M, Kp = A16.shape
-    N = Wt16.shape[0]
-    ok, tiles, wgs, wrow = gemm_f16_stream_plan(max(M, 1), N, Kp)
-    if not ok:
-        raise RuntimeError("gemm_f16_stream: unsupported shape %d x %d x %d" % (M, N, Kp))
-    if Wt16.shape[1] < wrow:
-        raise RuntimeError("gemm_f16_stream: weight rows must be %d halfs long, zero padded (round_weights_f16)" % wrow)
-    y = torch.empty((M, N), device=A16.device, dtype=torch.float32)
-    part = None
-    if (stats_n_valid is not None or want_stats) and M > 0:
-        part = torch.empty((wgs, 2, N), device=A16.device, dtype=torch.float32)      # the layout of gemm()'s epilogue partials
-    if M > 0:
-        check(lib().mvk_gemm_f16_stream(_p(A16), A16.stride(0), _p(Wt16), Wt16.stride(0), _p(y), M, N, Kp,
-                                        _p(stats_n_valid), _p(part), _stream()))
     return y, ((part, 16 * tiles) if part is not None else None)
 
 
@@ -503,8 +433,8 @@ def profile_collect(h_eff=None):
         if he is None:
             he = (h_eff or {}).get((Nq, Ns, H), H)
         # algorithmic bytes: feature row + xyz + int32 index per real neighbour,
-        # query xyz, and the [Nq,K,Cin] aggregate written by the gather kernel (s_x = 2 in the fp16 mode)
-        sx = 2 if "[f16]" in name else 4
+        # query xyz, and the [Nq,K,Cin] aggregate written by the gather kernel
+        sx = 4
         r["bytes_per_launch"] = Nq * he * (Cin * sx + 12 + 4) + Nq * 12 + Nq * K * Cin * sx
         r["kernel"] = name
         r["shape"] = {"Nq": Nq, "Ns": Ns, "H": H, "H_eff": he, "Cin": Cin, "K": K}
@@ -940,139 +870,6 @@ def _contraction_streams(A, M, Kd, N):
     return ok and A.is_contiguous() and _slack_floats(A) >= need
 
 
-def kpconv_gather_f16(q, s, idx, x16, kp, extent, influence="linear", aggregation="sum", row_stride=None):
-    """fp16-feature mode of kpconv_gather (rigid): x16 [Ns,Cin] fp16 -> A [Nq,K,Cin] fp16; with row_stride
-    (>= K*Cin, in halfs) A is [Nq, row_stride] with zeros beyond K*Cin (the operand layout of gemm_f16_stream)."""
-    _dev(q, s, idx, x16, kp)
-    if x16.dtype != torch.float16:
-        raise RuntimeError("kpconv_gather_f16: features must be float16")
-    q, s, kp, x16 = _f32c(q), _f32c(s), _f32c(kp), x16.contiguous()
-    idx, i64 = _idx(idx)
-    Nq, Ns, H, Cin, K = q.shape[0], s.shape[0], idx.shape[1] if idx.dim() == 2 else 0, x16.shape[1], kp.shape[0]
-    if x16.shape[0] != Ns:
-        raise RuntimeError("kpconv: features and support points differ in length")
-    if row_stride is None:
-        A = torch.empty((Nq, K, Cin), device=q.device, dtype=torch.float16)
-    else:
-        A = torch.empty((Nq, int(row_stride)), device=q.device, dtype=torch.float16)
-    if _PROF["on"]:
-        e0, e1 = _timing_events()
-    check(lib().mvk_kpconv_gather_fwd_f16_ld(_p(q), Nq, _p(s), Ns, _p(idx), i64, H, _p(x16), Cin, _p(kp), K, float(extent),
-                                             INFLUENCE[influence], AGGREGATION[aggregation], _p(A),
-                                             K * Cin if row_stride is None else int(row_stride), _stream()))
-    if _PROF["on"]:
-        e1.record()
-        _PROF["rec"].append(((_gather_kernel_label(Nq, Ns, H, Cin, False, 2) + "[f16]", Nq, Ns, H, Cin, K), e0, e1))
-    return A
-
-
-class _KPConv16Fn(torch.autograd.Function):
-    """KPConv in the fp16-feature mode (BASELINE config 5): the features entering the layer, the aggregate A
-    and the weights are rounded to fp16, the K x Cin x Cout contraction runs on the fp16 MFMA with f32
-    accumulation; geometry, correlation weights, aggregation sums, the output and the whole backward
-    (f32 MFMA on the rounded operands, no gradient is ever rounded to fp16) stay f32. Rigid layers read
-    fp16 feature rows and write an fp16 aggregate (half the gather bytes); deformable layers keep the f32
-    kernels on the fp16-rounded values. Gradients are those of y = A16 . W16 (straight-through rounding)."""
-
-    @staticmethod
-    def forward(ctx, q, s, idx, x, kp, W, offsets, modulations, extent, influence, aggregation, stats_n_valid=None,
-                order=None, rev=None, rev_order=None):          # (the fp16 gather entry points take no work list / reverse list)
-        K, Cin, Cout = W.shape
-        Kd = K * Cin
-        x16 = x.to(torch.float16)
-        min_d2 = part = None
-        # rigid layers whose contraction fits the streaming kernel: aggregate rows padded to 32 halfs, weights
-        # transposed + rounded (+ their f32 image for the backward) in one launch, statistics from the contraction
-        Kp = (Kd + 31) // 32 * 32
-        # rows of few or an odd number of halfs (the 3D net's first layer: Cin = 5) are 2-byte aligned scalar loads
-        # in the fp16 gather (135 us against 82 us on the f32 small-row kernel for 55 k points): f32 gather on the
-        # rounded features there, same values
-        f16_rows = offsets is None and Cin <= 512 and Cin % 2 == 0 and Cin >= 16
-        fast = (f16_rows and modulations is None and _STREAM16
-                and gemm_f16_stream_plan(max(q.shape[0], 1), Cout, Kp)[0])
-        if fast:
-            Wt16, W16f = round_weights_f16(W.reshape(Kd, Cout), gemm_f16_stream_plan(max(q.shape[0], 1), Cout, Kp)[3], True)
-            A = kpconv_gather_f16(q, s, idx, x16, kp, extent, influence, aggregation, row_stride=Kp)
-            if _PROF["on"]:
-                e0, e1 = _timing_events()
-            y, st = gemm_f16_stream(A, Wt16, stats_n_valid)
-            if _PROF["on"]:
-                e1.record()
-                _PROF["gemm"].append(((q.shape[0], Kd, Cout), e0, e1))
-            part = st[0] if st is not None else None
-            _LAST_STATS_ROWS[0] = st[1] if st is not None else 0
-            ctx.save_for_backward(q, s, idx, x16, kp, W16f, A, offsets, modulations)
-        else:
-            W16 = W.reshape(Kd, Cout).to(torch.float16)
-            if f16_rows:
-                A = kpconv_gather_f16(q, s, idx, x16, kp, extent, influence, aggregation)
-            else:
-                A, min_d2 = kpconv_gather(q, s, idx, x16.float(), kp, extent, influence, aggregation, offsets,
-                                          want_min_d2=offsets is not None)
-            Am = A.float() * modulations.unsqueeze(2) if modulations is not None else A
-            if _PROF["on"]:
-                e0, e1 = _timing_events()
-            y = gemm_f16(Am.view(-1, Kd), W16)
-            if _PROF["on"]:
-                e1.record()
-                _PROF["gemm"].append(((q.shape[0], Kd, Cout), e0, e1))
-            ctx.save_for_backward(q, s, idx, x16, kp, W16, A, offsets, modulations)
-        ctx.fast = bool(fast)
-        ctx.min_arg = getattr(min_d2, "_mvk_min_arg", None)
-        ctx.cfg = (extent, influence, aggregation, (K, Cin, Cout))
-        ctx.w_ref = weakref.ref(W)          # the f32 parameter the gradient is for (see _dw_gemm)
-        if part is not None:
-            ctx.mark_non_differentiable(part)
-        ctx.set_materialize_grads(False)
-        return y, min_d2, part
-
-    @staticmethod
-    def backward(ctx, gy, g_min_d2, g_part=None):
-        q, s, idx, x16, kp, W16, A, offsets, modulations = ctx.saved_tensors
-        extent, influence, aggregation, (K, Cin, Cout) = ctx.cfg
-        Nq, Kd = q.shape[0], K * Cin
-        if gy is None:
-            gy = torch.zeros((Nq, Cout), device=q.device, dtype=torch.float32)
-        gy = _f32c(gy)
-        if ctx.fast:
-            # A [Nq, Kp] fp16 (zero padded rows), W16 = the rounded weights as f32 [Kd, Cout]
-            A32 = A[:, :Kd].float().view(Nq, K, Cin)
-            Wf = W16
-        else:
-            A32 = A.float()
-            Wf = W16.float()
-        Am = A32 * modulations.unsqueeze(2) if modulations is not None else A32
-        dW = dx = d_off = d_mod = None
-        if ctx.needs_input_grad[5]:
-            dW = _dw_gemm(Am.view(Nq, Kd), gy, target=ctx.w_ref()).view(K, Cin, Cout)
-        if ctx.needs_input_grad[3] or offsets is not None:
-            dAm = gemm(gy, Wf, transB=True).view(Nq, K, Cin)
-            if modulations is not None:
-                if ctx.needs_input_grad[7]:
-                    d_mod = (dAm * A32).sum(dim=2)
-                dA = dAm * modulations.unsqueeze(2)
-            else:
-                dA = dAm
-            dx, d_off = kpconv_scatter(q, s, idx, dA, kp, extent, influence, aggregation,
-                                       x=x16.float() if offsets is not None else None, offsets=offsets,
-                                       g_min_d2=g_min_d2 if offsets is not None else None, min_arg=ctx.min_arg)
-        return None, None, None, dx, None, dW, d_off, d_mod, None, None, None, None, None, None, None
-
-
-_STREAM16 = os.environ.get("MVK_GEMM16_STREAM", "1") == "1"      # development switch: 0 = the LDS-staged fp16 kernel everywhere
-
-
-_FEATURE_DTYPE = {"dtype": torch.float32}
-
-
-def set_feature_dtype(dtype):
-    """torch.float32 (default) or torch.float16: the feature / weight storage type of every KPConv layer
-    (the fp16-feature mode of BASELINE config 5, see _KPConv16Fn)."""
-    if dtype not in (torch.float32, torch.float16):
-        raise ValueError("feature dtype must be torch.float32 or torch.float16")
-    _FEATURE_DTYPE["dtype"] = dtype
-
-
 def bn_finished(t):
     """True when t carries BatchNorm statistics FINISHED by its producer (mean, invstd; see _fin_request)."""
     e = getattr(t, "_mvk_bn_stats", None)
@@ -1085,9 +882,8 @@ def bn_stats_of(t):
 
 
 def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", offsets=None, modulations=None,
-           feature_dtype=None, stats_n_valid=None, order=None, rev=None, rev_order=None, bn=None):
-    """Returns (y [Nq,Cout], min_d2 [Nq,K] or None). feature_dtype: None = the mode set by
-    set_feature_dtype(). stats_n_valid (DEVICE int32 [1]): the contraction also produces the column statistics
+           stats_n_valid=None, order=None, rev=None, rev_order=None, bn=None):
+    """Returns (y [Nq,Cout], min_d2 [Nq,K] or None). stats_n_valid (DEVICE int32 [1]): the contraction also produces the column statistics
     of y over its first n_valid rows for the BatchNorm that follows (picked up by bn_lrelu via bn_stats_of).
     order (int32 [Nq], a permutation, e.g. neighbors_cell_order of the query level): the order the f32 gather works
     through the query points in (kpconv_gather); the layer's result does not depend on it.
@@ -1101,10 +897,9 @@ def kpconv(q, s, idx, x, kp, W, extent, influence="linear", aggregation="sum", o
         raise ValueError("Unknown influence function type (config.KP_influence)")
     if aggregation not in AGGREGATION:
         raise ValueError("Unknown convolution mode. Should be 'closest' or 'sum'")
-    fn = _KPConv16Fn if (feature_dtype or _FEATURE_DTYPE["dtype"]) == torch.float16 else _KPConvFn
-    _fin_request(bn if (fn is _KPConvFn and stats_n_valid is not None) else None)
+    _fin_request(bn if stats_n_valid is not None else None)
     try:
-        y, min_d2, part = fn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation,
+        y, min_d2, part = _KPConvFn.apply(q, s, idx, x, kp, W, offsets, modulations, float(extent), influence, aggregation,
                                    stats_n_valid, order, rev, rev_order)
     finally:
         fin = _fin_take()

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define MVK_ABI_VERSION 7   /* 7: BatchNorm folded into the GEMMs around it (statistics finished by the producer, apply in the consumer's operand load), reverse lists out of the neighbour search, grouped plan takes the stream; 6: ordered split reductions (mvk_gemm_split_arena), reverse neighbour lists; 5: gather with a work list (mvk_kpconv_gather_fwd_ordered); 4: fp16 mode on gfx950 forms: padded fp16 aggregate rows, streaming contraction (v_mfma_f32_16x16x32_f16) with statistics epilogue, one-launch weight rounding; 3: gemm plan / BatchNorm-statistics epilogue, BatchNorm takes epilogue partials, fused clip + SGD, offset gradient + regulariser, segmentation loss, gather launch plan, strided gather-rows backward, channels-last fusion gather; 2: masked BatchNorm takes the batch counter and a residual addend; enqueue-only / device-lens pyramid entry points; fp16-feature mode; capacity padding */
+#define MVK_ABI_VERSION 8   /* 8: the fp16-feature entry points (mvk_kpconv_gather_fwd_f16 / _ld, mvk_gemm_f16, mvk_gemm_f16_stream / _plan, mvk_round_weights_f16) are gone, mvk_deform_regularizer_many, sorted reverse lists of any width; 7: BatchNorm folded into the GEMMs around it (statistics finished by the producer, apply in the consumer's operand load), reverse lists out of the neighbour search, grouped plan takes the stream; 6: ordered split reductions (mvk_gemm_split_arena), reverse neighbour lists; 5: gather with a work list (mvk_kpconv_gather_fwd_ordered); 4: fp16 mode on gfx950 forms: padded fp16 aggregate rows, streaming contraction (v_mfma_f32_16x16x32_f16) with statistics epilogue, one-launch weight rounding; 3: gemm plan / BatchNorm-statistics epilogue, BatchNorm takes epilogue partials, fused clip + SGD, offset gradient + regulariser, segmentation loss, gather launch plan, strided gather-rows backward, channels-last fusion gather; 2: masked BatchNorm takes the batch counter and a residual addend; enqueue-only / device-lens pyramid entry points; fp16-feature mode; capacity padding */
 
 /* influence / aggregation codes (blocks.py:329-354) */
 #define MVK_INFL_CONSTANT 0
@@ -69,20 +69,9 @@ int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const float* s, in
                                   const float* offsets, float* min_d2, int32_t* min_arg, float* A_out,
                                   const int32_t* order, void* stream);
 
-/* fp16-feature mode of mvk_kpconv_gather_fwd (rigid KPConv, Cin <= 512): x [Ns,Cin] and A_out
- * [Nq,K,Cin] are fp16 in memory; geometry, correlation weights and the sums are f32. */
-int mvk_kpconv_gather_fwd_f16(const float* q, int64_t Nq, const float* s, int64_t Ns, const void* idx,
-                              int idx64, int H, const void* x_f16, int Cin, const float* kp, int K,
-                              float extent, int influence, int aggregation, void* A_out_f16, void* stream);
-/* The same with a row stride for the aggregate: A_out [Nq, ldA] fp16, ldA >= K*Cin (even when larger), the columns
- * beyond K*Cin written as zeros -- rows padded to a multiple of 32 halfs are what mvk_gemm_f16_stream reads. */
-int mvk_kpconv_gather_fwd_f16_ld(const float* q, int64_t Nq, const float* s, int64_t Ns, const void* idx,
-                                 int idx64, int H, const void* x_f16, int Cin, const float* kp, int K,
-                                 float extent, int influence, int aggregation, void* A_out_f16, int64_t ldA,
-                                 void* stream);
-
-/* Launch geometry the two gather entry points use for a layer with linear influence and sum aggregation
- * (elem_bytes 4 = mvk_kpconv_gather_fwd, 2 = mvk_kpconv_gather_fwd_f16; host only, no GPU call):
+/* Launch geometry mvk_kpconv_gather_fwd uses for a layer with linear influence and sum aggregation
+ * (elem_bytes: 4 -- feature rows are f32; the fp16-feature mode of rounds 2-4 left the tree in round 5, DESIGN.md 4.7;
+ * host only, no GPU call):
  * out[0..6] = lanes per point, points per wave, feature rows per batch of the branch-free kernel variant
  * (0 = general variant), first workgroup whose waves share their points, waves per workgroup, workgroups,
  * grid threads (the figure a kernel trace reports). out[5] = 0: the layer runs on another kernel (one point per wave;
@@ -309,31 +298,6 @@ int mvk_gemm_f32_tn_grouped(const void* table_dev, int n, int n_narrow, int64_t 
 int mvk_gemm_f32_stream_plan(int64_t M, int N, int64_t Kd, int64_t* out /* [4] */);
 int mvk_gemm_f32_stream(const float* A, int64_t a_slack_floats, const float* B, float* C, int64_t M, int N, int64_t Kd,
                         const int* n_valid, float* bn_part, void* stream);
-
-/* fp16-feature mode of the same contraction (BASELINE config 5): operands are rounded to fp16 (each may be
- * stored as f32 or f16 in memory: a_f16 / b_f16), multiplied on v_mfma_f32_32x32x8_f16 and accumulated in
- * f32; C is f32 [M,N] (split_k > 1: atomics onto a zero-initialised C) or, with c_f16, fp16 [M,N]. */
-int mvk_gemm_f16(const void* A, int a_f16, const void* B, int b_f16, void* C, int c_f16, int64_t M, int64_t N,
-                 int64_t Kd, int transA, int transB, int split_k, void* stream);
-
-/* The contraction of the RIGID fp16 layers as a stream (reference shape contract models/blocks.py:370-374:
- * [N, K*Cin] x [K*Cin, Cout]): C [M,N] f32 = A16 [M, lda] . Wt16 [N, ldb]^T over the first Kp columns, both operands
- * fp16, k-contiguous, 16-byte aligned, lda / ldb multiples of 8 halfs, Kp a multiple of 32 (zero padded beyond the
- * true reduction length), N = 32 or 64, Kp <= 1024. v_mfma_f32_16x16x32_f16, f32 accumulation; the weights stay in
- * registers, the rows of A stream through as 16-byte fragment loads (no LDS staging), partial blocks of the four
- * waves are added in a fixed order (deterministic, no atomics). bn_part != NULL: per workgroup (= plan[1] * 16 rows)
- * and column the sum and the centred sum of squares over the rows below *n_valid (NULL: all M), the partials format
- * of mvk_gemm_f32_ex: [2 * plan[2], N].
- * The weight rows must be allocated plan[3] (>= Kp) halfs long, zero beyond the reduction (every wave then loads whole
- * steps unconditionally).
- * _plan (host only): out[0] = 1 when the shape is supported, out[1] = 16-row tiles per workgroup, out[2] = workgroups,
- * out[3] = halfs per weight row. */
-int mvk_gemm_f16_stream_plan(int64_t M, int N, int64_t Kp, int64_t* out /* [4] */);
-int mvk_gemm_f16_stream(const void* A16, int64_t lda, const void* Wt16, int64_t ldb, float* C, int64_t M, int N,
-                        int64_t Kp, const int* n_valid, float* bn_part, void* stream);
-/* W [Kd,N] f32 -> Wt16 [N,Kp] fp16 (transposed, zero padded to Kp >= Kd) and, when W_rounded != NULL, the rounded
- * values back as f32 [Kd,N] (the operand of the f32 backward product dA = g . W16^T): one launch. */
-int mvk_round_weights_f16(const float* W, int64_t Kd, int N, int64_t Kp, void* Wt16, float* W_rounded, void* stream);
 
 /* ---------------- deformable KPConv: offset gradient, offset regulariser ---- */
 

@@ -333,15 +333,15 @@ def test_kpconv_every_kernel_variant_vs_numpy_oracle(ops, cin, cout, H):
     assert rel_err(Wt.grad.cpu().numpy(), dW) < FP_TOL
 
 
-@pytest.mark.parametrize("Nq,cin,H,f16", [(40000, 32, 12, False), (70000, 66, 30, False), (17000, 64, 40, False),
-                                          (40000, 32, 12, True), (21000, 128, 70, False), (19000, 66, 40, False), (17500, 65, 20, False)])
-def test_kpconv_gather_launches_with_sharing_workgroups_vs_numpy_oracle(ops, Nq, cin, H, f16):
+@pytest.mark.parametrize("Nq,cin,H", [(40000, 32, 12), (70000, 66, 30), (17000, 64, 40), (21000, 128, 70), (19000, 66, 40),
+                                      (17500, 65, 20)])
+def test_kpconv_gather_launches_with_sharing_workgroups_vs_numpy_oracle(ops, Nq, cin, H):
     """Launches large enough that their last partial round of waves runs as sharing workgroups (the waves of a workgroup
     split the neighbour chunks of ONE point group and wave 0 adds the partial aggregates, csrc/kpconv.hip): the
     aggregate of every region of the launch -- independent waves, sharing workgroups, the ragged last group --
     against the float64 numpy restatement."""
     from oracle import npref
-    plan = ops.kpconv_gather_plan(Nq, 3000, H, cin, elem_bytes=2 if f16 else 4)
+    plan = ops.kpconv_gather_plan(Nq, 3000, H, cin)
     if plan["mfma"]:
         # round 5: rigid f32 layers run on the MFMA gather (one wave per point, no sharing workgroups) -- the same rows
         # are checked all the same (shadow entries in the middle of rows, ragged last workgroup)
@@ -355,11 +355,7 @@ def test_kpconv_gather_launches_with_sharing_workgroups_vs_numpy_oracle(ops, Nq,
     idx[:, H // 2:][rng.random((Nq, H - H // 2)) < 0.4] = Ns
     x = rng.normal(size=(Ns, cin)).astype(np.float32)
     kp = (rng.normal(size=(K, 3)) * 0.05).astype(np.float32)
-    if f16:
-        x = x.astype(np.float16).astype(np.float32)
-        A = ops.kpconv_gather_f16(T(q), T(s), T(idx), T(x).half(), T(kp), 0.06).float().cpu().numpy()
-    else:
-        A = ops.kpconv_gather(T(q), T(s), T(idx), T(x), T(kp), 0.06)[0].cpu().numpy()
+    A = ops.kpconv_gather(T(q), T(s), T(idx), T(x), T(kp), 0.06)[0].cpu().numpy()
     ppw = plan["points_per_wave"]
     first_shared = plan["first_sharing_workgroup"] * 4 * ppw
     rows = np.unique(np.concatenate([np.arange(0, 64), np.arange(first_shared - 64, first_shared + 64),
@@ -367,7 +363,7 @@ def test_kpconv_gather_launches_with_sharing_workgroups_vs_numpy_oracle(ops, Nq,
     W1 = np.zeros((K, cin, 1))
     _, want, _ = npref.kpconv_forward(q[rows].astype(np.float64), s.astype(np.float64), idx[rows].astype(np.int64),
                                       x.astype(np.float64), kp.astype(np.float64), W1, 0.06, return_A=True)
-    assert rel_err(A[rows], want) < (2e-3 if f16 else FP_TOL)
+    assert rel_err(A[rows], want) < FP_TOL
 
 
 @pytest.mark.parametrize("Nq,cin,H", [(3001, 64, 30), (19000, 66, 40), (21000, 128, 30), (9000, 300, 20), (5000, 3, 20)])
@@ -701,64 +697,6 @@ def test_kpconv_deformable_golden(ops, name, modulated, use_rev):
     check_err("G4 %s x_grad" % name, rel_err(x.grad.cpu().numpy(), g["x_grad"]), DEFORM_TOL)
     check_err("G4 %s offset_weights_grad" % name, rel_err(Wo.grad.cpu().numpy(), g["offset_weights_grad"]), DEFORM_TOL)
     check_err("G4 %s offset_bias_grad" % name, rel_err(bo.grad.cpu().numpy(), g["offset_bias_grad"]), DEFORM_TOL)
-
-
-@pytest.mark.parametrize("cin,cout,H", [(66, 64, 40), (64, 128, 33), (7, 16, 20), (300, 32, 12), (600, 24, 9),
-                                        (32, 32, 30), (5, 64, 25), (64, 64, 20)])     # the last three + the first: streaming contraction
-def test_kpconv_fp16_feature_mode_vs_numpy_oracle(ops, cin, cout, H):
-    """BASELINE config 5 ("fp16 features with MFMA on the KP contraction"): features, aggregate and weights
-    rounded to fp16, exact products, f32 accumulation. The float64 oracle gets the same rounded operands
-    (x16, W16, and A rounded to fp16 before the contraction), so what is left is accumulation order:
-    tolerance 1e-3 on the output (fp16 rounding of A is reproduced only to its last bit), and the
-    backward (f32 MFMA on the rounded operands) against the oracle's backward on those operands."""
-    from oracle import npref
-    rng = np.random.default_rng(cin * 17 + H)
-    Nq, Ns, K = 257, 301, 15
-    q = (rng.random((Nq, 3)) * 0.3).astype(np.float32)
-    s = (rng.random((Ns, 3)) * 0.3).astype(np.float32)
-    idx = rng.integers(0, Ns + 1, (Nq, H)).astype(np.int32)
-    idx[5] = Ns
-    x = rng.normal(size=(Ns, cin)).astype(np.float32)
-    kp = (rng.normal(size=(K, 3)) * 0.05).astype(np.float32)
-    W = (rng.normal(size=(K, cin, cout)) * 0.1).astype(np.float32)
-    g = rng.normal(size=(Nq, cout)).astype(np.float32)
-    xt, Wt = T(x).requires_grad_(True), T(W).requires_grad_(True)
-    y, _ = ops.kpconv(T(q), T(s), T(idx), xt, T(kp), Wt, 0.06, feature_dtype=torch.float16)
-    (y * T(g)).sum().backward()
-    x16 = x.astype(np.float16).astype(np.float64)
-    W16 = W.astype(np.float16).astype(np.float64)
-    a64 = [q.astype(np.float64), s.astype(np.float64), idx.astype(np.int64), x16, kp.astype(np.float64), W16, 0.06]
-    _, A, _ = npref.kpconv_forward(*a64, return_A=True)
-    A16 = A.astype(np.float16).astype(np.float64)
-    want = np.einsum("nkc,kco->no", A16, W16)
-    assert rel_err(y.detach().cpu().numpy(), want) < 1e-3
-    dW = np.einsum("nkc,no->kco", A16, g.astype(np.float64))
-    dx, _ = npref.kpconv_backward(*a64, g.astype(np.float64))
-    assert rel_err(Wt.grad.cpu().numpy(), dW) < 1e-3
-    assert rel_err(xt.grad.cpu().numpy(), dx) < FP_TOL
-    # and the mode really is within fp16 rounding of the f32 operator
-    y32, _ = ops.kpconv(T(q), T(s), T(idx), T(x), T(kp), T(W), 0.06)
-    assert rel_err(y.detach().cpu().numpy(), y32.cpu().numpy()) < 5e-3
-
-
-def test_kpconv_fp16_feature_mode_deformable_close_to_f32(ops):
-    """Deformable + modulated layer in the fp16-feature mode (f32 kernels on fp16-rounded values, fp16 MFMA
-    contraction) against the reference golden of the f32 layer: within fp16 rounding."""
-    g = load_golden("g4_kpconv_deform_mod")
-    K = 15
-    q, s, idx = T(g["q"]), T(g["s"]), T(g["idx"])
-    ext = float(g["extent"])
-    x = T(g["x"]).requires_grad_(True)
-    W = T(g["weights"]).requires_grad_(True)
-    feat, _ = ops.kpconv(q, s, idx, x, T(g["offset_kernel_points"]), T(g["offset_weights"]), ext)
-    feat = feat + T(g["offset_bias"])
-    off, mod = feat[:, :3 * K].reshape(-1, K, 3) * ext, 2 * torch.sigmoid(feat[:, 3 * K:])
-    y, min_d2 = ops.kpconv(q, s, idx, x, T(g["kernel_points"]), W, ext, offsets=off, modulations=mod,
-                           feature_dtype=torch.float16)
-    (y * T(g["g"])).sum().backward()
-    assert rel_err(y.detach().cpu().numpy(), g["y"]) < 5e-3
-    assert rel_err(min_d2.detach().cpu().numpy(), g["min_d2"]) < FP_TOL        # geometry is untouched by the mode
-    assert x.grad is not None and torch.isfinite(x.grad).all() and torch.isfinite(W.grad).all()
 
 
 def test_kpconv_linearity_full_size(ops):
@@ -1359,79 +1297,6 @@ def test_masked_bn_lrelu_vs_torch(ops, R, D, n, slope):
     assert int(bn.num_batches_tracked) == int(ref.num_batches_tracked) == 2
 
 
-@pytest.mark.parametrize("M,N,K", [(19464, 64, 990), (65, 512, 7680), (990, 64, 19464), (130, 70, 37), (4096, 128, 960)])
-@pytest.mark.parametrize("ta,tb", [(False, False), (False, True), (True, False)])
-def test_gemm_f16_mfma(ops, M, N, K, ta, tb):
-    """fp16-feature contraction: operands rounded to fp16 (stored as f16 or f32), exact products, f32
-    accumulation -> equals an f32/f64 matmul of the rounded operands up to summation order."""
-    torch.manual_seed(M + N + K)
-    A = torch.randn((K, M) if ta else (M, K), device="cuda")
-    B = torch.randn((N, K) if tb else (K, N), device="cuda")
-    Ar, Br = A.half().double(), B.half().double()
-    want = ((Ar.t() if ta else Ar) @ (Br.t() if tb else Br))
-    scale = want.abs().max().item()
-    for a_in, b_in in ((A.half(), B.half()), (A, B.half()), (A.half(), B), (A, B)):
-        got = ops.gemm_f16(a_in, b_in, transA=ta, transB=tb)
-        assert got.dtype == torch.float32 and (got.double() - want).abs().max().item() / scale < 2e-5
-    got16 = ops.gemm_f16(A.half(), B.half(), transA=ta, transB=tb, out_f16=True)
-    assert got16.dtype == torch.float16 and (got16.double() - want).abs().max().item() / scale < 2e-3
-    one = ops.gemm_f16(A.half(), B.half(), transA=ta, transB=tb, split_k=1)
-    assert (one.double() - want).abs().max().item() / scale < 2e-5
-
-
-@pytest.mark.parametrize("M,N,Kd", [(19464, 64, 990), (4986, 64, 960), (19464, 32, 480), (40000, 64, 75), (1, 64, 990),
-                                    (17, 32, 33), (1233, 64, 1024), (700, 32, 96), (76700, 32, 480)])
-def test_gemm_f16_stream(ops, M, N, Kd):
-    """The streaming fp16 contraction of the rigid layers (csrc/gemm16.hip, v_mfma_f32_16x16x32_f16; reference shape
-    contract models/blocks.py:370-374): padded k-contiguous operands, exact fp16 products, f32 accumulation -> equals the
-    float64 product of the rounded operands to summation order (2e-5 of the largest output); the statistics partials of
-    the same launch (sum and centred squares per workgroup block, rows below a device count) against NumPy; two launches
-    give the same bits (no atomics); mvk_round_weights_f16 is exact."""
-    torch.manual_seed(M + N + Kd)
-    Kp = (Kd + 31) // 32 * 32
-    A = torch.zeros((M, Kp), device="cuda", dtype=torch.float16)
-    A[:, :Kd] = torch.randn((M, Kd), device="cuda").half()
-    W = torch.randn((Kd, N), device="cuda") * 0.2
-    ok, tiles, wgs, wrow = ops.gemm_f16_stream_plan(M, N, Kp)
-    assert ok and wgs == -(-(-(-M // 16)) // tiles) and wrow >= Kp and wrow % 32 == 0
-    Wt, Wr = ops.round_weights_f16(W, wrow, True)
-    assert Wt.shape == (N, wrow) and Wt.dtype == torch.float16
-    assert torch.equal(Wt[:, :Kd], W.half().t()) and (Wt[:, Kd:] == 0).all() and torch.equal(Wr, W.half().float())
-    want = A[:, :Kd].double() @ W.half().double()
-    scale = max(want.abs().max().item(), 1e-30)
-    y, st = ops.gemm_f16_stream(A, Wt)
-    assert st is None and y.dtype == torch.float32
-    err = (y.double() - want).abs().max().item() / scale
-    assert err < 2e-5, err
-    nv = max(1, M - 37) if M > 40 else M
-    n_valid = torch.tensor([nv], dtype=torch.int32, device="cuda")
-    y2, (part, rows) = ops.gemm_f16_stream(A, Wt, n_valid)
-    assert torch.equal(y, y2) and rows == 16 * tiles and part.shape == (wgs, 2, N)
-    yv = y.double().cpu().numpy()
-    for b in sorted({0, wgs // 2, wgs - 1}):
-        blk = yv[b * rows:min((b + 1) * rows, nv)]
-        got_sum, got_m2 = part[b, 0].double().cpu().numpy(), part[b, 1].double().cpu().numpy()
-        if blk.shape[0] == 0:
-            assert (got_sum == 0).all() and (got_m2 == 0).all()
-            continue
-        s_ref = blk.sum(0)
-        m2_ref = ((blk - blk.mean(0)) ** 2).sum(0)
-        assert np.abs(got_sum - s_ref).max() < 1e-5 * max(np.abs(blk).sum(0).max(), 1e-30)
-        assert np.abs(got_m2 - m2_ref).max() < 1e-4 * max(m2_ref.max(), 1e-30) + 1e-30
-    # the partials drive the masked BatchNorm exactly like a statistics pass over y would
-    if M > 200:
-        bn = torch.nn.BatchNorm1d(N, momentum=0.02).cuda()
-        ref = torch.nn.BatchNorm1d(N, momentum=0.02).cuda()
-        y2._mvk_bn_stats = (part, rows)
-        out = ops.bn_lrelu(y2, n_valid, bn, slope=0.1)
-        outr = torch.nn.functional.leaky_relu(ref(y[:nv]), 0.1)
-        assert rel_err(out[:nv].detach().cpu().numpy(), outr.detach().cpu().numpy()) < 2e-5 and (out[nv:] == 0).all()
-    with pytest.raises(RuntimeError):
-        ops.gemm_f16_stream(A, torch.zeros((48, wrow), device="cuda", dtype=torch.float16))     # N = 48: not a streaming shape
-    with pytest.raises(RuntimeError):
-        ops.gemm_f16_stream(A, Wt[:, :Kp - 8].contiguous())                                    # weight rows shorter than the plan asks for
-
-
 @pytest.mark.parametrize("M,N,Kd", [(19464, 64, 990), (19464, 32, 480), (4986, 64, 960), (4100, 64, 30), (40000, 32, 150),
                                     (55070, 64, 1024), (5000, 32, 16), (100003, 64, 990)])
 def test_gemm_f32_stream(ops, M, N, Kd, monkeypatch):
@@ -1478,29 +1343,6 @@ def test_gemm_f32_stream(ops, M, N, Kd, monkeypatch):
     # shapes no plan gives to the streaming kernel
     for (m, n, k) in ((3000, 64, 990), (19464, 128, 1920), (19464, 64, 75), (19464, 64, 1100), (19464, 48, 480)):
         assert not ops.gemm_f32_stream_plan(m, n, k)[0]
-
-
-def test_gather_f16_padded_rows_equal_the_plain_gather(ops):
-    """mvk_kpconv_gather_fwd_f16_ld: the aggregate with rows padded to 32 halfs holds the bits of the unpadded fp16
-    aggregate in its first K*Cin columns and zeros behind them (the streaming contraction multiplies the pad by zero
-    weights: it must be finite)."""
-    rng = np.random.default_rng(5)
-    for cin, H, Nq in ((66, 40, 1000), (5, 22, 777), (32, 31, 4100), (64, 17, 130), (33, 12, 257)):
-        Ns, K = Nq + 50, 15
-        q = T((rng.random((Nq, 3)) * 0.4).astype(np.float32))
-        s = T((rng.random((Ns, 3)) * 0.4).astype(np.float32))
-        idx = T(rng.integers(0, Ns + 1, (Nq, H)).astype(np.int32))
-        x16 = T(rng.normal(size=(Ns, cin)).astype(np.float16))
-        kp = T((rng.normal(size=(K, 3)) * 0.05).astype(np.float32))
-        Kd = K * cin
-        Kp = (Kd + 31) // 32 * 32
-        plain = ops.kpconv_gather_f16(q, s, idx, x16, kp, 0.06)
-        fill = torch.full((Nq, Kp), float("nan"), device="cuda", dtype=torch.float16)     # poison the allocator's next block
-        del fill
-        padded = ops.kpconv_gather_f16(q, s, idx, x16, kp, 0.06, row_stride=Kp)
-        assert padded.shape == (Nq, Kp)
-        assert torch.equal(padded[:, :Kd].contiguous().view(torch.int16), plain.view(Nq, Kd).view(torch.int16))
-        assert (padded[:, Kd:] == 0).all()
 
 
 @pytest.mark.parametrize("R,D,n", [(100, 64, 90), (3000, 128, 2873), (19464, 64, 19464), (4096, 200, 4000),

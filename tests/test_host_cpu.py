@@ -32,26 +32,26 @@ def test_library_exports_every_declared_symbol():
 
 def test_gather_launch_plan_is_a_host_function():
     """mvk_kpconv_gather_plan: the launch geometry of the gather kernel, no GPU call (bench.py finds the launch in the
-    PMC profile by it). First layer of the early-fusion net (66 = 4 x 16 + 2 channels): 16 lanes per point with the two
-    trailing channels beside the quads, 4 points per wave, 16-neighbour chunks in batches of 4 rows, one full round of
-    1 024 independent workgroups + the remaining 770 point groups as sharing workgroups."""
+    PMC profile by it). Round 5: layers of >= 5 channels with linear influence run on the MFMA gather -- one wave per
+    point, four per workgroup; first layer of the early-fusion net (66 = 64 + 2 channels): five 16-channel accumulator
+    tiles, one channel block; wide rows: blocks of 256 channels in gridDim.y; few points with long rows (coarse levels,
+    the deformable layers' deform-radius rows): the four waves of a workgroup share ONE point."""
     ops = importlib.import_module(PKG + ".ops")
     p = ops.kpconv_gather_plan(19464, 19464, 58, 66)
-    assert (p["lanes_per_point"], p["points_per_wave"], p["rows_per_batch"]) == (16, 4, 4)
-    assert p["first_sharing_workgroup"] == 1024 and p["workgroups"] == 1024 + (4866 - 4096)
-    assert p["grid_threads"] == p["workgroups"] * 64 * p["waves_per_workgroup"]
-    t = ops.kpconv_gather_plan(19464, 19464, 58, 70)           # 70 = 4 x 17 + 2: 21-neighbour chunks, no trailing-channel mode
-    assert (t["lanes_per_point"], t["points_per_wave"], t["rows_per_batch"]) == (18, 3, 7)
-    assert t["first_sharing_workgroup"] == 1024 and t["workgroups"] == 1024 + (6488 - 4096)
-    q = ops.kpconv_gather_plan(3000, 3000, 50, 64)            # under one round: independent waves only
-    assert q["workgroups"] == -(-(-(-3000 // 4)) // 4) or q["first_sharing_workgroup"] == 0
-    d = ops.kpconv_gather_plan(750, 750, 420, 128, deformable=True)    # deformable: every workgroup shares
-    assert d["first_sharing_workgroup"] == 0 and d["workgroups"] == 375 and d["waves_per_workgroup"] == 4
+    assert p["mfma"] == 1 and (p["lanes_per_point"], p["points_per_wave"], p["rows_per_batch"]) == (64, 1, 5)
+    assert p["workgroups"] == 4866 and p["first_sharing_workgroup"] == -1 and p["waves_per_workgroup"] == 4
+    assert p["grid_threads"] == p["workgroups"] * 256
+    t = ops.kpconv_gather_plan(19464, 19464, 58, 32)
+    assert t["mfma"] == 1 and t["rows_per_batch"] == 2 and t["workgroups"] == 4866
+    w = ops.kpconv_gather_plan(1300, 1300, 50, 512)            # two channel blocks of 256; too many points to share
+    assert w["mfma"] == 1 and w["rows_per_batch"] == 16 and w["workgroups"] == 325 * 2 and w["first_sharing_workgroup"] == -1
+    c = ops.kpconv_gather_plan(180, 180, 51, 256)              # a coarse level: a workgroup per point
+    assert c["mfma"] == 1 and c["first_sharing_workgroup"] == 0 and c["workgroups"] == 180
+    d = ops.kpconv_gather_plan(750, 750, 420, 128, deformable=True)    # deform-radius rows: every workgroup shares
+    assert d["mfma"] == 1 and d["first_sharing_workgroup"] == 0 and d["workgroups"] == 750 and d["waves_per_workgroup"] == 4
     assert ops.kpconv_gather_plan(100, 100, 20, 2)["workgroups"] == 0         # rows of <= 4 channels: one point per 4 lanes
-    assert ops.kpconv_gather_plan(100, 100, 20, 8)["rows_per_batch"] == 0     # 2 lanes per point: general variant
-    assert ops.kpconv_gather_plan(100, 100, 20, 600)["workgroups"] == 0        # Cin > 512: one-point-per-wave kernel
-    h = ops.kpconv_gather_plan(19464, 19464, 58, 64, elem_bytes=2)
-    assert h["rows_per_batch"] == 8 and h["points_per_wave"] == 4
+    with pytest.raises(RuntimeError):
+        ops.kpconv_gather_plan(100, 100, 20, 64, elem_bytes=2)                # the fp16-feature mode left the tree (round 5)
 
 
 def test_product_never_imports_the_oracle():
@@ -404,7 +404,7 @@ def test_bench_result_line_is_bounded():
     res = {"metric": "input points/s through MV-KPConv KPFCNN forward+backward (pyramid + fusion + fwd + bwd + SGD)",
            "value": 4236201.534778994, "unit": "points/s", "n_gpus": 8, "steps": 20, "warmup": 5,
            "ms_per_step": 4.5946822501719, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f16 features / f32 accumulate", "data": "synthetic",
+           "dtype": "f32", "data": "synthetic",
            "config": {"workload": "middle_fusion_kpfcnn5_sphere19k_x1_per_gpu_deformable", "points_per_step_per_gpu": 19464,
                       "views": 5, "image_hw": [120, 160], "parallelism": "dp8",
                       "execution": "hipGraph[net|chain|enc2d]+eager-rccl(3 graphs)", "ranks": 8, "backend": "rccl",

@@ -390,40 +390,6 @@ def test_capacity_padded_mode_equals_plain_mode(variant, deformable):
     assert (A @ B).item() / (A.norm().item() * B.norm().item()) > 0.9999
 
 
-def test_fp16_feature_mode_network_close_to_f32():
-    """BASELINE config 5's network (late fusion, deformable + modulated) in the fp16-feature mode: same
-    weights, same batch -> logits within fp16 rounding of the f32 network, finite loss and gradients."""
-    import mvkpconv
-    syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")
-    dev = torch.device("cuda:0")
-    torch.manual_seed(0)
-    np.random.seed(0)
-    cfg = syn.make_config("late", deformable=True, modulated=True)
-    sph = [syn.raw_sphere(seed=8, radius=0.8, density=3000.0)]
-    staged = syn.stage_spheres(sph, dev, [syn.sphere_views(s, nv=3, h=60, w=80) for s in sph])
-    limits = syn.calibrate_limits(cfg, staged)
-    batch, _ = syn.build_batch(cfg, staged, limits, torch.int32)
-    net = syn.build_model(cfg, dev)
-    net.train()
-    for m in net.net_2d._modules.values():
-        m.train(False)
-    sd0 = {k: v.clone() for k, v in net.state_dict().items()}
-    out32 = net(batch, cfg).detach().clone()
-    loss32 = net.loss(net(batch, cfg), batch.labels).item()
-    net.load_state_dict(sd0)
-    ops.set_feature_dtype(torch.float16)
-    try:
-        out = net(batch, cfg)
-        loss = net.loss(out, batch.labels)
-        loss.backward()
-    finally:
-        ops.set_feature_dtype(torch.float32)
-    rel = (out.detach() - out32).abs().max().item() / out32.abs().max().item()
-    assert rel < 3e-2 and abs(loss.item() - loss32) < 3e-2 * abs(loss32)
-    grads = [p.grad for p in net.parameters() if p.requires_grad and p.grad is not None]
-    assert grads and all(torch.isfinite(g).all() for g in grads)
-
-
 @pytest.mark.parametrize("variant,deformable,nspheres", [("early", False, 1), ("late", True, 2), ("baseline", False, 3)])
 def test_device_input_chain_equals_eager_input_side(variant, deformable, nspheres):
     """The sync-free, capturable input chain (device-side counts, fixed launch geometry) fills a static

@@ -39,18 +39,7 @@ for lvl, cins in ((0, (66, 32, 64)), (1, (64, 128))):
         print("level %d  N %5d  H %2d (eff %.1f)  Cin %3d : %6.1f us  %.2f TB/s algorithmic" % (
             lvl, pts.shape[0], nb.shape[1], heff, cin, us, by / us / 1e6))
 
-print("fp16-feature mode (x and A stored as fp16):")
-for lvl, cins in ((0, (66, 32, 64)), (1, (64, 128))):
-    pts, nb = pyr['points'][lvl], pyr['neighbors'][lvl]
-    for cin in cins:
-        x = torch.randn(pts.shape[0], cin, device=dev).half()
-        scale = 2.0 ** lvl
-        us = t(lambda: ops.kpconv_gather_f16(pts, pts, nb, x, kp * scale, 0.048 * scale))
-        heff = float((nb < pts.shape[0]).sum(1).float().mean())
-        by = pts.shape[0] * heff * (cin * 2 + 16) + pts.shape[0] * 12 + pts.shape[0] * 15 * cin * 2
-        print("level %d  N %5d  H %2d (eff %.1f)  Cin %3d : %6.1f us  %.2f TB/s algorithmic" % (
-            lvl, pts.shape[0], nb.shape[1], heff, cin, us, by / us / 1e6))
 A = torch.randn(19464, 990, device=dev); W = torch.randn(990, 64, device=dev)
-for name, fn in (("f32 MFMA 19464x990x64", lambda: ops.gemm(A, W)), ("f16 MFMA 19464x990x64", lambda: ops.gemm_f16(A.half(), W.half()))):
+for name, fn in (("f32 MFMA 19464x990x64", lambda: ops.gemm(A, W)),):
     us = t(fn)
     print("%s: %.1f us  %.1f TFLOP/s" % (name, us, 2 * 19464 * 990 * 64 / us / 1e6))

@@ -12,4 +12,3 @@ run --spheres 8
 run --workload baseline
 run --workload middle --deformable --views 5
 run --workload late --deformable --in-radius 2.0
-run --workload late --deformable --in-radius 2.0 --features f16

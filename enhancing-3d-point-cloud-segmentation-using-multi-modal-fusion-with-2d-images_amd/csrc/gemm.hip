@@ -30,7 +30,6 @@
 
 #include <mutex>
 #include <type_traits>
-#include <utility>
 
 #include "common.h"
 
@@ -39,15 +38,6 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 32;
-
-template <int N, typename F, int... Is>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
-  (f(std::integral_constant<int, Is>()), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-  static_for_impl<N>(static_cast<F&&>(f), std::make_integer_sequence<int, N>());
-}
 
 // One operand tile = ROWS (i) x 32 (k) elements staged by 256 threads.
 //   CONTIG_K == true : source element (i,k) at src[i*ld + k]; LDS image [i][40]
@@ -170,8 +160,8 @@ struct Tile {
         p = src + (k0 + k) * ld + gi;
       }
       if (VEC == 4) {
-        // (a typed vector load, not a float4 struct copy: a struct copy is a memcpy in the IR, and register sets held in
-        // an ARRAY of tiles -- the whole-range prefetch -- then stay allocas in scratch)
+        // (a typed vector load, not a float4 struct copy: a struct copy is a memcpy in the IR, which keeps register sets
+        // held in an ARRAY of tiles in scratch -- found with the whole-range prefetch experiment of round 5)
         const f32x4 q = *reinterpret_cast<const f32x4*>(p);
         v[u] = make_float4(q[0], q[1], q[2], q[3]);
       } else {
@@ -300,7 +290,7 @@ struct GemmArgs {
 
 constexpr int XF_KMAX = 512;     // longest k-range of one workgroup with an A-operand transform (LDS table of 4 floats per k)
 
-template <bool TA, bool TB, int PM, int QN, int WM, int WN, bool DUAL = false, bool XF = false, int NS = 0>
+template <bool TA, bool TB, int PM, int QN, int WM, int WN, bool DUAL = false, bool XF = false>
 __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const int by, const int bz) {
   static_assert(WM * WN == 4, "four waves per workgroup");
   constexpr int TM = 16 * PM * WM, TN = 16 * QN * WN;
@@ -345,7 +335,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
   TileA la0, la1;
   TileB lb0, lb1;
   const int ra = wm * 16 * PM, rb = wn * 16 * QN;
-  auto compute = [&](const float* __restrict__ Ta, const float* __restrict__ Tb) __attribute__((always_inline)) {
+  auto compute = [&](const float* __restrict__ Ta, const float* __restrict__ Tb) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       f32x4 fa[PM], fb[QN];
@@ -378,7 +368,7 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
     return (TB && !DUAL && a.seg_shift >= 0) ? pB + (k >> a.seg_shift) * a.seg_extra : pB;
   };
   // publishes an A tile (first k: kt) in LDS, through the operand transform in the XF instantiations
-  auto putA = [&](TileA& la, float* __restrict__ T, const int64_t kt) __attribute__((always_inline)) {
+  auto putA = [&](TileA& la, float* __restrict__ T, const int64_t kt) {
     if constexpr (XF) la.transform(xs, kt, kbeg_all, m0, a.M, a.Kd, x_nvalid, a.ax_slope, x_out, lda, tid);
     la.store(T, tid);
   };
@@ -417,47 +407,12 @@ __device__ __forceinline__ void gemm_body(const GemmArgs& a, const int bx, const
       __syncthreads();
     }
   };
-  // NS > 0 (round 5): a k-range of at most NS full tiles is fetched WHOLE before the first multiply -- NS register sets,
-  // every load unconditional (a tile beyond the range re-loads the last one and is never used: a branch around a load
-  // would make the compiler wait for everything in flight at the join) -- so the workgroup pays ONE memory latency
-  // instead of one per pair of tiles. The short reductions of the split coarse-level products (5-10 tiles per
-  // workgroup, 85 x 512 x 7680 in 24-30 slices) and of the unary layers (K = 64 .. 256) were chains of 3-5 latencies.
-  auto deep = [&](auto va, auto vb, const int64_t klim) __attribute__((always_inline)) {
-    constexpr int VA = decltype(va)::value, VB = decltype(vb)::value;
-    constexpr int ND = NS > 0 ? NS : 1;
-    TileA da[ND];
-    TileB db[ND];
-    const int64_t klast = klim - BK;          // first k of the last full tile
-    // (compile-time tile indices: the register sets must not become an indexed array in scratch)
-    static_for<ND>([&](auto ti) __attribute__((always_inline)) {
-      constexpr int t = decltype(ti)::value;
-      const int64_t kt = kbeg + (int64_t)t * BK < klast ? kbeg + (int64_t)t * BK : klast;
-      da[t].template fetch<VA>(pA, lda, m0, a.M, kt, klim, vecA, tid);
-      db[t].template fetch<VB>(Bat(kt), ldb, n0, a.N, kt, klim, vecB, tid);
-    });
-    static_for<ND>([&](auto ti) __attribute__((always_inline)) {
-      constexpr int t = decltype(ti)::value;
-      if (kbeg + (int64_t)t * BK < klim) {          // (uniform)
-        float* const Ab = (t & 1) ? A1 : A0;
-        float* const Bb = (t & 1) ? B1 : B0;
-        putA(da[t], Ab, kbeg + (int64_t)t * BK);
-        db[t].store(Bb, tid);
-        __syncthreads();          // (also: every wave is done with the multiply of tile t - 1, whose buffer tile t + 1 overwrites)
-        compute(Ab, Bb);
-      }
-    });
-  };
   const bool fastA = TileA::fast_ok(a.M, vecA), fastB = TileB::fast_ok(a.N, vecB);
   const int64_t kfull = kbeg + (kend - kbeg) / BK * BK;     // end of the full k-tiles of this split
   typedef std::integral_constant<int, 4> I4;
   typedef std::integral_constant<int, 2> I2;
   typedef std::integral_constant<int, 0> I0;
-  const bool short_range = NS > 0 && kfull > kbeg && kfull - kbeg <= (int64_t)NS * BK;
-  if (short_range && fastA && fastB && vecA == 4 && vecB == 4) {
-    deep(I4(), I4(), kfull);
-  } else if (short_range && fastA && fastB && vecA == 2 && vecB == 4) {
-    deep(I2(), I4(), kfull);
-  } else if (fastA && fastB && vecA == 4 && vecB == 4) {
+  if (fastA && fastB && vecA == 4 && vecB == 4) {
     pipeline(I4(), I4(), kfull);
   } else if (fastA && fastB && vecA == 2 && vecB == 4) {      // K*Cin = 990: rows of A are only 8-byte aligned
     pipeline(I2(), I4(), kfull);
@@ -756,16 +711,6 @@ __global__ __launch_bounds__(256) void gemm_f32_mfma(const GemmArgs a) {
   gemm_body<TA, TB, PM, QN, WM, WN>(a, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// wide tiles, A not transposed, with the whole-range prefetch for k-ranges of at most GEMM_DEEP_TILES tiles per workgroup
-// (longer ranges fall through to the two-stage pipeline inside the same kernel)
-constexpr int GEMM_DEEP_TILES = 8;
-// (at most 3 waves per SIMD: with the LDS footprint of 5 workgroups per CU the compiler would otherwise hold the kernel
-// to ~100 registers and park the register sets in scratch -- behind a wait for the very loads they are meant to keep in flight)
-template <bool TB, int PM>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 3))) void gemm_f32_mfma_deep(const GemmArgs a) {
-  gemm_body<false, TB, PM, 1, 1, 4, false, false, GEMM_DEEP_TILES>(a, blockIdx.x, blockIdx.y, blockIdx.z);
-}
-
 // the same with the A-operand transform (GemmArgs (b)): wide tiles, A not transposed
 template <bool TB, int PM>
 __global__ __launch_bounds__(256) void gemm_f32_mfma_xf(const GemmArgs a) {
@@ -968,20 +913,8 @@ void launch_one(dim3 grid, hipStream_t st, const GemmArgs& a) {
   hipLaunchKernelGGL((gemm_f32_mfma<TA, TB, PM, QN, WM, WN>), grid, dim3(256), 0, st, a);
 }
 
-bool deep_prefetch_on() {
-  static const bool on = getenv("MVK_GEMM_DEEP") != nullptr && atoi(getenv("MVK_GEMM_DEEP")) != 0;     // measured: no gain (profiles/r05_gemm_split_probe.txt)
-  return on;
-}
-
 template <bool TA, bool TB>
 bool launch_cfg(const Plan& p, dim3 grid, hipStream_t st, const GemmArgs& a) {
-  if (!TA && !p.narrow && p.qn == 1 && (p.pm == 2 || p.pm == 4) && deep_prefetch_on() &&
-      a.k_per_split <= (int64_t)GEMM_DEEP_TILES * BK + BK - 1) {
-    // short reductions per workgroup: the whole k-range in flight at once (gemm_body NS)
-    if (p.pm == 2) hipLaunchKernelGGL((gemm_f32_mfma_deep<TB, 2>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((gemm_f32_mfma_deep<TB, 4>), grid, dim3(256), 0, st, a);
-    return true;
-  }
   if (p.narrow) {
 #define NARROW(PMv, QNv) \
   if (p.pm == PMv && p.qn == QNv) return launch_one<TA, TB, PMv, QNv, 4, 1>(grid, st, a), true

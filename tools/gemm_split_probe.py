@@ -1,6 +1,6 @@
 """Development-only (GPU box): the split coarse-level products over the split count, atomic epilogue
-against the ordered hand-off (ops.set_deterministic), device time of graph-captured launches. Run once with
-MVK_GEMM_DEEP=0 and once with =1 for the whole-range prefetch.   usage: python tools/gemm_split_probe.py"""
+against the ordered hand-off (ops.set_deterministic), device time of graph-captured launches.
+usage: python tools/gemm_split_probe.py"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,7 +25,6 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / (3 * n) * 1e3
 
 
-print("deep prefetch:", os.environ.get("MVK_GEMM_DEEP", "1"))
 for (M, N, K) in ((85, 512, 7680), (330, 256, 3840), (1300, 128, 1920), (4986, 64, 960)):
     A = torch.randn(M, K, device=dev); B = torch.randn(K, N, device=dev)
     out = torch.zeros(M, N, device=dev)

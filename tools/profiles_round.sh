@@ -38,22 +38,24 @@ rm -rf $O/po
 cd $R && python3 bench.py > $O/${TAG}_bench_line.json 2> $O/bench_line.err; cp $R/gpurun_out/bench_detail.json $O/${TAG}_bench_detail.json; cd /tmp
 ls -la $O; cat $O/pmc_mfma.log; head -5 $O/pmc_traffic.log; head -3 $O/${TAG}_steady_state_per_step.txt
 # 7. (round 4) the reference's batch shape: 5 spheres x 5 views per step (train_ScanNet_sphere.py:232, :338)
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/k5 -- python3 $R/bench.py --spheres 5 --views 5 --steps 10 --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_line_5spheres.json 2> $O/k5.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/k5 -- python3 $R/bench.py --spheres 5 --views 5 --steps 10 --warmup 2 --no-cpu-baseline --no-eager-line > $O/${TAG}_bench_line_5spheres.json 2> $O/k5.err
 F5=$(ls $O/k5/*/*_kernel_trace.csv | head -1)
 python3 $R/tools/trace_steady.py $F5 5 90 > $O/${TAG}_steady_state_5spheres.txt
-{ echo "== kpconv_gather_vec (forward gathers and the gather-form feature gradients)"; python3 $R/tools/trace_by_grid.py $F5 kpconv_gather_vec | head -30;
+{ echo "== kpconv_gather (forward gathers and the gather-form feature gradients)"; python3 $R/tools/trace_by_grid.py $F5 kpconv_gather | head -30;
   for k in kpconv_gather_mfma kpconv_lane_channel kpconv_deform gemm_f32_mfma gemm_f32_stream gemm_f32_stream fa_gather_kernel subsample_cloud_kernel nb_query_kernel rev_fill_kernel rev_sort_kernel sgd_clip_kernel; do echo "== $k"; python3 $R/tools/trace_by_grid.py $F5 $k | head -16; done; } > $O/${TAG}_kernels_by_grid_5spheres.txt
 rm -rf $O/k5
 cd $R && python3 bench.py --spheres 5 --views 5 --steps 20 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_line_5spheres.json 2> $O/b5.err; cp $R/gpurun_out/bench_detail.json $O/${TAG}_bench_detail_5spheres.json; cd /tmp
 # 8. (round 4) deterministic mode against the default, gather-form feature gradient against the atomic scatter
-{ for e in X=0 MVK_DETERMINISTIC=1 MVK_REVERSE_DX=0 MVK_INPUTS_IN_GRAPH=0 MVK_BENCH_DUMMY_LAUNCHES=100; do echo -n "$e: "; env $e python3 $R/bench.py --dev --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done;
+{ for e in X=0 MVK_DETERMINISTIC=1 MVK_REVERSE_DX=0 MVK_GATHER_MFMA=0 MVK_REV_FUSED=0 MVK_BN_FOLD=1 MVK_INPUTS_IN_GRAPH=0 MVK_BENCH_DUMMY_LAUNCHES=100; do echo -n "$e: "; env $e python3 $R/bench.py --dev --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done;
   for e in X=0 MVK_REVERSE_DX=0; do echo -n "8 spheres, $e: "; env $e python3 $R/bench.py --spheres 8 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done; } > $O/${TAG}_modes.txt 2>&1
-hipcc --offload-arch=gfx950 -O3 $R/tools/park_probe.hip -o /tmp/park_probe 2>/dev/null && timeout -k 10 120 /tmp/park_probe > $O/${TAG}_park_probe.txt 2>&1
-bash $R/tools/env_knobs.sh > $O/${TAG}_env_knobs.txt 2>&1
 # 9. (round 4) what each side branch costs the step (pieces left out of the captured step: timing only), the input kernels'
 #    one-workgroup paths against the multi-workgroup front ends, and the level-0 neighbour kernels stand-alone
 cd $R
 { for e in X=0 MVK_BENCH_SKIP=enc MVK_BENCH_SKIP=chain MVK_BENCH_SKIP=fa MVK_BENCH_SKIP=enc,chain,fa MVK_BENCH_SKIP=chain,fa MVK_BENCH_SKIP=enc,fa "MVK_SUB_MULTI_MIN=0 MVK_NB_MULTI_MIN=0" X=0; do echo -n "$e: "; env $e python3 $R/bench.py --dev --steps 30 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done;
   for e in X=0 MVK_BENCH_SKIP=enc MVK_BENCH_SKIP=chain MVK_BENCH_SKIP=enc,chain,fa "MVK_SUB_MULTI_MIN=0 MVK_NB_MULTI_MIN=0"; do echo -n "5 spheres x 5 views, $e: "; env $e python3 $R/bench.py --dev --spheres 5 --views 5 --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], 'ms/step,', d['value'], d['unit'])"; done; } > $O/${TAG}_side_branches.txt 2>&1
-bash $R/tools/nb_probe.sh 0 > $O/${TAG}_nb_probe.txt 2>&1
+ls -la $O
+# 10. (round 5) operator bench of the MFMA gather against the vector kernel (the deformable configurations: tools/config_profiles.sh)
+cd $R
+MVK_GATHER_MFMA=1 python3 tools/gather_mfma_bench.py mfma > $O/${TAG}_gather_mfma_bench.txt 2>/dev/null
+MVK_GATHER_MFMA=0 python3 tools/gather_mfma_bench.py vec 2>/dev/null | grep "level" >> $O/${TAG}_gather_mfma_bench.txt
 ls -la $O

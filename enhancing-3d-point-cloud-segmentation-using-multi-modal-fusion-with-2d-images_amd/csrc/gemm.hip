@@ -824,7 +824,12 @@ int arena_take(hipStream_t st, int64_t tiles, int split, int64_t slot, float** w
     *cnt = g_arena.cnt + g_arena.cnt_top;
     return 0;
   }
-  if (g_arena.ws_off + need > g_arena.ws_top || g_arena.cnt_off + tiles > g_arena.cnt_top) {
+  // eager launches recycle the FIRST QUARTER of the arena (or what the captured slices left of it): a process that runs
+  // eager steps before it captures its graphs (bench.py's eager figure, a warm-up) must not leave its high-water mark
+  // where the captures' slices go
+  const int64_t ws_cap = g_arena.ws_top < g_arena.ws_floats / 4 ? g_arena.ws_top : (need > g_arena.ws_floats / 4 ? need : g_arena.ws_floats / 4);
+  const int64_t cnt_cap = g_arena.cnt_top < g_arena.n_cnt / 4 ? g_arena.cnt_top : (tiles > g_arena.n_cnt / 4 ? tiles : g_arena.n_cnt / 4);
+  if (g_arena.ws_off + need > ws_cap || g_arena.cnt_off + tiles > cnt_cap) {
     if (need > g_arena.ws_top || tiles > g_arena.cnt_top) return 2;
     if (hipDeviceSynchronize() != hipSuccess) return -2;     // every earlier owner of the bottom region has finished
     g_arena.ws_off = 0;

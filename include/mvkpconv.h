@@ -175,8 +175,8 @@ int mvk_gemm_f32_pair_bn(const float* A, const float* B0, const float* B1, float
  * once, and the BatchNorm-statistics epilogue works on split plans too (mvk_gemm_f32_plan then reports rows > 0 with
  * split > 1). Slices (round 5): a launch on a CAPTURING stream takes its slices from the top of the arena and keeps
  * them for good (graph nodes replay, graph branches run side by side); an eager launch takes the next slice of the
- * bottom region, and when that region is used up the library waits for the device once (hipDeviceSynchronize) and
- * starts it again from offset 0. A request that cannot be served under these rules -- a product larger than the arena,
+ * bottom region (the first quarter of the arena, or what the captured slices left of it), and when that region is used
+ * up the library waits for the device once (hipDeviceSynchronize) and starts it again from offset 0. A request that cannot be served under these rules -- a product larger than the arena,
  * or an arena used up by captured slices -- fails with an error; two launches that may run concurrently never share a
  * slice. The host state is mutex-protected. ws == NULL restores the atomic path. mvk_gemm_split_ordered() = 1 while an arena
  * is set. (The reference's products are single ATen matmuls: deterministic. This makes ours so.) */

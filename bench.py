@@ -218,10 +218,10 @@ def main():
     INSTRUMENTED = 16
     for _ in range(INSTRUMENTED):               # instrumented eager passes (same spheres, a fresh grid orientation each)
         lens, loss = eager_step()
-    recs = ops._PROF["rec"]
+    recs, rev_fill = ops._PROF["rec"], ops._PROF.get("h_eff", {})
     contraction = ops.profile_collect_contraction()
     ops.profile_reset(enabled=False)
-    ops._PROF["rec"] = recs
+    ops._PROF["rec"], ops._PROF["h_eff"] = recs, rev_fill      # (h_eff: mean fill of the reverse rows the [dx] gathers walked)
 
     step = eager_step
     graph_note = ("eager", "eager step (no graph)")

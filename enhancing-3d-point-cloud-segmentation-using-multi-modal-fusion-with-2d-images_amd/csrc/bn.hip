@@ -18,74 +18,14 @@
 
 namespace {
 
-// 16-byte accesses need 16-byte aligned rows: D % 4 == 0 and aligned bases (null pointers count as aligned)
-__device__ int g_bn_vec = 1;      // development: MVK_BN_VEC=0 keeps the dword kernels (A/B timing)
-__device__ __forceinline__ bool bn_vec_ok(int D, const void* a, const void* b = nullptr, const void* c = nullptr,
-                                          const void* d = nullptr, const void* e = nullptr) {
-  return g_bn_vec != 0 && (D & 3) == 0 && (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)e) & 15) == 0;
-}
-
-// a predicated 16-byte load as a typed vector: `cond ? *(const float4*)p : zero` selects between two ADDRESSES (the zero lives in
-// constant memory) and becomes a flat_load; an exec-masked global_load_dwordx4 is what is wanted
-typedef float bn_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ bn_f4 bn_ld4(bool on, const float* p) {
-  bn_f4 v = {0.f, 0.f, 0.f, 0.f};
-  if (on) v = *reinterpret_cast<const bn_f4*>(p);
-  return v;
-}
-__device__ __forceinline__ void bn_st4(float* p, float a, float b, float c, float d) {
-  *reinterpret_cast<bn_f4*>(p) = (bn_f4){a, b, c, d};
-}
-
 constexpr int BN_ROWS = 64;   // rows per workgroup in the reduction kernels
 constexpr int BN_T = 256;
 
 // grid (ceil(D/64), ceil(R/BN_ROWS)); block 256 = 64 channels x 4 row lanes
 __global__ __launch_bounds__(BN_T) void bn_stats_partial(const float* __restrict__ x, const int* __restrict__ n_valid,
                                                          int R, int D, float* __restrict__ part /* [nblk,2,D] */) {
-  const int n = min(*n_valid, R);
-  if (bn_vec_ok(D, x, part)) {
-    // Round 5: 16-byte accesses, 16 channel quads x 16 row lanes, the thread's four rows of the block all in flight (a
-    // dword per lane and four rows in flight left these kernels at ~2 TB/s: 14 us for 55 070 x 64)
-    __shared__ float4 v1[16][16], v2[16][16];
-    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 64 + 4 * cq;
-    const int r0 = blockIdx.y * BN_ROWS;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (c < D && r0 < n) {
-      const bn_f4 k = *reinterpret_cast<const bn_f4*>(x + c);          // shift: row 0 (n >= 1 here)
-      const int r1 = min(r0 + BN_ROWS, n);
-      bn_f4 xv[4];
-      bool on[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = r0 + rl + 16 * t;
-        on[t] = r < r1;
-        xv[t] = bn_ld4(on[t], x + (int64_t)r * D + c);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const bn_f4 v = on[t] ? xv[t] - k : (bn_f4){0.f, 0.f, 0.f, 0.f};
-        a.x += v[0]; a.y += v[1]; a.z += v[2]; a.w += v[3];
-        b.x += v[0] * v[0]; b.y += v[1] * v[1]; b.z += v[2] * v[2]; b.w += v[3] * v[3];
-      }
-    }
-    v1[rl][cq] = a;
-    v2[rl][cq] = b;
-    __syncthreads();
-    if (rl == 0 && c < D) {      // the 16 row lanes in lane order: a fixed order
-#pragma unroll
-      for (int i = 1; i < 16; ++i) {
-        const float4 p = v1[i][cq], q = v2[i][cq];
-        a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
-        b.x += q.x; b.y += q.y; b.z += q.z; b.w += q.w;
-      }
-      *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * 2) * D + c) = a;
-      *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * 2 + 1) * D + c) = b;
-    }
-    return;
-  }
   __shared__ float s1[4][64], s2[4][64];
+  const int n = min(*n_valid, R);
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int r0 = blockIdx.y * BN_ROWS;
   float a = 0.f, b = 0.f;
@@ -123,51 +63,10 @@ __global__ __launch_bounds__(BN_T) void bn_stats_partial(const float* __restrict
 
 // Sums the per-row-block partials of 64 channels with a 1024-thread block (64 channels x 16 row
 // parts; fixed summation tree -> bit-reproducible). Returns the two totals to the lanes with part == 0.
-__shared__ float bn_w1[64][64], bn_w2[64][64];          // [slot lane][channel of the block] of the two helpers below
-
-// (round 5: with 16-byte aligned partials the 1 024 threads read them as 16 channel quads x 64 slot lanes, eight 16-byte
-// loads in flight each -- 860 slots of a 55 070-row level were 13 dependent rounds of dword loads per thread, most of
-// the fused kernels' time; the sums are taken in a fixed order either way)
 __device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ part, int nblk, int D, float* a, float* b) {
+  __shared__ float r1[16][64], r2[16][64];
   const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  if (bn_vec_ok(D, part)) {
-    const int cq = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c4 = blockIdx.x * 64 + 4 * cq;
-    bn_f4 x4 = {0.f, 0.f, 0.f, 0.f}, y4 = x4;
-    if (c4 < D) {
-      for (int i = sl; i < nblk; i += 256) {
-        bn_f4 u[4], v[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          const int j = i + 64 * t;
-          u[t] = bn_ld4(j < nblk, part + ((int64_t)j * 2) * D + c4);
-          v[t] = bn_ld4(j < nblk, part + ((int64_t)j * 2 + 1) * D + c4);
-        }
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-          x4 += u[t];
-          y4 += v[t];
-        }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      bn_w1[sl][4 * cq + e] = x4[e];
-      bn_w2[sl][4 * cq + e] = y4[e];
-    }
-    __syncthreads();
-    if (pr != 0 || c >= D) return false;
-    float x = 0.f, y = 0.f;
-    for (int i = 0; i < 64; ++i) {
-      x += bn_w1[i][cl];
-      y += bn_w2[i][cl];
-    }
-    *a = x;
-    *b = y;
-    return true;
-  }
-  __shared__ float r1[16][64], r2[16][64];
   float x = 0.f, y = 0.f;
   if (c < D) {
     // four blocks per trip, all eight loads issued before the first add: the partials come from L2 and a chain of
@@ -214,57 +113,10 @@ __device__ __forceinline__ bool bn_sum_partials(const float* __restrict__ part, 
 // Returns (mean, M2) to the lanes with part == 0.
 __device__ __forceinline__ bool bn_sum_partials_m2(const float* __restrict__ part, int R, int blk, int n, int D, float* mean,
                                                    float* m2) {
+  __shared__ float q1[16][64], q2[16][64];
   const int cl = threadIdx.x & 63, pr = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
   const int nb = n > 0 ? (n + blk - 1) / blk : 0;          // blocks that hold valid rows
-  if (bn_vec_ok(D, part)) {          // (see bn_sum_partials)
-    const int cq = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c4 = blockIdx.x * 64 + 4 * cq;
-    bn_f4 x4 = {0.f, 0.f, 0.f, 0.f}, y4 = x4, ref4 = x4;
-    if (c4 < D && nb > 0) {
-      const int n0 = min(blk, n);
-      ref4 = *reinterpret_cast<const bn_f4*>(part + c4) / (float)n0;
-      for (int i = sl; i < nb; i += 128) {
-        bn_f4 u[2], v[2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int j = i + 64 * t;
-          u[t] = bn_ld4(j < nb, part + ((int64_t)j * 2) * D + c4);
-          v[t] = bn_ld4(j < nb, part + ((int64_t)j * 2 + 1) * D + c4);
-        }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int j = i + 64 * t;
-          if (j < nb) {
-            const float ni = (float)min(blk, n - j * blk);
-            const bn_f4 d = u[t] / ni - ref4;
-            x4 += u[t];
-            y4 += v[t] + ni * d * d;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      bn_w1[sl][4 * cq + e] = x4[e];
-      bn_w2[sl][4 * cq + e] = y4[e];
-    }
-    __syncthreads();
-    if (pr != 0 || c >= D) return false;
-    float x = 0.f, y = 0.f;
-    for (int i = 0; i < 64; ++i) {
-      x += bn_w1[i][cl];
-      y += bn_w2[i][cl];
-    }
-    const float ref = nb > 0 ? part[c] / (float)min(blk, n) : 0.f;
-    const float mu = n > 0 ? x / (float)n : 0.f;
-    const float dm = mu - ref;
-    const float M2 = y - (float)n * dm * dm;
-    *mean = mu;
-    *m2 = M2 > 0.f ? M2 : 0.f;
-    return true;
-  }
-  __shared__ float q1[16][64], q2[16][64];
   float x = 0.f, y = 0.f, ref = 0.f;
   if (c < D && nb > 0) {
     const int n0 = min(blk, n);
@@ -368,57 +220,8 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const float* __restrict__ x, 
                                                       float slope, const float* __restrict__ yout,
                                                       float* __restrict__ part /* [nblk,2,D] */) {
   // yout != NULL: the forward added a residual before the LeakyReLU, so its sign comes from the saved output
-  const int n = min(*n_valid, R);
-  if (bn_vec_ok(D, x, g, yout, part) && bn_vec_ok(D, mean, invstd, gamma, beta)) {          // 16-byte accesses (see bn_stats_partial)
-    __shared__ float4 v1[16][16], v2[16][16];
-    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 64 + 4 * cq;
-    const int r0 = blockIdx.y * BN_ROWS;
-    float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
-    if (c < D && r0 < n) {
-      const float4 mu4 = *reinterpret_cast<const float4*>(mean + c), is4 = *reinterpret_cast<const float4*>(invstd + c);
-      const float4 ga4 = *reinterpret_cast<const float4*>(gamma + c), be4 = *reinterpret_cast<const float4*>(beta + c);
-      const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
-      const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, be[4] = {be4.x, be4.y, be4.z, be4.w};
-      const int r1 = min(r0 + BN_ROWS, n);
-      bn_f4 xv[4], gv[4], yv[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        const int r = r0 + rl + 16 * t;
-        const bool on = r < r1;
-        xv[t] = bn_ld4(on, x + (int64_t)r * D + c);
-        gv[t] = bn_ld4(on, g + (int64_t)r * D + c);       // (zero gradient: contributes nothing)
-        yv[t] = bn_ld4(on && yout != nullptr, yout + (int64_t)r * D + c);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float xh = (xv[t][e] - mu[e]) * is[e];
-          float gg = gv[t][e];
-          if (yout ? yv[t][e] <= 0.f : xh * ga[e] + be[e] <= 0.f) gg *= slope;
-          a[e] += gg;
-          b[e] += gg * xh;
-        }
-      }
-    }
-    v1[rl][cq] = make_float4(a[0], a[1], a[2], a[3]);
-    v2[rl][cq] = make_float4(b[0], b[1], b[2], b[3]);
-    __syncthreads();
-    if (rl == 0 && c < D) {
-      float4 sa = v1[0][cq], sb = v2[0][cq];
-#pragma unroll
-      for (int i = 1; i < 16; ++i) {
-        const float4 p = v1[i][cq], q = v2[i][cq];
-        sa.x += p.x; sa.y += p.y; sa.z += p.z; sa.w += p.w;
-        sb.x += q.x; sb.y += q.y; sb.z += q.z; sb.w += q.w;
-      }
-      *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * 2) * D + c) = sa;
-      *reinterpret_cast<float4*>(part + ((int64_t)blockIdx.y * 2 + 1) * D + c) = sb;
-    }
-    return;
-  }
   __shared__ float s1[4][64], s2[4][64];
+  const int n = min(*n_valid, R);
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
   const int r0 = blockIdx.y * BN_ROWS;
   float a = 0.f, b = 0.f;
@@ -594,41 +397,6 @@ __device__ __forceinline__ void bn_finish_apply_body(const float* __restrict__ x
   }
   if (nbt && ext_rows >= 0 && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *nbt += 1;
   __syncthreads();
-  if (bn_vec_ok(D, x, y, addend, gamma, beta)) {
-    // apply with 16-byte accesses (round 5): thread = (channel quad, one of 64 row lanes), four rows in flight
-    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c4 = blockIdx.x * 64 + 4 * cq;
-    if (c4 >= D) return;
-    const float mu[4] = {smu[4 * cq], smu[4 * cq + 1], smu[4 * cq + 2], smu[4 * cq + 3]};
-    const float is[4] = {sis[4 * cq], sis[4 * cq + 1], sis[4 * cq + 2], sis[4 * cq + 3]};
-    const float4 ga4 = *reinterpret_cast<const float4*>(gamma + c4), be4 = *reinterpret_cast<const float4*>(beta + c4);
-    const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, be[4] = {be4.x, be4.y, be4.z, be4.w};
-    const int step = gridDim.y * 64;
-    for (int r = blockIdx.y * 64 + rl; r < R; r += 2 * step) {      // two rows per trip (x and the addend): 128 registers per thread at 1 024 threads
-      bn_f4 xv[2], av[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int rr = r + t * step;
-        xv[t] = bn_ld4(rr < n, x + (int64_t)rr * D + c4);
-        av[t] = bn_ld4(addend != nullptr && rr < n, addend + (int64_t)rr * D + c4);
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int rr = r + t * step;
-        if (rr < R) {
-          float o[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = (xv[t][e] - mu[e]) * is[e] * ga[e] + be[e] + av[t][e];
-            v = v > 0.f ? v : v * slope;
-            o[e] = rr < n ? v : 0.f;
-          }
-          bn_st4(y + (int64_t)rr * D + c4, o[0], o[1], o[2], o[3]);
-        }
-      }
-    }
-    return;
-  }
   if (c >= D) return;
   const float mu = smu[cl], is = sis[cl], ga = gamma[c], be = beta[c];
   const int step = gridDim.y * 16;
@@ -721,56 +489,6 @@ __device__ __forceinline__ void bn_bwd_finish_apply_body(const float* __restrict
     }
   }
   __syncthreads();
-  if (bn_vec_ok(D, x, g, yout, dx, d_addend) && bn_vec_ok(D, mean, invstd, gamma, beta)) {          // 16-byte accesses (see bn_finish_apply_body)
-    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int c4 = blockIdx.x * 64 + 4 * cq;
-    if (c4 >= D) return;
-    const float4 mu4 = *reinterpret_cast<const float4*>(mean + c4), is4 = *reinterpret_cast<const float4*>(invstd + c4);
-    const float4 ga4 = *reinterpret_cast<const float4*>(gamma + c4), be4 = *reinterpret_cast<const float4*>(beta + c4);
-    const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
-    const float ga[4] = {ga4.x, ga4.y, ga4.z, ga4.w}, be[4] = {be4.x, be4.y, be4.z, be4.w};
-    const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
-    float s1[4], s2[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      s1[e] = sa[4 * cq + e] * inv_n;
-      s2[e] = sb[4 * cq + e] * inv_n;
-    }
-    const int step = gridDim.y * 64;
-    for (int r = blockIdx.y * 64 + rl; r < R; r += 2 * step) {      // two rows per trip: three arrays each
-      bn_f4 xv[2], gv[2], yv[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int rr = r + t * step;
-        xv[t] = bn_ld4(rr < n, x + (int64_t)rr * D + c4);
-        gv[t] = bn_ld4(rr < n, g + (int64_t)rr * D + c4);
-        yv[t] = bn_ld4(yout != nullptr && rr < n, yout + (int64_t)rr * D + c4);
-      }
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int rr = r + t * step;
-        if (rr < R) {
-          float o[4], oa[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float v = 0.f, ga_out = 0.f;
-            if (rr < n) {
-              const float xh = (xv[t][e] - mu[e]) * is[e];
-              float gg = gv[t][e];
-              if (yout ? yv[t][e] <= 0.f : xh * ga[e] + be[e] <= 0.f) gg *= slope;
-              v = ga[e] * is[e] * (gg - s1[e] - xh * s2[e]);
-              ga_out = gg;
-            }
-            o[e] = v;
-            oa[e] = ga_out;
-          }
-          bn_st4(dx + (int64_t)rr * D + c4, o[0], o[1], o[2], o[3]);
-          if (d_addend) bn_st4(d_addend + (int64_t)rr * D + c4, oa[0], oa[1], oa[2], oa[3]);
-        }
-      }
-    }
-    return;
-  }
   if (c >= D) return;
   const float mu = mean[c], is = invstd[c], ga = gamma[c], be = beta[c], s1 = sa[cl], s2 = sb[cl];
   const float inv_n = n > 0 ? 1.f / (float)n : 0.f;
@@ -1345,20 +1063,6 @@ int bn_mid_rows() {
 }  // namespace
 
 // rows up to which mvk_bn_lrelu_fwd / _bwd are ONE launch for a D-channel input (a producer need not emit statistics)
-namespace {
-void bn_vec_switch() {
-  static const bool done = [] {
-    const char* e = getenv("MVK_BN_VEC");
-    if (e != nullptr && atoi(e) == 0) {
-      const int zero = 0;
-      (void)hipMemcpyToSymbol(HIP_SYMBOL(g_bn_vec), &zero, sizeof(int));
-    }
-    return true;
-  }();
-  (void)done;
-}
-}  // namespace
-
 extern "C" int mvk_bn_single_launch_rows(int D) {
   static const bool keep_stats = getenv("MVK_BN_MID_KEEP_STATS") != nullptr;     // development: producers still emit partials
   if (keep_stats) return bn_small_rows();
@@ -1370,7 +1074,6 @@ extern "C" int mvk_bn_lrelu_fwd(const float* x, const int32_t* n_valid, int64_t 
                                 float* running_var, float* mean, float* invstd, float* scratch2D /* [ceil(R/64),2,D] */, float* y,
                                 int64_t* num_batches_tracked, const float* addend, const float* ext_part, int ext_rows,
                                 void* stream) {
-  bn_vec_switch();
   MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
   MVK_REQUIRE((ext_part == nullptr) == (ext_rows <= 0) && ext_rows >= -1, "bn: ext_part and ext_rows go together (-1: finished statistics)");
   if (R == 0) return 0;
@@ -1428,7 +1131,6 @@ extern "C" int mvk_bn_lrelu_bwd(const float* x, const float* g, const int32_t* n
                                 float slope, float* scratch /* [ceil(R/64),2,D] */,
                                 float* dgamma_dbeta /* [2,D]: dbeta then dgamma */, float* dx, const float* y_out,
                                 float* d_addend, void* stream) {
-  bn_vec_switch();
   MVK_REQUIRE(R >= 0 && D > 0 && R < (1ll << 31), "bn: bad sizes");
   MVK_REQUIRE((y_out == nullptr) == (d_addend == nullptr), "bn: y_out and d_addend go together (residual-join mode)");
   hipStream_t st = (hipStream_t)stream;
@@ -1505,7 +1207,6 @@ int bn_bwd_single(const mvk_bn_bwd_problem& p, void* stream) {
 }  // namespace
 
 extern "C" int mvk_bn_lrelu_fwd_pair(const mvk_bn_fwd_problem* pa, const mvk_bn_fwd_problem* pb, void* stream) {
-  bn_vec_switch();
   MVK_REQUIRE(pa && pb, "bn pair: null problem");
   const mvk_bn_fwd_problem &a = *pa, &b = *pb;
   const int fam = bn_family_fwd(a);
@@ -1551,7 +1252,6 @@ extern "C" int mvk_bn_lrelu_fwd_pair(const mvk_bn_fwd_problem* pa, const mvk_bn_
 }
 
 extern "C" int mvk_bn_lrelu_bwd_pair(const mvk_bn_bwd_problem* pa, const mvk_bn_bwd_problem* pb, void* stream) {
-  bn_vec_switch();
   MVK_REQUIRE(pa && pb, "bn pair: null problem");
   const mvk_bn_bwd_problem &a = *pa, &b = *pb;
   const int fam = bn_family_bwd(a);

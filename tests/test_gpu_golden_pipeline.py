@@ -119,7 +119,8 @@ def referee_digest(label, names, hip_flat, idx_of, ref_of, f64_of, loose=1e-2):
     (the reference's classes for G12, the CPU port for G13). ROUNDING is bounded tightly: e_hip <= REFEREE_FACTOR x e_ref +
     REFEREE_FLOOR. What rounding cannot explain is the LeakyReLU kink: an activation input within float32 rounding of
     zero takes the other slope in another summation order, which moves the gradient of its layer by a quantum of ~1 /
-    rows (1e-3 at a few hundred rows) and, through the backward, EVERY tensor upstream of it in that branch. Measured
+    rows (1e-3 at a few hundred rows, 4.5e-2 at the 22 rows of G12's coarsest level: the callers pass `loose` = 1 / rows of
+    their coarsest level) and, through the backward, EVERY tensor upstream of it in that branch. Measured
     (tools/debug_g12_middle.py, round 5): three runs of the same command on G12 middle put the whole 2D encoder branch at
     3.4e-3, 4.6e-6 and 1.6e-3 from float64 -- the split products' float atomics add in a run-dependent order --, the
     deterministic mode at 3.9e-6, and the reference's own float32 fixture has the same quanta elsewhere (G12 early:
@@ -194,7 +195,10 @@ def test_fusion_networks_vs_reference_forward_texts(variant):
         check_err("G12 %s loss (abs)" % tag, abs(loss.item() - float(g[variant + "/loss"])), 1e-5)
         grads = {n: p.grad.cpu().numpy() for n, p in net.named_parameters() if p.grad is not None}
         assert any(k.startswith("feat_aggreg.") for k in grads) == (variant == "late")
-        g12_check_gradients(g, variant, grads, tag, 5e-3, 2e-3)
+        # what one LeakyReLU / max-pool kink flip can move: the coarsest level of this batch has 22 rows (6 in one sphere), a
+        # flip there is 1 / rows of its layer's gradient and reaches every tensor upstream (referee_digest's docstring)
+        quantum = 1.0 / min(int(p.shape[0]) for p in b["points"])
+        g12_check_gradients(g, variant, grads, tag, max(5e-3, 0.25 * quantum), 2e-3)
         # the float64 referee on the same digest: per parameter the 64 fixed elements and the norm -- the wide bounds above
         # are the REFERENCE's own float32 distance from the float64 network (early: 1.8e-3 in one norm), not the HIP path's
         r = load_golden("g14_f64_referee")
@@ -202,7 +206,8 @@ def test_fusion_networks_vs_reference_forward_texts(variant):
         referee_digest("G12 %s" % tag, sorted(k[len(variant) + 7:] for k in g if k.startswith(variant + "/gnorm/")),
                        lambda n: np.asarray(grads[n], np.float64).reshape(-1), lambda n: g["%s/gidx/%s" % (variant, n)],
                        lambda n: (g["%s/gval/%s" % (variant, n)], float(g["%s/gnorm/%s" % (variant, n)])),
-                       lambda n: (r["g12/%s/gval/%s" % (variant, n)], float(r["g12/%s/gnorm/%s" % (variant, n)])))
+                       lambda n: (r["g12/%s/gval/%s" % (variant, n)], float(r["g12/%s/gnorm/%s" % (variant, n)])),
+                       loose=max(1e-2, quantum))
 
 
 @pytest.mark.parametrize("name,variant,deformable,radius", [("g13_early_19k", "early", False, 1.2),
@@ -269,7 +274,8 @@ def test_full_size_gradients_vs_cpu_port_digest(name, variant, deformable, radiu
     referee_check("G13 %s 256 logit rows" % name, out.detach()[rows].cpu().numpy(), g["logits"], r[name + "/logits"])
     referee_digest("G13 %s" % name, names, lambda n: grads[n].reshape(-1).double().cpu().numpy(), lambda n: g["gidx/" + n],
                    lambda n: (g["gval/" + n], float(g["gnorm/" + n])),
-                   lambda n: (r["%s/gval/%s" % (name, n)], float(r["%s/gnorm/%s" % (name, n)])))
+                   lambda n: (r["%s/gval/%s" % (name, n)], float(r["%s/gnorm/%s" % (name, n)])),
+                   loose=max(1e-2, 1.0 / min(int(p.shape[0]) for p in batch.points)))     # (one kink flip at the coarsest level)
 
 
 def test_fusion_chain_vs_golden():

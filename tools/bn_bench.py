@@ -1,5 +1,5 @@
 """Development-only (GPU box): the masked BatchNorm + LeakyReLU of the big levels, forward and backward, device time of graph-
-captured launches. Run with MVK_BN_VEC=1 / 0.  usage: python tools/bn_bench.py"""
+captured launches (round 5: used to compare two builds of csrc/bn.hip, DESIGN 4.12 h).  usage: python tools/bn_bench.py"""
 import os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -24,7 +24,6 @@ def timeit(fn, n=20):
     return e0.elapsed_time(e1) / (3 * n) * 1e3
 
 
-print("MVK_BN_VEC =", os.environ.get("MVK_BN_VEC", "1"))
 for (R, D) in ((19464, 32), (19464, 64), (19464, 128), (55070, 32), (55070, 64), (55070, 128), (4986, 128), (4986, 256), (171123, 64)):
     torch.manual_seed(0)
     bn = torch.nn.BatchNorm1d(D).to(dev)

@@ -246,7 +246,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
 
         side_first = os.environ.get("MVK_NET_FIRST") != "1"      # development: 1 = capture the network's nodes first
 
-        def fork_encoder(work=True):
+        def fork_encoder(work=True, parts=("enc", "chain", "fa")):
             # parallel branches of the SAME graph (separate graph launches do not overlap on this runtime,
             # branches of one graph do): features of the NEXT batch's views, and the NEXT batch's pyramid /
             # unprojection / 3-NN, into the other static set.
@@ -255,18 +255,20 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
             # the chip. Capturing the network's nodes BEFORE the side branches' (work=False here, side_work() after the
             # network) makes it worse (5.04 ms): the side branches then start late and end after the network.
             cur = torch.cuda.current_stream()
-            if enc is not None:
+            if enc is not None and "enc" in parts:
                 enc_stream.wait_stream(cur)
-            if use_chain:
+            if use_chain and "chain" in parts:
                 build_stream.wait_stream(cur)
             if work:
-                side_work()
+                side_work(parts)
 
         skip = _knob("MVK_BENCH_SKIP", "").split(",")   # development (timing only, the step's inputs go stale):
                                                                    # leave "enc" / "chain" / "fa" out of the side branches
 
-        def side_work():
-            if enc is not None and "enc" not in skip and enc_pair:
+        def side_work(parts=("enc", "chain", "fa")):
+            if "enc" not in parts:
+                pass
+            elif enc is not None and "enc" not in skip and enc_pair:
                 with torch.cuda.stream(enc_stream):
                     if phase == 0:      # this replay: the views of batches k+1 (other set), k+2 (this set again), k+3, k+4 (held)
                         if in_graph_inputs:
@@ -285,14 +287,14 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
                     if in_graph_inputs:       # the views of batch k+1 enter on this branch, not by eager launches on the network's queue
                         enc_in.copy_(torch.stack(staged['images'], 0))
                     other.feature_2d.copy_(encode(enc_in))
-            if use_chain and "chain" not in skip:
+            if use_chain and "chain" not in skip and "chain" in parts:
                 with torch.cuda.stream(build_stream):
                     if in_graph_inputs:       # this step's grid orientations: a copy node reading the pinned draw of the host
                         chains[1 - statics.index(static)].upload_rotations()
                     chains[1 - statics.index(static)].build(other)
                     for _ in range(int(_knob("MVK_BENCH_DUMMY_LAUNCHES", "0"))):   # development: what is one more
                         _DUMMY.setdefault(dev, torch.zeros(64, device=dev)).add_(1.0)        # tiny launch on a side branch worth?
-            if fa_ahead and "fa" not in skip:        # needs both: the encoder's features and the chain's 3-NN pixels of batch k+1
+            if fa_ahead and "fa" not in skip and "fa" in parts:        # needs both: the encoder's features and the chain's 3-NN pixels of batch k+1
                 enc_stream.wait_stream(build_stream)
                 with torch.cuda.stream(enc_stream):
                     if stack_ahead:     # the network's input features in one go: [feature_3d | lifted features]
@@ -308,15 +310,37 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
 
         if reducer is None or getattr(reducer, "capturable", False):
             diag = _knob("MVK_BENCH_DIAG", "")    # development: "noside" / "onlyside" time the branches apart
+            # MVK_SIDE_AFTER_BLOCK = k >= 0: the side branches fork from the network's chain AFTER encoder block k instead of at
+            # the step's start -- their wide kernels then overlap the latency-bound coarse levels, not the wide level-0 kernels
+            # that open the step. Measured on six boxes, one sphere per step (DESIGN 4.12 k): 3.52-3.60 ms against 3.58-3.64
+            # (-0.4 .. -2.6 %); baseline net -1.5 %, configs[3] / [4] per rank -0.8 / -1.2 %; with 5-8 spheres per step the side
+            # branches are as long as the network and starting them late costs 0.4-0.7 %: default 3 for one or two spheres per
+            # step (two: 5.42 against 5.49 ms), off otherwise.
+            late = int(os.environ.get("MVK_SIDE_AFTER_BLOCK", "3" if len(staged['points']) <= 2 else "-1"))
+            late_enc = int(os.environ.get("MVK_ENC_AFTER_BLOCK", str(late)))        # (>= the chain's block: FeatureAggregation needs both)
+            hooks = []
             with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
                 if diag != "noside":
-                    fork_encoder(work=side_first)
+                    if (late >= 0 or late_enc >= 0) and diag != "onlyside":
+                        blocks = getattr(net, "encoder_blocks", None) or net.encoder_blocks_3d      # (middle fusion: the 3D tower runs first)
+                        if late < 0:
+                            fork_encoder(work=True, parts=("chain",))
+                        if late == late_enc:
+                            hooks.append(blocks[late].register_forward_hook(lambda *_: fork_encoder(work=True)))
+                        else:
+                            if late >= 0:
+                                hooks.append(blocks[late].register_forward_hook(lambda *_: fork_encoder(work=True, parts=("chain",))))
+                            hooks.append(blocks[late_enc].register_forward_hook(lambda *_: fork_encoder(work=True, parts=("enc", "fa"))))
+                    else:
+                        fork_encoder(work=side_first)
                 if diag != "onlyside":
                     loss = net_step_captured(net, static, cfg, params, opt, reducer)
                 else:
                     loss = torch.zeros((), device=dev)
+                for h in hooks:
+                    h.remove()
                 if diag != "noside":
-                    if not side_first:
+                    if not side_first and late < 0:
                         side_work()
                     join_encoder()
             return graph.replay, loss

@@ -308,8 +308,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
             if use_chain:
                 torch.cuda.current_stream().wait_stream(build_stream)
 
-        if reducer is None or getattr(reducer, "capturable", False):
-            diag = _knob("MVK_BENCH_DIAG", "")    # development: "noside" / "onlyside" time the branches apart
+        def fork_side_branches():
             # MVK_SIDE_AFTER_BLOCK = k >= 0: the side branches fork from the network's chain AFTER encoder block k instead of at
             # the step's start -- their wide kernels then overlap the latency-bound coarse levels, not the wide level-0 kernels
             # that open the step. Measured on six boxes, one sphere per step (DESIGN 4.12 k): 3.52-3.60 ms against 3.58-3.64
@@ -318,19 +317,28 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
             # step (two: 5.42 against 5.49 ms), off otherwise.
             late = int(os.environ.get("MVK_SIDE_AFTER_BLOCK", "3" if len(staged['points']) <= 2 else "-1"))
             late_enc = int(os.environ.get("MVK_ENC_AFTER_BLOCK", str(late)))        # (>= the chain's block: FeatureAggregation needs both)
+            if late < 0 and late_enc < 0:
+                fork_encoder(work=side_first)
+                return []
+            blocks = getattr(net, "encoder_blocks", None) or net.encoder_blocks_3d      # (middle fusion: the 3D tower runs first)
+            hooks = []
+            if late < 0:
+                fork_encoder(work=True, parts=("chain",))
+            if late == late_enc:
+                hooks.append(blocks[late].register_forward_hook(lambda *_: fork_encoder(work=True)))
+            else:
+                if late >= 0:
+                    hooks.append(blocks[late].register_forward_hook(lambda *_: fork_encoder(work=True, parts=("chain",))))
+                hooks.append(blocks[late_enc].register_forward_hook(lambda *_: fork_encoder(work=True, parts=("enc", "fa"))))
+            return hooks
+
+        if reducer is None or getattr(reducer, "capturable", False):
+            diag = _knob("MVK_BENCH_DIAG", "")    # development: "noside" / "onlyside" time the branches apart
             hooks = []
             with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
                 if diag != "noside":
-                    if (late >= 0 or late_enc >= 0) and diag != "onlyside":
-                        blocks = getattr(net, "encoder_blocks", None) or net.encoder_blocks_3d      # (middle fusion: the 3D tower runs first)
-                        if late < 0:
-                            fork_encoder(work=True, parts=("chain",))
-                        if late == late_enc:
-                            hooks.append(blocks[late].register_forward_hook(lambda *_: fork_encoder(work=True)))
-                        else:
-                            if late >= 0:
-                                hooks.append(blocks[late].register_forward_hook(lambda *_: fork_encoder(work=True, parts=("chain",))))
-                            hooks.append(blocks[late_enc].register_forward_hook(lambda *_: fork_encoder(work=True, parts=("enc", "fa"))))
+                    if diag != "onlyside":
+                        hooks = fork_side_branches()
                     else:
                         fork_encoder(work=side_first)
                 if diag != "onlyside":
@@ -340,7 +348,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
                 for h in hooks:
                     h.remove()
                 if diag != "noside":
-                    if not side_first and late < 0:
+                    if not side_first and not hooks:
                         side_work()
                     join_encoder()
             return graph.replay, loss
@@ -356,9 +364,11 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
         net.backward_cut = reducer.cut_block if staged_exchange else None
         scope = backward_scope(ops)
         with torch.cuda.graph(graph, stream=main_stream, capture_error_mode="thread_local"):
-            fork_encoder()
+            hooks = fork_side_branches()
             ops.step_begin()
             loss = net.loss(net(static, cfg), static.labels)
+            for h in hooks:
+                h.remove()
             if staged_exchange:
                 orig, leaves = net.cut_tensors
                 with scope():

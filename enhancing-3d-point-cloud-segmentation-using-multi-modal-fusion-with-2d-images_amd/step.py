@@ -320,6 +320,9 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
             if late < 0 and late_enc < 0:
                 fork_encoder(work=side_first)
                 return []
+            if late_enc < late:
+                raise ValueError("MVK_ENC_AFTER_BLOCK must not be smaller than MVK_SIDE_AFTER_BLOCK: FeatureAggregation runs on the "
+                                 "encoder's branch and waits for the input chain, which must have been forked by then")
             blocks = getattr(net, "encoder_blocks", None) or net.encoder_blocks_3d      # (middle fusion: the 3D tower runs first)
             hooks = []
             if late < 0:

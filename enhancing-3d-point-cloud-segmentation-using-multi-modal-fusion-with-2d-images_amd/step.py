@@ -316,23 +316,27 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
             # branches are as long as the network and starting them late costs 0.4-0.7 %: default 3 for one or two spheres per
             # step (two: 5.42 against 5.49 ms), off otherwise.
             late = int(os.environ.get("MVK_SIDE_AFTER_BLOCK", "3" if len(staged['points']) <= 2 else "-1"))
-            late_enc = int(os.environ.get("MVK_ENC_AFTER_BLOCK", str(late)))        # (>= the chain's block: FeatureAggregation needs both)
+            late_enc = int(os.environ.get("MVK_ENC_AFTER_BLOCK", str(late)))        # the frozen encoder separately (-1: at the start)
             if late < 0 and late_enc < 0:
                 fork_encoder(work=side_first)
                 return []
-            if late_enc < late:
-                raise ValueError("MVK_ENC_AFTER_BLOCK must not be smaller than MVK_SIDE_AFTER_BLOCK: FeatureAggregation runs on the "
-                                 "encoder's branch and waits for the input chain, which must have been forked by then")
             blocks = getattr(net, "encoder_blocks", None) or net.encoder_blocks_3d      # (middle fusion: the 3D tower runs first)
             hooks = []
-            if late < 0:
-                fork_encoder(work=True, parts=("chain",))
-            if late == late_enc:
-                hooks.append(blocks[late].register_forward_hook(lambda *_: fork_encoder(work=True)))
+
+            def at(block, parts):          # fork `parts` at the step's start (block < 0) or after encoder block `block`
+                if block < 0:
+                    fork_encoder(work=True, parts=parts)
+                else:
+                    hooks.append(blocks[block].register_forward_hook(lambda *_: fork_encoder(work=True, parts=parts)))
+            # FeatureAggregation runs on the encoder's branch and waits for the input chain: it goes with the LATER of the two
+            if late_enc == late:
+                at(late, ("enc", "chain", "fa"))
+            elif late_enc > late:
+                at(late, ("chain",))
+                at(late_enc, ("enc", "fa"))
             else:
-                if late >= 0:
-                    hooks.append(blocks[late].register_forward_hook(lambda *_: fork_encoder(work=True, parts=("chain",))))
-                hooks.append(blocks[late_enc].register_forward_hook(lambda *_: fork_encoder(work=True, parts=("enc", "fa"))))
+                at(late_enc, ("enc",))
+                at(late, ("chain", "fa"))
             return hooks
 
         if reducer is None or getattr(reducer, "capturable", False):

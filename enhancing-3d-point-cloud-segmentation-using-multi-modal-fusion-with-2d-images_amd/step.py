@@ -437,6 +437,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
                           "support its reverse-list width (status %s, capacities %s)" % (host.tolist(), statics[0].caps),
                           file=sys.stderr)
 
+        status_every = max(2, int(os.environ.get("MVK_STATUS_EVERY", "16")))
         chains[0].draw_rotations()
         chains[0].build(statics[0])             # batch 0; every later batch is built by the graph before it
         state["slot"] = 0
@@ -461,7 +462,12 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
                     enc_in.copy_(torch.stack(staged['images'], 0))      # the views of batch k+1
             ta = time.perf_counter()
             replays[phase][0]()
-            host = torch.empty(4, dtype=torch.int32).pin_memory() if len(pending) < 4 else None
+            # the chains' status words are sticky (atomicMax / atomicOr, never reset): reading them back on every
+            # MVK_STATUS_EVERY-th step (and in finish()) reports an overflow as surely as reading them after each replay,
+            # without a copy launch between every two graph launches
+            state["k"] += 1
+            host = (torch.empty(4, dtype=torch.int32).pin_memory()
+                    if len(pending) < 4 and state["k"] % status_every in (0, 1) else None)
             if host is not None:
                 host.copy_(chains[slot ^ 1].status4, non_blocking=True)
                 ev = torch.cuda.Event()
@@ -474,7 +480,16 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
             state["phase"] = (phase + 1) % len(replays)
             return lens0, replays[phase][1]
 
-        step_chain.finish = lambda: check_status(block=True)
+        def finish():
+            for c in chains:                     # both chains' words, whatever the step count was
+                host = torch.empty(4, dtype=torch.int32).pin_memory()
+                host.copy_(c.status4, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                pending.append((ev, host))
+            check_status(block=True)
+
+        step_chain.finish = finish
         if _knob("MVK_BENCH_DIAG") == "1":
             torch.cuda.synchronize()
             t0 = time.perf_counter()

@@ -322,6 +322,7 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
                 return []
             blocks = getattr(net, "encoder_blocks", None) or net.encoder_blocks_3d      # (middle fusion: the 3D tower runs first)
             hooks = []
+            late, late_enc = min(late, len(blocks) - 1), min(late_enc, len(blocks) - 1)      # (short architectures)
 
             def at(block, parts):          # fork `parts` at the step's start (block < 0) or after encoder block `block`
                 if block < 0:

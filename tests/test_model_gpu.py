@@ -452,12 +452,18 @@ def test_device_input_chain_equals_eager_input_side(variant, deformable, nsphere
         assert int(buf.abs().sum()) == 0
 
 
-@pytest.mark.parametrize("device_chain", [False, True])
-def test_graph_replay_trains_like_eager(device_chain):
+@pytest.mark.parametrize("device_chain,fork", [(False, None), (True, None), (True, "-1"), (True, "1")])
+def test_graph_replay_trains_like_eager(device_chain, fork, monkeypatch):
     """bench.py's hipGraph step (capacity-padded static batch, masked BatchNorm, input pyramid one batch
     ahead on a second stream) follows the same trajectory as plain eager steps: with the grid rotations
-    pinned (so every batch is identical) the losses and the weights after 5 optimizer steps agree."""
+    pinned (so every batch is identical) the losses and the weights after 5 optimizer steps agree. fork: where the side
+    branches leave the network's chain (step.py MVK_SIDE_AFTER_BLOCK; None = the default for one sphere: after encoder
+    block 3; "-1" = at the step's start, as for batches of more than two spheres; "1" with the encoder two blocks later)."""
     import types
+    if fork is not None:
+        monkeypatch.setenv("MVK_SIDE_AFTER_BLOCK", fork)
+        if fork == "1":
+            monkeypatch.setenv("MVK_ENC_AFTER_BLOCK", "3")
     import mvkpconv
     bench = mvkpconv.sub("step")          # the step executor lives in the package since round 5 (was bench.py)
     syn, ops = mvkpconv.sub("synthetic"), mvkpconv.sub("ops")

@@ -1219,7 +1219,8 @@ int launch_vec(KPParams P, int idx64, hipStream_t st) {
 // channel tiles per wave of the MFMA gather for rows of Cin channels (0: the layer stays on the vector kernels)
 int mfma_tiles(int64_t Ns, int Cin, int K, int influence, int aggregation) {
   static const bool on = getenv("MVK_GATHER_MFMA") == nullptr || atoi(getenv("MVK_GATHER_MFMA")) != 0;
-  if (!on || influence != MVK_INFL_LINEAR || aggregation != MVK_AGG_SUM || K > 16 || Cin < 5) return 0;
+  static const int min_cin = getenv("MVK_GATHER_MFMA_MIN_CIN") ? atoi(getenv("MVK_GATHER_MFMA_MIN_CIN")) : 1;      // (5: rows of <= 4 channels stay on kpconv_gather_small)
+  if (!on || influence != MVK_INFL_LINEAR || aggregation != MVK_AGG_SUM || K > 16 || Cin < min_cin) return 0;
   if ((uint64_t)Ns * (uint64_t)Cin >= (1ull << 32) - 4096) return 0;
   if (Cin <= 32) return 2;
   if (Cin <= 64) return 4;
@@ -1379,6 +1380,9 @@ extern "C" int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const f
     } else {
       launch_lane_channel<0, true>(P, idx64, st);
     }
+  } else if (Cin <= 4 && launch_mfma<0>(P, idx64, st)) {
+    // (narrow rows -- the first layer of the baseline / middle / late nets -- on the matrix pipe too: 21.7 against 28.8 us
+    // for 19 464 points x 4 channels; most of the 16 x 16 tile is idle, but the kernel's cost there is the geometry)
   } else if (Cin <= 4) {
     const bool fast = influence == MVK_INFL_LINEAR && aggregation == MVK_AGG_SUM;
     dim3 grid((unsigned)cdiv64(Nq * 4, 256)), block(256);       // four lanes per point
@@ -1390,7 +1394,7 @@ extern "C" int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const f
       else hipLaunchKernelGGL((kpconv_gather_small<false, false>), grid, block, 0, st, P);
     }
   } else if (launch_mfma<0>(P, idx64, st)) {
-    // (the aggregation on the matrix pipe: linear influence, sum aggregation, 5 <= Cin, feature table < 2^32 elements)
+    // (the aggregation on the matrix pipe: linear influence, sum aggregation, feature table < 2^32 elements)
   } else if (Cin <= 256) {
     launch_vec<1>(P, idx64, st);
   } else if (Cin <= 512) {
@@ -1477,7 +1481,7 @@ extern "C" int mvk_kpconv_gather_plan(int64_t Nq, int64_t Ns, int H, int Cin, in
     out[6] = out[5] * 256; out[7] = 1;
     return 0;
   }
-  if (Nq <= 0 || Cin <= 0 || Cin > 512 || (deformable && Cin < 13) || (!deformable && Cin <= 4)) return 0;
+  if (Nq <= 0 || Cin <= 0 || Cin > 512 || (deformable && Cin < 13) || (!deformable && Cin <= 4)) return 0;      // (one point per 4 lanes: kpconv_gather_small)
   const VecPlan v = plan_vec(Nq, Ns, H, Cin, true, deformable != 0);
   out[0] = v.LPP; out[1] = v.PPW; out[2] = v.fub; out[3] = v.B1; out[4] = v.nw; out[5] = v.wgs;
   out[6] = v.wgs * 64 * v.nw;

@@ -603,8 +603,14 @@ def _defer_slots(device):
     if _DEFER["slots"] is None:
         nb = _DW_MAX * int(lib().mvk_gemm_group_entry_bytes())
         _DEFER["slots"] = [{"host": torch.empty(nb, dtype=torch.uint8).pin_memory(),
-                            "dev": torch.empty(nb, dtype=torch.uint8, device=device), "event": None} for _ in range(10)]
+                            "dev": torch.empty(nb, dtype=torch.uint8, device=device), "event": None} for _ in range(34)]
     return _DEFER["slots"]
+
+
+def capture_table_slots_left(device):
+    """Captured passes of defer_weight_grads this process can still record (each keeps one pre-pinned table for good; two
+    stay with the eager passes). Ask BEFORE starting a capture: running out inside one raises in the middle of the capture."""
+    return max(0, len(_defer_slots(device)) - 2)
 
 
 class defer_weight_grads:

@@ -418,6 +418,9 @@ def make_graph_step(syn, ops, cfg, net, staged, limits, params, opt, reducer, st
 
     _SEED.setdefault(dev, torch.ones((), device=dev))      # (before the captures: see backward())
     _DUMMY.setdefault(dev, torch.zeros(64, device=dev))
+    if ops.capture_table_slots_left(dev) < max(2, enc_cycle):      # (an error inside a capture leaves the stream unusable)
+        raise RuntimeError("GraphStep: this process has captured too many steps (the pre-pinned launch tables of "
+                           "ops.defer_weight_grads are used up: 32 captured passes per process)")
     replays = [capture(statics[ph % 2], ph) for ph in range(max(2, enc_cycle))]      # (phase of the encoder's cycle; set = phase % 2)
     # "lookahead": the input pipeline must hold the views of this many upcoming batches when a step starts
     state = {"next": None, "k": 0, "free": [None, None], "lookahead": enc_cycle}

@@ -75,8 +75,8 @@ int mvk_kpconv_gather_fwd_ordered(const float* q, int64_t Nq, const float* s, in
  * out[0..6] = lanes per point, points per wave, feature rows per batch of the branch-free kernel variant
  * (0 = general variant), first workgroup whose waves share their points, waves per workgroup, workgroups,
  * grid threads (the figure a kernel trace reports). out[5] = 0: the layer runs on another kernel (one point per wave;
- * one point per lane for rows of <= 4 channels). out[7] (ABI 7) = 1: the MFMA gather (kpconv_gather_mfma, round 5: rigid
- * f32 layers of >= 5 channels -- one wave per point, out[2] = its 16-channel accumulator tiles), 0: the vector kernel. */
+ * one point per lane for rows of <= 4 channels). out[7] (ABI 7) = 1: the MFMA gather (kpconv_gather_mfma, round 5: layers
+ * with linear influence and sum aggregation -- one wave per point, out[2] = its 16-channel accumulator tiles), 0: the vector kernel. */
 int mvk_kpconv_gather_plan(int64_t Nq, int64_t Ns, int H, int Cin, int elem_bytes, int deformable, int64_t* out /* [8] */);
 
 /* Gather-form feature gradient of a DEFORMABLE KPConv (round 5): A2 [Ns, K, C] = the forward aggregation over the

@@ -656,7 +656,7 @@ def test_input_kernels_on_both_paths_at_every_size():
         r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                             os.path.join(here, "test_gpu_parity.py"), os.path.join(here, "test_gpu_golden_pipeline.py"),
                             "-k", "(subsample or neighbors or cell_order or pyramid or scene_load) and not both_paths"],
-                           env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=900)
+                           env=env, cwd=os.path.dirname(here), capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, "thresholds %s:\n%s" % (thr, (r.stdout + r.stderr)[-3000:])
         assert " passed" in r.stdout and "failed" not in r.stdout
 
@@ -1681,7 +1681,7 @@ def test_randomised_sweep_index_kernels_vs_oracle():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), "3", "12"], capture_output=True,
-                       text=True, timeout=600, cwd=root)
+                       text=True, timeout=300, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     assert "fuzz done, mismatches: 0" in p.stdout, p.stdout[-2000:]
 

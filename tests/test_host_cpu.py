@@ -49,7 +49,8 @@ def test_gather_launch_plan_is_a_host_function():
     assert c["mfma"] == 1 and c["first_sharing_workgroup"] == 0 and c["workgroups"] == 180
     d = ops.kpconv_gather_plan(750, 750, 420, 128, deformable=True)    # deform-radius rows: every workgroup shares
     assert d["mfma"] == 1 and d["first_sharing_workgroup"] == 0 and d["workgroups"] == 750 and d["waves_per_workgroup"] == 4
-    assert ops.kpconv_gather_plan(100, 100, 20, 2)["workgroups"] == 0         # rows of <= 4 channels: one point per 4 lanes
+    n = ops.kpconv_gather_plan(100, 100, 20, 2)                                # narrow rows: two tiles, mostly idle
+    assert n["mfma"] == 1 and n["rows_per_batch"] == 2 and n["workgroups"] == 25
     with pytest.raises(RuntimeError):
         ops.kpconv_gather_plan(100, 100, 20, 64, elem_bytes=2)                # the fp16-feature mode left the tree (round 5)
 

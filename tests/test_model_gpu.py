@@ -302,7 +302,7 @@ def test_sync_batchnorm_two_ranks_equal_one_rank_with_two_spheres(tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
     procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "_syncbn_worker.py"), str(r), "2", str(port), str(tmp_path)],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    logs = [p.communicate(timeout=600)[0] for p in procs]
+    logs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(l[-1500:] for l in logs)
     r0, r1 = (torch.load(str(tmp_path / ("rank%d.pt" % r)), weights_only=False) for r in range(2))
     assert [r0["n"], r1["n"]] == lens
@@ -546,7 +546,7 @@ def test_bench_emits_one_valid_json_line():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1"],
-                       capture_output=True, text=True, timeout=600, cwd=root)
+                       capture_output=True, text=True, timeout=300, cwd=root)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -628,7 +628,7 @@ def test_dataloader_workers_build_the_pyramid_without_forking(tmp_path):
         "    print('WORKER PYRAMIDS OK')\n" % (os.path.join(root, pkg, "dropin"), str(tmp_path), root))
     env = dict(os.environ)
     env.pop("MVK_DATALOADER_START", None)
-    r = subprocess.run([sys.executable, str(script)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, str(script)], cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "WORKER PYRAMIDS OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
@@ -673,8 +673,9 @@ def test_default_multi_gpu_step_structure_trains_like_the_single_graph_step():
 
     def run(extra_env):
         env = dict(os.environ, MVK_BENCH_DETAIL=os.path.join(root, "gpurun_out", "bench_detail_test.json"), **extra_env)
+        # (240 s: a run takes ~15 s; a hung child must end as a failure with its stderr, not as a silent test process)
         p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"],
-                           capture_output=True, text=True, timeout=600, cwd=root, env=env)
+                           capture_output=True, text=True, timeout=240, cwd=root, env=env)
         assert p.returncode == 0, p.stderr[-2000:]
         return json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
 
